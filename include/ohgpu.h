@@ -1,0 +1,180 @@
+/*
+ * ohgpu.h -- C ABI of the MI355X-native PCM hot path of ohPipeline.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ types, no torch types, never
+ * throws.  Every entry point returns OHGPU_OK (0) or a negative OHGPU_ERR_* code; the message
+ * for the most recent failure on the calling thread is available from ohgpu_last_error().
+ *
+ * What it stands in for (file:line relative to the reference tree, openhome/ohPipeline):
+ *
+ *   reference call chain (per message, on the animator thread)          replaced by
+ *   ------------------------------------------------------------------  ---------------------------
+ *   MsgFactory::CreateMsgAudioPcm -> DecodedAudio::ConstructPcm          src_endian in the descriptor
+ *       (OpenHome/Media/Pipeline/Msg.cpp:3961-3965, 347-408)             (LE->BE fused into the load)
+ *   MsgAudioPcm::CreatePlayable (Msg.cpp:2234-2262)                      host fills src_offset/n_frames
+ *   MsgPlayable::Read(IPcmProcessor&) (Msg.cpp:2646-2653)                ohgpu_pcm_batch_run()
+ *     MsgPlayablePcm::ApplyAttenuation (Msg.cpp:2736-2751)                 attenuation field
+ *     RampApplicator::GetNextSample    (Msg.cpp:832-899)                   OHGPU_FLAG_RAMP + ramp_start/end
+ *     MsgPlayableSilence::ReadBlock    (Msg.cpp:2874-2893)                 OHGPU_FLAG_SILENCE
+ *   IPcmProcessor::ProcessFragment doing depth conversion                dst_bits / dst_endian
+ *     FlywheelInput::AppendSubsample8/16/24/32 (StarvationRamper.cpp:117-186)
+ *     RampGenerator::ProcessFragment           (StarvationRamper.cpp:281-327)
+ *   "SampleRateConverter" -- NOT PRESENT in the reference  ohgpu_src_* (own spec)
+ *
+ * The reference binds nothing through FFI today (it is one C++ static library); INTEGRATION.md
+ * shows the adapter a maintainer would add: an IPcmProcessor-shaped C++ shim over this ABI.
+ *
+ * Threading: an ohgpu_ctx may be used from one thread at a time (the reference's element
+ * contract is the same: one puller thread per element, Msg.h:1844-1849).  Different contexts
+ * are independent.  All *_run calls are asynchronous on the given stream.
+ */
+#ifndef OHGPU_H
+#define OHGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OHGPU_ABI_VERSION 1
+
+/* ---- error codes ---- */
+#define OHGPU_OK                0
+#define OHGPU_ERR_INVALID      (-1)  /* bad argument / descriptor fails validation (reference: ASSERT) */
+#define OHGPU_ERR_DEVICE       (-2)  /* HIP runtime error (message holds hipGetErrorString)            */
+#define OHGPU_ERR_NO_DEVICE    (-3)  /* no GPU visible; the product path never falls back to the CPU   */
+#define OHGPU_ERR_NOMEM        (-4)
+#define OHGPU_ERR_BOUNDS       (-5)  /* descriptor addresses bytes outside the declared arenas         */
+#define OHGPU_ERR_UNSUPPORTED  (-6)  /* e.g. attenuation on non-16-bit audio (Msg.cpp:2741)            */
+
+/* ---- enums mirroring the reference ---- */
+#define OHGPU_ENDIAN_LITTLE 1   /* AudioDataEndian::Little  Msg.h:107-112 */
+#define OHGPU_ENDIAN_BIG    2   /* AudioDataEndian::Big */
+
+#define OHGPU_RAMP_MAX 16384u          /* Ramp::kMax  Msg.h:258 */
+#define OHGPU_UNITY_ATTENUATION 256u   /* MsgAudioPcm::kUnityAttenuation  Msg.cpp:2219 */
+#define OHGPU_MAX_CHANNELS 8u          /* DecodedAudio::kMaxNumChannels   Msg.h:170 (Sender maps 10 -> handled on host) */
+
+/* ---- descriptor flags ---- */
+#define OHGPU_FLAG_RAMP       0x01u  /* Ramp::IsEnabled(): apply RampApplicator semantics (16-bit, low bytes zeroed) */
+#define OHGPU_FLAG_SILENCE    0x02u  /* MsgPlayableSilence: emit zeros (+ the 6-channel id bytes of Msg.cpp:2877);
+                                        src is not read */
+#define OHGPU_FLAG_ZERO_LSB32 0x04u  /* RampGenerator::ProcessFragment "case 32" (StarvationRamper.cpp:311-320):
+                                        when dst_bits == 32 write a zero least-significant byte */
+
+/*
+ * One MsgPlayable (Msg.cpp:2684-2696, 2722-2734) flattened for the device.  32 bytes.
+ * Audio is packed, interleaved; src_offset already includes MsgPlayable::iOffset.
+ * Output is packed interleaved at dst_bits, big endian unless dst_endian says otherwise.
+ */
+typedef struct ohgpu_msg_desc {
+    uint64_t src_offset;    /* bytes from src_base to the first frame                               */
+    uint64_t dst_offset;    /* bytes from dst_base to the first output frame                        */
+    uint32_t n_frames;      /* sample instants ("samples" in the reference, Msg.cpp:826)            */
+    uint16_t ramp_start;    /* Ramp::Start()  [0, 16384]                                            */
+    uint16_t ramp_end;      /* Ramp::End()                                                          */
+    uint16_t attenuation;   /* 256 = unity; other values only with src_bits == 16 (Msg.cpp:2741)    */
+    uint8_t  channels;      /* 1..8                                                                 */
+    uint8_t  src_bits;      /* 8, 16, 24, 32                                                        */
+    uint8_t  src_endian;    /* OHGPU_ENDIAN_*                                                       */
+    uint8_t  dst_bits;      /* 8, 16, 24, 32                                                        */
+    uint8_t  dst_endian;    /* OHGPU_ENDIAN_*                                                       */
+    uint8_t  flags;         /* OHGPU_FLAG_*                                                         */
+} ohgpu_msg_desc;
+
+/*
+ * One OUTPUT message of a sample-rate-converted stream.  64 bytes.
+ * The input buffer holds frames [src_frame0, src_frame0 + src_frames) of the stream starting at
+ * src_offset; frames with a negative absolute index are zeros (stream start); every other frame the
+ * filter needs, n0(out_frame0) - T + 1 .. n0(out_frame0 + n_frames - 1), must be present.
+ * The resampler runs in the S24 domain (sources are left-justified to 24 bits first), so ramping
+ * follows RampApplicator's 24-bit case and attenuation must be unity.
+ */
+typedef struct ohgpu_src_msg_desc {
+    uint64_t src_offset;    /* bytes from src_base to input frame src_frame0                        */
+    uint64_t src_frame0;    /* absolute index of the first input frame held in the buffer           */
+    uint64_t src_frames;    /* number of input frames held                                          */
+    uint64_t out_frame0;    /* absolute index of this message's first output frame                  */
+    uint64_t dst_offset;    /* bytes from dst_base                                                  */
+    uint32_t n_frames;      /* output frames in this message                                        */
+    uint16_t ramp_start;
+    uint16_t ramp_end;
+    uint16_t attenuation;   /* must be 256                                                          */
+    uint8_t  channels;
+    uint8_t  src_bits;
+    uint8_t  src_endian;
+    uint8_t  dst_bits;
+    uint8_t  dst_endian;
+    uint8_t  flags;         /* OHGPU_FLAG_RAMP | OHGPU_FLAG_ZERO_LSB32                              */
+    uint8_t  reserved[8];
+} ohgpu_src_msg_desc;
+
+typedef struct ohgpu_ctx   ohgpu_ctx;     /* one per GPU / per pipeline thread            */
+typedef struct ohgpu_batch ohgpu_batch;   /* validated, device-resident descriptor batch  */
+typedef struct ohgpu_src   ohgpu_src;     /* a designed polyphase filter on the device    */
+
+/* ---- library / device ---- */
+int         ohgpu_abi_version(void);
+const char* ohgpu_last_error(void);
+int         ohgpu_device_count(void);                       /* >= 0, or OHGPU_ERR_DEVICE */
+int         ohgpu_init(int device, ohgpu_ctx** ctx);         /* OHGPU_ERR_NO_DEVICE when there is no GPU */
+int         ohgpu_shutdown(ohgpu_ctx* ctx);
+int         ohgpu_device_name(ohgpu_ctx* ctx, char* buf, size_t buf_bytes);
+
+/* ---- plumbing: device memory, streams, events (thin wrappers, so hosts need no HIP headers) ---- */
+int ohgpu_malloc(ohgpu_ctx* ctx, size_t bytes, void** dptr);
+int ohgpu_free(ohgpu_ctx* ctx, void* dptr);
+int ohgpu_malloc_host(ohgpu_ctx* ctx, size_t bytes, void** hptr);   /* pinned */
+int ohgpu_free_host(ohgpu_ctx* ctx, void* hptr);
+int ohgpu_memcpy_h2d(ohgpu_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int ohgpu_memcpy_d2h(ohgpu_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int ohgpu_memset(ohgpu_ctx* ctx, void* dptr, int value, size_t bytes, void* stream);
+int ohgpu_stream_create(ohgpu_ctx* ctx, void** stream);
+int ohgpu_stream_destroy(ohgpu_ctx* ctx, void* stream);
+int ohgpu_stream_sync(ohgpu_ctx* ctx, void* stream);                /* NULL = the context's own stream */
+int ohgpu_event_create(ohgpu_ctx* ctx, void** event);
+int ohgpu_event_destroy(ohgpu_ctx* ctx, void* event);
+int ohgpu_event_record(ohgpu_ctx* ctx, void* event, void* stream);
+int ohgpu_event_elapsed_ms(ohgpu_ctx* ctx, void* start, void* stop, float* ms);  /* synchronises on stop */
+
+/* ---- RampArray.h:7-74: the 512 Q15 multipliers the device uses (generated) ---- */
+int ohgpu_ramp_table(uint16_t out[512]);
+
+/* ---- unpack -> attenuate -> ramp -> pack over a batch of playables ---- */
+/* Validates every descriptor against the arena sizes (OHGPU_ERR_BOUNDS / _INVALID / _UNSUPPORTED),
+ * then keeps a device-resident copy.  descs is host memory and may be freed after the call. */
+int ohgpu_pcm_batch_create(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
+/* Launches the batch: src_base / dst_base are DEVICE pointers to arenas at least as large as declared. */
+int ohgpu_pcm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch);
+/* Totals recorded at creation (for throughput accounting). */
+int ohgpu_batch_info(const ohgpu_batch* batch, uint64_t* n_msgs, uint64_t* in_frames, uint64_t* out_frames,
+                     uint64_t* src_bytes_touched, uint64_t* dst_bytes_written);
+
+/* Convenience for hosts that hold host buffers (a live pipeline's 5 ms cadence): H2D, run, D2H, sync. */
+int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
+                           const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
+
+/* ---- sample-rate converter (own specification; DESIGN.md "Resampler") ---- */
+/* Host-side filter design: Kaiser-windowed sinc, Q28 coefficients, coef_q28[p*T + k] = h[p + k*L].
+ * Pass coef_q28 = NULL to query L, M only.  Capacity must be >= L*T. */
+int ohgpu_src_design(uint32_t rate_in, uint32_t rate_out, uint32_t taps_per_phase, double beta, double f_pass_hz,
+                     int32_t* coef_q28, size_t coef_capacity, uint32_t* L, uint32_t* M);
+int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t taps_per_phase, const int32_t* coef_q28, ohgpu_src** src);
+int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src);
+/* ceil(in_frames * L / M): output frames available once in_frames input frames have arrived */
+uint64_t ohgpu_src_out_frames(uint32_t L, uint32_t M, uint64_t in_frames);
+int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
+int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+
+/* Kernel selection for A/B measurement (0 = default/best, 1 = baseline "v1" kernels). */
+int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OHGPU_H */

@@ -1,0 +1,223 @@
+"""ctypes binding of oracle/libohp_oracle.so -- the CPU checker (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (ohpipeline_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_LIB_PATH = os.path.join(_ORACLE_DIR, "libohp_oracle.so")
+
+OK, ERR_ASSERT, ERR_SAMPLE_RATE, ERR_UNSUPPORTED = 0, -1, -2, -3
+ENDIAN_LITTLE, ENDIAN_BIG = 1, 2
+RAMP_NONE, RAMP_UP, RAMP_DOWN, RAMP_MUTE = 0, 1, 2, 3
+RAMP_MAX, RAMP_MIN = 1 << 14, 0
+JIFFIES_PER_SEC = 56448000
+JIFFIES_PER_MS = 56448
+MAX_BYTES = 9216
+UNITY_ATTENUATION = 256
+FLAG_RAMP, FLAG_SILENCE, FLAG_ZERO_LSB32 = 1, 2, 4
+
+# Same layout as include/ohgpu.h's ohgpu_msg_desc / ohgpu_src_msg_desc (tests/test_capi_loads.py checks).
+MSG_DESC = np.dtype([
+    ("src_offset", "<u8"), ("dst_offset", "<u8"), ("n_frames", "<u4"),
+    ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
+    ("channels", "u1"), ("src_bits", "u1"), ("src_endian", "u1"),
+    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1")], align=False)
+SRC_MSG_DESC = np.dtype([
+    ("src_offset", "<u8"), ("src_frame0", "<u8"), ("src_frames", "<u8"), ("out_frame0", "<u8"),
+    ("dst_offset", "<u8"), ("n_frames", "<u4"),
+    ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
+    ("channels", "u1"), ("src_bits", "u1"), ("src_endian", "u1"),
+    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1"), ("reserved", "u1", (8,))], align=False)
+assert MSG_DESC.itemsize == 32 and SRC_MSG_DESC.itemsize == 64
+
+
+class Ramp(C.Structure):
+    _fields_ = [("start", C.c_uint32), ("end", C.c_uint32), ("direction", C.c_uint32), ("enabled", C.c_uint32)]
+
+    def __repr__(self):
+        return f"Ramp({self.start}..{self.end}, dir={self.direction}, enabled={self.enabled})"
+
+
+class MsgAudio(C.Structure):
+    _fields_ = [("size_jiffies", C.c_uint32), ("offset_jiffies", C.c_uint32), ("sample_rate", C.c_uint32),
+                ("bit_depth", C.c_uint32), ("channels", C.c_uint32), ("attenuation", C.c_uint32),
+                ("is_silence", C.c_uint32), ("ramp", Ramp)]
+
+
+class Playable(C.Structure):
+    _fields_ = [("offset_bytes", C.c_uint32), ("size_bytes", C.c_uint32), ("jiffies", C.c_uint32),
+                ("sample_rate", C.c_uint32), ("bit_depth", C.c_uint32), ("channels", C.c_uint32),
+                ("attenuation", C.c_uint32), ("is_silence", C.c_uint32), ("ramp", Ramp)]
+
+
+def build(force=False):
+    """Compile the oracle with its own Makefile (gcc -O2)."""
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("ohp_oracle.c", "ohp_pipeline.c", "ohp_oracle.h", "ohp_pipeline.h")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    u8p, u32p, i32p, f64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    vp = C.c_void_p
+    sig = {
+        "ohp_ramp_table": (C.POINTER(C.c_uint16), []),
+        "ohp_construct_pcm": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, vp]),
+        "ohp_jiffies_per_sample": (C.c_int, [C.c_uint32]),
+        "ohp_jiffies_to_bytes": (C.c_uint32, [u32p, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "ohp_jiffies_to_bytes_sample_block": (C.c_uint32, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "ohp_jiffies_round_down": (C.c_int, [u32p, C.c_uint32]),
+        "ohp_jiffies_round_up": (C.c_int, [u32p, C.c_uint32]),
+        "ohp_jiffies_round_down_nonzero_sample_block": (None, [u32p, C.c_uint32]),
+        "ohp_jiffies_to_songcast_time": (C.c_int, [C.c_uint32, C.c_uint32, u32p]),
+        "ohp_ramp_reset": (None, [C.POINTER(Ramp)]),
+        "ohp_ramp_set": (C.c_int, [C.POINTER(Ramp), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Ramp), u32p]),
+        "ohp_ramp_set_muted": (None, [C.POINTER(Ramp)]),
+        "ohp_ramp_validate": (C.c_int, [C.POINTER(Ramp)]),
+        "ohp_ramp_split": (C.c_int, [C.POINTER(Ramp), C.c_uint32, C.c_uint32, C.POINTER(Ramp)]),
+        "ohp_ramp_median_multiplier": (C.c_uint32, [C.POINTER(Ramp)]),
+        "ohp_msg_audio_init_pcm": (C.c_int, [C.POINTER(MsgAudio), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "ohp_msg_audio_init_silence": (C.c_int, [C.POINTER(MsgAudio), u32p, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "ohp_msg_audio_split": (C.c_int, [C.POINTER(MsgAudio), C.c_uint32, C.POINTER(MsgAudio)]),
+        "ohp_msg_audio_set_ramp": (C.c_int, [C.POINTER(MsgAudio), C.c_uint32, u32p, C.c_uint32, C.POINTER(MsgAudio),
+                                             C.POINTER(C.c_int), u32p]),
+        "ohp_create_playable": (C.c_int, [C.POINTER(MsgAudio), C.POINTER(Playable)]),
+        "ohp_playable_split": (C.c_int, [C.POINTER(Playable), C.c_uint32, C.POINTER(Playable), C.POINTER(C.c_int)]),
+        "ohp_apply_attenuation": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "ohp_ramp_apply": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+        "ohp_playable_read": (C.c_int, [C.POINTER(Playable), vp, vp, C.c_uint32, u32p, C.c_uint32, u32p, u32p]),
+        "ohp_flywheel_unpack": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, u32p]),
+        "ohp_rampgen_pack": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, u32p]),
+        "ohp_sender_pack": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]),
+        "ohp_flac_pack": (C.c_int, [C.POINTER(i32p), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, u32p]),
+        "ohp_unpack_s24": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, vp]),
+        "ohp_pack_from_s24": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, vp]),
+        "ohp_convert_format": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, vp]),
+        "ohp_msg_process": (C.c_int, [vp, vp, vp]),
+        "ohp_msg_process_batch": (C.c_int, [vp, C.c_size_t, vp, vp]),
+        "ohp_src_msg_process": (C.c_int, [vp, vp, vp, vp]),
+        "ohp_src_msg_process_batch": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+        "ohp_src_msg_process_f64": (C.c_int, [vp, vp, vp, vp]),
+        "ohp_src_new": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
+        "ohp_src_delete": (None, [vp]),
+        "ohp_src_L": (C.c_uint32, [vp]), "ohp_src_M": (C.c_uint32, [vp]), "ohp_src_T": (C.c_uint32, [vp]),
+        "ohp_src_coef_q28": (i32p, [vp]), "ohp_src_coef_f64": (f64p, [vp]),
+        "ohp_src_sum_abs_max": (C.c_int64, [vp]), "ohp_src_f_stop": (C.c_double, [vp]),
+        "ohp_src_out_frames": (C.c_uint64, [vp, C.c_uint64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+# ------------------------------------------------------------------ numpy-friendly helpers
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ramp_table():
+    return np.ctypeslib.as_array(lib().ohp_ramp_table(), shape=(512,)).copy()
+
+
+def construct_pcm(data, bit_depth, endian):
+    src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+    dst = np.empty_like(src)
+    err = lib().ohp_construct_pcm(_ptr(src), src.size, bit_depth, endian, _ptr(dst))
+    return err, dst
+
+
+def apply_attenuation(data, bit_depth, attenuation):
+    buf = np.array(np.frombuffer(bytes(data), dtype=np.uint8))
+    err = lib().ohp_apply_attenuation(_ptr(buf), buf.size, bit_depth, attenuation)
+    return err, buf
+
+
+def ramp_apply(data, bit_depth, channels, start, end):
+    src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+    dst = np.empty_like(src)
+    err = lib().ohp_ramp_apply(_ptr(src), src.size, bit_depth, channels, start, end, _ptr(dst))
+    return err, dst
+
+
+def convert_format(data, src_bits, src_endian, dst_bits, dst_endian, zero_lsb32=0):
+    src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+    n = src.size // (src_bits // 8)
+    dst = np.empty(n * (dst_bits // 8), dtype=np.uint8)
+    err = lib().ohp_convert_format(_ptr(src), n, src_bits, src_endian, dst_bits, dst_endian, zero_lsb32, _ptr(dst))
+    return err, dst
+
+
+def playable_read(playable, audio):
+    """Returns (err, out_bytes ndarray, [fragment sizes]).  audio is attenuated in place like the reference."""
+    out = np.zeros(max(int(playable.size_bytes), 1), dtype=np.uint8)
+    frags = np.zeros(max(int(playable.size_bytes), 1) + 4, dtype=np.uint32)
+    nf, ob = C.c_uint32(0), C.c_uint32(0)
+    aptr = _ptr(audio) if audio is not None else None
+    err = lib().ohp_playable_read(C.byref(playable), aptr, _ptr(out), out.size,
+                                  frags.ctypes.data_as(C.POINTER(C.c_uint32)), frags.size, C.byref(nf), C.byref(ob))
+    return err, out[:ob.value].copy(), [int(v) for v in frags[:nf.value]]
+
+
+def msg_process_batch(descs, src, dst):
+    descs = np.ascontiguousarray(descs)
+    assert descs.dtype == MSG_DESC
+    return lib().ohp_msg_process_batch(_ptr(descs), descs.size, _ptr(src), _ptr(dst))
+
+
+class Src:
+    """The oracle's resampler design + exact integer model (own specification, parity unpinned)."""
+
+    def __init__(self, rate_in, rate_out, taps_per_phase=32, beta=9.0, f_pass=20000.0):
+        self.h = lib().ohp_src_new(rate_in, rate_out, taps_per_phase, beta, f_pass)
+        if not self.h:
+            raise ValueError("ohp_src_design failed")
+        L = lib()
+        self.L, self.M, self.T = L.ohp_src_L(self.h), L.ohp_src_M(self.h), L.ohp_src_T(self.h)
+        n = self.L * self.T
+        self.coef_q28 = np.ctypeslib.as_array(L.ohp_src_coef_q28(self.h), shape=(n,)).copy()
+        self.coef_f64 = np.ctypeslib.as_array(L.ohp_src_coef_f64(self.h), shape=(n,)).copy()
+        self.sum_abs_max = L.ohp_src_sum_abs_max(self.h)
+        self.f_stop = L.ohp_src_f_stop(self.h)
+
+    def out_frames(self, in_frames):
+        return int(lib().ohp_src_out_frames(self.h, in_frames))
+
+    def process_batch(self, descs, src, dst):
+        descs = np.ascontiguousarray(descs)
+        assert descs.dtype == SRC_MSG_DESC
+        return lib().ohp_src_msg_process_batch(self.h, _ptr(descs), descs.size, _ptr(src), _ptr(dst))
+
+    def process_f64(self, desc, src):
+        desc = np.ascontiguousarray(desc).reshape(1)
+        y = np.zeros(int(desc["n_frames"][0]) * int(desc["channels"][0]), dtype=np.float64)
+        err = lib().ohp_src_msg_process_f64(self.h, _ptr(desc), _ptr(src), _ptr(y))
+        return err, y
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().ohp_src_delete(self.h)
+                self.h = None
+        except Exception:
+            pass
