@@ -1,0 +1,247 @@
+"""ctypes binding of libohgpu.so -- exactly the entry points include/ohgpu.h declares.
+
+There is no CPU fallback: if the library is missing this module raises, and if there is no GPU
+ohgpu_init() returns OHGPU_ERR_NO_DEVICE which `Context` turns into an exception.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libohgpu.so")
+
+OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_NO_DEVICE, ERR_NOMEM, ERR_BOUNDS, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+ENDIAN_LITTLE, ENDIAN_BIG = 1, 2
+RAMP_MAX = 16384
+UNITY_ATTENUATION = 256
+FLAG_RAMP, FLAG_SILENCE, FLAG_ZERO_LSB32 = 1, 2, 4
+
+# numpy views of ohgpu_msg_desc (32 B) and ohgpu_src_msg_desc (64 B)
+MSG_DESC = np.dtype([
+    ("src_offset", "<u8"), ("dst_offset", "<u8"), ("n_frames", "<u4"),
+    ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
+    ("channels", "u1"), ("src_bits", "u1"), ("src_endian", "u1"),
+    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1")], align=False)
+SRC_MSG_DESC = np.dtype([
+    ("src_offset", "<u8"), ("src_frame0", "<u8"), ("src_frames", "<u8"), ("out_frame0", "<u8"),
+    ("dst_offset", "<u8"), ("n_frames", "<u4"),
+    ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
+    ("channels", "u1"), ("src_bits", "u1"), ("src_endian", "u1"),
+    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1"), ("reserved", "u1", (8,))], align=False)
+
+# every symbol of include/ohgpu.h: name -> (restype, argtypes)
+_vp, _vpp = C.c_void_p, C.POINTER(C.c_void_p)
+_u64p = C.POINTER(C.c_uint64)
+SYMBOLS = {
+    "ohgpu_abi_version": (C.c_int, []),
+    "ohgpu_last_error": (C.c_char_p, []),
+    "ohgpu_device_count": (C.c_int, []),
+    "ohgpu_init": (C.c_int, [C.c_int, _vpp]),
+    "ohgpu_shutdown": (C.c_int, [_vp]),
+    "ohgpu_device_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "ohgpu_malloc": (C.c_int, [_vp, C.c_size_t, _vpp]),
+    "ohgpu_free": (C.c_int, [_vp, _vp]),
+    "ohgpu_malloc_host": (C.c_int, [_vp, C.c_size_t, _vpp]),
+    "ohgpu_free_host": (C.c_int, [_vp, _vp]),
+    "ohgpu_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "ohgpu_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "ohgpu_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp]),
+    "ohgpu_stream_create": (C.c_int, [_vp, _vpp]),
+    "ohgpu_stream_destroy": (C.c_int, [_vp, _vp]),
+    "ohgpu_stream_sync": (C.c_int, [_vp, _vp]),
+    "ohgpu_event_create": (C.c_int, [_vp, _vpp]),
+    "ohgpu_event_destroy": (C.c_int, [_vp, _vp]),
+    "ohgpu_event_record": (C.c_int, [_vp, _vp, _vp]),
+    "ohgpu_event_elapsed_ms": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
+    "ohgpu_ramp_table": (C.c_int, [C.POINTER(C.c_uint16)]),
+    "ohgpu_pcm_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
+    "ohgpu_pcm_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ohgpu_batch_destroy": (C.c_int, [_vp, _vp]),
+    "ohgpu_batch_info": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p, _u64p]),
+    "ohgpu_pcm_process_host": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
+    "ohgpu_src_design": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp, C.c_size_t,
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ohgpu_src_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vpp]),
+    "ohgpu_src_destroy": (C.c_int, [_vp, _vp]),
+    "ohgpu_src_out_frames": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint64]),
+    "ohgpu_src_batch_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
+    "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ohgpu_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+}
+
+
+class OhGpuError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"ohgpu error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libohgpu.so (build it first with `python -m ohpipeline_amd.build` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (python ohpipeline_amd/build.py); "
+                          "there is no CPU fallback for the product path")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)          # AttributeError here = the library does not export what ohgpu.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().ohgpu_last_error().decode("utf-8", "replace")
+
+
+def check(code):
+    if code != OK:
+        raise OhGpuError(code, last_error())
+    return code
+
+
+def ramp_table():
+    out = (C.c_uint16 * 512)()
+    check(lib().ohgpu_ramp_table(out))
+    return np.frombuffer(out, dtype=np.uint16).copy()
+
+
+def src_design(rate_in, rate_out, taps_per_phase=32, beta=9.0, f_pass=20000.0):
+    """Returns (L, M, coef_q28[L*T]) from the library's own host-side filter design."""
+    L_, M_ = C.c_uint32(0), C.c_uint32(0)
+    check(lib().ohgpu_src_design(rate_in, rate_out, taps_per_phase, beta, f_pass, None, 0, C.byref(L_), C.byref(M_)))
+    coef = np.zeros(L_.value * taps_per_phase, dtype=np.int32)
+    check(lib().ohgpu_src_design(rate_in, rate_out, taps_per_phase, beta, f_pass, coef.ctypes.data_as(C.c_void_p),
+                                 coef.size, C.byref(L_), C.byref(M_)))
+    return L_.value, M_.value, coef
+
+
+class Context:
+    """One GPU context (ohgpu_ctx).  Owns device allocations made through it."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().ohgpu_init(device, C.byref(self._h)))
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def name(self):
+        buf = C.create_string_buffer(128)
+        check(lib().ohgpu_device_name(self._h, buf, 128))
+        return buf.value.decode()
+
+    def close(self):
+        if self._h:
+            lib().ohgpu_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- memory
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().ohgpu_malloc(self._h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, dptr):
+        check(lib().ohgpu_free(self._h, dptr))
+
+    def upload(self, array, stream=None):
+        a = np.ascontiguousarray(array)
+        p = self.malloc(max(a.nbytes, 1))
+        check(lib().ohgpu_memcpy_h2d(self._h, p, a.ctypes.data_as(C.c_void_p), a.nbytes, stream))
+        self.sync(stream)
+        return p
+
+    def download(self, dptr, nbytes, stream=None):
+        out = np.empty(nbytes, dtype=np.uint8)
+        check(lib().ohgpu_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), dptr, nbytes, stream))
+        self.sync(stream)
+        return out
+
+    def memset(self, dptr, value, nbytes, stream=None):
+        check(lib().ohgpu_memset(self._h, dptr, value, nbytes, stream))
+
+    def sync(self, stream=None):
+        check(lib().ohgpu_stream_sync(self._h, stream))
+
+    def set_kernel_variant(self, v):
+        check(lib().ohgpu_set_kernel_variant(self._h, v))
+
+    # ---- events (HIP events on the launch stream)
+    def event(self):
+        e = C.c_void_p()
+        check(lib().ohgpu_event_create(self._h, C.byref(e)))
+        return e
+
+    def record(self, event, stream=None):
+        check(lib().ohgpu_event_record(self._h, event, stream))
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float(0)
+        check(lib().ohgpu_event_elapsed_ms(self._h, start, stop, C.byref(ms)))
+        return ms.value
+
+    # ---- batches
+    def pcm_batch(self, descs, src_arena_bytes, dst_arena_bytes):
+        d = np.ascontiguousarray(descs)
+        assert d.dtype == MSG_DESC
+        b = C.c_void_p()
+        check(lib().ohgpu_pcm_batch_create(self._h, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes,
+                                           dst_arena_bytes, C.byref(b)))
+        return b
+
+    def pcm_run(self, batch, d_src, d_dst, stream=None):
+        check(lib().ohgpu_pcm_batch_run(self._h, batch, d_src, d_dst, stream))
+
+    def batch_destroy(self, batch):
+        check(lib().ohgpu_batch_destroy(self._h, batch))
+
+    def batch_info(self, batch):
+        v = [C.c_uint64(0) for _ in range(5)]
+        check(lib().ohgpu_batch_info(batch, *[C.byref(x) for x in v]))
+        keys = ("n_msgs", "in_frames", "out_frames", "src_bytes_touched", "dst_bytes_written")
+        return dict(zip(keys, (int(x.value) for x in v)))
+
+    def pcm_process_host(self, descs, src, dst):
+        d = np.ascontiguousarray(descs)
+        assert d.dtype == MSG_DESC
+        check(lib().ohgpu_pcm_process_host(self._h, d.ctypes.data_as(C.c_void_p), d.size,
+                                           src.ctypes.data_as(C.c_void_p), src.nbytes,
+                                           dst.ctypes.data_as(C.c_void_p), dst.nbytes))
+        return dst
+
+    def src_create(self, L, M, T, coef_q28):
+        c = np.ascontiguousarray(coef_q28, dtype=np.int32)
+        s = C.c_void_p()
+        check(lib().ohgpu_src_create(self._h, L, M, T, c.ctypes.data_as(C.c_void_p), C.byref(s)))
+        return s
+
+    def src_destroy(self, src):
+        check(lib().ohgpu_src_destroy(self._h, src))
+
+    def src_batch(self, src, descs, src_arena_bytes, dst_arena_bytes):
+        d = np.ascontiguousarray(descs)
+        assert d.dtype == SRC_MSG_DESC
+        b = C.c_void_p()
+        check(lib().ohgpu_src_batch_create(self._h, src, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes,
+                                           dst_arena_bytes, C.byref(b)))
+        return b
+
+    def src_run(self, batch, d_src, d_dst, stream=None):
+        check(lib().ohgpu_src_batch_run(self._h, batch, d_src, d_dst, stream))

@@ -1,0 +1,537 @@
+// ohgpu_api.hip -- the C ABI of include/ohgpu.h: validation, descriptor upload, launches.
+// No exception crosses this boundary; every failure is a negative code plus ohgpu_last_error().
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ohgpu_internal.h"
+
+namespace ohgpu {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static bool valid_bits(uint32_t bits) { return bits == 8 || bits == 16 || bits == 24 || bits == 32; }
+static bool valid_endian(uint32_t e) { return e == OHGPU_ENDIAN_LITTLE || e == OHGPU_ENDIAN_BIG; }
+
+static hipStream_t pick_stream(const ohgpu_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+}  // namespace ohgpu
+
+using namespace ohgpu;
+
+extern "C" {
+
+int ohgpu_abi_version(void) { return OHGPU_ABI_VERSION; }
+
+const char* ohgpu_last_error(void) { return g_err; }
+
+int ohgpu_device_count(void)
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return set_error(OHGPU_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int ohgpu_init(int device, ohgpu_ctx** out)
+{
+    if (!out) return set_error(OHGPU_ERR_INVALID, "ohgpu_init: null out pointer");
+    *out = nullptr;
+    const int n = ohgpu_device_count();
+    if (n < 0) return n;
+    if (n == 0) return set_error(OHGPU_ERR_NO_DEVICE, "ohgpu_init: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return set_error(OHGPU_ERR_INVALID, "ohgpu_init: device %d out of range [0,%d)", device, n);
+    OHGPU_HIP_TRY(hipSetDevice(device));
+    ohgpu_ctx* ctx = new (std::nothrow) ohgpu_ctx();
+    if (!ctx) return set_error(OHGPU_ERR_NOMEM, "ohgpu_init: out of host memory");
+    ctx->device = device;
+    ctx->variant = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) {
+        snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+        ctx->num_cus = prop.multiProcessorCount;
+    } else {
+        snprintf(ctx->name, sizeof(ctx->name), "unknown");
+        ctx->num_cus = 256;
+    }
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return set_error(OHGPU_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    uint16_t table[512];
+    build_ramp_table(table);
+    e = hipMalloc((void**)&ctx->d_ramp_table, sizeof(table));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_ramp_table, table, sizeof(table), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return set_error(OHGPU_ERR_DEVICE, "ramp table upload: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return OHGPU_OK;
+}
+
+int ohgpu_shutdown(ohgpu_ctx* ctx)
+{
+    if (!ctx) return OHGPU_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->d_ramp_table);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return OHGPU_OK;
+}
+
+int ohgpu_device_name(ohgpu_ctx* ctx, char* buf, size_t buf_bytes)
+{
+    if (!ctx || !buf || buf_bytes == 0) return set_error(OHGPU_ERR_INVALID, "ohgpu_device_name: bad argument");
+    snprintf(buf, buf_bytes, "%s", ctx->name);
+    return OHGPU_OK;
+}
+
+int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant)
+{
+    if (!ctx || variant < 0 || variant > 1) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
+    ctx->variant = variant;
+    return OHGPU_OK;
+}
+
+/* ---------------------------------------------------------------- plumbing */
+#define CTX_GUARD(name)                                                                    \
+    if (!ctx) return set_error(OHGPU_ERR_INVALID, name ": null context");                 \
+    OHGPU_HIP_TRY(hipSetDevice(ctx->device))
+
+int ohgpu_malloc(ohgpu_ctx* ctx, size_t bytes, void** dptr)
+{
+    CTX_GUARD("ohgpu_malloc");
+    if (!dptr) return set_error(OHGPU_ERR_INVALID, "ohgpu_malloc: null out pointer");
+    *dptr = nullptr;
+    const hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) return set_error(OHGPU_ERR_NOMEM, "hipMalloc(%zu): out of device memory", bytes);
+    OHGPU_HIP_TRY(e);
+    return OHGPU_OK;
+}
+
+int ohgpu_free(ohgpu_ctx* ctx, void* dptr)
+{
+    CTX_GUARD("ohgpu_free");
+    if (dptr) OHGPU_HIP_TRY(hipFree(dptr));
+    return OHGPU_OK;
+}
+
+int ohgpu_malloc_host(ohgpu_ctx* ctx, size_t bytes, void** hptr)
+{
+    CTX_GUARD("ohgpu_malloc_host");
+    if (!hptr) return set_error(OHGPU_ERR_INVALID, "ohgpu_malloc_host: null out pointer");
+    OHGPU_HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return OHGPU_OK;
+}
+
+int ohgpu_free_host(ohgpu_ctx* ctx, void* hptr)
+{
+    CTX_GUARD("ohgpu_free_host");
+    if (hptr) OHGPU_HIP_TRY(hipHostFree(hptr));
+    return OHGPU_OK;
+}
+
+int ohgpu_memcpy_h2d(ohgpu_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream)
+{
+    CTX_GUARD("ohgpu_memcpy_h2d");
+    if (bytes) OHGPU_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+int ohgpu_memcpy_d2h(ohgpu_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream)
+{
+    CTX_GUARD("ohgpu_memcpy_d2h");
+    if (bytes) OHGPU_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+int ohgpu_memset(ohgpu_ctx* ctx, void* dptr, int value, size_t bytes, void* stream)
+{
+    CTX_GUARD("ohgpu_memset");
+    if (bytes) OHGPU_HIP_TRY(hipMemsetAsync(dptr, value, bytes, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+int ohgpu_stream_create(ohgpu_ctx* ctx, void** stream)
+{
+    CTX_GUARD("ohgpu_stream_create");
+    if (!stream) return set_error(OHGPU_ERR_INVALID, "ohgpu_stream_create: null out pointer");
+    hipStream_t s;
+    OHGPU_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return OHGPU_OK;
+}
+
+int ohgpu_stream_destroy(ohgpu_ctx* ctx, void* stream)
+{
+    CTX_GUARD("ohgpu_stream_destroy");
+    if (stream) OHGPU_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return OHGPU_OK;
+}
+
+int ohgpu_stream_sync(ohgpu_ctx* ctx, void* stream)
+{
+    CTX_GUARD("ohgpu_stream_sync");
+    OHGPU_HIP_TRY(hipStreamSynchronize(pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+int ohgpu_event_create(ohgpu_ctx* ctx, void** event)
+{
+    CTX_GUARD("ohgpu_event_create");
+    if (!event) return set_error(OHGPU_ERR_INVALID, "ohgpu_event_create: null out pointer");
+    hipEvent_t ev;
+    OHGPU_HIP_TRY(hipEventCreate(&ev));
+    *event = (void*)ev;
+    return OHGPU_OK;
+}
+
+int ohgpu_event_destroy(ohgpu_ctx* ctx, void* event)
+{
+    CTX_GUARD("ohgpu_event_destroy");
+    if (event) OHGPU_HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return OHGPU_OK;
+}
+
+int ohgpu_event_record(ohgpu_ctx* ctx, void* event, void* stream)
+{
+    CTX_GUARD("ohgpu_event_record");
+    OHGPU_HIP_TRY(hipEventRecord((hipEvent_t)event, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+int ohgpu_event_elapsed_ms(ohgpu_ctx* ctx, void* start, void* stop, float* ms)
+{
+    CTX_GUARD("ohgpu_event_elapsed_ms");
+    if (!ms) return set_error(OHGPU_ERR_INVALID, "ohgpu_event_elapsed_ms: null out pointer");
+    OHGPU_HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    OHGPU_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return OHGPU_OK;
+}
+
+int ohgpu_ramp_table(uint16_t out[512])
+{
+    if (!out) return set_error(OHGPU_ERR_INVALID, "ohgpu_ramp_table: null out pointer");
+    build_ramp_table(out);
+    return OHGPU_OK;
+}
+
+/* ---------------------------------------------------------------- pcm batches */
+static int validate_msg(const ohgpu_msg_desc& d, size_t i, uint64_t src_arena, uint64_t dst_arena)
+{
+    if (d.channels < 1 || d.channels > OHGPU_MAX_CHANNELS)
+        return set_error(OHGPU_ERR_INVALID, "desc %zu: channels %u outside 1..8", i, d.channels);
+    if (!valid_bits(d.src_bits) || !valid_bits(d.dst_bits))
+        return set_error(OHGPU_ERR_INVALID, "desc %zu: bit depth %u -> %u (must be 8/16/24/32)", i, d.src_bits, d.dst_bits);
+    if (!valid_endian(d.src_endian) || !valid_endian(d.dst_endian))
+        return set_error(OHGPU_ERR_INVALID, "desc %zu: endian %u -> %u", i, d.src_endian, d.dst_endian);
+    if (d.flags & ~(OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE | OHGPU_FLAG_ZERO_LSB32))
+        return set_error(OHGPU_ERR_INVALID, "desc %zu: unknown flag bits 0x%x", i, d.flags);
+    if (d.ramp_start > OHGPU_RAMP_MAX || d.ramp_end > OHGPU_RAMP_MAX)
+        return set_error(OHGPU_ERR_INVALID, "desc %zu: ramp [%u..%u] beyond Ramp::kMax", i, d.ramp_start, d.ramp_end);
+    if ((d.flags & OHGPU_FLAG_RAMP) && d.n_frames > 131071u)     // i*iTotalRamp is TInt arithmetic (Msg.cpp:835)
+        return set_error(OHGPU_ERR_INVALID, "desc %zu: ramped message of %u frames overflows the reference's TInt ramp product", i, d.n_frames);
+    if (d.attenuation != OHGPU_UNITY_ATTENUATION && d.src_bits != 16)   // ASSERT(iBitDepth == 16), Msg.cpp:2741
+        return set_error(OHGPU_ERR_UNSUPPORTED, "desc %zu: attenuation %u on %u-bit audio (16-bit only)", i, d.attenuation, d.src_bits);
+    const uint64_t src_bytes = (uint64_t)d.n_frames * d.channels * (d.src_bits / 8);
+    const uint64_t dst_bytes = (uint64_t)d.n_frames * d.channels * (d.dst_bits / 8);
+    if (!(d.flags & OHGPU_FLAG_SILENCE) && (d.src_offset > src_arena || src_bytes > src_arena - d.src_offset))
+        return set_error(OHGPU_ERR_BOUNDS, "desc %zu: reads [%llu, +%llu) beyond the %llu-byte source arena", i,
+                         (unsigned long long)d.src_offset, (unsigned long long)src_bytes, (unsigned long long)src_arena);
+    if (d.dst_offset > dst_arena || dst_bytes > dst_arena - d.dst_offset)
+        return set_error(OHGPU_ERR_BOUNDS, "desc %zu: writes [%llu, +%llu) beyond the %llu-byte destination arena", i,
+                         (unsigned long long)d.dst_offset, (unsigned long long)dst_bytes, (unsigned long long)dst_arena);
+    return OHGPU_OK;
+}
+
+static int upload_batch(ohgpu_ctx* ctx, ohgpu_batch* b, const void* host_descs, size_t bytes)
+{
+    if (bytes == 0) return OHGPU_OK;
+    hipError_t e = hipMalloc(&b->d_descs, bytes);
+    if (e == hipErrorOutOfMemory) return set_error(OHGPU_ERR_NOMEM, "descriptor upload: out of device memory");
+    OHGPU_HIP_TRY(e);
+    e = hipMemcpy(b->d_descs, host_descs, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(b->d_descs);
+        b->d_descs = nullptr;
+        return set_error(OHGPU_ERR_DEVICE, "descriptor upload: %s", hipGetErrorString(e));
+    }
+    return OHGPU_OK;
+}
+
+int ohgpu_pcm_batch_create(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
+{
+    CTX_GUARD("ohgpu_pcm_batch_create");
+    if (!out || (n && !descs)) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_create: null argument");
+    *out = nullptr;
+    if (n > 0xffffffffull) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_create: too many descriptors");
+    ohgpu_batch* b = new (std::nothrow) ohgpu_batch();
+    if (!b) return set_error(OHGPU_ERR_NOMEM, "ohgpu_pcm_batch_create: out of host memory");
+    b->kind = kBatchPcm;
+    b->n = n;
+    b->src_arena_bytes = src_arena_bytes;
+    b->dst_arena_bytes = dst_arena_bytes;
+    b->uniform = true;
+    for (size_t i = 0; i < n; i++) {
+        const int err = validate_msg(descs[i], i, src_arena_bytes, dst_arena_bytes);
+        if (err != OHGPU_OK) { delete b; return err; }
+        const ohgpu_msg_desc& d = descs[i];
+        b->in_frames += d.n_frames;
+        b->out_frames += d.n_frames;
+        if (!(d.flags & OHGPU_FLAG_SILENCE)) b->src_bytes_touched += (uint64_t)d.n_frames * d.channels * (d.src_bits / 8);
+        b->dst_bytes_written += (uint64_t)d.n_frames * d.channels * (d.dst_bits / 8);
+        if (d.n_frames > b->max_frames) b->max_frames = d.n_frames;
+        if (i == 0) {
+            b->channels = d.channels; b->src_bits = d.src_bits; b->src_endian = d.src_endian;
+            b->dst_bits = d.dst_bits; b->dst_endian = d.dst_endian;
+        } else if (d.channels != b->channels || d.src_bits != b->src_bits || d.src_endian != b->src_endian ||
+                   d.dst_bits != b->dst_bits || d.dst_endian != b->dst_endian) {
+            b->uniform = false;
+        }
+    }
+    const int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_msg_desc));
+    if (err != OHGPU_OK) { delete b; return err; }
+    *out = b;
+    return OHGPU_OK;
+}
+
+int ohgpu_pcm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
+{
+    CTX_GUARD("ohgpu_pcm_batch_run");
+    if (!batch || batch->kind != kBatchPcm) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_run: not a pcm batch");
+    if (batch->n == 0) return OHGPU_OK;
+    if (!dst_base || (!src_base && batch->src_bytes_touched)) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_run: null arena pointer");
+    OHGPU_HIP_TRY(launch_pcm_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
+{
+    CTX_GUARD("ohgpu_batch_destroy");
+    if (!batch) return OHGPU_OK;
+    if (batch->d_descs) hipFree(batch->d_descs);
+    delete batch;
+    return OHGPU_OK;
+}
+
+int ohgpu_batch_info(const ohgpu_batch* b, uint64_t* n_msgs, uint64_t* in_frames, uint64_t* out_frames,
+                     uint64_t* src_bytes_touched, uint64_t* dst_bytes_written)
+{
+    if (!b) return set_error(OHGPU_ERR_INVALID, "ohgpu_batch_info: null batch");
+    if (n_msgs) *n_msgs = b->n;
+    if (in_frames) *in_frames = b->in_frames;
+    if (out_frames) *out_frames = b->out_frames;
+    if (src_bytes_touched) *src_bytes_touched = b->src_bytes_touched;
+    if (dst_bytes_written) *dst_bytes_written = b->dst_bytes_written;
+    return OHGPU_OK;
+}
+
+int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
+                           const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes)
+{
+    CTX_GUARD("ohgpu_pcm_process_host");
+    ohgpu_batch* b = nullptr;
+    int err = ohgpu_pcm_batch_create(ctx, descs, n, src_bytes, dst_bytes, &b);
+    if (err != OHGPU_OK) return err;
+    void *d_src = nullptr, *d_dst = nullptr;
+    err = ohgpu_malloc(ctx, src_bytes, &d_src);
+    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
+    if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
+    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);  // bytes no message covers stay as given
+    if (err == OHGPU_OK) err = ohgpu_pcm_batch_run(ctx, b, d_src, d_dst, nullptr);
+    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
+    if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
+    if (d_src) hipFree(d_src);
+    if (d_dst) hipFree(d_dst);
+    ohgpu_batch_destroy(ctx, b);
+    return err;
+}
+
+/* ---------------------------------------------------------------- sample-rate converter */
+int ohgpu_src_design(uint32_t rate_in, uint32_t rate_out, uint32_t taps_per_phase, double beta, double f_pass_hz,
+                     int32_t* coef_q28, size_t coef_capacity, uint32_t* L, uint32_t* M)
+{
+    if (!L || !M) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_design: null L/M");
+    if (!coef_q28) return design_src(rate_in, rate_out, taps_per_phase, beta, f_pass_hz, nullptr, L, M);
+    std::vector<int32_t> coef;
+    const int err = design_src(rate_in, rate_out, taps_per_phase, beta, f_pass_hz, &coef, L, M);
+    if (err != OHGPU_OK) return err;
+    if (coef.size() > coef_capacity)
+        return set_error(OHGPU_ERR_INVALID, "ohgpu_src_design: capacity %zu < L*T = %zu", coef_capacity, coef.size());
+    memcpy(coef_q28, coef.data(), coef.size() * sizeof(int32_t));
+    return OHGPU_OK;
+}
+
+uint64_t ohgpu_src_out_frames(uint32_t L, uint32_t M, uint64_t in_frames)
+{
+    if (in_frames == 0 || M == 0) return 0;
+    return (in_frames * L + M - 1) / M;
+}
+
+int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, ohgpu_src** out)
+{
+    CTX_GUARD("ohgpu_src_create");
+    if (!out || !coef_q28) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: null argument");
+    *out = nullptr;
+    if (L == 0 || M == 0 || T == 0 || (uint64_t)L * T > (1u << 22))
+        return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: bad geometry L=%u M=%u T=%u", L, M, T);
+    const size_t n = (size_t)L * T;
+    std::vector<double> cd(n);
+    for (uint32_t p = 0; p < L; p++) {
+        int64_t sabs = 0;
+        for (uint32_t k = 0; k < T; k++) {
+            const int32_t q = coef_q28[(size_t)p * T + k];
+            sabs += q < 0 ? -(int64_t)q : (int64_t)q;
+            cd[(size_t)p * T + k] = (double)q;
+        }
+        if (sabs >= ((int64_t)1 << 30))
+            return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: phase %u has sum|c| = %lld >= 2^30 (exact fp64 accumulation bound)", p, (long long)sabs);
+    }
+    ohgpu_src* s = new (std::nothrow) ohgpu_src();
+    if (!s) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_create: out of host memory");
+    s->L = L; s->M = M; s->T = T;
+    hipError_t e = hipMalloc((void**)&s->d_coef, n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_coef_q28, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(s->d_coef, cd.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_coef_q28, coef_q28, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (s->d_coef) hipFree(s->d_coef);
+        if (s->d_coef_q28) hipFree(s->d_coef_q28);
+        delete s;
+        return set_error(OHGPU_ERR_DEVICE, "ohgpu_src_create: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return OHGPU_OK;
+}
+
+int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src)
+{
+    CTX_GUARD("ohgpu_src_destroy");
+    if (!src) return OHGPU_OK;
+    hipFree(src->d_coef);
+    hipFree(src->d_coef_q28);
+    delete src;
+    return OHGPU_OK;
+}
+
+int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
+{
+    CTX_GUARD("ohgpu_src_batch_create");
+    if (!out || !src || (n && !descs)) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_create: null argument");
+    *out = nullptr;
+    if (n > 0xffffffffull) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_create: too many descriptors");
+    ohgpu_batch* b = new (std::nothrow) ohgpu_batch();
+    if (!b) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory");
+    b->kind = kBatchSrc;
+    b->n = n;
+    b->src = src;
+    b->src_arena_bytes = src_arena_bytes;
+    b->dst_arena_bytes = dst_arena_bytes;
+    b->uniform = true;
+    std::vector<DevSrcDesc> dev(n);
+    const uint64_t L = src->L, M = src->M, T = src->T;
+    for (size_t i = 0; i < n; i++) {
+        const ohgpu_src_msg_desc& d = descs[i];
+        int err = OHGPU_OK;
+        if (d.channels < 1 || d.channels > OHGPU_MAX_CHANNELS) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: channels %u outside 1..8", i, d.channels);
+        else if (!valid_bits(d.src_bits) || !valid_bits(d.dst_bits)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: bit depth %u -> %u", i, d.src_bits, d.dst_bits);
+        else if (!valid_endian(d.src_endian) || !valid_endian(d.dst_endian)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: endian %u -> %u", i, d.src_endian, d.dst_endian);
+        else if (d.flags & ~(OHGPU_FLAG_RAMP | OHGPU_FLAG_ZERO_LSB32)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: flag bits 0x%x not valid for a resampled message", i, d.flags);
+        else if (d.ramp_start > OHGPU_RAMP_MAX || d.ramp_end > OHGPU_RAMP_MAX) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: ramp beyond Ramp::kMax", i);
+        else if ((d.flags & OHGPU_FLAG_RAMP) && d.n_frames > 131071u) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: ramped message of %u frames", i, d.n_frames);
+        else if (d.attenuation != OHGPU_UNITY_ATTENUATION) err = set_error(OHGPU_ERR_UNSUPPORTED, "src desc %zu: attenuation %u (resampled audio is 24-bit; Msg.cpp:2741 allows 16-bit only)", i, d.attenuation);
+        else if (d.out_frame0 > (1ull << 48) || d.src_frame0 > (1ull << 48) || d.src_frames > (1ull << 40)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: frame index out of range", i);
+        if (err != OHGPU_OK) { delete b; return err; }
+        const uint64_t fb_src = (uint64_t)d.channels * (d.src_bits / 8);
+        const uint64_t fb_dst = (uint64_t)d.channels * (d.dst_bits / 8);
+        const uint64_t src_bytes = d.src_frames * fb_src;
+        const uint64_t dst_bytes = (uint64_t)d.n_frames * fb_dst;
+        if (d.src_offset > src_arena_bytes || src_bytes > src_arena_bytes - d.src_offset) {
+            delete b;
+            return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: input window [%llu, +%llu) beyond the %llu-byte source arena", i,
+                             (unsigned long long)d.src_offset, (unsigned long long)src_bytes, (unsigned long long)src_arena_bytes);
+        }
+        if (d.dst_offset > dst_arena_bytes || dst_bytes > dst_arena_bytes - d.dst_offset) {
+            delete b;
+            return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: writes [%llu, +%llu) beyond the %llu-byte destination arena", i,
+                             (unsigned long long)d.dst_offset, (unsigned long long)dst_bytes, (unsigned long long)dst_arena_bytes);
+        }
+        DevSrcDesc& o = dev[i];
+        memset(&o, 0, sizeof(o));
+        if (d.n_frames > 0) {
+            const uint64_t t_first = d.out_frame0 * M, t_last = (d.out_frame0 + d.n_frames - 1) * M;
+            const int64_t n0_first = (int64_t)(t_first / L), n0_last = (int64_t)(t_last / L);
+            const int64_t n_lo = n0_first - (int64_t)(T - 1);
+            if (n_lo >= 0 ? (uint64_t)n_lo < d.src_frame0 : d.src_frame0 != 0) {
+                delete b;
+                return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: filter history starts at input frame %lld but the buffer starts at %llu", i,
+                                 (long long)(n_lo < 0 ? 0 : n_lo), (unsigned long long)d.src_frame0);
+            }
+            if ((uint64_t)n0_last >= d.src_frame0 + d.src_frames) {
+                delete b;
+                return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: needs input frame %lld but the buffer ends at %llu", i,
+                                 (long long)n0_last, (unsigned long long)(d.src_frame0 + d.src_frames));
+            }
+            o.in_rel0 = n0_first - (int64_t)d.src_frame0;
+            o.phase0 = (uint32_t)(t_first % L);
+            const int64_t lo = n_lo < 0 ? 0 : n_lo;
+            b->in_frames += (uint64_t)(n0_last - n0_first + 1);   // new input frames this message advances over
+            b->src_bytes_touched += (uint64_t)(n0_last - lo + 1) * fb_src;
+        }
+        o.src_offset = d.src_offset;
+        o.dst_offset = d.dst_offset;
+        o.n_frames = d.n_frames;
+        o.ramp_start = d.ramp_start;
+        o.ramp_end = d.ramp_end;
+        o.channels = d.channels;
+        o.src_bits = d.src_bits;
+        o.src_endian = d.src_endian;
+        o.dst_bits = d.dst_bits;
+        o.dst_endian = d.dst_endian;
+        o.flags = d.flags;
+        b->out_frames += d.n_frames;
+        b->dst_bytes_written += dst_bytes;
+        if (d.n_frames > b->max_frames) b->max_frames = d.n_frames;
+        if (i == 0) {
+            b->channels = d.channels; b->src_bits = d.src_bits; b->src_endian = d.src_endian;
+            b->dst_bits = d.dst_bits; b->dst_endian = d.dst_endian;
+        } else if (d.channels != b->channels || d.src_bits != b->src_bits || d.src_endian != b->src_endian ||
+                   d.dst_bits != b->dst_bits || d.dst_endian != b->dst_endian) {
+            b->uniform = false;
+        }
+    }
+    const int err = upload_batch(ctx, b, dev.data(), n * sizeof(DevSrcDesc));
+    if (err != OHGPU_OK) { delete b; return err; }
+    *out = b;
+    return OHGPU_OK;
+}
+
+int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
+{
+    CTX_GUARD("ohgpu_src_batch_run");
+    if (!batch || batch->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: not a src batch");
+    if (batch->n == 0) return OHGPU_OK;
+    if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
+    OHGPU_HIP_TRY(launch_src_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+}  // extern "C"

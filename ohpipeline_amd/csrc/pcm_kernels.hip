@@ -1,0 +1,112 @@
+// pcm_kernels.hip -- baseline ("v1") kernels: one workgroup per message, one thread per frame, byte
+// loads and stores.  They define the device semantics and serve as the A/B baseline for the tuned
+// kernels (ohgpu_set_kernel_variant(ctx, 1) selects them).
+#include <hip/hip_runtime.h>
+
+#include "ohgpu_internal.h"
+#include "pcm_device.h"
+
+namespace ohgpu {
+
+// unpack -> attenuate -> ramp | silence -> pack for a batch of MsgPlayables
+// (MsgPlayablePcm::ReadBlock, Msg.cpp:2753-2786, with the processor's depth conversion fused).
+__global__ __launch_bounds__(256) void pcm_msg_kernel_v1(const ohgpu_msg_desc* __restrict__ descs, uint32_t n_msgs,
+                                                         const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                         const uint16_t* __restrict__ ramp_table)
+{
+    for (uint32_t m = blockIdx.x; m < n_msgs; m += gridDim.x) {
+        const ohgpu_msg_desc d = descs[m];
+        const uint32_t ch = d.channels, sb = d.src_bits >> 3, db = d.dst_bits >> 3;
+        const bool src_le = d.src_endian == OHGPU_ENDIAN_LITTLE && sb > 1;
+        const bool dst_le = d.dst_endian == OHGPU_ENDIAN_LITTLE;
+        const bool ramp = (d.flags & OHGPU_FLAG_RAMP) != 0;
+        const bool silence = (d.flags & OHGPU_FLAG_SILENCE) != 0;
+        const bool zero_lsb = (d.flags & OHGPU_FLAG_ZERO_LSB32) != 0;
+        const bool atten = d.attenuation != OHGPU_UNITY_ATTENUATION;
+        const int32_t total = (int32_t)((uint32_t)d.ramp_start - (uint32_t)d.ramp_end);
+        const uint8_t* s = src + d.src_offset;
+        uint8_t* o = dst + d.dst_offset;
+        for (uint32_t i = threadIdx.x; i < d.n_frames; i += blockDim.x) {
+            uint32_t mult = 0;
+            if (ramp) mult = ramp_table[ramp_index(d.ramp_start, total, (int32_t)i, (int32_t)d.n_frames)];
+            for (uint32_t c = 0; c < ch; c++) {
+                const uint64_t sub = (uint64_t)i * ch + c;
+                uint32_t w;
+                if (silence) {
+                    w = silence_word(sub * sb, sb, ch);
+                } else {
+                    w = load_be_word(s + sub * sb, sb, src_le);
+                    if (atten) w = attenuate_word(w, d.attenuation);
+                    if (ramp) w = ramp_word(w, mult, sb, ch, c);
+                }
+                store_word(o + sub * db, w, db, dst_le, zero_lsb);
+            }
+        }
+    }
+}
+
+// resample -> ramp -> pack for a batch of OUTPUT messages of rate-converted streams.
+// Straightforward form: each thread owns one output frame and walks its T taps from global memory.
+__global__ __launch_bounds__(256) void src_msg_kernel_v1(const DevSrcDesc* __restrict__ descs, uint32_t n_msgs,
+                                                         const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                         const uint16_t* __restrict__ ramp_table,
+                                                         const double* __restrict__ coef, uint32_t L, uint32_t M, uint32_t T)
+{
+    for (uint32_t m = blockIdx.x; m < n_msgs; m += gridDim.x) {
+        const DevSrcDesc d = descs[m];
+        const uint32_t ch = d.channels, sb = d.src_bits >> 3, db = d.dst_bits >> 3;
+        const bool src_le = d.src_endian == OHGPU_ENDIAN_LITTLE && sb > 1;
+        const bool dst_le = d.dst_endian == OHGPU_ENDIAN_LITTLE;
+        const bool ramp = (d.flags & OHGPU_FLAG_RAMP) != 0;
+        const bool zero_lsb = (d.flags & OHGPU_FLAG_ZERO_LSB32) != 0;
+        const int32_t total = (int32_t)((uint32_t)d.ramp_start - (uint32_t)d.ramp_end);
+        const uint8_t* s = src + d.src_offset;
+        uint8_t* o = dst + d.dst_offset;
+        for (uint32_t i = threadIdx.x; i < d.n_frames; i += blockDim.x) {
+            const uint64_t t = (uint64_t)d.phase0 + (uint64_t)i * M;
+            const int64_t r0 = d.in_rel0 + (int64_t)(t / L);
+            const uint32_t p = (uint32_t)(t % L);
+            const double* cp = coef + (size_t)p * T;
+            uint32_t mult = 0;
+            if (ramp) mult = ramp_table[ramp_index(d.ramp_start, total, (int32_t)i, (int32_t)d.n_frames)];
+            for (uint32_t c = 0; c < ch; c++) {
+                double acc = 0.0;
+                for (uint32_t k = 0; k < T; k++) {
+                    const int64_t r = r0 - (int64_t)k;
+                    if (r < 0) break;                              // frames before the stream start are zeros
+                    const uint32_t w = load_be_word(s + ((uint64_t)r * ch + c) * sb, sb, src_le);
+                    const int32_t x = ((int32_t)w) >> 8;           // S24 domain
+                    acc = fma(cp[k], (double)x, acc);
+                }
+                uint32_t w = ((uint32_t)src_round_s24(acc)) << 8;
+                if (ramp) w = ramp_word(w, mult, 3, ch, c);
+                store_word(o + ((uint64_t)i * ch + c) * db, w, db, dst_le, zero_lsb);
+            }
+        }
+    }
+}
+
+static uint32_t grid_for(size_t n)
+{
+    const size_t cap = 1u << 20;
+    return (uint32_t)(n < cap ? n : cap);
+}
+
+hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    if (b->n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pcm_msg_kernel_v1, dim3(grid_for(b->n)), dim3(256), 0, s,
+                       (const ohgpu_msg_desc*)b->d_descs, (uint32_t)b->n, src, dst, ctx->d_ramp_table);
+    return hipGetLastError();
+}
+
+hipError_t launch_src_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    if (b->n == 0) return hipSuccess;
+    hipLaunchKernelGGL(src_msg_kernel_v1, dim3(grid_for(b->n)), dim3(256), 0, s,
+                       (const DevSrcDesc*)b->d_descs, (uint32_t)b->n, src, dst, ctx->d_ramp_table,
+                       b->src->d_coef, b->src->L, b->src->M, b->src->T);
+    return hipGetLastError();
+}
+
+}  // namespace ohgpu

@@ -753,7 +753,7 @@ int ohp_src_design(ohp_src* s, uint32_t rate_in, uint32_t rate_out, uint32_t T, 
         if (sabs > s->sum_abs_max) s->sum_abs_max = sabs;
     }
     free(h);
-    if (s->sum_abs_max >= ((int64_t)1 << 29)) { ohp_src_free(s); return OHP_ERR_ASSERT; } /* keeps |acc| < 2^52 */
+    if (s->sum_abs_max >= ((int64_t)1 << 30)) { ohp_src_free(s); return OHP_ERR_ASSERT; } /* keeps |acc| < 2^53 */
     return OHP_OK;
 }
 

@@ -164,7 +164,7 @@ typedef struct {
     uint32_t rate_in, rate_out;
     int32_t* coef_q28;     /* [L][T]  */
     double*  coef_f64;     /* [L][T], unquantised */
-    int64_t  sum_abs_max;  /* max over phases of sum |c| (must be < 2^29 for exact fp64 accumulation) */
+    int64_t  sum_abs_max;  /* max over phases of sum |c| (must be < 2^30 for exact fp64 accumulation) */
 } ohp_src;
 
 int  ohp_src_design(ohp_src* s, uint32_t rate_in, uint32_t rate_out, uint32_t taps_per_phase, double beta, double f_pass);

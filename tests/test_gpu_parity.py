@@ -1,0 +1,356 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Bit-exact for unpack / attenuate / ramp / silence / pack; the resampler is bit-exact against
+the oracle's exact-integer model and within +/-1 LSB (S24) of the oracle's fp64 model.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import workloads as W
+from ohpipeline_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+LE, BE = O.ENDIAN_LITTLE, O.ENDIAN_BIG
+kMax = O.RAMP_MAX
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", params=[0, 1], ids=["tuned", "v1"])
+def vctx(ctx, request):
+    ctx.set_kernel_variant(request.param)
+    yield ctx
+    ctx.set_kernel_variant(0)
+
+
+def run_pcm(ctx, descs, src, dst_bytes, fill=0xA5):
+    """GPU run of a pcm batch; untouched destination bytes keep the fill pattern."""
+    d_src = ctx.upload(src if src.size else np.zeros(1, np.uint8))
+    d_dst = ctx.malloc(max(dst_bytes, 1))
+    ctx.memset(d_dst, fill, max(dst_bytes, 1))
+    b = ctx.pcm_batch(descs, src.size, dst_bytes)
+    ctx.pcm_run(b, d_src, d_dst)
+    out = ctx.download(d_dst, dst_bytes)
+    ctx.batch_destroy(b)
+    ctx.free(d_src)
+    ctx.free(d_dst)
+    return out
+
+
+def oracle_pcm(descs, src, dst_bytes, fill=0xA5):
+    dst = np.full(max(dst_bytes, 1), fill, dtype=np.uint8)
+    assert O.msg_process_batch(descs, src if src.size else np.zeros(1, np.uint8), dst) == 0
+    return dst[:dst_bytes]
+
+
+def run_src(ctx, src_handle, descs, src, dst_bytes, fill=0xA5):
+    d_src = ctx.upload(src)
+    d_dst = ctx.malloc(max(dst_bytes, 1))
+    ctx.memset(d_dst, fill, max(dst_bytes, 1))
+    b = ctx.src_batch(src_handle, descs, src.size, dst_bytes)
+    ctx.src_run(b, d_src, d_dst)
+    out = ctx.download(d_dst, dst_bytes)
+    ctx.batch_destroy(b)
+    ctx.free(d_src)
+    ctx.free(d_dst)
+    return out
+
+
+def oracle_src(ref, descs, src, dst_bytes, fill=0xA5):
+    dst = np.full(max(dst_bytes, 1), fill, dtype=np.uint8)
+    assert ref.process_batch(descs, src, dst) == 0
+    return dst[:dst_bytes]
+
+
+RAMPS = [(kMax, 0), (0, kMax), (kMax, 8192), (8191, 8190), (5, 5), (kMax, kMax), (0, 0), (12345, 54), (17, 16001)]
+
+
+def matrix_descs(rng, depths, chans, counts, src_endians, dst_fmts, odd_offsets=True):
+    """One descriptor per combination, each reading its own slice of a shared noise arena."""
+    rows, src_parts, src_pos, dst_pos = [], [], 0, 0
+    combos = itertools.product(depths, chans, counts, src_endians, dst_fmts)
+    for k, (bits, ch, n, se, (db, de)) in enumerate(combos):
+        ramp = RAMPS[k % len(RAMPS)]
+        enabled = (k % 4) != 3
+        pad = int(rng.integers(0, 7)) if odd_offsets else 0      # arbitrary byte alignment (MsgPlayable::iOffset)
+        nbytes = n * ch * bits // 8
+        src_parts.append(rng.integers(0, 256, size=pad + nbytes, dtype=np.uint8))
+        rows.append((src_pos + pad, dst_pos, n, ramp[0], ramp[1], 256, ch, bits, se, db, de,
+                     (O.FLAG_RAMP if enabled else 0) | (O.FLAG_ZERO_LSB32 if (k % 5 == 0) else 0)))
+        src_pos += pad + nbytes
+        dst_pos += n * ch * db // 8 + int(rng.integers(0, 5))
+    descs = np.array(rows, dtype=O.MSG_DESC)
+    return descs, np.concatenate(src_parts), dst_pos
+
+
+def test_capi_and_oracle_descriptor_layouts_agree():
+    assert capi.MSG_DESC == O.MSG_DESC and capi.SRC_MSG_DESC == O.SRC_MSG_DESC
+
+
+def test_pcm_matrix_bit_exact(vctx):
+    """a1+a7+a11/a12: depth x channels x N x endian x dst format, ramps up/down/flat/disabled, ragged offsets."""
+    rng = np.random.default_rng(1234)
+    descs, src, dst_bytes = matrix_descs(
+        rng, depths=[8, 16, 24, 32], chans=[1, 2, 6, 8], counts=[1, 2, 3, 42, 43, 220],
+        src_endians=[LE, BE], dst_fmts=[(8, BE), (16, BE), (24, BE), (32, BE), (16, LE), (24, LE), (32, LE)])
+    got = run_pcm(vctx, descs, src, dst_bytes)
+    want = oracle_pcm(descs, src, dst_bytes)
+    assert got.size == want.size
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} byte mismatches, first at {bad[:5]}"
+
+
+def test_pcm_extremes_bit_exact(vctx):
+    """Full-scale +/-, all-ones, alternating patterns under every ramp endpoint pair, N up to a full 9216-byte cell."""
+    rng = np.random.default_rng(7)
+    patterns = [bytes([0x7f, 0xff, 0xff, 0xff]), bytes([0x80, 0, 0, 0]), bytes([0xff] * 4), bytes([0x80, 0x00, 0x7f, 0xff])]
+    rows, parts, sp, dp = [], [], 0, 0
+    for bits, ch, pat, ramp in itertools.product([8, 16, 24, 32], [2, 6], patterns, RAMPS):
+        frame_bytes = ch * bits // 8
+        n = O.MAX_BYTES // frame_bytes
+        data = np.frombuffer((pat * (n * frame_bytes // 4 + 1))[:n * frame_bytes], dtype=np.uint8)
+        parts.append(data)
+        rows.append((sp, dp, n, ramp[0], ramp[1], 256, ch, bits, BE, bits, BE, O.FLAG_RAMP))
+        sp += data.size
+        dp += n * frame_bytes
+    descs = np.array(rows, dtype=O.MSG_DESC)
+    src = np.concatenate(parts)
+    assert np.array_equal(run_pcm(vctx, descs, src, dp), oracle_pcm(descs, src, dp))
+
+
+def test_attenuation_all_s16_values(vctx):
+    """a6 over every 16-bit value for att in {0,1,64,255,256} (floor semantics of the unsigned multiply/divide)."""
+    vals = np.arange(65536, dtype=np.uint32)
+    src = np.stack([(vals >> 8).astype(np.uint8), (vals & 0xff).astype(np.uint8)], axis=1).reshape(-1)
+    src_le = np.stack([(vals & 0xff).astype(np.uint8), (vals >> 8).astype(np.uint8)], axis=1).reshape(-1)
+    rows = []
+    for k, att in enumerate([0, 1, 64, 255, 256, 77]):
+        rows.append((0, k * 131072, 32768, kMax, kMax, att, 2, 16, BE, 16, BE, 0))
+    descs = np.array(rows, dtype=O.MSG_DESC)
+    assert np.array_equal(run_pcm(vctx, descs, src, 6 * 131072), oracle_pcm(descs, src, 6 * 131072))
+    descs["src_endian"] = LE                    # attenuation after the LE->BE ingest, with a ramp on top
+    descs["flags"] = O.FLAG_RAMP
+    descs["ramp_start"], descs["ramp_end"] = 9000, 300
+    assert np.array_equal(run_pcm(vctx, descs, src_le, 6 * 131072), oracle_pcm(descs, src_le, 6 * 131072))
+
+
+def test_silence_including_six_channel_id_bytes(vctx):
+    """a9: zeros, the 6-channel id bytes restarting every <=9216-byte chunk, through each depth conversion."""
+    rows, dp = [], 0
+    for bits, ch, db in itertools.product([8, 16, 24, 32], [1, 2, 6, 8], [8, 16, 24, 32]):
+        frame = ch * bits // 8
+        n = (2 * O.MAX_BYTES + 100) // frame + 3
+        rows.append((0, dp, n, kMax, kMax, 256, ch, bits, BE, db, BE, O.FLAG_SILENCE))
+        dp += n * ch * db // 8
+    descs = np.array(rows, dtype=O.MSG_DESC)
+    src = np.zeros(0, dtype=np.uint8)
+    got, want = run_pcm(vctx, descs, src, dp), oracle_pcm(descs, src, dp)
+    assert np.array_equal(got, want)
+    assert want.any(), "6-channel 32-bit silence must carry channel-id bytes"
+
+
+def test_empty_and_zero_length(vctx):
+    got = run_pcm(vctx, np.zeros(0, dtype=O.MSG_DESC), np.zeros(0, np.uint8), 16)
+    assert (got == 0xA5).all()
+    descs = np.array([(0, 0, 0, kMax, 0, 256, 2, 24, LE, 24, BE, O.FLAG_RAMP),
+                      (0, 4, 1, kMax, 0, 256, 2, 24, LE, 24, BE, O.FLAG_RAMP)], dtype=O.MSG_DESC)
+    src = np.arange(6, dtype=np.uint8)
+    got, want = run_pcm(vctx, descs, src, 16), oracle_pcm(descs, src, 16)
+    assert np.array_equal(got, want) and (got[:4] == 0xA5).all() and (got[10:] == 0xA5).all()
+
+
+def test_descriptor_validation_errors(ctx):
+    """Errors surface as return codes (never a fault on the device): bounds, depth, attenuation, flags."""
+    base = (0, 0, 10, kMax, 0, 256, 2, 24, LE, 24, BE, 0)
+
+    def expect(code, **kw):
+        d = np.array([base], dtype=O.MSG_DESC)
+        for k, v in kw.items():
+            d[k] = v
+        with pytest.raises(capi.OhGpuError) as e:
+            ctx.pcm_batch(d, 60, 60)
+        assert e.value.code == code, str(e.value)
+
+    expect(capi.ERR_BOUNDS, n_frames=11)
+    expect(capi.ERR_BOUNDS, src_offset=1)
+    expect(capi.ERR_BOUNDS, dst_offset=1)
+    expect(capi.ERR_BOUNDS, dst_bits=32)
+    expect(capi.ERR_INVALID, channels=0)
+    expect(capi.ERR_INVALID, channels=9)
+    expect(capi.ERR_INVALID, src_bits=12)
+    expect(capi.ERR_INVALID, dst_endian=0)
+    expect(capi.ERR_INVALID, flags=0x80)
+    expect(capi.ERR_INVALID, ramp_start=kMax + 1)
+    expect(capi.ERR_UNSUPPORTED, attenuation=128)            # ASSERT(iBitDepth == 16), Msg.cpp:2741
+    b = ctx.pcm_batch(np.array([base], dtype=O.MSG_DESC), 60, 60)
+    info = ctx.batch_info(b)
+    assert info == {"n_msgs": 1, "in_frames": 10, "out_frames": 10, "src_bytes_touched": 60, "dst_bytes_written": 60}
+    ctx.batch_destroy(b)
+
+
+def test_pcm_process_host_round_trip(ctx):
+    """The host-buffer convenience entry point (5 ms cadence shape): config 1, S16LE -> ramp -> S24."""
+    src = W.noise_pcm(0, 220, 2, 16, LE)
+    descs = np.array([(0, 0, 220, 0, 3345, 256, 2, 16, LE, 24, BE, O.FLAG_RAMP)], dtype=O.MSG_DESC)
+    dst = np.zeros(220 * 6, dtype=np.uint8)
+    ctx.pcm_process_host(descs, src, dst)
+    assert np.array_equal(dst, oracle_pcm(descs, src, dst.size))
+
+
+def test_config1_stream_s16le_ramp_s24(vctx):
+    """BASELINE config 1: 1 stream stereo S16LE 44.1 kHz, 220-frame msgs, up-ramp 50 ms / down-ramp 500 ms, S16->S24."""
+    frames = 44100
+    n_msgs = (frames + 219) // 220
+    sched = W.ramp_schedule(n_msgs, 220 * 1280, 50 * O.JIFFIES_PER_MS, 500 * O.JIFFIES_PER_MS)
+    descs, sb, db = W.pcm_stream_descs(1, frames, 220, 2, 16, LE, 24, BE, sched)
+    assert sum(1 for s in sched if s[0]) >= 100
+    src = W.noise_pcm(0, frames, 2, 16, LE)
+    assert np.array_equal(run_pcm(vctx, descs, src, db), oracle_pcm(descs, src, db))
+
+
+def test_passthrough_identity_and_endian_round_trip(vctx):
+    """Size-independent properties: no ramp + same format = byte copy; LE->BE->LE returns the input."""
+    n_streams, frames = 64, 44100
+    descs, sb, db = W.pcm_stream_descs(n_streams, frames, 220, 2, 24, BE, 24, BE)
+    src = np.concatenate([W.noise_pcm(s, frames, 2, 24, BE) for s in range(n_streams)])
+    out = run_pcm(vctx, descs, src, db)
+    assert np.array_equal(out, src)
+    d1, _, _ = W.pcm_stream_descs(n_streams, frames, 220, 2, 24, LE, 24, BE)
+    be = run_pcm(vctx, d1, src, db)
+    d2, _, _ = W.pcm_stream_descs(n_streams, frames, 220, 2, 24, BE, 24, LE)
+    assert np.array_equal(run_pcm(vctx, d2, be, db), src)
+
+
+# ------------------------------------------------------------------------------------------ resampler
+def make_src(ctx, rin, rout, T):
+    L_, M_, coef = capi.src_design(rin, rout, T, 9.0, 20000.0)
+    ref = O.Src(rin, rout, T, 9.0, 20000.0)
+    assert np.array_equal(coef, ref.coef_q28)
+    return ctx.src_create(L_, M_, T, coef), ref
+
+
+def decode_s24_be(buf):
+    b = buf.reshape(-1, 3).astype(np.int32)
+    v = (b[:, 0] << 16) | (b[:, 1] << 8) | b[:, 2]
+    return np.where(v >= 1 << 23, v - (1 << 24), v)
+
+
+def test_src_config2_one_stream_s24(vctx):
+    """BASELINE config 2: 1 stream stereo S24 44.1->48 kHz, resample + ramp + fmt; bit-exact vs the integer
+    model, and the un-ramped output within +/-1 LSB of the fp64 model (tolerance stated by north_star)."""
+    h, ref = make_src(vctx, 44100, 48000, 32)
+    in_frames = 44100
+    for kind in ("noise", "sine"):
+        src = W.noise_pcm(3, in_frames, 2, 24, LE) if kind == "noise" else W.sine_impulse_pcm(in_frames, 2, 24, LE)
+        out_total = ref.out_frames(in_frames)
+        n_msgs = (out_total + 239) // 240
+        sched = W.ramp_schedule(n_msgs, 240 * 1176, 50 * O.JIFFIES_PER_MS, 500 * O.JIFFIES_PER_MS)
+        descs, sbytes, dbytes, out_total2, _ = W.src_stream_descs(1, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, sched)
+        assert out_total2 == out_total == 48000
+        got = run_src(vctx, h, descs, src, dbytes)
+        want = oracle_src(ref, descs, src, dbytes)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"{kind}: {bad.size} mismatches, first {bad[:5]}"
+        plain, _, _, _, _ = W.src_stream_descs(1, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, None)
+        y_gpu = decode_s24_be(run_src(vctx, h, plain, src, dbytes))
+        worst = 0.0
+        for d in plain[:: max(1, plain.size // 40)]:
+            err, y64 = ref.process_f64(d, src)
+            assert err == 0
+            first = int(d["out_frame0"]) * 2
+            ideal = np.clip(y64, -8388608.0, 8388607.0)
+            worst = max(worst, float(np.abs(y_gpu[first:first + y64.size] - ideal).max()))
+        assert worst <= 1.0, f"{kind}: {worst} LSB from the fp64 model"
+    vctx.src_destroy(h)
+
+
+@pytest.mark.parametrize("rin,rout,T,ch,sbits,send,dbits,dend", [
+    (96000, 48000, 64, 8, 24, BE, 24, BE),
+    (96000, 48000, 64, 6, 16, BE, 32, LE),
+    (44100, 48000, 32, 6, 32, LE, 16, BE),
+    (44100, 48000, 32, 1, 8, BE, 24, LE),
+    (88200, 48000, 24, 2, 24, LE, 32, BE),
+    (48000, 44100, 32, 2, 16, LE, 16, LE),
+    (32000, 48000, 16, 8, 24, LE, 8, BE),
+])
+def test_src_formats_bit_exact(vctx, rin, rout, T, ch, sbits, send, dbits, dend):
+    h, ref = make_src(vctx, rin, rout, T)
+    in_frames = 6000 + 37
+    src = np.concatenate([W.noise_pcm(10 + s, in_frames, ch, sbits, send) for s in range(3)])
+    out_total = ref.out_frames(in_frames)
+    per_msg = 240 if rout == 48000 else 220
+    n_msgs = (out_total + per_msg - 1) // per_msg
+    jps = O.lib().ohp_jiffies_per_sample(rout)
+    sched = W.ramp_schedule(n_msgs, per_msg * jps, 20 * O.JIFFIES_PER_MS, 60 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(3, in_frames, ref.L, ref.M, per_msg, ch, sbits, send, dbits, dend, sched)
+    descs["flags"][::7] |= O.FLAG_ZERO_LSB32
+    got, want = run_src(vctx, h, descs, src, dbytes), oracle_src(ref, descs, src, dbytes)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}"
+    vctx.src_destroy(h)
+
+
+def test_src_chunked_streaming_equals_whole(vctx):
+    """Cross-chunk state = (T-1 frames of history, phase): feeding windows with src_frame0 > 0 gives the same bytes."""
+    h, ref = make_src(vctx, 44100, 48000, 32)
+    in_frames, ch = 22050, 2
+    src = W.noise_pcm(99, in_frames, ch, 24, LE)
+    whole, sbytes, dbytes, out_total, n_msgs = W.src_stream_descs(1, in_frames, ref.L, ref.M, 240, ch, 24, LE, 24, BE, None)
+    want = run_src(vctx, h, whole, src, dbytes)
+    chunked = whole.copy()
+    for d in chunked:
+        m0, n = int(d["out_frame0"]), int(d["n_frames"])
+        lo = max(0, (m0 * ref.M) // ref.L - (ref.T - 1))
+        hi = ((m0 + n - 1) * ref.M) // ref.L
+        d["src_frame0"], d["src_frames"], d["src_offset"] = lo, hi - lo + 1, lo * ch * 3
+    got = run_src(vctx, h, chunked, src, dbytes)
+    assert np.array_equal(got, want)
+    bad = chunked[5:6].copy()
+    bad["src_frame0"] += 1
+    bad["src_offset"] += ch * 3
+    bad["src_frames"] -= 1
+    with pytest.raises(capi.OhGpuError) as e:
+        vctx.src_batch(h, bad, src.size, dbytes)
+    assert e.value.code == capi.ERR_BOUNDS
+    vctx.src_destroy(h)
+
+
+def test_src_time_shift_invariance(vctx):
+    """Size-independent exact property: delaying the input by M frames delays the output by L frames."""
+    h, ref = make_src(vctx, 44100, 48000, 32)
+    ch, in_frames = 2, 147 * 300
+    x = W.noise_pcm(5, in_frames, ch, 24, LE)
+    shifted = np.concatenate([np.zeros(ref.M * ch * 3, np.uint8), x])
+    d0, _, db0, out0, _ = W.src_stream_descs(1, in_frames, ref.L, ref.M, 240, ch, 24, LE, 24, BE, None)
+    d1, _, db1, out1, _ = W.src_stream_descs(1, in_frames + ref.M, ref.L, ref.M, 240, ch, 24, LE, 24, BE, None)
+    y0 = run_src(vctx, h, d0, x, db0)
+    y1 = run_src(vctx, h, d1, shifted, db1)
+    assert out1 == out0 + ref.L
+    assert not y1[: ref.L * ch * 3].any()
+    assert np.array_equal(y1[ref.L * ch * 3:], y0)
+    vctx.src_destroy(h)
+
+
+def test_src_config3_shape_256_streams(ctx):
+    """BASELINE config 3 shape at a size the oracle finishes in seconds: 256 stereo S24 streams, 0.5 s each."""
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    n_streams, in_frames = 256, 22050
+    src = np.concatenate([W.noise_pcm(s, in_frames, 2, 24, LE) for s in range(n_streams)])
+    out_total = ref.out_frames(in_frames)
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 50 * O.JIFFIES_PER_MS, 200 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, sched)
+    got = run_src(ctx, h, descs, src, dbytes)
+    want = oracle_src(ref, descs, src, dbytes)
+    assert np.array_equal(got, want)
+    ctx.src_destroy(h)

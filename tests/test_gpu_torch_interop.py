@@ -1,0 +1,36 @@
+"""The C ABI takes plain device pointers and a HIP stream: check that torch-owned memory and torch's
+current stream work through it (torch is plumbing only -- device memory, streams, torch.distributed)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_torch_tensors_and_stream_through_the_c_abi():
+    import torch
+    import oracle_lib as O
+    import workloads as W
+    from ohpipeline_amd import capi
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    ctx = capi.Context(0)
+    frames = 44100
+    descs, sb, db = W.pcm_stream_descs(4, frames, 220, 2, 16, O.ENDIAN_LITTLE, 24, O.ENDIAN_BIG,
+                                       W.ramp_schedule((frames + 219) // 220, 220 * 1280, 50 * O.JIFFIES_PER_MS,
+                                                       500 * O.JIFFIES_PER_MS))
+    src = np.concatenate([W.noise_pcm(s, frames, 2, 16, O.ENDIAN_LITTLE) for s in range(4)])
+    t_src = torch.from_numpy(src).to(dev)
+    t_dst = torch.zeros(db, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    batch = ctx.pcm_batch(descs, src.size, db)
+    ctx.pcm_run(batch, C.c_void_p(t_src.data_ptr()), C.c_void_p(t_dst.data_ptr()), C.c_void_p(stream.cuda_stream))
+    stream.synchronize()
+    got = t_dst.cpu().numpy()
+    want = np.zeros(db, dtype=np.uint8)
+    assert O.msg_process_batch(descs, src, want) == 0
+    assert np.array_equal(got, want)
+    ctx.batch_destroy(batch)
+    ctx.close()
