@@ -100,7 +100,7 @@ def cpu_baseline(work, n_streams, in_frames):
     ref = O.Src(RATE_IN, RATE_OUT, TAPS, BETA, F_PASS)
     assert np.array_equal(ref.coef_q28, work["coef"])
     cores = len(os.sched_getaffinity(0))
-    threads = max(1, min(cores, n_streams))
+    threads = max(1, min(cores, n_streams, int(os.environ.get("OHGPU_BENCH_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share
     descs, src = work["descs"], work["src"]
     dst = np.zeros(work["dst_bytes"], dtype=np.uint8)
     n_msgs = work["n_msgs"]
@@ -156,6 +156,7 @@ def main():
     ctx.memset(d_dst, 0, work["dst_bytes"])
     batch = ctx.src_batch(h, work["descs"], work["src"].size, work["dst_bytes"])
     info = ctx.batch_info(batch)
+    plan = ctx.src_plan(batch)
     ctx.sync()
 
     def barrier():
@@ -209,6 +210,7 @@ def main():
                                    f"ramp up 50 ms / down 500 ms, S24 BE out",
                        "streams_per_gpu": n_streams, "frames_per_stream": in_frames, "taps_per_phase": TAPS,
                        "msgs_per_step": int(info["n_msgs"]), "kernel_variant": args.variant,
+                       "block_kernel_out_frames": plan["block_kernel_out_frames"], "generic_pieces": plan["generic_pieces"],
                        "sharding": f"streams x{world} ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved_gbps / HBM_PEAK_GBPS, 4), "traffic": None,

@@ -171,6 +171,10 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
 
+/* How a resampler batch was planned: output frames handled by the block kernel, and the number of message pieces
+ * (block-unaligned heads/tails, unsupported layouts) left to the generic kernel. */
+int ohgpu_src_batch_plan(const ohgpu_batch* batch, uint64_t* block_kernel_out_frames, uint64_t* generic_pieces);
+
 /* Kernel selection for A/B measurement (0 = default/best, 1 = baseline "v1" kernels). */
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant);
 

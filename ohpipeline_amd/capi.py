@@ -68,6 +68,7 @@ SYMBOLS = {
     "ohgpu_src_out_frames": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint64]),
     "ohgpu_src_batch_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }
 
@@ -242,6 +243,11 @@ class Context:
         check(lib().ohgpu_src_batch_create(self._h, src, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes,
                                            dst_arena_bytes, C.byref(b)))
         return b
+
+    def src_plan(self, batch):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().ohgpu_src_batch_plan(batch, C.byref(a), C.byref(b)))
+        return {"block_kernel_out_frames": int(a.value), "generic_pieces": int(b.value)}
 
     def src_run(self, batch, d_src, d_dst, stream=None):
         check(lib().ohgpu_src_batch_run(self._h, batch, d_src, d_dst, stream))

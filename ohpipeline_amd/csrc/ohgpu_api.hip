@@ -327,6 +327,7 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     CTX_GUARD("ohgpu_batch_destroy");
     if (!batch) return OHGPU_OK;
     if (batch->d_descs) hipFree(batch->d_descs);
+    if (batch->kind == kBatchSrc) free_src_fast(batch);
     delete batch;
     return OHGPU_OK;
 }
@@ -499,6 +500,8 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         o.src_offset = d.src_offset;
         o.dst_offset = d.dst_offset;
         o.n_frames = d.n_frames;
+        o.ramp_i0 = 0;
+        o.ramp_n = d.n_frames;
         o.ramp_start = d.ramp_start;
         o.ramp_end = d.ramp_end;
         o.channels = d.channels;
@@ -518,9 +521,22 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
             b->uniform = false;
         }
     }
-    const int err = upload_batch(ctx, b, dev.data(), n * sizeof(DevSrcDesc));
-    if (err != OHGPU_OK) { delete b; return err; }
+    int err = upload_batch(ctx, b, dev.data(), n * sizeof(DevSrcDesc));
+    if (err == OHGPU_OK) err = plan_src_fast(ctx, b, descs, n, dev);
+    if (err != OHGPU_OK) {
+        if (b->d_descs) hipFree(b->d_descs);
+        delete b;
+        return err;
+    }
     *out = b;
+    return OHGPU_OK;
+}
+
+int ohgpu_src_batch_plan(const ohgpu_batch* b, uint64_t* block_kernel_out_frames, uint64_t* generic_pieces)
+{
+    if (!b || b->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_plan: not a src batch");
+    if (block_kernel_out_frames) *block_kernel_out_frames = b->fast.enabled ? b->fast.fast_out_frames : 0;
+    if (generic_pieces) *generic_pieces = b->fast.enabled ? b->fast.n_rem : b->n;
     return OHGPU_OK;
 }
 
@@ -530,7 +546,15 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!batch || batch->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: not a src batch");
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
-    OHGPU_HIP_TRY(launch_src_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    hipStream_t s = pick_stream(ctx, stream);
+    const bool aligned = (((uintptr_t)src_base | (uintptr_t)dst_base) & 15u) == 0;
+    if (ctx->variant == 0 && batch->fast.enabled && aligned) {
+        // whole phase-aligned blocks on the block kernel, block-unaligned heads/tails on the generic one
+        OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+        OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+    } else {
+        OHGPU_HIP_TRY(launch_src_v1(ctx, batch->d_descs, batch->n, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+    }
     return OHGPU_OK;
 }
 

@@ -10,15 +10,19 @@
 
 namespace ohgpu {
 
-// Device-side form of one resampled output message: everything 64-bit that can be precomputed on the
-// host has been (48 bytes).  in_rel0 = n0(out_frame0) - src_frame0 (may be negative only at stream start,
-// where frames with negative absolute index read as zero); phase0 = (out_frame0 * M) % L.
+// Device-side form of one piece of a resampled output message (56 bytes): everything 64-bit that can be
+// precomputed on the host has been.  in_rel0 = n0(first output) - src_frame0 (negative only at a stream
+// start, where frames with a negative absolute index read as zero); phase0 = (first output * M) % L.
+// A piece is a whole message, or the part of one that the block kernel leaves to the generic kernel;
+// ramp_i0 / ramp_n place it inside its message for RampApplicator's (iLoopCount, iNumSamples).
 struct DevSrcDesc {
     uint64_t src_offset;
     uint64_t dst_offset;
     int64_t  in_rel0;
     uint32_t phase0;
     uint32_t n_frames;
+    uint32_t ramp_i0;
+    uint32_t ramp_n;
     uint16_t ramp_start;
     uint16_t ramp_end;
     uint8_t  channels;
@@ -29,9 +33,65 @@ struct DevSrcDesc {
     uint8_t  flags;
     uint8_t  pad[6];
 };
-static_assert(sizeof(DevSrcDesc) == 48, "DevSrcDesc layout");
+static_assert(sizeof(DevSrcDesc) == 56, "DevSrcDesc layout");
 static_assert(sizeof(ohgpu_msg_desc) == 32, "ohgpu_msg_desc layout");
 static_assert(sizeof(ohgpu_src_msg_desc) == 64, "ohgpu_src_msg_desc layout");
+
+// ---- block ("fast") resampler plan: contiguous runs of output messages cut into phase-aligned blocks ----
+struct SrcSeg {               // one contiguous run of output messages of one stream
+    int64_t  src_base;        // byte offset (in the source arena) of the stream's absolute input frame 0
+    int64_t  dst_base;        // byte offset (in the destination arena) of the stream's absolute output frame 0
+    uint32_t msg_begin;       // [msg_begin, msg_end) in the SegMsg array, ordered by out0
+    uint32_t msg_end;
+};
+struct SegMsg {               // ramp parameters of one output message, 24 bytes
+    uint64_t out0;            // absolute index of its first output frame
+    uint32_t n;               // frames
+    uint16_t ramp_start;
+    uint16_t ramp_end;
+    uint8_t  flags;
+    uint8_t  pad[7];
+};
+struct SrcWork {              // one workgroup's share: up to `rows` consecutive blocks of one segment
+    uint64_t first_block;     // absolute block index (block b covers outputs [b*L_blk, (b+1)*L_blk))
+    uint32_t seg;
+    uint32_t n_blocks;
+};
+static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 16 && sizeof(SrcSeg) == 24, "plan layouts");
+
+struct SrcFastParams {        // kernel argument block
+    const SrcSeg*  segs;
+    const SegMsg*  msgs;
+    const SrcWork* work;
+    const double*  coef;      // [L][T]
+    const uint16_t* ramp_table;
+    const uint8_t* src;
+    uint8_t*       dst;
+    uint64_t src_arena_bytes;
+    uint32_t L, M;
+    uint32_t L_blk, M_blk;    // outputs / inputs per block
+    uint32_t rows;            // blocks per workgroup
+    uint32_t cgn;             // lanes per block (channel groups)
+    uint32_t oc_log2;         // outputs per store stage = 1 << oc_log2
+    uint32_t in_blocks;       // 16-byte pieces per staged input row
+    uint32_t out_blocks;      // 16-byte pieces per staged output row
+    uint32_t channels, sb, db;
+    uint32_t src_le, dst_le;
+};
+
+struct SrcFastPlan {
+    bool     enabled = false;
+    uint32_t T = 0, cpl = 0;
+    SrcFastParams params{};
+    uint32_t n_work = 0;
+    uint32_t lds_bytes = 0;
+    void*    d_segs = nullptr;
+    void*    d_msgs = nullptr;
+    void*    d_work = nullptr;
+    void*    d_rem = nullptr;     // DevSrcDesc[] the generic kernel finishes (block-unaligned heads and tails)
+    size_t   n_rem = 0;
+    uint64_t fast_out_frames = 0;
+};
 
 enum BatchKind { kBatchPcm = 1, kBatchSrc = 2 };
 
@@ -55,13 +115,14 @@ struct ohgpu_src {
 struct ohgpu_batch {
     int      kind;
     size_t   n;
-    void*    d_descs;             // ohgpu_msg_desc[] or DevSrcDesc[]
+    void*    d_descs;             // ohgpu_msg_desc[] or DevSrcDesc[] (every message, generic kernels)
     const ohgpu_src* src;         // kBatchSrc only
     uint64_t src_arena_bytes, dst_arena_bytes;
     uint64_t in_frames, out_frames, src_bytes_touched, dst_bytes_written;
     uint32_t max_frames;          // largest n_frames in the batch
     bool     uniform;             // every descriptor has the same format fields
     uint8_t  channels, src_bits, src_endian, dst_bits, dst_endian;
+    ohgpu::SrcFastPlan fast;      // kBatchSrc only
 };
 
 namespace ohgpu {
@@ -75,13 +136,19 @@ int set_error(int code, const char* fmt, ...);
                                                         hipGetErrorString(e_));                     \
     } while (0)
 
-// kernels (pcm_kernels.hip)
+// kernels
 hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
-hipError_t launch_src_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* src_filter,
+                         const uint8_t* src, uint8_t* dst, hipStream_t s);
+hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+bool src_block_supported(uint32_t T, uint32_t cpl);
 
-// host helpers (host_design.cpp)
+// host helpers
 void build_ramp_table(uint16_t out[512]);
 int  design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, double f_pass,
                 std::vector<int32_t>* coef_q28, uint32_t* L, uint32_t* M);
+int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n,
+                   const std::vector<DevSrcDesc>& dev);
+void free_src_fast(ohgpu_batch* b);
 
 }  // namespace ohgpu

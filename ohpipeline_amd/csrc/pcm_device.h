@@ -97,10 +97,9 @@ __device__ __forceinline__ void store_word(uint8_t* __restrict__ p, uint32_t w, 
 // (DESIGN.md "Resampler": y = clamp((acc + 2^27) >> 28)).  |acc| < 2^53 so every step below is exact.
 __device__ __forceinline__ int32_t src_round_s24(double acc)
 {
-    double v = floor(acc * (1.0 / 268435456.0) + 0.5);
-    v = v > 8388607.0 ? 8388607.0 : v;
-    v = v < -8388608.0 ? -8388608.0 : v;
-    return (int32_t)v;
+    // |acc * 2^-28| < 2^25: the scaled sum, the +0.5 and the floor are all exact, the conversion is in range
+    const int32_t y = (int32_t)floor(fma(acc, 1.0 / 268435456.0, 0.5));
+    return y > 8388607 ? 8388607 : (y < -8388608 ? -8388608 : y);
 }
 
 }  // namespace ohgpu

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void src_msg_kernel_v1(const DevSrcDesc* __res
             const uint32_t p = (uint32_t)(t % L);
             const double* cp = coef + (size_t)p * T;
             uint32_t mult = 0;
-            if (ramp) mult = ramp_table[ramp_index(d.ramp_start, total, (int32_t)i, (int32_t)d.n_frames)];
+            if (ramp) mult = ramp_table[ramp_index(d.ramp_start, total, (int32_t)(d.ramp_i0 + i), (int32_t)d.ramp_n)];
             for (uint32_t c = 0; c < ch; c++) {
                 double acc = 0.0;
                 for (uint32_t k = 0; k < T; k++) {
@@ -100,12 +100,13 @@ hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8
     return hipGetLastError();
 }
 
-hipError_t launch_src_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* flt,
+                         const uint8_t* src, uint8_t* dst, hipStream_t s)
 {
-    if (b->n == 0) return hipSuccess;
-    hipLaunchKernelGGL(src_msg_kernel_v1, dim3(grid_for(b->n)), dim3(256), 0, s,
-                       (const DevSrcDesc*)b->d_descs, (uint32_t)b->n, src, dst, ctx->d_ramp_table,
-                       b->src->d_coef, b->src->L, b->src->M, b->src->T);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(src_msg_kernel_v1, dim3(grid_for(n)), dim3(256), 0, s,
+                       (const DevSrcDesc*)d_descs, (uint32_t)n, src, dst, ctx->d_ramp_table,
+                       flt->d_coef, flt->L, flt->M, flt->T);
     return hipGetLastError();
 }
 

@@ -1,0 +1,190 @@
+// src_plan.cpp -- host-side planning for the block resampler kernel: group output messages into
+// contiguous stream segments, cut the segments into phase-aligned blocks, hand everything that is not a whole
+// block (segment heads/tails, segments that break an alignment rule) to the generic kernel as message pieces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "ohgpu_internal.h"
+
+namespace ohgpu {
+
+static uint32_t gcd_u32(uint32_t a, uint32_t b)
+{
+    while (b) { const uint32_t t = a % b; a = b; b = t; }
+    return a;
+}
+
+void free_src_fast(ohgpu_batch* b)
+{
+    SrcFastPlan& f = b->fast;
+    if (f.d_segs) hipFree(f.d_segs);
+    if (f.d_msgs) hipFree(f.d_msgs);
+    if (f.d_work) hipFree(f.d_work);
+    if (f.d_rem) hipFree(f.d_rem);
+    f = SrcFastPlan();
+}
+
+template <typename V>
+static int upload_vec(const std::vector<V>& v, void** dptr)
+{
+    *dptr = nullptr;
+    if (v.empty()) return OHGPU_OK;
+    hipError_t e = hipMalloc(dptr, v.size() * sizeof(V));
+    if (e == hipSuccess) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE,
+                                          "block plan upload: %s", hipGetErrorString(e));
+    return OHGPU_OK;
+}
+
+// piece [m_lo, m_hi) of message d (device form dv) for the generic kernel
+static DevSrcDesc make_piece(const ohgpu_src_msg_desc& d, const DevSrcDesc& dv, uint64_t m_lo, uint64_t m_hi,
+                             uint64_t L, uint64_t M)
+{
+    DevSrcDesc o = dv;
+    const uint64_t t_first = m_lo * M;
+    o.in_rel0 = (int64_t)(t_first / L) - (int64_t)d.src_frame0;
+    o.phase0 = (uint32_t)(t_first % L);
+    o.n_frames = (uint32_t)(m_hi - m_lo);
+    o.ramp_i0 = (uint32_t)(m_lo - d.out_frame0);
+    o.ramp_n = d.n_frames;
+    o.dst_offset = d.dst_offset + (m_lo - d.out_frame0) * (uint64_t)d.channels * (d.dst_bits / 8);
+    return o;
+}
+
+int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n,
+                  const std::vector<DevSrcDesc>& dev)
+{
+    (void)ctx;
+    SrcFastPlan& f = b->fast;
+    f = SrcFastPlan();
+    if (n == 0 || !b->uniform) return OHGPU_OK;
+    const ohgpu_src* flt = b->src;
+    const uint32_t L = flt->L, M = flt->M, T = flt->T;
+    const uint32_t ch = b->channels, sb = b->src_bits / 8, db = b->dst_bits / 8;
+    const uint32_t cpl = ch;                                      // the block kernel owns whole (mono/stereo) frames per lane
+    if (ch > 2 || !src_block_supported(T, cpl)) return OHGPU_OK;
+    const uint32_t cgn = 1;
+    const uint32_t rows = 256;
+    const uint32_t fb_src = ch * sb, fb_dst = ch * db;
+    const uint32_t oc_log2 = (fb_dst % 2 == 0) ? 3 : 4;          // Oc * fb_dst must be a multiple of 16
+    const uint32_t Oc = 1u << oc_log2;
+    const uint32_t base = L / gcd_u32(L, Oc) * Oc;               // lcm(L, Oc): phase-aligned and store-aligned
+    const uint32_t L_blk = base * ((128 + base - 1) / base);
+    const uint64_t M_blk64 = (uint64_t)L_blk * M / L;
+    if (M_blk64 + T > 32000) return OHGPU_OK;
+    const uint32_t M_blk = (uint32_t)M_blk64;
+    uint32_t in_blocks = (8 * fb_src + 15 + 15) / 16;
+    if (in_blocks % 2 == 0) in_blocks++;                         // odd row stride: 4-way instead of 16-way LDS conflicts
+    const uint32_t out_blocks = Oc * fb_dst / 16;
+    const uint32_t ring = 2 * Oc;                                // lane-private ring of rounded outputs
+    const uint32_t max_out_per_stage = (8 * L + M - 1) / M;      // #{j : a <= floor(j*M/L) < a+8} <= ceil(8L/M)
+    if (Oc - 1 + max_out_per_stage > ring) return OHGPU_OK;
+    const uint32_t lds_bytes = 1024 + 2 * rows * in_blocks * 16 + ring * rows * cpl * 4;
+    if (lds_bytes > 80 * 1024) return OHGPU_OK;                  // two workgroups per CU must fit in 160 KiB
+
+    // order messages by (stream, output position); a stream is identified by where its absolute frame 0 lives
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    auto src_base_of = [&](const ohgpu_src_msg_desc& d) { return (int64_t)d.src_offset - (int64_t)(d.src_frame0 * fb_src); };
+    auto dst_base_of = [&](const ohgpu_src_msg_desc& d) { return (int64_t)d.dst_offset - (int64_t)(d.out_frame0 * fb_dst); };
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const int64_t sx = src_base_of(descs[x]), sy = src_base_of(descs[y]);
+        if (sx != sy) return sx < sy;
+        const int64_t dx = dst_base_of(descs[x]), dy = dst_base_of(descs[y]);
+        if (dx != dy) return dx < dy;
+        return descs[x].out_frame0 < descs[y].out_frame0;
+    });
+
+    std::vector<SrcSeg> segs;
+    std::vector<SegMsg> msgs;
+    std::vector<SrcWork> work;
+    std::vector<DevSrcDesc> rem;
+    uint64_t fast_frames = 0;
+
+    size_t i = 0;
+    while (i < n) {
+        // grow a run of messages that tile a contiguous output range of one stream
+        size_t e = i + 1;
+        const ohgpu_src_msg_desc& d0 = descs[order[i]];
+        const int64_t sbase = src_base_of(d0), dbase = dst_base_of(d0);
+        uint64_t next_out = d0.out_frame0 + d0.n_frames;
+        bool zero_len = d0.n_frames == 0;
+        while (!zero_len && e < n) {
+            const ohgpu_src_msg_desc& d = descs[order[e]];
+            if (d.n_frames == 0 || src_base_of(d) != sbase || dst_base_of(d) != dbase || d.out_frame0 != next_out) break;
+            next_out += d.n_frames;
+            e++;
+        }
+        const uint64_t m_begin = d0.out_frame0, m_end = next_out;
+        uint64_t blk_lo = (m_begin + L_blk - 1) / L_blk, blk_hi = m_end / L_blk;
+        bool fast_ok = !zero_len && blk_hi > blk_lo && (dbase % 16 == 0);
+        if (fast_ok) {
+            // every whole block's history must be present in the windows the caller declared (they were validated
+            // per message; the block reads nothing a message of the block does not itself need)
+            const uint32_t msg_begin = (uint32_t)msgs.size();
+            for (size_t k = i; k < e; k++) {
+                const ohgpu_src_msg_desc& d = descs[order[k]];
+                SegMsg sm;
+                memset(&sm, 0, sizeof(sm));
+                sm.out0 = d.out_frame0; sm.n = d.n_frames; sm.ramp_start = d.ramp_start; sm.ramp_end = d.ramp_end; sm.flags = d.flags;
+                msgs.push_back(sm);
+            }
+            SrcSeg sg;
+            sg.src_base = sbase; sg.dst_base = dbase; sg.msg_begin = msg_begin; sg.msg_end = (uint32_t)msgs.size();
+            const uint32_t seg_index = (uint32_t)segs.size();
+            segs.push_back(sg);
+            for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
+                SrcWork w;
+                w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
+                work.push_back(w);
+            }
+            fast_frames += (blk_hi - blk_lo) * L_blk;
+        } else {
+            blk_lo = blk_hi = 0;   // everything goes to the generic kernel
+        }
+        const uint64_t fast_lo = fast_ok ? blk_lo * L_blk : m_end, fast_hi = fast_ok ? blk_hi * L_blk : m_end;
+        for (size_t k = i; k < e; k++) {
+            const ohgpu_src_msg_desc& d = descs[order[k]];
+            if (d.n_frames == 0) continue;
+            const uint64_t lo = d.out_frame0, hi = d.out_frame0 + d.n_frames;
+            if (!fast_ok) { rem.push_back(make_piece(d, dev[order[k]], lo, hi, L, M)); continue; }
+            if (lo < fast_lo) rem.push_back(make_piece(d, dev[order[k]], lo, std::min(hi, fast_lo), L, M));
+            if (hi > fast_hi) rem.push_back(make_piece(d, dev[order[k]], std::max(lo, fast_hi), hi, L, M));
+        }
+        i = e;
+    }
+    if (work.empty()) return OHGPU_OK;
+
+    int err = upload_vec(segs, &f.d_segs);
+    if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
+    if (err == OHGPU_OK) err = upload_vec(work, &f.d_work);
+    if (err == OHGPU_OK) err = upload_vec(rem, &f.d_rem);
+    if (err != OHGPU_OK) { free_src_fast(b); return err; }
+    f.enabled = true;
+    f.T = T;
+    f.cpl = cpl;
+    f.n_work = (uint32_t)work.size();
+    f.n_rem = rem.size();
+    f.lds_bytes = lds_bytes;
+    f.fast_out_frames = fast_frames;
+    SrcFastParams& p = f.params;
+    memset(&p, 0, sizeof(p));
+    p.segs = (const SrcSeg*)f.d_segs;
+    p.msgs = (const SegMsg*)f.d_msgs;
+    p.work = (const SrcWork*)f.d_work;
+    p.coef = flt->d_coef;
+    p.src_arena_bytes = b->src_arena_bytes;
+    p.L = L; p.M = M; p.L_blk = L_blk; p.M_blk = M_blk;
+    p.rows = rows; p.cgn = cgn; p.oc_log2 = oc_log2;
+    p.in_blocks = in_blocks; p.out_blocks = out_blocks;
+    p.channels = ch; p.sb = sb; p.db = db;
+    p.src_le = (b->src_endian == OHGPU_ENDIAN_LITTLE && sb > 1) ? 1 : 0;
+    p.dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
+    return OHGPU_OK;
+}
+
+}  // namespace ohgpu
