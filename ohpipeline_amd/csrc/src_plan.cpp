@@ -66,7 +66,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint32_t L = flt->L, M = flt->M, T = flt->T;
     const uint32_t ch = b->channels, sb = b->src_bits / 8, db = b->dst_bits / 8;
     const uint32_t cpl = ch;                                      // the block kernel owns whole (mono/stereo) frames per lane
-    if (ch > 2 || !src_block_supported(T, cpl)) return OHGPU_OK;
+    const uint32_t src_le = (b->src_endian == OHGPU_ENDIAN_LITTLE && sb > 1) ? 1 : 0;
+    const uint32_t dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
+    if (ch > 2 || !src_block_supported(T, cpl, sb, src_le, db, dst_le)) return OHGPU_OK;
     const uint32_t cgn = 1;
     const uint32_t rows = 256;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
@@ -75,10 +77,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint32_t base = L / gcd_u32(L, Oc) * Oc;               // lcm(L, Oc): phase-aligned and store-aligned
     const uint32_t L_blk = base * ((128 + base - 1) / base);
     const uint64_t M_blk64 = (uint64_t)L_blk * M / L;
-    if (M_blk64 + T > 32000) return OHGPU_OK;
+    if (M_blk64 + T > 32000 || M_blk64 < T) return OHGPU_OK;    // a block is at least one filter length of input
     const uint32_t M_blk = (uint32_t)M_blk64;
-    uint32_t in_blocks = (8 * fb_src + 15 + 15) / 16;
-    if (in_blocks % 2 == 0) in_blocks++;                         // odd row stride: 4-way instead of 16-way LDS conflicts
+    const uint32_t in_blocks = src_block_in_blocks(cpl, sb);     // odd row stride: 4-way instead of 16-way LDS conflicts
     const uint32_t out_blocks = Oc * fb_dst / 16;
     const uint32_t ring = 2 * Oc;                                // lane-private ring of rounded outputs
     const uint32_t max_out_per_stage = (8 * L + M - 1) / M;      // #{j : a <= floor(j*M/L) < a+8} <= ceil(8L/M)
@@ -182,8 +183,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     p.rows = rows; p.cgn = cgn; p.oc_log2 = oc_log2;
     p.in_blocks = in_blocks; p.out_blocks = out_blocks;
     p.channels = ch; p.sb = sb; p.db = db;
-    p.src_le = (b->src_endian == OHGPU_ENDIAN_LITTLE && sb > 1) ? 1 : 0;
-    p.dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
+    p.src_le = src_le;
+    p.dst_le = dst_le;
     return OHGPU_OK;
 }
 

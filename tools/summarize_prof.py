@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarises gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh) into profiles/<tag>_summary.md/json:
+per-kernel time statistics from the kernel trace and per-kernel, per-dispatch means of every PMC counter."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = name.split("(")[0]
+    for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_msg_kernel_v1", "pcm_stream_kernel"):
+        if k in name:
+            return k
+    return name[-60:]
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    out = {"tag": tag, "kernels": {}, "counters": {}}
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        per = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        for k, v in per.items():
+            v.sort()
+            out["kernels"][k] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": v[0], "max_us": v[-1],
+                                 "median_us": v[len(v) // 2]}
+    for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            for c, v in cs.items():
+                out["counters"].setdefault(k, {})[c] = sum(v) / len(v)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1, sort_keys=True)
+    with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as md:
+        md.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu` "
+                 "plus one `--pmc` pass per counter set (tools/profile_bench.sh).\n\n## Kernel time (kernel trace)\n\n")
+        md.write("| kernel | calls | avg us | median us | min us | max us |\n|---|---|---|---|---|---|\n")
+        for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["calls"]):
+            md.write(f"| {k} | {v['calls']} | {v['avg_us']:.1f} | {v['median_us']:.1f} | {v['min_us']:.1f} | {v['max_us']:.1f} |\n")
+        if stats:
+            md.write("\n## rocprofv3 --stats (verbatim)\n\n```\n" + open(stats[0]).read() + "```\n")
+        md.write("\n## PMC counters (mean per dispatch)\n\n")
+        for k, cs in out["counters"].items():
+            md.write(f"### {k}\n\n| counter | value |\n|---|---|\n")
+            for c, v in sorted(cs.items()):
+                md.write(f"| {c} | {v:.6g} |\n")
+            md.write("\n")
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
