@@ -1,26 +1,30 @@
-// src_block_kernel.hip -- the tuned resample -> ramp -> pack kernel ("block kernel") for mono/stereo streams.
+// src_block_kernel.hip -- the tuned resample -> ramp -> pack kernel ("block kernel").
 //
 // Mapping (DESIGN.md "Resampler kernel"):
 //   * A stream's output is cut into BLOCKS of L_blk frames that start where the polyphase phase is 0
 //     (L_blk is a multiple of L), so every block walks the same phase sequence.
-//   * One lane owns one block (all CPL channels of it).  All 64 lanes of a wave are therefore at the SAME phase at
-//     the same instruction: the coefficient address is wave-uniform, coefficients come through the scalar cache
-//     into SGPRs and each tap is ONE v_fma_f64 (SGPR coefficient, VGPR sample, VGPR accumulator).
-//   * The lane keeps its T-frame sliding window in registers as exact integer-valued doubles.  The advance loop
-//     is unrolled T times so that the circular window is indexed statically (slot = advance mod T).
+//   * One lane owns one CHANNEL of one block; the CH lanes of a block sit side by side in one wave.  All 64 lanes
+//     of a wave are therefore at the SAME phase at the same instruction: the coefficient address is wave-uniform,
+//     coefficients come through the scalar cache into SGPRs, one 64-byte line (8 taps) at a time through two
+//     16-SGPR buffers, and each tap is ONE v_fma_f64 (SGPR coefficient, VGPR sample, VGPR accumulator).
+//   * The lane keeps its T-sample sliding window in registers as exact integer-valued doubles.  The advance loop
+//     is unrolled T times so that the circular window is indexed statically (slot = advance mod T).  At 2*T + ~50
+//     VGPRs three to four waves fit per SIMD, which is what hides the scalar-cache latency.
 //   * Input is staged through LDS by direct global->LDS loads (16 B per lane, two buffers, eight advances per
-//     stage).  Rounded outputs go to a lane-private LDS ring; at each stage boundary a lane turns every complete
-//     group of 8 (or 16) outputs into packed bytes (ramp + depth/endian conversion, pcm_device.h's code) and
-//     writes them with aligned 16-byte stores.
+//     stage).  Rounded outputs go to an LDS ring; at each stage boundary every complete group of OC outputs is
+//     ramped and packed (pcm_device.h's code) into a small LDS row per block and written back by the same wave
+//     as aligned 16-byte pieces, consecutive lanes on consecutive pieces.
 //   * Accumulation is fp64 FMA on integer-valued operands with |sum| < 2^53: exact, hence bit-identical to the
 //     integer model regardless of order.  No MFMA: this is a 1-D filter.
 // Formats are template parameters (the per-advance unpack sits in the unrolled hot path); layouts without an
 // instantiation run on the generic kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "ohgpu_internal.h"
 #include "pcm_device.h"
@@ -30,6 +34,7 @@ namespace ohgpu {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* global_ptr_t;
 typedef const __attribute__((address_space(4))) double* const_f64_ptr_t;   // constant address space: scalar loads
+typedef __attribute__((address_space(3))) uint8_t* lds_u8_t;
 
 // calls f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a compile-time unrolled loop
 template <typename F, int... S>
@@ -39,15 +44,16 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S..
 }
 
 // ---- explicit scalar-cache loads (the compiler does not see them: every use is fenced by coef_wait) ----
+// Every register an in-flight scalar load writes stays live until a wait covers it: a destination that dies early
+// would be reallocated and then overwritten by the late data.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// eight consecutive coefficients (64 bytes = one scalar-cache line) into 16 SGPRs
-__device__ __forceinline__ void coef_load8(u32x16& q, const_f64_ptr_t p)
+__device__ __forceinline__ void coef_load8(u32x16& q, const_f64_ptr_t p)     // 8 coefficients = one 64-byte line
 {
     asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(q) : "s"(p));
 }
-// all outstanding scalar loads (and LDS operations) have landed; q is usable afterwards
-__device__ __forceinline__ void coef_wait(u32x16& q)
+__device__ __forceinline__ void coef_wait(u32x16& q)                          // all scalar loads (and LDS ops) have landed
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q));
 }
@@ -56,75 +62,71 @@ __device__ __forceinline__ double coef_get(const u32x16& q, int k)
     return __hiloint2double((int)q[2 * k + 1], (int)q[2 * k]);
 }
 
-// one frame (CPL subsamples of SB bytes, packed; 2-byte aligned when CPL*SB is even) from LDS -> S24 integers
-template <int CPL, int SB, bool LE>
-__device__ __forceinline__ void lds_load_frame(const __attribute__((address_space(3))) uint8_t* fp, int32_t (&x)[CPL])
+// one subsample (SB packed bytes at any byte alignment) from LDS -> S24 integer
+template <int SB, bool LE>
+__device__ __forceinline__ int32_t lds_load_subsample(const __attribute__((address_space(3))) uint8_t* p)
 {
-    typedef const __attribute__((address_space(3))) uint16_t* lds_u16_t;
-    if constexpr (CPL == 2 && SB == 3) {
-        // three 16-bit reads: h0 = b0 b1, h1 = b2 b3, h2 = b4 b5 (little-endian halves)
-        const uint32_t h0 = *(lds_u16_t)(fp), h1 = *(lds_u16_t)(fp + 2), h2 = *(lds_u16_t)(fp + 4);
-        if constexpr (LE) {
-            x[0] = ((int32_t)((h0 | (h1 << 16)) << 8)) >> 8;                       // b2 b1 b0
-            x[1] = ((int32_t)(((h1 >> 8) | (h2 << 8)) << 8)) >> 8;                 // b5 b4 b3
-        } else {
-            x[0] = ((int32_t)__builtin_bswap32(h0 | (h1 << 16))) >> 8;             // b0 b1 b2 (b0 = MSB)
-            x[1] = ((int32_t)__builtin_bswap32((h1 >> 8) | (h2 << 8))) >> 8;       // b3 b4 b5
-        }
-    } else if constexpr (SB == 2) {
+    uint32_t w = 0;
 #pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const uint32_t h = *(lds_u16_t)(fp + 2 * c);                            // b0 | b1 << 8
-            const uint32_t v = LE ? h : (((h & 0xffu) << 8) | (h >> 8));
-            x[c] = ((int32_t)(v << 16)) >> 8;                                      // left-justify to 32, then S24
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int b = 0; b < SB; b++) w |= (uint32_t)fp[c * SB + (LE ? SB - 1 - b : b)] << (24 - 8 * b);
-            x[c] = ((int32_t)w) >> 8;
-        }
-    }
+    for (int b = 0; b < SB; b++) w |= (uint32_t)p[LE ? SB - 1 - b : b] << (24 - 8 * b);
+    return ((int32_t)w) >> 8;
 }
 
-template <int T, int CPL, int SB, bool SRC_LE, int DB, bool DST_LE>
-__global__ __launch_bounds__(256, 2)
+__device__ __forceinline__ uint64_t stamp_now()                               // diagnostic builds only
+{
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+template <int T, int CH>
+struct BlockGeom {
+    static constexpr int BPW = 64 / CH;                 // blocks per wave
+    static constexpr int ROWS = 4 * BPW;                // blocks per 256-thread workgroup
+    static constexpr int WAVES_PER_SIMD = T <= 32 ? 3 : 2;
+};
+
+template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
+__global__ __launch_bounds__(256, (BlockGeom<T, CH>::WAVES_PER_SIMD))
 void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
                       const double* __restrict__ coef, const uint16_t* __restrict__ ramp_table,
                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                      const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk)
+                      const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
+                      uint64_t* __restrict__ dbg)
 {
-    constexpr int OC = (CPL * DB * 8) % 16 == 0 ? 8 : 16;     // outputs per store group: OC*CPL*DB is a multiple of 16
+    constexpr int BPW = BlockGeom<T, CH>::BPW, ROWS = BlockGeom<T, CH>::ROWS;
+    constexpr int FB_SRC = CH * SB, FB_DST = CH * DB;
+    constexpr int OC = (FB_DST * 8) % 16 == 0 ? 8 : 16;            // outputs per store group: OC*FB_DST is a multiple of 16
     constexpr int OC_LOG2 = OC == 8 ? 3 : 4;
-    constexpr int RING = 2 * OC;                              // ring entries per lane; the planner checks OC-1 + outputs/stage <= RING
-    constexpr int GROUP_DWORDS = OC * CPL * DB / 4;
-    constexpr int FB_SRC = CPL * SB, FB_DST = CPL * DB;
+    constexpr int RING = 2 * OC;                                   // the planner checks OC-1 + outputs per stage <= RING
+    constexpr int GROUP_BYTES = OC * FB_DST, PIECES = GROUP_BYTES / 16;
     constexpr int IN_BLOCKS = ((8 * FB_SRC + 15 + 15) / 16) | 1;   // 16-byte pieces per staged row, odd (bank spread)
     constexpr int IN_STRIDE = IN_BLOCKS * 16;
+    constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 255) / 256;
+    constexpr uint32_t OFF_IN = 1024, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_STAGE = OFF_RING + RING * 256 * 4;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const lds_u8_t lds = (lds_u8_t)smem;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lane = tid & 63;
     const const_f64_ptr_t coef_c = (const_f64_ptr_t)coef;
+    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0;
+    if constexpr (STAMP) st_mark = stamp_now();
 
-    uint16_t* s_ramp = (uint16_t*)smem;                              // 1 KiB: RampArray
-    uint8_t* s_in = smem + 1024;                                     // 2 x 256 x IN_STRIDE raw packed input
-    int32_t* s_ring = (int32_t*)(s_in + 2 * 256 * IN_STRIDE);        // [RING][256][CPL] rounded S24 outputs
-
-    for (uint32_t i = tid; i < kRampTableCount; i += 256) s_ramp[i] = ramp_table[i];
+    for (uint32_t i = tid; i < kRampTableCount; i += 256) ((__attribute__((address_space(3))) uint16_t*)lds)[i] = ramp_table[i];
 
     const SrcWork wk = work[blockIdx.x];
     const SrcSeg seg = segs[wk.seg];
     const uint32_t n_blocks = wk.n_blocks;
-    const uint32_t row = tid;
-    const bool lane_valid = row < n_blocks;
+    const uint32_t bw = lane / CH;                       // block within the wave
+    const uint32_t c = lane - bw * CH;                   // this lane's channel
+    const uint32_t row = wave * BPW + bw;                // block within the workgroup
+    const bool lane_valid = bw < BPW && row < n_blocks;
     const uint64_t blk = wk.first_block + row;
-    const int64_t n_start = (int64_t)(blk * M_blk);     // absolute input frame at advance a = 0
-    const uint64_t m_start = blk * L_blk;               // absolute output frame at j = 0
+    const int64_t n_start = (int64_t)(blk * M_blk);      // absolute input frame at advance a = 0
+    const uint64_t m_start = blk * L_blk;                // absolute output frame at j = 0
     const int64_t row_g = seg.src_base + (n_start - T) * (int64_t)FB_SRC;   // byte offset of the frame at a_lin = 0
-    uint8_t* const row_dst = dst + seg.dst_base + (int64_t)(m_start * FB_DST);
     // The stream start reads as zeros.  Blocks are at least T input frames long (planner), so only a block that
     // starts at input frame 0 reaches before the stream: its whole warm-up pass (advances a < 0) must be zeros.
     const bool first_block = n_start == 0;
@@ -144,28 +146,30 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     }
 
     // ---- input staging: stage q holds advances [8q - T, 8q + 8 - T) of every row, as raw packed bytes.
-    // Thread `tid` moves pieces idx = it*256 + tid (it < IN_BLOCKS): piece `part` of row r = idx / IN_BLOCKS.
-    int64_t piece_g[IN_BLOCKS];      // unaligned byte offset of that row's frame at a_lin = 0
-    int32_t piece_part[IN_BLOCKS];   // -1: nothing to move
+    // Thread `tid` moves pieces idx = it*256 + tid: piece `part` of row r = idx / IN_BLOCKS.
+    int64_t piece_g[IN_ITERS];       // unaligned byte offset of that row's frame at a_lin = 0
+    int32_t piece_part[IN_ITERS];    // -1: nothing to move
 #pragma unroll
-    for (int it = 0; it < IN_BLOCKS; it++) {
+    for (int it = 0; it < IN_ITERS; it++) {
         const uint32_t idx = it * 256 + tid;
         const uint32_t r = idx / IN_BLOCKS;
         piece_g[it] = seg.src_base + ((int64_t)((wk.first_block + r) * M_blk) - T) * (int64_t)FB_SRC;
-        piece_part[it] = (r < n_blocks) ? (int32_t)(idx - r * IN_BLOCKS) : -1;
+        piece_part[it] = (r < n_blocks && r < (uint32_t)ROWS) ? (int32_t)(idx - r * IN_BLOCKS) : -1;
     }
     auto issue_stage = [&](int q) __attribute__((always_inline)) {
-        uint8_t* buf = s_in + (uint32_t)(q & 1) * 256 * IN_STRIDE;
+        const uint32_t buf = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
         const int64_t shift = (int64_t)q * 8 * FB_SRC;
 #pragma unroll
-        for (int it = 0; it < IN_BLOCKS; it++) {
+        for (int it = 0; it < IN_ITERS; it++) {
             if (piece_part[it] >= 0) {
                 const int64_t addr = ((piece_g[it] + shift) & ~(int64_t)15) + 16 * (int64_t)piece_part[it];
                 if (addr >= 0 && (uint64_t)addr + 16 <= src_arena_bytes) {
-                    uint8_t* wave_dst = buf + (size_t)(it * 256 + wave * 64) * 16;   // LDS dest = wave-uniform base + lane*16
-                    __builtin_amdgcn_global_load_lds((global_ptr_t)(src + addr), (lds_ptr_t)wave_dst, 16, 0, 0);
+                    // LDS destination = wave-uniform base + lane*16
+                    __builtin_amdgcn_global_load_lds((global_ptr_t)(src + addr),
+                                                     (lds_ptr_t)(smem + buf + (uint32_t)(it * 256 + wave * 64) * 16), 16, 0, 0);
                 } else {
-                    uint8_t* d = buf + (size_t)(it * 256 + tid) * 16;               // piece straddles an end of the arena
+                    // piece straddles an end of the arena: copy only the bytes that exist
+                    const lds_u8_t d = lds + buf + (uint32_t)(it * 256 + tid) * 16;
                     for (int b = 0; b < 16; b++) {
                         const int64_t a1 = addr + b;
                         d[b] = (a1 >= 0 && (uint64_t)a1 < src_arena_bytes) ? src[a1] : (uint8_t)0;
@@ -175,66 +179,65 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         }
     };
 
-    // ---- tail: ramp + pack + store every complete group of OC outputs sitting in the lane's ring ----
+    // ---- tail: every complete group of OC outputs in the ring is ramped, packed and written back ----
+    const __attribute__((address_space(3))) int32_t* ring = (const __attribute__((address_space(3))) int32_t*)(lds + OFF_RING);
+    const __attribute__((address_space(3))) uint16_t* s_ramp = (const __attribute__((address_space(3))) uint16_t*)lds;
+    const int64_t wave_dst = seg.dst_base + (int64_t)((wk.first_block + wave * BPW) * L_blk) * FB_DST;   // first block of this wave
+    const uint32_t wave_rows = (wave * BPW >= n_blocks) ? 0u : (n_blocks - wave * BPW < (uint32_t)BPW ? n_blocks - wave * BPW : (uint32_t)BPW);
     uint32_t drained = 0;                                 // groups written so far (wave-uniform)
     auto drain = [&](int j_now) __attribute__((always_inline)) {
         while (drained < ((uint32_t)j_now >> OC_LOG2)) {
+            const uint32_t j0 = drained << OC_LOG2;
             if (lane_valid) {
-                uint32_t packed[GROUP_DWORDS];
+                // step 1: this lane's channel of the OC outputs -> bytes in the block's row of the store stage
+                const lds_u8_t srow = lds + OFF_STAGE + row * GROUP_BYTES + c * DB;
 #pragma unroll
-                for (int d = 0; d < GROUP_DWORDS; d++) packed[d] = 0;
-                const uint32_t j0 = drained << OC_LOG2;
-                static_for([&](auto oc) __attribute__((always_inline)) {
-                    constexpr int o = decltype(oc)::value;
+                for (int o = 0; o < OC; o++) {
                     const uint32_t jo = j0 + o;
-                    const int32_t* e = s_ring + ((jo & (RING - 1)) * 256 + row) * CPL;
                     uint32_t i = (uint32_t)(m_start + jo - cur.out0);
                     while (i >= cur.n) {
                         mi++;
                         cur = msgs[mi];
                         i = (uint32_t)(m_start + jo - cur.out0);
                     }
-                    const bool ramp = (cur.flags & OHGPU_FLAG_RAMP) != 0;
-                    uint32_t mult = 0;
-                    if (ramp) {
+                    uint32_t w = ((uint32_t)ring[(jo & (RING - 1)) * 256 + tid]) << 8;     // left-justified BE word
+                    if (cur.flags & OHGPU_FLAG_RAMP) {
                         const int32_t tot = (int32_t)((uint32_t)cur.ramp_start - (uint32_t)cur.ramp_end);
-                        mult = s_ramp[ramp_index(cur.ramp_start, tot, (int32_t)i, (int32_t)cur.n)];
+                        const uint32_t mult = s_ramp[ramp_index(cur.ramp_start, tot, (int32_t)i, (int32_t)cur.n)];
+                        w = ramp_word(w, mult, 3, CH, c);
                     }
+                    if (DB == 4 && (cur.flags & OHGPU_FLAG_ZERO_LSB32)) w &= 0xffffff00u;
 #pragma unroll
-                    for (int c = 0; c < CPL; c++) {
-                        uint32_t w = ((uint32_t)e[c]) << 8;                 // left-justified BE word
-                        if (ramp) w = ramp_word(w, mult, 3, CPL, c);
-                        if (DB == 4 && (cur.flags & OHGPU_FLAG_ZERO_LSB32)) w &= 0xffffff00u;
-                        // v = the DB bytes in memory order, first byte in the low bits
-                        const uint32_t v = DST_LE ? (w >> (32 - 8 * DB))
-                                                  : (__builtin_bswap32(w) & (DB == 4 ? 0xffffffffu : ((1u << (8 * (DB & 3))) - 1)));
-                        constexpr int pos = (o * CPL) * DB;
-                        const int bp = pos + c * DB;
-                        const int dw = bp >> 2, sh = (bp & 3) * 8;
-                        packed[dw] |= v << sh;
-                        if (sh + 8 * DB > 32) packed[dw + 1] |= v >> (32 - sh);
-                    }
-                }, std::make_integer_sequence<int, OC>{});
-                uint4* out = (uint4*)(row_dst + (size_t)j0 * FB_DST);
-#pragma unroll
-                for (int q4 = 0; q4 < GROUP_DWORDS / 4; q4++)
-                    out[q4] = make_uint4(packed[4 * q4], packed[4 * q4 + 1], packed[4 * q4 + 2], packed[4 * q4 + 3]);
+                    for (int b = 0; b < DB; b++) srow[o * FB_DST + (DST_LE ? DB - 1 - b : b)] = (uint8_t)(w >> (24 - 8 * b));
+                }
             }
+            // step 2: the wave writes its blocks' rows back, consecutive lanes on consecutive 16-byte pieces
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int pp = 0; pp < (BPW * PIECES + 63) / 64; pp++) {
+                const uint32_t piece = pp * 64 + lane;
+                const uint32_t r = piece / PIECES, part = piece - r * PIECES;
+                if (r < wave_rows) {
+                    const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(lds + OFF_STAGE + (wave * BPW + r) * GROUP_BYTES + part * 16);
+                    *(u32x4*)(dst + wave_dst + (int64_t)((uint64_t)r * L_blk + j0) * FB_DST + part * 16) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             drained++;
         }
     };
 
-    double win[T][CPL];
+    double win[T];
 #pragma unroll
-    for (int s = 0; s < T; s++)
-#pragma unroll
-        for (int c = 0; c < CPL; c++) win[s][c] = 0.0;
+    for (int s = 0; s < T; s++) win[s] = 0.0;
 
     const int total = (int)M_blk + T;         // advances a = a_lin - T for a_lin in [0, total)
     int j = 0;                                // outputs emitted so far (wave-uniform)
     int t = 0;                                // j * M
-    uint32_t in_off = 0;                      // byte offset (from smem) of the current stage's first frame of this row
-    const __attribute__((address_space(3))) uint8_t* smem_lds = (const __attribute__((address_space(3))) uint8_t*)smem;
+    uint32_t in_off = OFF_IN;                 // LDS offset of this lane's subsample in the current stage's first frame
     const bool any_first = __any(first_block) != 0;
 
     issue_stage(0);
@@ -247,76 +250,65 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             const int a = a_lin - T;
             if constexpr ((s & 7) == 0) {
                 const int q = a_lin >> 3;
+                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_compute += n - st_mark; st_mark = n; }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();                          // stage q landed everywhere; stage q-1 fully consumed
+                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
                 if ((q + 1) * 8 < total) issue_stage(q + 1);
+                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
                 drain(j);
-                in_off = 1024 + (uint32_t)(q & 1) * 256 * IN_STRIDE + row * IN_STRIDE +
-                         (uint32_t)((row_g + (int64_t)q * 8 * FB_SRC) & 15);
+                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_drain += n - st_mark; st_mark = n; }
+                in_off = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE + row * IN_STRIDE +
+                         (uint32_t)((row_g + (int64_t)q * 8 * FB_SRC) & 15) + c * SB;
             }
-            // coefficients of this advance's first output: the first line is requested before the frame is unpacked
+            // Coefficients of this advance's first output: all four lines (T = 32) are requested at once, before the
+            // sample is unpacked, so that an output costs ONE scalar-cache round trip (hidden by the SIMD's other waves).
+            static_assert(T == 32, "this body holds one output's coefficients in four 16-SGPR lines");
             const bool emits = t < L * (a + 1);
-            u32x16 qa, qb;
-            const_f64_ptr_t cp = coef_c;
-            if (emits) {
-                cp = coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T;
-                coef_load8(qa, cp);
-            }
-            // ---- advance: frame (n_start + a) enters slot s ----
-            {
-                int32_t x[CPL];
-                lds_load_frame<CPL, SB, SRC_LE>(smem_lds + in_off + (s & 7) * FB_SRC, x);
-#pragma unroll
-                for (int c = 0; c < CPL; c++) win[s][c] = (double)x[c];
-            }
+            u32x16 q0, q1, q2, q3;
+            auto load_lines = [&](const_f64_ptr_t cp) __attribute__((always_inline)) {
+                asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\t"
+                             "s_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0"
+                             : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3) : "s"(cp));
+            };
+            if (emits) load_lines(coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T);
+            // ---- advance: this channel's sample of frame (n_start + a) enters slot s ----
+            win[s] = (double)lds_load_subsample<SB, SRC_LE>(lds + in_off + (s & 7) * FB_SRC);
             // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
-            // Coefficients move through two 16-SGPR buffers, one 64-byte line (8 taps) at a time: while the FMAs of
-            // line i run, line i+1 is in flight.  (Every register an in-flight scalar load writes stays live until
-            // a wait covers it: a destination that dies early would be reused and then overwritten by the late data.)
             if (emits) {
                 while (true) {
-                    double acc[CPL][2];
-#pragma unroll
-                    for (int c = 0; c < CPL; c++) acc[c][0] = acc[c][1] = 0.0;
-                    static_for([&](auto line) __attribute__((always_inline)) {
-                        constexpr int li = decltype(line)::value;
-                        u32x16& qcur = (li & 1) ? qb : qa;
-                        u32x16& qnext = (li & 1) ? qa : qb;
-                        coef_wait(qcur);
-                        if constexpr (li + 1 < T / 8) {
-                            coef_load8(qnext, cp + 8 * (li + 1));
-                        }
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++) {
-                            constexpr int k0 = li * 8;
-                            const double ck = coef_get(qcur, kk);
-#pragma unroll
-                            for (int c = 0; c < CPL; c++)
-                                acc[c][kk & 1] = fma(ck, win[(s - (k0 + kk) + 2 * T) % T][c], acc[c][kk & 1]);
-                        }
-                    }, std::make_integer_sequence<int, T / 8>{});
-                    int32_t* e = s_ring + (((uint32_t)j & (RING - 1)) * 256 + row) * CPL;
-#pragma unroll
-                    for (int c = 0; c < CPL; c++) e[c] = src_round_s24(acc[c][0] + acc[c][1]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));   // the lines have landed
+                    double acc0 = 0.0, acc1 = 0.0;
+                    static_for([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = 2 * decltype(kc)::value;
+                        const u32x16& qk = (k < 8) ? q0 : (k < 16) ? q1 : (k < 24) ? q2 : q3;
+                        acc0 = fma(coef_get(qk, k & 7), win[(s - k + 2 * T) % T], acc0);
+                        acc1 = fma(coef_get(qk, (k + 1) & 7), win[(s - (k + 1) + 2 * T) % T], acc1);
+                    }, std::make_integer_sequence<int, T / 2>{});
+                    ((__attribute__((address_space(3))) int32_t*)(lds + OFF_RING))[((uint32_t)j & (RING - 1)) * 256 + tid] =
+                        src_round_s24(acc0 + acc1);
                     j++;
                     t += M;
                     if (!(t < L * (a + 1))) break;
-                    cp = coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T;
-                    coef_load8(qa, cp);
+                    load_lines(coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T);
                 }
             }
         }, std::make_integer_sequence<int, T>{});
         if (g == 0 && any_first) {                        // warm-up pass done: a stream's first block starts from silence
 #pragma unroll
-            for (int s = 0; s < T; s++)
-#pragma unroll
-                for (int c = 0; c < CPL; c++) win[s][c] = first_block ? 0.0 : win[s][c];
+            for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
         }
     }
     drain(j);
+    if constexpr (STAMP) {
+        if (dbg != nullptr && lane == 0) {
+            uint64_t* o = dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+            o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute;
+        }
+    }
 }
 
-// ---- instantiations: (T, CPL, source bytes, source LE, destination bytes, destination LE) ----
+// ---- instantiations: (T, channels, source bytes, source LE, destination bytes, destination LE) ----
 #define OHGPU_BLOCK_KERNELS(X)      \
     X(32, 2, 3, true, 3, false)     \
     X(32, 2, 3, true, 3, true)      \
@@ -327,30 +319,70 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     X(32, 2, 2, true, 2, true)      \
     X(32, 2, 2, true, 2, false)
 
-template <int T, int CPL, int SB, bool SRC_LE, int DB, bool DST_LE>
+template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
 static hipError_t launch_one(const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
 {
-    auto kernel = src_block_kernel<T, CPL, SB, SRC_LE, DB, DST_LE>;
+    auto kernel = src_block_kernel<T, CH, SB, SRC_LE, DB, DST_LE>;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fast.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(256), b->fast.lds_bytes, s,
                        p.segs, p.msgs, p.work, p.coef, p.ramp_table, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk);
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
-bool src_block_supported(uint32_t T, uint32_t cpl, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le)
+bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le)
 {
 #define X(t, c, s_, sl, d, dl) \
-    if (T == t && cpl == c && sb == s_ && (src_le != 0) == sl && db == d && (dst_le != 0) == dl) return true;
+    if (T == t && ch == c && sb == s_ && (src_le != 0) == sl && db == d && (dst_le != 0) == dl) return true;
     OHGPU_BLOCK_KERNELS(X)
 #undef X
     return false;
 }
 
-uint32_t src_block_in_blocks(uint32_t cpl, uint32_t sb)
+// geometry the planner needs (must match the kernel's constexprs)
+void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* oc, uint32_t* lds_bytes)
 {
-    return ((8 * cpl * sb + 15 + 15) / 16) | 1;
+    const uint32_t bpw = 64 / ch, r = 4 * bpw;
+    const uint32_t fb_src = ch * sb, fb_dst = ch * db;
+    const uint32_t o = (fb_dst * 8) % 16 == 0 ? 8 : 16;
+    const uint32_t in_blocks = ((8 * fb_src + 15 + 15) / 16) | 1;
+    *rows = r;
+    *oc = o;
+    *lds_bytes = 1024 + 2 * r * in_blocks * 16 + (2 * o) * 256 * 4 + r * o * fb_dst;
+    (void)T;
+}
+
+// Diagnostic only (OHGPU_STAMP_FILE=<path>): runs the stamped build of the S24LE->S24BE stereo kernel once, waits,
+// and writes per-wave {wait, issue, drain, compute} cycle sums as text.  Never used by the product path.
+static hipError_t launch_stamped(const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s, const char* path)
+{
+    auto kernel = src_block_kernel<32, 2, 3, true, 3, false, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fast.lds_bytes);
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)b->fast.n_work * 16;
+    uint64_t* d = nullptr;
+    e = hipMalloc((void**)&d, n * sizeof(uint64_t));
+    if (e != hipSuccess) return e;
+    hipMemsetAsync(d, 0, n * sizeof(uint64_t), s);
+    hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(256), b->fast.lds_bytes, s,
+                       p.segs, p.msgs, p.work, p.coef, p.ramp_table, p.src, p.dst,
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, d);
+    e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+        std::vector<uint64_t> h(n);
+        e = hipMemcpy(h.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(path, "w")) {
+            double sum[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i < n; i += 4) for (int k = 0; k < 4; k++) sum[k] += (double)h[i + k];
+            const double waves = (double)n / 4;
+            fprintf(f, "waves %.0f mean cycles per wave: wait %.0f issue %.0f drain %.0f compute %.0f\n", waves,
+                    sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves);
+            fclose(f);
+        }
+    }
+    hipFree(d);
+    return e;
 }
 
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
@@ -360,9 +392,13 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
     prm.src = src;
     prm.dst = dst;
     prm.ramp_table = ctx->d_ramp_table;
-    const uint32_t T = b->fast.T, cpl = b->fast.cpl;
-#define X(t, c, s_, sl, d, dl)                                                                                   \
-    if (T == t && cpl == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
+    if (const char* path = getenv("OHGPU_STAMP_FILE")) {
+        if (b->fast.T == 32 && prm.channels == 2 && prm.sb == 3 && prm.src_le && prm.db == 3 && !prm.dst_le)
+            return launch_stamped(b, prm, s, path);
+    }
+    const uint32_t T = b->fast.T;
+#define X(t, c, s_, sl, d, dl)                                                                                            \
+    if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
         return launch_one<t, c, s_, sl, d, dl>(b, prm, s);
     OHGPU_BLOCK_KERNELS(X)
 #undef X

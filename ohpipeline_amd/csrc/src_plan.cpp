@@ -65,27 +65,22 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const ohgpu_src* flt = b->src;
     const uint32_t L = flt->L, M = flt->M, T = flt->T;
     const uint32_t ch = b->channels, sb = b->src_bits / 8, db = b->dst_bits / 8;
-    const uint32_t cpl = ch;                                      // the block kernel owns whole (mono/stereo) frames per lane
     const uint32_t src_le = (b->src_endian == OHGPU_ENDIAN_LITTLE && sb > 1) ? 1 : 0;
     const uint32_t dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
-    if (ch > 2 || !src_block_supported(T, cpl, sb, src_le, db, dst_le)) return OHGPU_OK;
-    const uint32_t cgn = 1;
-    const uint32_t rows = 256;
+    if (!src_block_supported(T, ch, sb, src_le, db, dst_le)) return OHGPU_OK;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
-    const uint32_t oc_log2 = (fb_dst % 2 == 0) ? 3 : 4;          // Oc * fb_dst must be a multiple of 16
-    const uint32_t Oc = 1u << oc_log2;
+    uint32_t rows = 0, Oc = 0, lds_bytes = 0;
+    src_block_geometry(T, ch, sb, db, &rows, &Oc, &lds_bytes);
+    const uint32_t oc_log2 = Oc == 8 ? 3 : 4;                    // Oc * fb_dst is a multiple of 16
     const uint32_t base = L / gcd_u32(L, Oc) * Oc;               // lcm(L, Oc): phase-aligned and store-aligned
     const uint32_t L_blk = base * ((128 + base - 1) / base);
     const uint64_t M_blk64 = (uint64_t)L_blk * M / L;
     if (M_blk64 + T > 32000 || M_blk64 < T) return OHGPU_OK;    // a block is at least one filter length of input
     const uint32_t M_blk = (uint32_t)M_blk64;
-    const uint32_t in_blocks = src_block_in_blocks(cpl, sb);     // odd row stride: 4-way instead of 16-way LDS conflicts
-    const uint32_t out_blocks = Oc * fb_dst / 16;
-    const uint32_t ring = 2 * Oc;                                // lane-private ring of rounded outputs
     const uint32_t max_out_per_stage = (8 * L + M - 1) / M;      // #{j : a <= floor(j*M/L) < a+8} <= ceil(8L/M)
-    if (Oc - 1 + max_out_per_stage > ring) return OHGPU_OK;
-    const uint32_t lds_bytes = 1024 + 2 * rows * in_blocks * 16 + ring * rows * cpl * 4;
-    if (lds_bytes > 80 * 1024) return OHGPU_OK;                  // two workgroups per CU must fit in 160 KiB
+    if (Oc - 1 + max_out_per_stage > 2 * Oc) return OHGPU_OK;    // the LDS ring holds 2*Oc outputs per lane
+    if (lds_bytes > 160 * 1024) return OHGPU_OK;
+    (void)fb_src;
 
     // order messages by (stream, output position); a stream is identified by where its absolute frame 0 lives
     std::vector<uint32_t> order(n);
@@ -167,7 +162,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
     f.enabled = true;
     f.T = T;
-    f.cpl = cpl;
+    f.cpl = 1;
     f.n_work = (uint32_t)work.size();
     f.n_rem = rem.size();
     f.lds_bytes = lds_bytes;
@@ -180,8 +175,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     p.coef = flt->d_coef;
     p.src_arena_bytes = b->src_arena_bytes;
     p.L = L; p.M = M; p.L_blk = L_blk; p.M_blk = M_blk;
-    p.rows = rows; p.cgn = cgn; p.oc_log2 = oc_log2;
-    p.in_blocks = in_blocks; p.out_blocks = out_blocks;
+    p.rows = rows; p.cgn = ch; p.oc_log2 = oc_log2;
     p.channels = ch; p.sb = sb; p.db = db;
     p.src_le = src_le;
     p.dst_le = dst_le;
