@@ -62,14 +62,25 @@ __device__ __forceinline__ double coef_get(const u32x16& q, int k)
     return __hiloint2double((int)q[2 * k + 1], (int)q[2 * k]);
 }
 
-// one subsample (SB packed bytes at any byte alignment) from LDS -> S24 integer
+// one subsample (SB packed bytes at any byte alignment) from LDS -> S24 integer.  LDS reads need no alignment
+// on gfx950 (unaligned access mode); a 3-byte subsample is read as the 4 bytes that start at it.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 template <int SB, bool LE>
 __device__ __forceinline__ int32_t lds_load_subsample(const __attribute__((address_space(3))) uint8_t* p)
 {
-    uint32_t w = 0;
-#pragma unroll
-    for (int b = 0; b < SB; b++) w |= (uint32_t)p[LE ? SB - 1 - b : b] << (24 - 8 * b);
-    return ((int32_t)w) >> 8;
+    if constexpr (SB == 3) {
+        const uint32_t w = *(const __attribute__((address_space(3))) u32_unaligned*)p;     // b0 b1 b2 (+1 byte)
+        return LE ? ((int32_t)(w << 8)) >> 8 : ((int32_t)__builtin_bswap32(w)) >> 8;
+    } else if constexpr (SB == 2) {
+        const uint32_t h = *(const __attribute__((address_space(3))) u16_unaligned*)p;
+        return LE ? ((int32_t)(h << 16)) >> 8 : ((int32_t)(__builtin_bswap32(h) & 0xffff0000u)) >> 8;
+    } else if constexpr (SB == 4) {
+        const uint32_t w = *(const __attribute__((address_space(3))) u32_unaligned*)p;
+        return LE ? ((int32_t)w) >> 8 : ((int32_t)__builtin_bswap32(w)) >> 8;
+    } else {
+        return ((int32_t)((uint32_t)p[0] << 24)) >> 8;
+    }
 }
 
 __device__ __forceinline__ uint64_t stamp_now()                               // diagnostic builds only
@@ -99,11 +110,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     constexpr int OC = (FB_DST * 8) % 16 == 0 ? 8 : 16;            // outputs per store group: OC*FB_DST is a multiple of 16
     constexpr int OC_LOG2 = OC == 8 ? 3 : 4;
     constexpr int RING = 2 * OC;                                   // the planner checks OC-1 + outputs per stage <= RING
-    constexpr int GROUP_BYTES = OC * FB_DST, PIECES = GROUP_BYTES / 16;
     constexpr int IN_BLOCKS = ((8 * FB_SRC + 15 + 15) / 16) | 1;   // 16-byte pieces per staged row, odd (bank spread)
     constexpr int IN_STRIDE = IN_BLOCKS * 16;
     constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 255) / 256;
-    constexpr uint32_t OFF_IN = 1024, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_STAGE = OFF_RING + RING * 256 * 4;
+    constexpr uint32_t OFF_IN = 1024, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const lds_u8_t lds = (lds_u8_t)smem;
@@ -131,10 +141,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // starts at input frame 0 reaches before the stream: its whole warm-up pass (advances a < 0) must be zeros.
     const bool first_block = n_start == 0;
 
-    // message that holds this lane's first output frame (messages of a segment tile its output range)
+    // Message that holds this lane's first output frame (messages of a segment tile its output range).  Kept
+    // relative to the block: msg_rel0 = (message's first output) - m_start, so output j is frame j - msg_rel0 of it.
     uint32_t mi = seg.msg_begin;
-    SegMsg cur;
-    cur.out0 = 0; cur.n = 0xffffffffu; cur.ramp_start = 0; cur.ramp_end = 0; cur.flags = 0;
+    int32_t msg_rel0 = 0;
+    uint32_t msg_n = 0x7fffffffu, msg_ramp = 0, msg_flags = 0;     // msg_ramp = start | end << 16
     if (lane_valid) {
         uint32_t lo = seg.msg_begin, hi = seg.msg_end;
         while (hi - lo > 1) {
@@ -142,8 +153,12 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             if (msgs[mid].out0 <= m_start) lo = mid; else hi = mid;
         }
         mi = lo;
-        cur = msgs[mi];
+        const SegMsg m0 = msgs[mi];
+        msg_rel0 = (int32_t)(int64_t)(m0.out0 - m_start);
+        msg_n = m0.n; msg_ramp = (uint32_t)m0.ramp_start | ((uint32_t)m0.ramp_end << 16); msg_flags = m0.flags;
     }
+    // first output index at which this lane needs the slow path: always while ramping, else at the message's end
+    int32_t evt_j = (msg_flags & OHGPU_FLAG_RAMP) ? 0 : msg_rel0 + (int32_t)msg_n;
 
     // ---- input staging: stage q holds advances [8q - T, 8q + 8 - T) of every row, as raw packed bytes.
     // Thread `tid` moves pieces idx = it*256 + tid: piece `part` of row r = idx / IN_BLOCKS.
@@ -179,8 +194,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         }
     };
 
-    // ---- tail: every complete group of OC outputs in the ring is ramped, packed and written back ----
-    const __attribute__((address_space(3))) int32_t* ring = (const __attribute__((address_space(3))) int32_t*)(lds + OFF_RING);
+    // ---- tail: every complete group of OC outputs in the ring is packed and written back by the wave that produced
+    // it.  Lane l of pass `it` owns frame (it*64 + l): block (frame / OC) of the wave, output (frame % OC) of the group.
+    const __attribute__((address_space(3))) uint32_t* ring = (const __attribute__((address_space(3))) uint32_t*)(lds + OFF_RING);
     const __attribute__((address_space(3))) uint16_t* s_ramp = (const __attribute__((address_space(3))) uint16_t*)lds;
     const int64_t wave_dst = seg.dst_base + (int64_t)((wk.first_block + wave * BPW) * L_blk) * FB_DST;   // first block of this wave
     const uint32_t wave_rows = (wave * BPW >= n_blocks) ? 0u : (n_blocks - wave * BPW < (uint32_t)BPW ? n_blocks - wave * BPW : (uint32_t)BPW);
@@ -188,44 +204,34 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     auto drain = [&](int j_now) __attribute__((always_inline)) {
         while (drained < ((uint32_t)j_now >> OC_LOG2)) {
             const uint32_t j0 = drained << OC_LOG2;
-            if (lane_valid) {
-                // step 1: this lane's channel of the OC outputs -> bytes in the block's row of the store stage
-                const lds_u8_t srow = lds + OFF_STAGE + row * GROUP_BYTES + c * DB;
 #pragma unroll
-                for (int o = 0; o < OC; o++) {
-                    const uint32_t jo = j0 + o;
-                    uint32_t i = (uint32_t)(m_start + jo - cur.out0);
-                    while (i >= cur.n) {
-                        mi++;
-                        cur = msgs[mi];
-                        i = (uint32_t)(m_start + jo - cur.out0);
-                    }
-                    uint32_t w = ((uint32_t)ring[(jo & (RING - 1)) * 256 + tid]) << 8;     // left-justified BE word
-                    if (cur.flags & OHGPU_FLAG_RAMP) {
-                        const int32_t tot = (int32_t)((uint32_t)cur.ramp_start - (uint32_t)cur.ramp_end);
-                        const uint32_t mult = s_ramp[ramp_index(cur.ramp_start, tot, (int32_t)i, (int32_t)cur.n)];
-                        w = ramp_word(w, mult, 3, CH, c);
-                    }
-                    if (DB == 4 && (cur.flags & OHGPU_FLAG_ZERO_LSB32)) w &= 0xffffff00u;
-#pragma unroll
-                    for (int b = 0; b < DB; b++) srow[o * FB_DST + (DST_LE ? DB - 1 - b : b)] = (uint8_t)(w >> (24 - 8 * b));
-                }
-            }
-            // step 2: the wave writes its blocks' rows back, consecutive lanes on consecutive 16-byte pieces
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int pp = 0; pp < (BPW * PIECES + 63) / 64; pp++) {
-                const uint32_t piece = pp * 64 + lane;
-                const uint32_t r = piece / PIECES, part = piece - r * PIECES;
+            for (int it = 0; it < BPW * OC / 64; it++) {
+                const uint32_t frame = it * 64 + lane;
+                const uint32_t r = frame >> OC_LOG2, o = frame & (OC - 1);
                 if (r < wave_rows) {
-                    const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(lds + OFF_STAGE + (wave * BPW + r) * GROUP_BYTES + part * 16);
-                    *(u32x4*)(dst + wave_dst + (int64_t)((uint64_t)r * L_blk + j0) * FB_DST + part * 16) = v;
+                    const __attribute__((address_space(3))) uint32_t* e = ring + ((j0 + o) & (RING - 1)) * 256 + wave * 64 + r * CH;
+                    uint32_t packed[(FB_DST + 3) / 4];
+#pragma unroll
+                    for (int d = 0; d < (FB_DST + 3) / 4; d++) packed[d] = 0;
+#pragma unroll
+                    for (int cc = 0; cc < CH; cc++) {
+                        const uint32_t w = e[cc];                          // left-justified BE word, ramp already applied
+                        // v = the DB bytes in memory order, first byte in the low bits
+                        const uint32_t v = DST_LE ? (w >> (32 - 8 * DB))
+                                                  : (__builtin_bswap32(w) & (DB == 4 ? 0xffffffffu : ((1u << (8 * (DB & 3))) - 1)));
+                        constexpr int dummy = 0; (void)dummy;
+                        const int bp = cc * DB;
+                        const int dw = bp >> 2, sh = (bp & 3) * 8;
+                        packed[dw] |= v << sh;
+                        if (sh + 8 * DB > 32) packed[dw + 1] |= v >> (32 - sh);
+                    }
+                    uint8_t* out = dst + wave_dst + (int64_t)((uint64_t)r * L_blk + j0 + o) * FB_DST;
+#pragma unroll
+                    for (int d = 0; d < FB_DST / 4; d++) *(u32_unaligned*)(out + 4 * d) = packed[d];
+                    if constexpr ((FB_DST & 3) >= 2) *(u16_unaligned*)(out + (FB_DST & ~3)) = (uint16_t)packed[FB_DST / 4];
+                    if constexpr (FB_DST & 1) out[FB_DST - 1] = (uint8_t)(packed[FB_DST / 4] >> ((FB_DST & 2) * 8));
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             drained++;
         }
     };
@@ -285,8 +291,26 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                         acc0 = fma(coef_get(qk, k & 7), win[(s - k + 2 * T) % T], acc0);
                         acc1 = fma(coef_get(qk, (k + 1) & 7), win[(s - (k + 1) + 2 * T) % T], acc1);
                     }, std::make_integer_sequence<int, T / 2>{});
-                    ((__attribute__((address_space(3))) int32_t*)(lds + OFF_RING))[((uint32_t)j & (RING - 1)) * 256 + tid] =
-                        src_round_s24(acc0 + acc1);
+                    uint32_t w = ((uint32_t)src_round_s24(acc0 + acc1)) << 8;      // left-justified BE word (a11)
+                    if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
+                        if (lane_valid && j >= evt_j) {
+                            while ((uint32_t)(j - msg_rel0) >= msg_n) {             // next message of the segment
+                                mi++;
+                                const SegMsg mm = msgs[mi];
+                                msg_rel0 = (int32_t)(int64_t)(mm.out0 - m_start);
+                                msg_n = mm.n; msg_ramp = (uint32_t)mm.ramp_start | ((uint32_t)mm.ramp_end << 16); msg_flags = mm.flags;
+                            }
+                            if (msg_flags & OHGPU_FLAG_RAMP) {
+                                const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
+                                const uint32_t mult = s_ramp[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
+                                w = ramp_word(w, mult, 3, CH, c);
+                                evt_j = j + 1;
+                            } else {
+                                evt_j = msg_rel0 + (int32_t)msg_n;
+                            }
+                        }
+                    }
+                    ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_RING))[((uint32_t)j & (RING - 1)) * 256 + tid] = w;
                     j++;
                     t += M;
                     if (!(t < L * (a + 1))) break;
@@ -349,7 +373,7 @@ void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint3
     const uint32_t in_blocks = ((8 * fb_src + 15 + 15) / 16) | 1;
     *rows = r;
     *oc = o;
-    *lds_bytes = 1024 + 2 * r * in_blocks * 16 + (2 * o) * 256 * 4 + r * o * fb_dst;
+    *lds_bytes = 1024 + 2 * r * in_blocks * 16 + (2 * o) * 256 * 4;
     (void)T;
 }
 
@@ -376,8 +400,10 @@ static hipError_t launch_stamped(const ohgpu_batch* b, const SrcFastParams& p, h
             double sum[4] = {0, 0, 0, 0};
             for (size_t i = 0; i < n; i += 4) for (int k = 0; k < 4; k++) sum[k] += (double)h[i + k];
             const double waves = (double)n / 4;
-            fprintf(f, "waves %.0f mean cycles per wave: wait %.0f issue %.0f drain %.0f compute %.0f\n", waves,
-                    sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves);
+            int occ = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)src_block_kernel<32, 2, 3, true, 3, false, false>, 256, b->fast.lds_bytes);
+            fprintf(f, "waves %.0f mean cycles per wave: wait %.0f issue %.0f drain %.0f compute %.0f | lds %u B, occupancy API %d WG/CU\n", waves,
+                    sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, b->fast.lds_bytes, occ);
             fclose(f);
         }
     }
