@@ -43,6 +43,7 @@ def build(force=False, verbose=False, save_temps=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           *os.environ.get("OHGPU_EXTRA_FLAGS", "").split(),
            "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + _sources()
     if save_temps:
         tmp = os.path.join(PKG, "build")

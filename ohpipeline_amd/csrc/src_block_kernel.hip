@@ -92,13 +92,13 @@ __device__ __forceinline__ uint64_t stamp_now()                               //
 
 template <int T, int CH>
 struct BlockGeom {
-    static constexpr int BPW = 64 / CH;                 // blocks per wave
-    static constexpr int ROWS = 4 * BPW;                // blocks per 256-thread workgroup
-    static constexpr int WAVES_PER_SIMD = T <= 32 ? 3 : 2;
+    static constexpr int BPW = 64 / CH;                 // blocks per wave = blocks per (single-wave) workgroup
+    static constexpr int ROWS = BPW;
+    static constexpr int WAVES_PER_SIMD = T <= 32 ? 4 : 2;
 };
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
-__global__ __launch_bounds__(256, (BlockGeom<T, CH>::WAVES_PER_SIMD))
+__global__ __launch_bounds__(64, (BlockGeom<T, CH>::WAVES_PER_SIMD))
 void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
                       const double* __restrict__ coef, const uint16_t* __restrict__ ramp_table,
                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
@@ -112,19 +112,18 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     constexpr int RING = 2 * OC;                                   // the planner checks OC-1 + outputs per stage <= RING
     constexpr int IN_BLOCKS = ((8 * FB_SRC + 15 + 15) / 16) | 1;   // 16-byte pieces per staged row, odd (bank spread)
     constexpr int IN_STRIDE = IN_BLOCKS * 16;
-    constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 255) / 256;
-    constexpr uint32_t OFF_IN = 1024, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE;
+    constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
+    constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const lds_u8_t lds = (lds_u8_t)smem;
+    // One wave per workgroup: staging, ring and write-back are private to the wave, so no workgroup barrier exists.
     const uint32_t tid = threadIdx.x;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lane = tid & 63;
+    const uint32_t lane = tid;
+    constexpr uint32_t wave = 0;
     const const_f64_ptr_t coef_c = (const_f64_ptr_t)coef;
     uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0;
     if constexpr (STAMP) st_mark = stamp_now();
-
-    for (uint32_t i = tid; i < kRampTableCount; i += 256) ((__attribute__((address_space(3))) uint16_t*)lds)[i] = ramp_table[i];
 
     const SrcWork wk = work[blockIdx.x];
     const SrcSeg seg = segs[wk.seg];
@@ -166,10 +165,14 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     int32_t piece_part[IN_ITERS];    // -1: nothing to move
 #pragma unroll
     for (int it = 0; it < IN_ITERS; it++) {
-        const uint32_t idx = it * 256 + tid;
+        const uint32_t idx = it * 64 + tid;
         const uint32_t r = idx / IN_BLOCKS;
         piece_g[it] = seg.src_base + ((int64_t)((wk.first_block + r) * M_blk) - T) * (int64_t)FB_SRC;
+#ifdef OHGPU_EXP_NODMA
+        piece_part[it] = -1; (void)n_blocks;
+#else
         piece_part[it] = (r < n_blocks && r < (uint32_t)ROWS) ? (int32_t)(idx - r * IN_BLOCKS) : -1;
+#endif
     }
     auto issue_stage = [&](int q) __attribute__((always_inline)) {
         const uint32_t buf = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
@@ -181,10 +184,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 if (addr >= 0 && (uint64_t)addr + 16 <= src_arena_bytes) {
                     // LDS destination = wave-uniform base + lane*16
                     __builtin_amdgcn_global_load_lds((global_ptr_t)(src + addr),
-                                                     (lds_ptr_t)(smem + buf + (uint32_t)(it * 256 + wave * 64) * 16), 16, 0, 0);
+                                                     (lds_ptr_t)(smem + buf + (uint32_t)(it * 64) * 16), 16, 0, 0);
                 } else {
                     // piece straddles an end of the arena: copy only the bytes that exist
-                    const lds_u8_t d = lds + buf + (uint32_t)(it * 256 + tid) * 16;
+                    const lds_u8_t d = lds + buf + (uint32_t)(it * 64 + tid) * 16;
                     for (int b = 0; b < 16; b++) {
                         const int64_t a1 = addr + b;
                         d[b] = (a1 >= 0 && (uint64_t)a1 < src_arena_bytes) ? src[a1] : (uint8_t)0;
@@ -197,7 +200,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // ---- tail: every complete group of OC outputs in the ring is packed and written back by the wave that produced
     // it.  Lane l of pass `it` owns frame (it*64 + l): block (frame / OC) of the wave, output (frame % OC) of the group.
     const __attribute__((address_space(3))) uint32_t* ring = (const __attribute__((address_space(3))) uint32_t*)(lds + OFF_RING);
-    const __attribute__((address_space(3))) uint16_t* s_ramp = (const __attribute__((address_space(3))) uint16_t*)lds;
     const int64_t wave_dst = seg.dst_base + (int64_t)((wk.first_block + wave * BPW) * L_blk) * FB_DST;   // first block of this wave
     const uint32_t wave_rows = (wave * BPW >= n_blocks) ? 0u : (n_blocks - wave * BPW < (uint32_t)BPW ? n_blocks - wave * BPW : (uint32_t)BPW);
     uint32_t drained = 0;                                 // groups written so far (wave-uniform)
@@ -208,8 +210,12 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             for (int it = 0; it < BPW * OC / 64; it++) {
                 const uint32_t frame = it * 64 + lane;
                 const uint32_t r = frame >> OC_LOG2, o = frame & (OC - 1);
+#ifdef OHGPU_EXP_NODRAIN
+                if (r < wave_rows && j0 == 0x7fffffffu) {
+#else
                 if (r < wave_rows) {
-                    const __attribute__((address_space(3))) uint32_t* e = ring + ((j0 + o) & (RING - 1)) * 256 + wave * 64 + r * CH;
+#endif
+                    const __attribute__((address_space(3))) uint32_t* e = ring + ((j0 + o) & (RING - 1)) * 64 + r * CH;
                     uint32_t packed[(FB_DST + 3) / 4];
 #pragma unroll
                     for (int d = 0; d < (FB_DST + 3) / 4; d++) packed[d] = 0;
@@ -257,8 +263,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             if constexpr ((s & 7) == 0) {
                 const int q = a_lin >> 3;
                 if constexpr (STAMP) { const uint64_t n = stamp_now(); st_compute += n - st_mark; st_mark = n; }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                          // stage q landed everywhere; stage q-1 fully consumed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage q has landed (this wave issued all of it)
                 if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
                 if ((q + 1) * 8 < total) issue_stage(q + 1);
                 if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
@@ -277,7 +282,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                              "s_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0"
                              : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3) : "s"(cp));
             };
+#ifdef OHGPU_EXP_NOCOEF
+            if (emits) load_lines(coef_c);
+#else
             if (emits) load_lines(coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T);
+#endif
             // ---- advance: this channel's sample of frame (n_start + a) enters slot s ----
             win[s] = (double)lds_load_subsample<SB, SRC_LE>(lds + in_off + (s & 7) * FB_SRC);
             // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
@@ -285,12 +294,27 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 while (true) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));   // the lines have landed
                     double acc0 = 0.0, acc1 = 0.0;
+#ifdef OHGPU_EXP_NOFMA
+                    acc0 = win[s] + coef_get(q0, 0) + coef_get(q1, 0) + coef_get(q2, 0) + coef_get(q3, 0);
+#elif defined(OHGPU_EXP_ACC4)
+                    double acc2 = 0.0, acc3 = 0.0;
+                    static_for([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = 4 * decltype(kc)::value;
+                        const u32x16& qk = (k < 8) ? q0 : (k < 16) ? q1 : (k < 24) ? q2 : q3;
+                        acc0 = fma(coef_get(qk, k & 7), win[(s - k + 2 * T) % T], acc0);
+                        acc1 = fma(coef_get(qk, (k + 1) & 7), win[(s - (k + 1) + 2 * T) % T], acc1);
+                        acc2 = fma(coef_get(qk, (k + 2) & 7), win[(s - (k + 2) + 2 * T) % T], acc2);
+                        acc3 = fma(coef_get(qk, (k + 3) & 7), win[(s - (k + 3) + 2 * T) % T], acc3);
+                    }, std::make_integer_sequence<int, T / 4>{});
+                    acc0 += acc2; acc1 += acc3;
+#else
                     static_for([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = 2 * decltype(kc)::value;
                         const u32x16& qk = (k < 8) ? q0 : (k < 16) ? q1 : (k < 24) ? q2 : q3;
                         acc0 = fma(coef_get(qk, k & 7), win[(s - k + 2 * T) % T], acc0);
                         acc1 = fma(coef_get(qk, (k + 1) & 7), win[(s - (k + 1) + 2 * T) % T], acc1);
                     }, std::make_integer_sequence<int, T / 2>{});
+#endif
                     uint32_t w = ((uint32_t)src_round_s24(acc0 + acc1)) << 8;      // left-justified BE word (a11)
                     if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
                         if (lane_valid && j >= evt_j) {
@@ -302,7 +326,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                             }
                             if (msg_flags & OHGPU_FLAG_RAMP) {
                                 const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
-                                const uint32_t mult = s_ramp[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
+                                const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
                                 w = ramp_word(w, mult, 3, CH, c);
                                 evt_j = j + 1;
                             } else {
@@ -310,11 +334,15 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                             }
                         }
                     }
-                    ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_RING))[((uint32_t)j & (RING - 1)) * 256 + tid] = w;
+                    ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_RING))[((uint32_t)j & (RING - 1)) * 64 + tid] = w;
                     j++;
                     t += M;
                     if (!(t < L * (a + 1))) break;
+#ifdef OHGPU_EXP_NOCOEF
+                    load_lines(coef_c);
+#else
                     load_lines(coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T);
+#endif
                 }
             }
         }, std::make_integer_sequence<int, T>{});
@@ -326,13 +354,16 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     drain(j);
     if constexpr (STAMP) {
         if (dbg != nullptr && lane == 0) {
-            uint64_t* o = dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+            uint64_t* o = dbg + (size_t)blockIdx.x * 4;
             o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute;
         }
     }
 }
 
 // ---- instantiations: (T, channels, source bytes, source LE, destination bytes, destination LE) ----
+#ifdef OHGPU_EXP_ONE_KERNEL
+#define OHGPU_BLOCK_KERNELS(X) X(32, 2, 3, true, 3, false)
+#else
 #define OHGPU_BLOCK_KERNELS(X)      \
     X(32, 2, 3, true, 3, false)     \
     X(32, 2, 3, true, 3, true)      \
@@ -342,6 +373,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     X(32, 2, 2, true, 3, false)     \
     X(32, 2, 2, true, 2, true)      \
     X(32, 2, 2, true, 2, false)
+#endif
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
 static hipError_t launch_one(const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
@@ -349,7 +381,7 @@ static hipError_t launch_one(const ohgpu_batch* b, const SrcFastParams& p, hipSt
     auto kernel = src_block_kernel<T, CH, SB, SRC_LE, DB, DST_LE>;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fast.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(256), b->fast.lds_bytes, s,
+    hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(64), b->fast.lds_bytes, s,
                        p.segs, p.msgs, p.work, p.coef, p.ramp_table, p.src, p.dst,
                        p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, (uint64_t*)nullptr);
     return hipGetLastError();
@@ -367,13 +399,13 @@ bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, 
 // geometry the planner needs (must match the kernel's constexprs)
 void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* oc, uint32_t* lds_bytes)
 {
-    const uint32_t bpw = 64 / ch, r = 4 * bpw;
+    const uint32_t bpw = 64 / ch, r = bpw;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
     const uint32_t o = (fb_dst * 8) % 16 == 0 ? 8 : 16;
     const uint32_t in_blocks = ((8 * fb_src + 15 + 15) / 16) | 1;
     *rows = r;
     *oc = o;
-    *lds_bytes = 1024 + 2 * r * in_blocks * 16 + (2 * o) * 256 * 4;
+    *lds_bytes = 2 * r * in_blocks * 16 + (2 * o) * 64 * 4;
     (void)T;
 }
 
@@ -384,12 +416,12 @@ static hipError_t launch_stamped(const ohgpu_batch* b, const SrcFastParams& p, h
     auto kernel = src_block_kernel<32, 2, 3, true, 3, false, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fast.lds_bytes);
     if (e != hipSuccess) return e;
-    const size_t n = (size_t)b->fast.n_work * 16;
+    const size_t n = (size_t)b->fast.n_work * 4;
     uint64_t* d = nullptr;
     e = hipMalloc((void**)&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return e;
     hipMemsetAsync(d, 0, n * sizeof(uint64_t), s);
-    hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(256), b->fast.lds_bytes, s,
+    hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(64), b->fast.lds_bytes, s,
                        p.segs, p.msgs, p.work, p.coef, p.ramp_table, p.src, p.dst,
                        p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, d);
     e = hipStreamSynchronize(s);
@@ -401,7 +433,7 @@ static hipError_t launch_stamped(const ohgpu_batch* b, const SrcFastParams& p, h
             for (size_t i = 0; i < n; i += 4) for (int k = 0; k < 4; k++) sum[k] += (double)h[i + k];
             const double waves = (double)n / 4;
             int occ = -1;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)src_block_kernel<32, 2, 3, true, 3, false, false>, 256, b->fast.lds_bytes);
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)src_block_kernel<32, 2, 3, true, 3, false, false>, 64, b->fast.lds_bytes);
             fprintf(f, "waves %.0f mean cycles per wave: wait %.0f issue %.0f drain %.0f compute %.0f | lds %u B, occupancy API %d WG/CU\n", waves,
                     sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, b->fast.lds_bytes, occ);
             fclose(f);
