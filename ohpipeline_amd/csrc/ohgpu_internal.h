@@ -143,7 +143,7 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
-void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* oc, uint32_t* lds_bytes);
+void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* ring, uint32_t* lds_bytes);
 
 // host helpers
 void build_ramp_table(uint16_t out[512]);

@@ -95,6 +95,15 @@ struct BlockGeom {
     static constexpr int BPW = 64 / CH;                 // blocks per wave = blocks per (single-wave) workgroup
     static constexpr int ROWS = BPW;
     static constexpr int WAVES_PER_SIMD = T <= 32 ? 4 : 2;
+    // A 64-byte output line leaves as soon as it is complete; between two stage boundaries at most `per_stage`
+    // outputs arrive, so at most 63 bytes + per_stage frames are pending: the ring must hold that many outputs.
+    static constexpr int ring_entries(int fb_dst, int per_stage = 9)
+    {
+        const int need = (63 + fb_dst - 1) / fb_dst + per_stage + 1;
+        int r = 8;
+        while (r < need) r *= 2;
+        return r;
+    }
 };
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
@@ -107,9 +116,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 {
     constexpr int BPW = BlockGeom<T, CH>::BPW, ROWS = BlockGeom<T, CH>::ROWS;
     constexpr int FB_SRC = CH * SB, FB_DST = CH * DB;
-    constexpr int OC = (FB_DST * 8) % 16 == 0 ? 8 : 16;            // outputs per store group: OC*FB_DST is a multiple of 16
-    constexpr int OC_LOG2 = OC == 8 ? 3 : 4;
-    constexpr int RING = 2 * OC;                                   // the planner checks OC-1 + outputs per stage <= RING
+    constexpr int RING = BlockGeom<T, CH>::ring_entries(FB_DST);  // outputs the LDS ring holds per lane (power of two)
     constexpr int IN_BLOCKS = ((8 * FB_SRC + 15 + 15) / 16) | 1;   // 16-byte pieces per staged row, odd (bank spread)
     constexpr int IN_STRIDE = IN_BLOCKS * 16;
     constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
@@ -197,45 +204,49 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         }
     };
 
-    // ---- tail: every complete group of OC outputs in the ring is packed and written back by the wave that produced
-    // it.  Lane l of pass `it` owns frame (it*64 + l): block (frame / OC) of the wave, output (frame % OC) of the group.
+    // ---- tail: the block's output is a byte stream of L_blk*FB_DST bytes that starts 64-byte aligned (planner).
+    // Whenever a 64-byte line of it is complete in the ring, the wave writes that line of all its blocks: lane l of
+    // pass `it` owns 16-byte piece (l & 3) of block (it*16 + l/4), gathers the <= NS subsamples that overlap it from
+    // the ring, lays their bytes out in memory order and shifts the stream to the piece's first byte.  Four
+    // neighbouring lanes write one whole line: every HBM write is a full, aligned line.
     const __attribute__((address_space(3))) uint32_t* ring = (const __attribute__((address_space(3))) uint32_t*)(lds + OFF_RING);
     const int64_t wave_dst = seg.dst_base + (int64_t)((wk.first_block + wave * BPW) * L_blk) * FB_DST;   // first block of this wave
     const uint32_t wave_rows = (wave * BPW >= n_blocks) ? 0u : (n_blocks - wave * BPW < (uint32_t)BPW ? n_blocks - wave * BPW : (uint32_t)BPW);
-    uint32_t drained = 0;                                 // groups written so far (wave-uniform)
+    uint32_t drained = 0;                                 // lines written so far (wave-uniform)
     auto drain = [&](int j_now) __attribute__((always_inline)) {
-        while (drained < ((uint32_t)j_now >> OC_LOG2)) {
-            const uint32_t j0 = drained << OC_LOG2;
+        constexpr int NS = (DB - 1 + 16 + DB - 1) / DB;   // subsamples that can overlap a 16-byte piece
+        while (drained < (((uint32_t)j_now * FB_DST) >> 6)) {
 #pragma unroll
-            for (int it = 0; it < BPW * OC / 64; it++) {
-                const uint32_t frame = it * 64 + lane;
-                const uint32_t r = frame >> OC_LOG2, o = frame & (OC - 1);
+            for (int it = 0; it < (BPW * 4 + 63) / 64; it++) {
+                const uint32_t piece = it * 64 + lane;
+                const uint32_t r = piece >> 2, part = piece & 3;
 #ifdef OHGPU_EXP_NODRAIN
-                if (r < wave_rows && j0 == 0x7fffffffu) {
+                if (r < wave_rows && drained == 0x7fffffffu) {
 #else
                 if (r < wave_rows) {
 #endif
-                    const __attribute__((address_space(3))) uint32_t* e = ring + ((j0 + o) & (RING - 1)) * 64 + r * CH;
-                    uint32_t packed[(FB_DST + 3) / 4];
+                    const uint32_t b0 = drained * 64 + part * 16;          // first byte of the piece in the block's stream
+                    const uint32_t q0 = b0 / DB, delta = b0 - q0 * DB;     // first overlapping subsample, bytes to skip in it
+                    uint32_t u[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int d = 0; d < (FB_DST + 3) / 4; d++) packed[d] = 0;
-#pragma unroll
-                    for (int cc = 0; cc < CH; cc++) {
-                        const uint32_t w = e[cc];                          // left-justified BE word, ramp already applied
+                    for (int i = 0; i < NS; i++) {
+                        const uint32_t q = q0 + i, jq = q / CH, cq = q - jq * CH;
+                        const uint32_t w = ring[(jq & (RING - 1)) * 64 + r * CH + cq];     // left-justified BE word, ramp applied
                         // v = the DB bytes in memory order, first byte in the low bits
                         const uint32_t v = DST_LE ? (w >> (32 - 8 * DB))
                                                   : (__builtin_bswap32(w) & (DB == 4 ? 0xffffffffu : ((1u << (8 * (DB & 3))) - 1)));
                         constexpr int dummy = 0; (void)dummy;
-                        const int bp = cc * DB;
+                        const int bp = i * DB;
                         const int dw = bp >> 2, sh = (bp & 3) * 8;
-                        packed[dw] |= v << sh;
-                        if (sh + 8 * DB > 32) packed[dw + 1] |= v >> (32 - sh);
+                        if (dw < 5) u[dw] |= v << sh;
+                        if (sh + 8 * DB > 32 && dw + 1 < 5) u[dw + 1] |= v >> (32 - sh);
                     }
-                    uint8_t* out = dst + wave_dst + (int64_t)((uint64_t)r * L_blk + j0 + o) * FB_DST;
-#pragma unroll
-                    for (int d = 0; d < FB_DST / 4; d++) *(u32_unaligned*)(out + 4 * d) = packed[d];
-                    if constexpr ((FB_DST & 3) >= 2) *(u16_unaligned*)(out + (FB_DST & ~3)) = (uint16_t)packed[FB_DST / 4];
-                    if constexpr (FB_DST & 1) out[FB_DST - 1] = (uint8_t)(packed[FB_DST / 4] >> ((FB_DST & 2) * 8));
+                    u32x4 v4;
+                    v4.x = __builtin_amdgcn_alignbyte(u[1], u[0], delta);
+                    v4.y = __builtin_amdgcn_alignbyte(u[2], u[1], delta);
+                    v4.z = __builtin_amdgcn_alignbyte(u[3], u[2], delta);
+                    v4.w = __builtin_amdgcn_alignbyte(u[4], u[3], delta);
+                    *(u32x4*)(dst + wave_dst + (int64_t)((uint64_t)r * L_blk) * FB_DST + b0) = v4;
                 }
             }
             drained++;
@@ -397,15 +408,17 @@ bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, 
 }
 
 // geometry the planner needs (must match the kernel's constexprs)
-void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* oc, uint32_t* lds_bytes)
+void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* ring, uint32_t* lds_bytes)
 {
     const uint32_t bpw = 64 / ch, r = bpw;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
-    const uint32_t o = (fb_dst * 8) % 16 == 0 ? 8 : 16;
     const uint32_t in_blocks = ((8 * fb_src + 15 + 15) / 16) | 1;
+    const uint32_t need = (63 + fb_dst - 1) / fb_dst + 9 + 1;
+    uint32_t rg = 8;
+    while (rg < need) rg *= 2;
     *rows = r;
-    *oc = o;
-    *lds_bytes = 2 * r * in_blocks * 16 + (2 * o) * 64 * 4;
+    *ring = rg;
+    *lds_bytes = 2 * r * in_blocks * 16 + rg * 64 * 4;
     (void)T;
 }
 

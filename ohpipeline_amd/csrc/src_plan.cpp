@@ -69,18 +69,24 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint32_t dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
     if (!src_block_supported(T, ch, sb, src_le, db, dst_le)) return OHGPU_OK;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
-    uint32_t rows = 0, Oc = 0, lds_bytes = 0;
-    src_block_geometry(T, ch, sb, db, &rows, &Oc, &lds_bytes);
-    const uint32_t oc_log2 = Oc == 8 ? 3 : 4;                    // Oc * fb_dst is a multiple of 16
-    const uint32_t base = L / gcd_u32(L, Oc) * Oc;               // lcm(L, Oc): phase-aligned and store-aligned
-    const uint32_t L_blk = base * ((128 + base - 1) / base);
+    uint32_t rows = 0, ring = 0, lds_bytes = 0;
+    src_block_geometry(T, ch, sb, db, &rows, &ring, &lds_bytes);
+    // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
+    uint32_t L_blk = L * ((128 + L - 1) / L);
+    {
+        uint32_t k = 1;
+        while (k <= 64 && ((uint64_t)L_blk * k * fb_dst) % 64 != 0) k++;
+        if (k > 64) return OHGPU_OK;
+        L_blk *= k;
+    }
     const uint64_t M_blk64 = (uint64_t)L_blk * M / L;
     if (M_blk64 + T > 32000 || M_blk64 < T) return OHGPU_OK;    // a block is at least one filter length of input
     const uint32_t M_blk = (uint32_t)M_blk64;
     const uint32_t max_out_per_stage = (8 * L + M - 1) / M;      // #{j : a <= floor(j*M/L) < a+8} <= ceil(8L/M)
-    if (Oc - 1 + max_out_per_stage > 2 * Oc) return OHGPU_OK;    // the LDS ring holds 2*Oc outputs per lane
+    if (max_out_per_stage > 9) return OHGPU_OK;                  // the LDS ring is sized for <= 9 outputs per stage
     if (lds_bytes > 160 * 1024) return OHGPU_OK;
-    (void)fb_src;
+    const uint32_t oc_log2 = 0;
+    (void)fb_src; (void)gcd_u32;
 
     // order messages by (stream, output position); a stream is identified by where its absolute frame 0 lives
     std::vector<uint32_t> order(n);
@@ -117,7 +123,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         }
         const uint64_t m_begin = d0.out_frame0, m_end = next_out;
         uint64_t blk_lo = (m_begin + L_blk - 1) / L_blk, blk_hi = m_end / L_blk;
-        bool fast_ok = !zero_len && blk_hi > blk_lo && (dbase % 16 == 0);
+        bool fast_ok = !zero_len && blk_hi > blk_lo && (dbase % 64 == 0);   // output lines are written whole
         if (fast_ok) {
             // every whole block's history must be present in the windows the caller declared (they were validated
             // per message; the block reads nothing a message of the block does not itself need)
