@@ -171,6 +171,11 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
 
+/* Host-buffer convenience (a live pipeline's 5 ms cadence): H2D, run, D2H, sync.  dst_host bytes that no message
+ * covers are preserved. */
+int ohgpu_src_process_host(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
+                           const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
+
 /* How a resampler batch was planned: output frames handled by the block kernel, and the number of message pieces
  * (block-unaligned heads/tails, unsupported layouts) left to the generic kernel. */
 int ohgpu_src_batch_plan(const ohgpu_batch* batch, uint64_t* block_kernel_out_frames, uint64_t* generic_pieces);

@@ -69,6 +69,7 @@ SYMBOLS = {
     "ohgpu_src_batch_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
+    "ohgpu_src_process_host": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
     "ohgpu_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }
 

@@ -1,0 +1,436 @@
+// test_host.cpp -- tests of the C++ host adapter (ohpipeline_amd/host), written the way the reference's own suites are
+// (OpenHome/Media/Tests/TestMsg.cpp SuiteMsgAudio / SuiteMsgPlayable / SuiteRamp, Tests/TestRamper.cpp): hand-built
+// messages, elements pulled through a suite that acts as the upstream element, results inspected through an
+// IPcmProcessor.  `test_host cpu` runs the control-plane checks (no GPU); `test_host gpu` also reads audio through the
+// C ABI and compares the bytes with the CPU oracle.
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <vector>
+
+#include "../../ohpipeline_amd/host/Elements.h"
+#include "../../ohpipeline_amd/host/Msg.h"
+#include "../../ohpipeline_amd/host/SampleRateConverter.h"
+#include "../../oracle/ohp_pipeline.h"
+
+using namespace OpenHome;
+using namespace OpenHome::Media;
+
+static int gFailures = 0, gChecks = 0;
+#define TEST(x) do { gChecks++; if (!(x)) { gFailures++; printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #x); } } while (0)
+#define TEST_THROWS(expr, Ex) do { gChecks++; bool thrown_ = false; try { expr; } catch (Ex&) { thrown_ = true; } \
+    if (!thrown_) { gFailures++; printf("FAILED %s:%d  %s did not throw %s\n", __FILE__, __LINE__, #expr, #Ex); } } while (0)
+
+// ------------------------------------------------------------------------------------------- control plane
+static void SuiteRampControl()
+{   // TestMsg.cpp:1391-1443, 1593-1625
+    TUint jiffies = Jiffies::kPerMs;
+    Ramp ramp, split;
+    TUint splitPos;
+    TEST(!ramp.Set(Ramp::kMax, jiffies, jiffies, Ramp::EDown, split, splitPos));
+    TEST(ramp.Start() == Ramp::kMax && ramp.End() == Ramp::kMin && ramp.Direction() == Ramp::EDown);
+    ramp.Reset();
+    TEST_THROWS(ramp.Set(Ramp::kMax, jiffies, jiffies, Ramp::EUp, split, splitPos), AssertionFailed);
+    ramp.Reset();
+    TEST(!ramp.Set(Ramp::kMin, jiffies, jiffies, Ramp::EUp, split, splitPos));
+    TEST(ramp.Start() == Ramp::kMin && ramp.End() == Ramp::kMax && ramp.Direction() == Ramp::EUp);
+    ramp.Reset();
+    TEST(!ramp.Set(Ramp::kMax, jiffies, 2 * jiffies, Ramp::EDown, split, splitPos));
+    TEST(ramp.End() == (Ramp::kMax - Ramp::kMin) / 2);
+    ramp.Reset();
+    TUint start = (Ramp::kMax - Ramp::kMin) / 2;
+    TEST(!ramp.Set(start, jiffies, 2 * jiffies, Ramp::EUp, split, splitPos));
+    TEST(ramp.End() == Ramp::kMax - ((Ramp::kMax - Ramp::kMin) / 4));
+    // [50%..Min] then [Min..50%]: split into [Min..25%], [25%..Min]
+    ramp.Reset();
+    TEST(!ramp.Set(Ramp::kMax / 2, jiffies, jiffies, Ramp::EDown, split, splitPos));
+    TEST(ramp.Set(Ramp::kMin, jiffies, 2 * jiffies, Ramp::EUp, split, splitPos));
+    TEST(ramp.Start() == 0 && ramp.End() == Ramp::kMax / 4 && ramp.Direction() == Ramp::EUp);
+    TEST(split.Start() == ramp.End() && split.End() == 0 && split.Direction() == Ramp::EDown);
+    // same direction: lower points win
+    ramp.Reset();
+    TEST(!ramp.Set(Ramp::kMax / 2, jiffies, 2 * jiffies, Ramp::EDown, split, splitPos));
+    start = (TUint)(((TUint64)2 * Ramp::kMax) / 5);
+    TEST(!ramp.Set(start, jiffies, jiffies, Ramp::EDown, split, splitPos));
+    TEST(ramp.Start() == start && ramp.End() == 0);
+    ramp.Reset();
+    ramp.SetMuted();
+    TEST(ramp.Direction() == Ramp::EMute && ramp.Start() == Ramp::kMin && ramp.End() == Ramp::kMin);
+    TEST_THROWS(Jiffies::PerSample(44101), SampleRateInvalid);
+    TEST(Jiffies::PerSample(44100) == 1280 && Jiffies::PerSample(48000) == 1176);
+}
+
+static void SuiteMsgAudioControl(MsgFactory& f)
+{   // TestMsg.cpp:780-836, 926-945
+    std::vector<TByte> data(1200, 0xde);
+    Brn buf(data.data(), (TUint)data.size());
+    const TUint rates[] = { 7350, 8000, 11025, 12000, 14700, 16000, 22050, 24000, 29400, 32000, 44100, 48000, 88200, 96000, 176400, 192000 };
+    TUint prev = 0xffffffff;
+    for (TUint r : rates) {
+        MsgAudio* msg = f.CreateMsgAudioPcm(buf, 2, r, 8, AudioDataEndian::Little, 0);
+        TEST(prev > msg->Jiffies());
+        prev = msg->Jiffies();
+        msg->RemoveRef();
+    }
+    MsgAudioPcm* msg = f.CreateMsgAudioPcm(buf, 2, 44100, 8, AudioDataEndian::Little, Jiffies::kPerSecond);
+    const TUint jiffies = msg->Jiffies();
+    MsgAudio* remaining = msg->Split(800);
+    TEST(msg->Jiffies() + remaining->Jiffies() == jiffies);
+    TEST(static_cast<MsgAudioPcm*>(remaining)->TrackOffset() == msg->TrackOffset() + msg->Jiffies());
+    remaining->RemoveRef();
+    TEST_THROWS(remaining = msg->Split(0), AssertionFailed);
+    TEST_THROWS(remaining = msg->Split(msg->Jiffies()), AssertionFailed);
+    TEST_THROWS(remaining = msg->Split(msg->Jiffies() + 1), AssertionFailed);
+    MsgAudio* clone = msg->Clone();
+    TEST(clone->Jiffies() == msg->Jiffies());
+    msg->RemoveRef();
+    clone->RemoveRef();
+    TEST_THROWS(f.CreateMsgAudioPcm(Brn(data.data(), 0), 2, 44100, 8, AudioDataEndian::Little, 0), AssertionFailed);
+    // aggregate: lengths add, mismatches assert
+    std::vector<TByte> d1(4596, 1), d2(4596, 2);
+    MsgAudioPcm* a1 = f.CreateMsgAudioPcm(Brn(d1.data(), 4596), 2, 44100, 8, AudioDataEndian::Little, 0);
+    MsgAudioPcm* a2 = f.CreateMsgAudioPcm(Brn(d2.data(), 4596), 2, 44100, 8, AudioDataEndian::Little, a1->Jiffies());
+    const TUint expected = a1->Jiffies() + a2->Jiffies();
+    a1->Aggregate(a2);
+    TEST(a1->Jiffies() == expected);
+    MsgAudioPcm* a3 = f.CreateMsgAudioPcm(Brn(d2.data(), 4596), 1, 44100, 8, AudioDataEndian::Little, a1->Jiffies());
+    TEST_THROWS(a1->Aggregate(a3), AssertionFailed);
+    a3->RemoveRef();
+    a1->RemoveRef();
+    // silence
+    TUint sj = Jiffies::kPerMs;
+    MsgSilence* silence = f.CreateMsgSilence(sj, 44100, 8, 2);
+    TEST(sj == silence->Jiffies());
+    MsgAudio* rest = silence->Split(sj / 4);
+    TEST(silence->Jiffies() + rest->Jiffies() == sj);
+    MsgPlayable* p = silence->CreatePlayable();
+    MsgPlayable* rp = static_cast<MsgSilence*>(rest)->CreatePlayable();
+    TEST(p->Bytes() + rp->Bytes() == (sj / Jiffies::PerSample(44100)) * 2);
+    p->RemoveRef();
+    rp->RemoveRef();
+}
+
+static void SuitePlayableControl(MsgFactory& f)
+{   // TestMsg.cpp:1106-1251 (sizes and split points; contents are checked in the gpu pass)
+    TByte data[256];
+    for (TUint i = 0; i < 256; i++) data[i] = (TByte)(0xff - i);
+    Brn buf(data, 256);
+    MsgAudioPcm* pcm = f.CreateMsgAudioPcm(buf, 2, 44100, 8, AudioDataEndian::Little, 0);
+    MsgAudioPcm* rem = static_cast<MsgAudioPcm*>(pcm->Split(pcm->Jiffies() / 4));
+    MsgPlayable* p = pcm->CreatePlayable();
+    MsgPlayable* rp = rem->CreatePlayable();
+    TEST(rp->Bytes() == 3 * p->Bytes());
+    MsgPlayable* tail = rp->Split(rp->Bytes() / 2);
+    TEST(tail != nullptr && tail->Bytes() + rp->Bytes() == 3 * p->Bytes());
+    TEST(rp->Split(rp->Bytes()) == nullptr);
+    TEST_THROWS(rp->Split(0), AssertionFailed);
+    TEST_THROWS(rp->Split(rp->Bytes() + 1), AssertionFailed);
+    p->RemoveRef(); rp->RemoveRef(); tail->RemoveRef();
+    pcm = f.CreateMsgAudioPcm(buf, 2, 44100, 8, AudioDataEndian::Little, 0);      // split at 1 jiffy
+    rem = static_cast<MsgAudioPcm*>(pcm->Split(1));
+    p = pcm->CreatePlayable();
+    rp = rem->CreatePlayable();
+    TEST(p->Bytes() == 0 && rp->Bytes() == 256);
+    p->RemoveRef(); rp->RemoveRef();
+    pcm = f.CreateMsgAudioPcm(buf, 2, 44100, 8, AudioDataEndian::Little, 0);      // muted -> silence playable
+    pcm->SetMuted();
+    p = pcm->CreatePlayable();
+    TEST(p->Work().silence && p->Bytes() == 256);
+    p->RemoveRef();
+}
+
+// ------------------------------------------------------------------------------------------- data plane (GPU)
+static std::vector<TByte> OracleRead(const PlayableWork& w, TUint outBits, int outEndian)
+{
+    ohp_msg_desc d;
+    memset(&d, 0, sizeof(d));
+    d.src_offset = w.offsetBytes;
+    d.n_frames = w.frames;
+    d.ramp_start = (uint16_t)w.ramp.Start();
+    d.ramp_end = (uint16_t)w.ramp.End();
+    d.attenuation = (uint16_t)w.attenuation;
+    d.channels = (uint8_t)w.channels;
+    d.src_bits = (uint8_t)w.bitDepth;
+    d.src_endian = (w.audio && w.audio->Endian() == AudioDataEndian::Little) ? OHP_ENDIAN_LITTLE : OHP_ENDIAN_BIG;
+    d.dst_bits = (uint8_t)outBits;
+    d.dst_endian = (uint8_t)outEndian;
+    d.flags = (uint8_t)((w.silence ? OHP_FLAG_SILENCE : 0) | (w.ramp.IsEnabled() && !w.silence ? OHP_FLAG_RAMP : 0));
+    std::vector<TByte> out((size_t)w.frames * w.channels * (outBits / 8));
+    const TByte* src = w.audio ? w.audio->Ptr(0) : nullptr;
+    TEST(ohp_msg_process(&d, src, out.data()) == 0);
+    return out;
+}
+
+class SuiteRamperGpu : public IPipelineElementUpstream, private IMsgProcessor {
+    // Tests/TestRamper.cpp:18-105, 252-360 restated: the suite is the upstream element and the inspecting processor
+    static const TUint kRampLong = Jiffies::kPerMs * 50, kRampShort = Jiffies::kPerMs * 20;
+public:
+    explicit SuiteRamperGpu(MsgFactory& aFactory) : iFactory(aFactory), iRamper(*this, kRampLong, kRampShort) {}
+    void Run()
+    {
+        // not live, starts at 0: no ramp, audio comes through untouched
+        Push(iFactory.CreateMsgMode(ModeInfo()));
+        Push(Stream(false, 0));
+        Push(Audio());
+        iRamping = false;
+        for (int i = 0; i < 3; i++) PullNext();
+        TEST(iJiffies > 0);
+        // live: ramps up over kRampLong, then stays at full level
+        iJiffies = 0;
+        Push(Stream(true, 0));
+        PullNext();
+        iRamping = true;
+        iLastSubsample = 0;
+        while (iRamping) {
+            Push(Audio());
+            PullNextAll();
+        }
+        TEST(iJiffies >= kRampLong);
+        TEST(iRampedJiffies == kRampLong);
+        Push(Audio());
+        PullNextAll();
+        // mid-track start of a new stream: ramp; short mode: short ramp
+        ModeInfo shortMode;
+        shortMode.iRampPauseResumeLong = false;
+        Push(iFactory.CreateMsgMode(shortMode));
+        PullNext();
+        iJiffies = 0; iRampedJiffies = 0;
+        Push(Stream(false, 100));
+        PullNext();
+        iRamping = true;
+        iLastSubsample = 0;
+        while (iRamping) {
+            Push(Audio());
+            PullNextAll();
+        }
+        TEST(iRampedJiffies == kRampShort);
+    }
+private:
+    void Push(Msg* aMsg) { iPending.push_back(aMsg); }
+    Msg* Pull() override { ASSERT(!iPending.empty()); Msg* m = iPending.front(); iPending.pop_front(); return m; }
+    void PullNext() { Msg* m = iRamper.Pull(); m = m->Process(*this); m->RemoveRef(); }
+    void PullNextAll() { do { PullNext(); } while (!iPending.empty() || iMoreQueued); }
+    Msg* Stream(TBool aLive, TUint64 aSampleStart)
+    {
+        DecodedStreamInfo info;
+        info.iStreamId = iNextStreamId++; info.iBitDepth = 24; info.iSampleRate = 44100; info.iNumChannels = 2;
+        info.iLive = aLive; info.iSampleStart = aSampleStart;
+        return iFactory.CreateMsgDecodedStream(info);
+    }
+    Msg* Audio()
+    {
+        TByte data[3 * 1024];
+        memset(data, 0x7f, sizeof data);
+        MsgAudioPcm* audio = iFactory.CreateMsgAudioPcm(Brn(data, sizeof data), 2, 44100, 24, AudioDataEndian::Little, iTrackOffset);
+        iTrackOffset += audio->Jiffies();
+        return audio;
+    }
+    Msg* ProcessMsg(MsgAudioPcm* aMsg) override
+    {
+        iJiffies += aMsg->Jiffies();
+        if (aMsg->Ramp().IsEnabled()) iRampedJiffies += aMsg->Jiffies();
+        iMoreQueued = false;
+        MsgPlayable* playable = aMsg->CreatePlayable();
+        const std::vector<TByte> expected = OracleRead(playable->Work(), 24, OHP_ENDIAN_BIG);
+        ProcessorPcmBufTest pcm;
+        playable->Read(pcm);
+        const Brn buf(pcm.Buf());
+        TEST(buf.Bytes() == expected.size() && memcmp(buf.Ptr(), expected.data(), expected.size()) == 0);   // bit-exact vs oracle
+        const TByte* ptr = buf.Ptr();
+        const TUint bytes = buf.Bytes();
+        const TUint first = (ptr[0] << 16) | (ptr[1] << 8) | ptr[2];
+        if (iRamping) {
+            TEST(first >= iLastSubsample || iLastSubsample == 0);
+            iLastSubsample = (ptr[bytes - 3] << 16) | (ptr[bytes - 2] << 8) | ptr[bytes - 1];
+            TEST(iLastSubsample >= first);
+            if (!playable->Ramp().IsEnabled()) iRamping = false;     // ramp finished: this message is at full level
+            else iMoreQueued = playable->Ramp().End() != Ramp::kMax ? false : true;
+            if (playable->Ramp().IsEnabled()) {
+                const TUint perFrag = 256 / 6;
+                TEST(pcm.Fragments().size() == (bytes / 6 + perFrag - 1) / perFrag);   // 42-frame fragments (Msg.cpp:2766)
+            }
+        }
+        else {
+            TEST(first == 0x7f7f7f);
+            TEST(pcm.Fragments().size() == 1);
+        }
+        return playable;
+    }
+    Msg* ProcessMsg(MsgMode* m) override { return m; }
+    Msg* ProcessMsg(MsgTrack* m) override { return m; }
+    Msg* ProcessMsg(MsgDrain* m) override { return m; }
+    Msg* ProcessMsg(MsgDelay* m) override { return m; }
+    Msg* ProcessMsg(MsgEncodedStream* m) override { return m; }
+    Msg* ProcessMsg(MsgStreamSegment* m) override { return m; }
+    Msg* ProcessMsg(MsgAudioEncoded* m) override { return m; }
+    Msg* ProcessMsg(MsgMetaText* m) override { return m; }
+    Msg* ProcessMsg(MsgStreamInterrupted* m) override { return m; }
+    Msg* ProcessMsg(MsgHalt* m) override { return m; }
+    Msg* ProcessMsg(MsgFlush* m) override { return m; }
+    Msg* ProcessMsg(MsgWait* m) override { return m; }
+    Msg* ProcessMsg(MsgDecodedStream* m) override { return m; }
+    Msg* ProcessMsg(MsgAudioDsd* m) override { return m; }
+    Msg* ProcessMsg(MsgSilence* m) override { return m; }
+    Msg* ProcessMsg(MsgPlayable* m) override { return m; }
+    Msg* ProcessMsg(MsgQuit* m) override { return m; }
+private:
+    MsgFactory& iFactory;
+    Ramper iRamper;
+    std::deque<Msg*> iPending;
+    TUint iNextStreamId = 1;
+    TUint64 iTrackOffset = 0;
+    TUint iJiffies = 0, iRampedJiffies = 0, iLastSubsample = 0;
+    TBool iRamping = false, iMoreQueued = false;
+};
+
+static void SuitePlayableGpu(MsgFactory& f)
+{   // TestMsg.cpp:1133-1236: byte-exact pass-through across split points; attenuation KAT :982-996; batch read
+    TByte data[256];
+    for (TUint i = 0; i < 256; i++) data[i] = (TByte)(0xff - i);
+    MsgAudioPcm* pcm = f.CreateMsgAudioPcm(Brn(data, 256), 2, 44100, 8, AudioDataEndian::Little, 0);
+    MsgAudioPcm* rem = static_cast<MsgAudioPcm*>(pcm->Split(pcm->Jiffies() / 4 - 1));       // non-sample boundary
+    MsgPlayable* p = pcm->CreatePlayable();
+    MsgPlayable* rp = rem->CreatePlayable();
+    ProcessorPcmBufTest a, b;
+    PlayableBatch batch(f);
+    batch.Add(p, a);
+    batch.Add(rp, b);
+    batch.Run();
+    TUint v = 0xff;
+    for (TUint i = 0; i < a.Buf().Bytes(); i++, v--) TEST(a.Buf()[i] == v);
+    for (TUint i = 0; i < b.Buf().Bytes(); i++, v--) TEST(b.Buf()[i] == v);
+    TEST(a.Buf().Bytes() + b.Buf().Bytes() == 256);
+    const TByte s = 0x7f;
+    TByte sample[] = { s, s, s, s };
+    MsgAudioPcm* att = f.CreateMsgAudioPcm(Brn(sample, 4), 2, 44100, 16, AudioDataEndian::Little, 0);
+    att->SetAttenuation(MsgAudioPcm::kUnityAttenuation / 4);
+    MsgPlayable* ap = att->CreatePlayable();
+    ProcessorPcmBufTest c;
+    ap->Read(c);
+    ap->RemoveRef();
+    const TInt16 sub = (TInt16)((c.Ptr()[0] << 8) + c.Ptr()[1]);
+    TEST(sub == ((s << 8) + s) / 4);
+    // silence, 6 channels, 32 bit: zeros plus the channel-id bytes (Msg.cpp:2877)
+    TUint sj = Jiffies::kPerMs;
+    MsgSilence* sil = f.CreateMsgSilence(sj, 192000, 32, 6);
+    MsgPlayable* sp = sil->CreatePlayable();
+    const std::vector<TByte> expected = OracleRead(sp->Work(), 32, OHP_ENDIAN_BIG);
+    ProcessorPcmBufTest d;
+    sp->Read(d);
+    sp->RemoveRef();
+    TEST(d.Buf().Bytes() == expected.size() && memcmp(d.Ptr(), expected.data(), expected.size()) == 0);
+    TEST(d.Ptr()[7] == 0x10 && d.Ptr()[31] == 0x70 && d.Ptr()[35] == 0x00);
+}
+
+class SuiteSrcGpu : public IPipelineElementUpstream {
+    // SampleRateConverter -> Ramper -> PreDriver, 44.1 kHz S24LE stereo in, 48 kHz out: the chain of BASELINE config 2.
+public:
+    explicit SuiteSrcGpu(MsgFactory& aFactory)
+        : iFactory(aFactory), iSrc(aFactory, *this, 48000), iRamper(iSrc, Jiffies::kPerMs * 50, Jiffies::kPerMs * 20), iPreDriver(iRamper) {}
+    void Run()
+    {
+        DecodedStreamInfo info;
+        info.iStreamId = 7; info.iBitDepth = 24; info.iSampleRate = 44100; info.iNumChannels = 2; info.iLive = true;
+        iPending.push_back(iFactory.CreateMsgDecodedStream(info));
+        uint32_t x = 12345;
+        const TUint kMsgs = 40;                       // 200 ms of 220-frame messages
+        for (TUint m = 0; m < kMsgs; m++) {
+            TByte data[220 * 6];
+            for (TUint i = 0; i < sizeof data; i += 3) {
+                x = x * 1664525u + 1013904223u;
+                data[i] = (TByte)(x >> 8); data[i + 1] = (TByte)(x >> 16); data[i + 2] = (TByte)(x >> 24);
+            }
+            iInput.insert(iInput.end(), data, data + sizeof data);
+            iPending.push_back(iFactory.CreateMsgAudioPcm(Brn(data, sizeof data), 2, 44100, 24, AudioDataEndian::Little, 0));
+        }
+        iPending.push_back(iFactory.CreateMsgQuit());
+        // drive like an animator: pull, batch the playables of this "period", read them in one launch
+        std::vector<TByte> got;
+        std::vector<ProcessorPcmBufTest> sinks(64);
+        TUint64 outFrames = 0;
+        TBool quit = false, sawStream = false;
+        std::vector<ohp_src_msg_desc> descs;
+        while (!quit) {
+            PlayableBatch batch(iFactory);
+            size_t n = 0;
+            while (n < 8 && !quit) {
+                Msg* msg = iPreDriver.Pull();
+                if (MsgPlayable* p = dynamic_cast<MsgPlayable*>(msg)) {
+                    ohp_src_msg_desc d;
+                    memset(&d, 0, sizeof(d));
+                    d.src_frames = iInput.size() / 6; d.out_frame0 = outFrames; d.dst_offset = outFrames * 6;
+                    d.n_frames = p->Bytes() / 6; d.ramp_start = (uint16_t)p->Ramp().Start(); d.ramp_end = (uint16_t)p->Ramp().End();
+                    d.attenuation = 256; d.channels = 2; d.src_bits = 24; d.src_endian = OHP_ENDIAN_LITTLE; d.dst_bits = 24;
+                    d.dst_endian = OHP_ENDIAN_BIG; d.flags = p->Ramp().IsEnabled() ? OHP_FLAG_RAMP : 0;
+                    descs.push_back(d);
+                    outFrames += d.n_frames;
+                    batch.Add(p, sinks[n++]);
+                }
+                else if (MsgDecodedStream* s = dynamic_cast<MsgDecodedStream*>(msg)) {
+                    TEST(s->StreamInfo().SampleRate() == 48000 && s->StreamInfo().BitDepth() == 24);
+                    sawStream = true;
+                    msg->RemoveRef();
+                }
+                else {
+                    quit = dynamic_cast<MsgQuit*>(msg) != nullptr;
+                    msg->RemoveRef();
+                }
+            }
+            batch.Run();
+            for (size_t i = 0; i < n; i++) got.insert(got.end(), sinks[i].Ptr(), sinks[i].Ptr() + sinks[i].Buf().Bytes());
+        }
+        TEST(sawStream);
+        TEST(outFrames == (kMsgs * 220ull * 160 + 146) / 147);
+        // the same messages through the oracle's resample -> ramp -> fmt
+        ohp_src* ref = ohp_src_new(44100, 48000, 32, 9.0, 20000.0);
+        std::vector<TByte> want(got.size());
+        TEST(ohp_src_msg_process_batch(ref, descs.data(), descs.size(), iInput.data(), want.data()) == 0);
+        ohp_src_delete(ref);
+        TEST(got.size() == outFrames * 6 && memcmp(got.data(), want.data(), got.size()) == 0);
+        TUint ramped = 0;
+        for (auto& d : descs) if (d.flags & OHP_FLAG_RAMP) ramped += d.n_frames;
+        TEST(ramped == 50 * 48);                      // the live stream's 50 ms ramp, at the OUTPUT rate
+    }
+    Msg* Pull() override { ASSERT(!iPending.empty()); Msg* m = iPending.front(); iPending.pop_front(); return m; }
+private:
+    MsgFactory& iFactory;
+    SampleRateConverter iSrc;
+    Ramper iRamper;
+    PreDriver iPreDriver;
+    std::deque<Msg*> iPending;
+    std::vector<TByte> iInput;
+};
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
+    try {
+        SuiteRampControl();
+        {
+            MsgFactory control(-1);
+            SuiteMsgAudioControl(control);
+            SuitePlayableControl(control);
+            MsgAudioPcm* pcm = nullptr;
+            TByte b[4] = { 1, 2, 3, 4 };
+            pcm = control.CreateMsgAudioPcm(Brn(b, 4), 2, 44100, 16, AudioDataEndian::Little, 0);
+            MsgPlayable* p = pcm->CreatePlayable();
+            ProcessorPcmBufTest sink;
+            TEST_THROWS(p->Read(sink), AssertionFailed);      // no GPU context: reading audio fails loudly, no CPU fallback
+            p->RemoveRef();
+        }
+        if (gpu) {
+            MsgFactory f(0);
+            SuitePlayableGpu(f);
+            SuiteRamperGpu ramper(f);
+            ramper.Run();
+            SuiteSrcGpu src(f);
+            src.Run();
+        }
+    }
+    catch (const std::exception& e) {
+        printf("UNEXPECTED EXCEPTION %s\n", e.what());
+        gFailures++;
+    }
+    printf("%s: %d checks, %d failures\n", gpu ? "gpu" : "cpu", gChecks, gFailures);
+    return gFailures == 0 ? 0 : 1;
+}

@@ -55,6 +55,18 @@ def main():
             for c, v in sorted(cs.items()):
                 md.write(f"| {c} | {v:.6g} |\n")
             md.write("\n")
+    # HBM traffic of the dominant kernel, corrected as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and
+    # WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads half the bytes of a wide (16 B/lane) streaming read -> x2.
+    dom = max(out["kernels"].items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["calls"])[0] if out["kernels"] else None
+    if dom and dom in out["counters"] and "FETCH_SIZE" in out["counters"][dom] and "WRITE_SIZE" in out["counters"][dom]:
+        c = out["counters"][dom]
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        pmc = {"kernel": dom, "hbm_bytes_per_launch": int(traffic), "fetch_size_kib": c["FETCH_SIZE"],
+               "write_size_kib": c["WRITE_SIZE"], "kernel_avg_us_trace": out["kernels"][dom]["avg_us"],
+               "source": f"profiles/{tag}_summary.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes",
+               "streams_per_gpu": 256, "frames_per_stream": 441000, "kernel_variant": 0}
+        json.dump(pmc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+        out["hbm_traffic"] = pmc
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
