@@ -158,6 +158,32 @@ int ohgpu_batch_info(const ohgpu_batch* batch, uint64_t* n_msgs, uint64_t* in_fr
 int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
                            const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
 
+/* ---- the in-tree IPcmProcessor conversions that are not plain interleaved -> interleaved ---- */
+#define OHGPU_FMT_UNPACK_PLANAR 1  /* FlywheelInput::DoProcessFragment + AppendSubsample8/16/24/32 (Pipeline/StarvationRamper.cpp:
+                                      117-186): packed BE interleaved -> PLANAR 4-byte BE, left-justified, low bytes zero;
+                                      channel c's plane starts at dst_offset + c * dst_plane_stride */
+#define OHGPU_FMT_SENDER_PACK   2  /* Sender::DoProcessFragment (Av/Songcast/Sender.cpp:351-377): first two channels (from
+                                      channel 8 when there are >= 10), min(bytes, 3) most significant bytes each */
+#define OHGPU_FMT_FLAC_PACK     3  /* CodecFlac::CallbackWrite (Codec/Flac.cpp:379-417): planar host-endian TInt32 (channel c at
+                                      src_offset + c * src_plane_stride) -> packed BE interleaved 8/16/24 bit */
+
+typedef struct ohgpu_fmt_desc {     /* 48 bytes */
+    uint64_t src_offset;
+    uint64_t dst_offset;
+    uint64_t src_plane_stride;      /* FLAC_PACK only   */
+    uint64_t dst_plane_stride;      /* UNPACK_PLANAR only */
+    uint32_t n_frames;
+    uint8_t  kind;                  /* OHGPU_FMT_* */
+    uint8_t  channels;              /* 1..10 (Sender is told about up to 10) */
+    uint8_t  src_bits;              /* packed depth of the source (UNPACK/SENDER); 32 for FLAC_PACK's TInt32 planes */
+    uint8_t  dst_bits;              /* FLAC_PACK: 8/16/24; ignored otherwise (UNPACK -> 32, SENDER -> min(src,24)) */
+    uint8_t  reserved[8];
+} ohgpu_fmt_desc;
+
+int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
+int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+
 /* ---- sample-rate converter (own specification; DESIGN.md "Resampler") ---- */
 /* Host-side filter design: Kaiser-windowed sinc, Q28 coefficients, coef_q28[p*T + k] = h[p + k*L].
  * Pass coef_q28 = NULL to query L, M only.  Capacity must be >= L*T. */

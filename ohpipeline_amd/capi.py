@@ -31,6 +31,12 @@ SRC_MSG_DESC = np.dtype([
     ("channels", "u1"), ("src_bits", "u1"), ("src_endian", "u1"),
     ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1"), ("reserved", "u1", (8,))], align=False)
 
+FMT_UNPACK_PLANAR, FMT_SENDER_PACK, FMT_FLAC_PACK = 1, 2, 3
+FMT_DESC = np.dtype([
+    ("src_offset", "<u8"), ("dst_offset", "<u8"), ("src_plane_stride", "<u8"), ("dst_plane_stride", "<u8"),
+    ("n_frames", "<u4"), ("kind", "u1"), ("channels", "u1"), ("src_bits", "u1"), ("dst_bits", "u1"),
+    ("reserved", "u1", (8,))], align=False)
+
 # every symbol of include/ohgpu.h: name -> (restype, argtypes)
 _vp, _vpp = C.c_void_p, C.POINTER(C.c_void_p)
 _u64p = C.POINTER(C.c_uint64)
@@ -61,6 +67,8 @@ SYMBOLS = {
     "ohgpu_batch_destroy": (C.c_int, [_vp, _vp]),
     "ohgpu_batch_info": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p, _u64p]),
     "ohgpu_pcm_process_host": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
+    "ohgpu_fmt_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
+    "ohgpu_fmt_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_design": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp, C.c_size_t,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ohgpu_src_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vpp]),
@@ -227,6 +235,17 @@ class Context:
                                            src.ctypes.data_as(C.c_void_p), src.nbytes,
                                            dst.ctypes.data_as(C.c_void_p), dst.nbytes))
         return dst
+
+    def fmt_batch(self, descs, src_arena_bytes, dst_arena_bytes):
+        d = np.ascontiguousarray(descs)
+        assert d.dtype == FMT_DESC
+        b = C.c_void_p()
+        check(lib().ohgpu_fmt_batch_create(self._h, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes,
+                                           dst_arena_bytes, C.byref(b)))
+        return b
+
+    def fmt_run(self, batch, d_src, d_dst, stream=None):
+        check(lib().ohgpu_fmt_batch_run(self._h, batch, d_src, d_dst, stream))
 
     def src_create(self, L, M, T, coef_q28):
         c = np.ascontiguousarray(coef_q28, dtype=np.int32)

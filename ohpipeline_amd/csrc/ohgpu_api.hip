@@ -365,6 +365,75 @@ int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n
     return err;
 }
 
+/* ---------------------------------------------------------------- layout-changing processors (a11, a13, a14) */
+int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
+{
+    CTX_GUARD("ohgpu_fmt_batch_create");
+    if (!out || (n && !descs)) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_create: null argument");
+    *out = nullptr;
+    if (n > 0xffffffffull) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_create: too many descriptors");
+    ohgpu_batch* b = new (std::nothrow) ohgpu_batch();
+    if (!b) return set_error(OHGPU_ERR_NOMEM, "ohgpu_fmt_batch_create: out of host memory");
+    b->kind = kBatchFmt;
+    b->n = n;
+    b->src_arena_bytes = src_arena_bytes;
+    b->dst_arena_bytes = dst_arena_bytes;
+    for (size_t i = 0; i < n; i++) {
+        const ohgpu_fmt_desc& d = descs[i];
+        int err = OHGPU_OK;
+        const uint64_t ch = d.channels, nf = d.n_frames, sb = d.src_bits / 8;
+        uint64_t src_lo = d.src_offset, src_hi = 0, dst_lo = d.dst_offset, dst_hi = 0;
+        if (ch < 1 || ch > 10) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: channels %u outside 1..10", i, d.channels);
+        else if (d.kind == OHGPU_FMT_UNPACK_PLANAR || d.kind == OHGPU_FMT_SENDER_PACK) {
+            if (!valid_bits(d.src_bits)) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: source depth %u", i, d.src_bits);   // ASSERTS(), StarvationRamper.cpp:178-180
+            else {
+                src_hi = d.src_offset + nf * ch * sb;
+                if (d.kind == OHGPU_FMT_UNPACK_PLANAR) {
+                    if (ch > 1 && d.dst_plane_stride < nf * 4) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: planes overlap (stride %llu < %llu)", i, (unsigned long long)d.dst_plane_stride, (unsigned long long)(nf * 4));
+                    dst_hi = d.dst_offset + (ch - 1) * d.dst_plane_stride + nf * 4;
+                } else {
+                    dst_hi = d.dst_offset + nf * (ch < 2 ? ch : 2) * (sb < 3 ? sb : 3);
+                }
+            }
+        } else if (d.kind == OHGPU_FMT_FLAC_PACK) {
+            if (!(d.dst_bits == 8 || d.dst_bits == 16 || d.dst_bits == 24))       // THROW(CodecStreamFeatureUnsupported), Flac.cpp:404-407
+                err = set_error(OHGPU_ERR_UNSUPPORTED, "fmt desc %zu: FLAC bit depth %u (8/16/24 only)", i, d.dst_bits);
+            else if (d.src_bits != 32) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: FLAC planes are TInt32 (src_bits must be 32)", i);
+            else if (d.src_offset % 4 != 0 || d.src_plane_stride % 4 != 0) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: TInt32 planes must be 4-byte aligned", i);
+            else {
+                src_hi = d.src_offset + (ch - 1) * d.src_plane_stride + nf * 4;
+                dst_hi = d.dst_offset + nf * ch * (d.dst_bits / 8);
+            }
+        } else {
+            err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: unknown kind %u", i, d.kind);
+        }
+        if (err == OHGPU_OK && nf > 0 && (src_lo > src_arena_bytes || src_hi > src_arena_bytes || src_hi < src_lo))
+            err = set_error(OHGPU_ERR_BOUNDS, "fmt desc %zu: reads up to %llu beyond the %llu-byte source arena", i, (unsigned long long)src_hi, (unsigned long long)src_arena_bytes);
+        if (err == OHGPU_OK && nf > 0 && (dst_lo > dst_arena_bytes || dst_hi > dst_arena_bytes || dst_hi < dst_lo))
+            err = set_error(OHGPU_ERR_BOUNDS, "fmt desc %zu: writes up to %llu beyond the %llu-byte destination arena", i, (unsigned long long)dst_hi, (unsigned long long)dst_arena_bytes);
+        if (err != OHGPU_OK) { delete b; return err; }
+        b->in_frames += nf;
+        b->out_frames += nf;
+        b->src_bytes_touched += nf ? src_hi - src_lo : 0;
+        b->dst_bytes_written += nf ? dst_hi - dst_lo : 0;
+    }
+    const int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_fmt_desc));
+    if (err != OHGPU_OK) { delete b; return err; }
+    *out = b;
+    return OHGPU_OK;
+}
+
+int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
+{
+    CTX_GUARD("ohgpu_fmt_batch_run");
+    if (!batch || batch->kind != kBatchFmt) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: not a fmt batch");
+    if (batch->n == 0) return OHGPU_OK;
+    if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: null arena pointer");
+    OHGPU_HIP_TRY(launch_fmt_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
 /* ---------------------------------------------------------------- sample-rate converter */
 int ohgpu_src_design(uint32_t rate_in, uint32_t rate_out, uint32_t taps_per_phase, double beta, double f_pass_hz,
                      int32_t* coef_q28, size_t coef_capacity, uint32_t* L, uint32_t* M)

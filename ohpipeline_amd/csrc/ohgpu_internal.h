@@ -36,6 +36,7 @@ struct DevSrcDesc {
 static_assert(sizeof(DevSrcDesc) == 56, "DevSrcDesc layout");
 static_assert(sizeof(ohgpu_msg_desc) == 32, "ohgpu_msg_desc layout");
 static_assert(sizeof(ohgpu_src_msg_desc) == 64, "ohgpu_src_msg_desc layout");
+static_assert(sizeof(ohgpu_fmt_desc) == 48, "ohgpu_fmt_desc layout");
 
 // ---- block ("fast") resampler plan: contiguous runs of output messages cut into phase-aligned blocks ----
 struct SrcSeg {               // one contiguous run of output messages of one stream
@@ -94,7 +95,7 @@ struct SrcFastPlan {
     uint64_t fast_out_frames = 0;
 };
 
-enum BatchKind { kBatchPcm = 1, kBatchSrc = 2 };
+enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3 };
 
 }  // namespace ohgpu
 
@@ -138,6 +139,7 @@ int set_error(int code, const char* fmt, ...);
     } while (0)
 
 // kernels
+hipError_t launch_fmt_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* src_filter,
                          const uint8_t* src, uint8_t* dst, hipStream_t s);

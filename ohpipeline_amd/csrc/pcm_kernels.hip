@@ -86,6 +86,40 @@ __global__ __launch_bounds__(256) void src_msg_kernel_v1(const DevSrcDesc* __res
     }
 }
 
+// The in-tree processors that change layout (a11, a13, a14 of SURVEY.md 8a): one workgroup per descriptor, one
+// thread per frame.  Byte for byte what the cited reference loops write.
+__global__ __launch_bounds__(256) void fmt_kernel_v1(const ohgpu_fmt_desc* __restrict__ descs, uint32_t n_descs,
+                                                     const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+{
+    for (uint32_t m = blockIdx.x; m < n_descs; m += gridDim.x) {
+        const ohgpu_fmt_desc d = descs[m];
+        const uint32_t ch = d.channels, sb = d.src_bits >> 3;
+        for (uint32_t i = threadIdx.x; i < d.n_frames; i += blockDim.x) {
+            if (d.kind == OHGPU_FMT_UNPACK_PLANAR) {            // StarvationRamper.cpp:117-147, 159-186
+                const uint8_t* s = src + d.src_offset + (uint64_t)i * ch * sb;
+                for (uint32_t c = 0; c < ch; c++) {
+                    uint8_t* o = dst + d.dst_offset + c * d.dst_plane_stride + (uint64_t)i * 4;
+                    for (uint32_t b = 0; b < 4; b++) o[b] = b < sb ? s[c * sb + b] : (uint8_t)0;
+                }
+            } else if (d.kind == OHGPU_FMT_SENDER_PACK) {       // Sender.cpp:351-377
+                const uint32_t first = ch < 10 ? 0u : 8u;
+                const uint32_t db = sb < 3 ? sb : 3, out_ch = ch < 2 ? ch : 2;
+                const uint8_t* s = src + d.src_offset + (uint64_t)i * ch * sb + first * sb;
+                uint8_t* o = dst + d.dst_offset + (uint64_t)i * out_ch * db;
+                for (uint32_t c = 0; c < out_ch; c++)
+                    for (uint32_t b = 0; b < db; b++) o[c * db + b] = s[c * sb + b];
+            } else {                                            // Flac.cpp:379-417
+                const uint32_t db = d.dst_bits >> 3;
+                uint8_t* o = dst + d.dst_offset + (uint64_t)i * ch * db;
+                for (uint32_t c = 0; c < ch; c++) {
+                    const uint32_t v = *(const uint32_t*)(src + d.src_offset + c * d.src_plane_stride + (uint64_t)i * 4);
+                    for (uint32_t b = 0; b < db; b++) o[c * db + b] = (uint8_t)(v >> (8 * (db - 1 - b)));
+                }
+            }
+        }
+    }
+}
+
 static uint32_t grid_for(size_t n)
 {
     const size_t cap = 1u << 20;
@@ -97,6 +131,14 @@ hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8
     if (b->n == 0) return hipSuccess;
     hipLaunchKernelGGL(pcm_msg_kernel_v1, dim3(grid_for(b->n)), dim3(256), 0, s,
                        (const ohgpu_msg_desc*)b->d_descs, (uint32_t)b->n, src, dst, ctx->d_ramp_table);
+    return hipGetLastError();
+}
+
+hipError_t launch_fmt_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    (void)ctx;
+    if (b->n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fmt_kernel_v1, dim3(grid_for(b->n)), dim3(256), 0, s, (const ohgpu_fmt_desc*)b->d_descs, (uint32_t)b->n, src, dst);
     return hipGetLastError();
 }
 

@@ -1,0 +1,84 @@
+"""GPU parity for the layout-changing processors against the oracle's restatement
+of FlywheelInput::DoProcessFragment, Sender::DoProcessFragment and CodecFlac::CallbackWrite."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ohpipeline_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def run_fmt(ctx, descs, src, dst_bytes):
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dst_bytes)
+    ctx.memset(d_dst, 0xA5, dst_bytes)
+    b = ctx.fmt_batch(descs, src.size, dst_bytes)
+    ctx.fmt_run(b, d_src, d_dst)
+    out = ctx.download(d_dst, dst_bytes)
+    ctx.batch_destroy(b)
+    ctx.free(d_src)
+    ctx.free(d_dst)
+    return out
+
+
+def test_flywheel_unpack_planar(ctx):
+    """a11: packed BE interleaved 1/2/3/4 bytes -> planar 4-byte BE left-justified (StarvationRamper.cpp:117-186)."""
+    rng = np.random.default_rng(3)
+    for sb, ch, n in [(1, 2, 44), (2, 2, 44), (3, 2, 44), (4, 2, 44), (3, 8, 192), (2, 10, 7), (3, 1, 1)]:
+        src = rng.integers(0, 256, size=n * ch * sb, dtype=np.uint8)
+        stride = n * 4 + 8
+        d = np.zeros(1, dtype=capi.FMT_DESC)
+        d["kind"], d["channels"], d["src_bits"], d["n_frames"], d["dst_plane_stride"] = capi.FMT_UNPACK_PLANAR, ch, sb * 8, n, stride
+        got = run_fmt(ctx, d, src, ch * stride)
+        want = np.full(ch * stride, 0xA5, dtype=np.uint8)
+        pos = np.zeros(ch, dtype=np.uint32)
+        assert O.lib().ohp_flywheel_unpack(src.ctypes.data_as(C.c_void_p), src.size, ch, sb, want.ctypes.data_as(C.c_void_p),
+                                           stride, pos.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+        assert np.array_equal(got, want), (sb, ch, n)
+
+
+def test_sender_pack(ctx):
+    """a13: first two channels (from channel 8 when >= 10), min(bytes, 3) MSBs each (Sender.cpp:351-377)."""
+    rng = np.random.default_rng(4)
+    for sb, ch, n in [(2, 2, 220), (3, 2, 240), (4, 2, 240), (3, 6, 100), (3, 8, 100), (4, 10, 33), (1, 2, 5)]:
+        src = rng.integers(0, 256, size=n * ch * sb, dtype=np.uint8)
+        out_bytes = n * 2 * min(sb, 3)
+        d = np.zeros(1, dtype=capi.FMT_DESC)
+        d["kind"], d["channels"], d["src_bits"], d["n_frames"] = capi.FMT_SENDER_PACK, ch, sb * 8, n
+        got = run_fmt(ctx, d, src, out_bytes)
+        want = np.zeros(out_bytes, dtype=np.uint8)
+        nb = C.c_uint32(0)
+        assert O.lib().ohp_sender_pack(src.ctypes.data_as(C.c_void_p), src.size, ch, sb, want.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0
+        assert nb.value == out_bytes and np.array_equal(got, want), (sb, ch, n)
+
+
+def test_flac_pack(ctx):
+    """a14: planar TInt32 -> packed BE interleaved 8/16/24; 32-bit is unsupported as in the reference (Flac.cpp:379-417)."""
+    rng = np.random.default_rng(5)
+    for bits, ch, n in [(8, 2, 100), (16, 2, 4096), (24, 2, 4096), (24, 6, 1152), (16, 1, 17)]:
+        planes = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(ch, n + 3), dtype=np.int64).astype(np.int32)
+        src = planes.view(np.uint8).reshape(-1)
+        d = np.zeros(1, dtype=capi.FMT_DESC)
+        d["kind"], d["channels"], d["src_bits"], d["dst_bits"], d["n_frames"] = capi.FMT_FLAC_PACK, ch, 32, bits, n
+        d["src_plane_stride"] = (n + 3) * 4
+        out_bytes = n * ch * bits // 8
+        got = run_fmt(ctx, d, src, out_bytes)
+        want = np.zeros(out_bytes, dtype=np.uint8)
+        ptrs = (C.POINTER(C.c_int32) * ch)(*[planes[c].ctypes.data_as(C.POINTER(C.c_int32)) for c in range(ch)])
+        nb = C.c_uint32(0)
+        assert O.lib().ohp_flac_pack(ptrs, ch, 0, n, bits, want.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0
+        assert np.array_equal(got, want), (bits, ch, n)
+    d = np.zeros(1, dtype=capi.FMT_DESC)
+    d["kind"], d["channels"], d["src_bits"], d["dst_bits"], d["n_frames"], d["src_plane_stride"] = capi.FMT_FLAC_PACK, 2, 32, 32, 4, 16
+    with pytest.raises(capi.OhGpuError) as e:
+        ctx.fmt_batch(d, 32, 32)
+    assert e.value.code == capi.ERR_UNSUPPORTED
