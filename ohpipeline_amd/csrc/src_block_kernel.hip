@@ -62,24 +62,24 @@ __device__ __forceinline__ double coef_get(const u32x16& q, int k)
     return __hiloint2double((int)q[2 * k + 1], (int)q[2 * k]);
 }
 
-// one subsample (SB packed bytes at any byte alignment) from LDS -> S24 integer.  LDS reads need no alignment
-// on gfx950 (unaligned access mode); a 3-byte subsample is read as the 4 bytes that start at it.
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+// one subsample (SB packed bytes at any byte alignment) from LDS -> S24 integer.  The LDS accepts unaligned
+// addresses but serialises such an access lane by lane (SQ_LDS_UNALIGNED_STALL was half of the kernel's time), so
+// the two ALIGNED words that hold the subsample are read (one ds_read2_b32) and shifted into place.
 template <int SB, bool LE>
 __device__ __forceinline__ int32_t lds_load_subsample(const __attribute__((address_space(3))) uint8_t* p)
 {
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    const __attribute__((address_space(3))) uint32_t* q = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(a & ~3u);
+    const uint32_t lo = q[0], hi = q[1];
+    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, a & 3u);                  // the 4 bytes that start at p
     if constexpr (SB == 3) {
-        const uint32_t w = *(const __attribute__((address_space(3))) u32_unaligned*)p;     // b0 b1 b2 (+1 byte)
         return LE ? ((int32_t)(w << 8)) >> 8 : ((int32_t)__builtin_bswap32(w)) >> 8;
     } else if constexpr (SB == 2) {
-        const uint32_t h = *(const __attribute__((address_space(3))) u16_unaligned*)p;
-        return LE ? ((int32_t)(h << 16)) >> 8 : ((int32_t)(__builtin_bswap32(h) & 0xffff0000u)) >> 8;
+        return LE ? ((int32_t)(w << 16)) >> 8 : ((int32_t)(__builtin_bswap32(w) & 0xffff0000u)) >> 8;
     } else if constexpr (SB == 4) {
-        const uint32_t w = *(const __attribute__((address_space(3))) u32_unaligned*)p;
         return LE ? ((int32_t)w) >> 8 : ((int32_t)__builtin_bswap32(w)) >> 8;
     } else {
-        return ((int32_t)((uint32_t)p[0] << 24)) >> 8;
+        return ((int32_t)(w << 24)) >> 8;
     }
 }
 
@@ -94,7 +94,7 @@ template <int T, int CH>
 struct BlockGeom {
     static constexpr int BPW = 64 / CH;                 // blocks per wave = blocks per (single-wave) workgroup
     static constexpr int ROWS = BPW;
-    static constexpr int WAVES_PER_SIMD = T <= 32 ? 4 : 2;
+    static constexpr int WAVES_PER_SIMD = T <= 32 ? 3 : 2;    // what the LDS footprint allows anyway
     // A 64-byte output line leaves as soon as it is complete; between two stage boundaries at most `per_stage`
     // outputs arrive, so at most 63 bytes + per_stage frames are pending: the ring must hold that many outputs.
     static constexpr int ring_entries(int fb_dst, int per_stage = 9)
@@ -120,7 +120,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     constexpr int IN_BLOCKS = ((8 * FB_SRC + 15 + 15) / 16) | 1;   // 16-byte pieces per staged row, odd (bank spread)
     constexpr int IN_STRIDE = IN_BLOCKS * 16;
     constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
-    constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE;
+    constexpr int MSG_SLOTS = 32;                                  // messages of the wave's output range kept in LDS
+    constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_MSG = OFF_RING + RING * 64 * 4;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const lds_u8_t lds = (lds_u8_t)smem;
@@ -129,7 +130,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const uint32_t lane = tid;
     constexpr uint32_t wave = 0;
     const const_f64_ptr_t coef_c = (const_f64_ptr_t)coef;
-    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0;
+    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0, st_smem = 0, st_fma = 0, st_fma0 = 0;
     if constexpr (STAMP) st_mark = stamp_now();
 
     const SrcWork wk = work[blockIdx.x];
@@ -147,21 +148,54 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // starts at input frame 0 reaches before the stream: its whole warm-up pass (advances a < 0) must be zeros.
     const bool first_block = n_start == 0;
 
-    // Message that holds this lane's first output frame (messages of a segment tile its output range).  Kept
-    // relative to the block: msg_rel0 = (message's first output) - m_start, so output j is frame j - msg_rel0 of it.
-    uint32_t mi = seg.msg_begin;
+    // Messages (ramp parameters) of the wave's output range.  Lane 0's block starts the range: its message is found
+    // by bisection; the next MSG_SLOTS messages go to an LDS table, compacted and made relative to the wave's first
+    // output frame, so that the per-output path never issues a global load (it would have to wait for the staging
+    // loads in flight).  A range with more messages than the table holds falls back to reading them from memory.
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(3))) u32x4_t* msg_tab = (const __attribute__((address_space(3))) u32x4_t*)(lds + OFF_MSG);
+    const uint64_t wave_m0 = (wk.first_block + wave * BPW) * (uint64_t)L_blk;
+    uint32_t tab_lo;
+    {
+        uint32_t lo = seg.msg_begin, hi = seg.msg_end;
+        while (hi - lo > 1) {                                       // wave-uniform bisection
+            const uint32_t mid = (lo + hi) >> 1;
+            if (msgs[mid].out0 <= wave_m0) lo = mid; else hi = mid;
+        }
+        tab_lo = lo;
+        if (lane < (uint32_t)MSG_SLOTS) {
+            u32x4_t e = {0x7fffffffu, 0u, 0u, 0u};                 // past the segment: starts "never"
+            if (tab_lo + lane < seg.msg_end) {
+                const SegMsg m = msgs[tab_lo + lane];
+                e.x = (uint32_t)(int32_t)(int64_t)(m.out0 - wave_m0);
+                e.y = m.n;
+                e.z = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16);
+                e.w = m.flags;
+            }
+            ((__attribute__((address_space(3))) u32x4_t*)(lds + OFF_MSG))[lane] = e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // this lane's message cursor, relative to its own block: output j is frame j - msg_rel0 of the message
+    const int32_t lane_off = (int32_t)(bw * L_blk);                // block's first output relative to the wave's
+    uint32_t mi = 0;                                                // index into the table (tab_lo + mi in memory)
     int32_t msg_rel0 = 0;
     uint32_t msg_n = 0x7fffffffu, msg_ramp = 0, msg_flags = 0;     // msg_ramp = start | end << 16
-    if (lane_valid) {
-        uint32_t lo = seg.msg_begin, hi = seg.msg_end;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (msgs[mid].out0 <= m_start) lo = mid; else hi = mid;
+    auto load_msg = [&](uint32_t idx) __attribute__((always_inline)) {
+        if (idx < (uint32_t)MSG_SLOTS) {
+            const u32x4_t e = msg_tab[idx];
+            msg_rel0 = (int32_t)e.x - lane_off; msg_n = e.y; msg_ramp = e.z; msg_flags = e.w;
+        } else {
+            const SegMsg m = msgs[tab_lo + idx];
+            msg_rel0 = (int32_t)(int64_t)(m.out0 - wave_m0) - lane_off;
+            msg_n = m.n; msg_ramp = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16); msg_flags = m.flags;
         }
-        mi = lo;
-        const SegMsg m0 = msgs[mi];
-        msg_rel0 = (int32_t)(int64_t)(m0.out0 - m_start);
-        msg_n = m0.n; msg_ramp = (uint32_t)m0.ramp_start | ((uint32_t)m0.ramp_end << 16); msg_flags = m0.flags;
+    };
+    if (lane_valid) {
+        load_msg(0);
+        while ((uint32_t)(0 - msg_rel0) >= msg_n) load_msg(++mi);   // first message that holds this block's output 0
     }
     // first output index at which this lane needs the slow path: always while ramping, else at the message's end
     int32_t evt_j = (msg_flags & OHGPU_FLAG_RAMP) ? 0 : msg_rel0 + (int32_t)msg_n;
@@ -303,6 +337,14 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
             if (emits) {
                 while (true) {
+                    if constexpr (STAMP) {
+                        uint64_t t0, t1;
+                        asm volatile("s_memtime %0" : "=s"(t0));
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(t0));
+                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+                        st_smem += t1 - t0;
+                        st_fma0 = t1;
+                    }
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));   // the lines have landed
                     double acc0 = 0.0, acc1 = 0.0;
 #ifdef OHGPU_EXP_NOFMA
@@ -326,15 +368,15 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                         acc1 = fma(coef_get(qk, (k + 1) & 7), win[(s - (k + 1) + 2 * T) % T], acc1);
                     }, std::make_integer_sequence<int, T / 2>{});
 #endif
+                    if constexpr (STAMP) {
+                        uint64_t t1;
+                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(acc0), "v"(acc1));
+                        st_fma += t1 - st_fma0;
+                    }
                     uint32_t w = ((uint32_t)src_round_s24(acc0 + acc1)) << 8;      // left-justified BE word (a11)
                     if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
                         if (lane_valid && j >= evt_j) {
-                            while ((uint32_t)(j - msg_rel0) >= msg_n) {             // next message of the segment
-                                mi++;
-                                const SegMsg mm = msgs[mi];
-                                msg_rel0 = (int32_t)(int64_t)(mm.out0 - m_start);
-                                msg_n = mm.n; msg_ramp = (uint32_t)mm.ramp_start | ((uint32_t)mm.ramp_end << 16); msg_flags = mm.flags;
-                            }
+                            while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
                             if (msg_flags & OHGPU_FLAG_RAMP) {
                                 const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
                                 const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
@@ -366,7 +408,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     if constexpr (STAMP) {
         if (dbg != nullptr && lane == 0) {
             uint64_t* o = dbg + (size_t)blockIdx.x * 4;
-            o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute;
+            o[0] = st_wait + (st_fma << 32); o[1] = st_issue + (st_smem << 32); o[2] = st_drain; o[3] = st_compute;
         }
     }
 }
@@ -418,7 +460,7 @@ void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint3
     while (rg < need) rg *= 2;
     *rows = r;
     *ring = rg;
-    *lds_bytes = 2 * r * in_blocks * 16 + rg * 64 * 4;
+    *lds_bytes = 2 * r * in_blocks * 16 + rg * 64 * 4 + 32 * 16;
     (void)T;
 }
 
@@ -443,12 +485,19 @@ static hipError_t launch_stamped(const ohgpu_batch* b, const SrcFastParams& p, h
         e = hipMemcpy(h.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(path, "w")) {
             double sum[4] = {0, 0, 0, 0};
-            for (size_t i = 0; i < n; i += 4) for (int k = 0; k < 4; k++) sum[k] += (double)h[i + k];
+            double smem = 0, fma = 0;
+            for (size_t i = 0; i < n; i += 4) {
+                smem += (double)(h[i + 1] >> 32);
+                h[i + 1] &= 0xffffffffull;
+                fma += (double)(h[i] >> 32);
+                h[i] &= 0xffffffffull;
+                for (int k = 0; k < 4; k++) sum[k] += (double)h[i + k];
+            }
             const double waves = (double)n / 4;
             int occ = -1;
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)src_block_kernel<32, 2, 3, true, 3, false, false>, 64, b->fast.lds_bytes);
-            fprintf(f, "waves %.0f mean cycles per wave: wait %.0f issue %.0f drain %.0f compute %.0f | lds %u B, occupancy API %d WG/CU\n", waves,
-                    sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, b->fast.lds_bytes, occ);
+            fprintf(f, "waves %.0f mean cycles per wave: wait %.0f issue %.0f drain %.0f compute %.0f (of which waiting for coefficient lines %.0f, inside the FMA blocks %.0f) | lds %u B, occupancy API %d WG/CU\n", waves,
+                    sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, smem / waves, fma / waves, b->fast.lds_bytes, occ);
             fclose(f);
         }
     }
