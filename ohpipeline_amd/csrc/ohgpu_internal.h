@@ -86,7 +86,10 @@ struct SrcFastPlan {
     uint32_t T = 0, cpl = 0;
     SrcFastParams params{};
     uint32_t n_work = 0;
-    uint32_t lds_bytes = 0;
+    uint32_t coef_lds_bytes = 0;  // the coefficient table's share of a workgroup's LDS
+    uint32_t wave_lds_bytes = 0;  // per wave: input stages, message table, output ring
+    uint32_t max_waves = 0;       // waves per workgroup the LDS allows (<= 12)
+    uint32_t ring_entries = 0;    // outputs the LDS ring holds per lane (power of two)
     void*    d_segs = nullptr;
     void*    d_msgs = nullptr;
     void*    d_work = nullptr;
@@ -145,7 +148,8 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
-void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* ring, uint32_t* lds_bytes);
+bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
+                        uint32_t* rows, uint32_t* ring, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);
 
 // host helpers
 void build_ramp_table(uint16_t out[512]);

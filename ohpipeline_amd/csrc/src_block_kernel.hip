@@ -4,16 +4,18 @@
 //   * A stream's output is cut into BLOCKS of L_blk frames that start where the polyphase phase is 0
 //     (L_blk is a multiple of L), so every block walks the same phase sequence.
 //   * One lane owns one CHANNEL of one block; the CH lanes of a block sit side by side in one wave.  All 64 lanes
-//     of a wave are therefore at the SAME phase at the same instruction: the coefficient address is wave-uniform,
-//     coefficients come through the scalar cache into SGPRs, one 64-byte line (8 taps) at a time through two
-//     16-SGPR buffers, and each tap is ONE v_fma_f64 (SGPR coefficient, VGPR sample, VGPR accumulator).
+//     of a wave are therefore at the SAME phase at the same instruction.
+//   * The whole coefficient table ([L][T] doubles, 40 KB for 160 x 32) lives in LDS, loaded once per workgroup; a
+//     workgroup is up to 12 waves that stay on their CU and loop over work units.  For an output, lane l reads taps
+//     (l & 15) and (l & 15) + 16 of the phase's row with ONE ds_read2_b64 (conflict-free: 16 consecutive doubles,
+//     the four 16-lane rows read the same addresses), and tap k is ONE v_fmac_f64_dpp row_newbcast:(k & 15), which
+//     broadcasts lane k of every row as the coefficient -- full fp64 rate (tools/micro/dpp_fma.hip), no scalar
+//     cache in the loop (its 16 KB thrashed on the table: 59 % misses, the waves spent half their time waiting).
 //   * The lane keeps its T-sample sliding window in registers as exact integer-valued doubles.  The advance loop
-//     is unrolled T times so that the circular window is indexed statically (slot = advance mod T).  At 2*T + ~50
-//     VGPRs three to four waves fit per SIMD, which is what hides the scalar-cache latency.
+//     is unrolled T times so that the circular window is indexed statically (slot = advance mod T).
 //   * Input is staged through LDS by direct global->LDS loads (16 B per lane, two buffers, eight advances per
-//     stage).  Rounded outputs go to an LDS ring; at each stage boundary every complete group of OC outputs is
-//     ramped and packed (pcm_device.h's code) into a small LDS row per block and written back by the same wave
-//     as aligned 16-byte pieces, consecutive lanes on consecutive pieces.
+//     stage).  Rounded, ramped outputs go to an LDS ring as left-justified words; every four advances the wave
+//     writes the 64-byte output lines that have become complete, four lanes per line, each HBM write a whole line.
 //   * Accumulation is fp64 FMA on integer-valued operands with |sum| < 2^53: exact, hence bit-identical to the
 //     integer model regardless of order.  No MFMA: this is a 1-D filter.
 // Formats are template parameters (the per-advance unpack sits in the unrolled hot path); layouts without an
@@ -33,7 +35,6 @@ namespace ohgpu {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* global_ptr_t;
-typedef const __attribute__((address_space(4))) double* const_f64_ptr_t;   // constant address space: scalar loads
 typedef __attribute__((address_space(3))) uint8_t* lds_u8_t;
 
 // calls f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a compile-time unrolled loop
@@ -43,23 +44,18 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S..
     (f(std::integral_constant<int, S>{}), ...);
 }
 
-// ---- explicit scalar-cache loads (the compiler does not see them: every use is fenced by coef_wait) ----
-// Every register an in-flight scalar load writes stays live until a wait covers it: a destination that dies early
-// would be reallocated and then overwritten by the late data.
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void coef_load8(u32x16& q, const_f64_ptr_t p)     // 8 coefficients = one 64-byte line
+// acc += (lane K of this lane's 16-lane row of cv) * x.  cv is only ever written by LDS loads (a VALU write would
+// need two wait states before a DPP read; the s_nop in front of each output's first tap covers moves the
+// compiler might insert anyway).
+template <int K, bool FIRST>
+__device__ __forceinline__ void fmac_bcast(double& acc, const double cv, const double x)
 {
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(q) : "s"(p));
-}
-__device__ __forceinline__ void coef_wait(u32x16& q)                          // all scalar loads (and LDS ops) have landed
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q));
-}
-__device__ __forceinline__ double coef_get(const u32x16& q, int k)
-{
-    return __hiloint2double((int)q[2 * k + 1], (int)q[2 * k]);
+    if constexpr (FIRST)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cv), "v"(x), "i"(K));
+    else
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cv), "v"(x), "i"(K));
 }
 
 // one subsample (SB packed bytes at any byte alignment) from LDS -> S24 integer.  The LDS accepts unaligned
@@ -92,69 +88,81 @@ __device__ __forceinline__ uint64_t stamp_now()                               //
 
 template <int T, int CH>
 struct BlockGeom {
-    static constexpr int BPW = 64 / CH;                 // blocks per wave = blocks per (single-wave) workgroup
+    static constexpr int BPW = 64 / CH;                 // blocks per wave
     static constexpr int ROWS = BPW;
-    static constexpr int WAVES_PER_SIMD = T <= 32 ? 3 : 2;    // what the LDS footprint allows anyway
-    // A 64-byte output line leaves as soon as it is complete; between two stage boundaries at most `per_stage`
-    // outputs arrive, so at most 63 bytes + per_stage frames are pending: the ring must hold that many outputs.
-    static constexpr int ring_entries(int fb_dst, int per_stage = 9)
-    {
-        const int need = (63 + fb_dst - 1) / fb_dst + per_stage + 1;
-        int r = 8;
-        while (r < need) r *= 2;
-        return r;
-    }
+    static constexpr int MAX_WAVES = 12;                // waves per workgroup (3 per SIMD: 168 VGPRs each)
+    static constexpr int MSG_SLOTS = 32;                // messages of a wave's output range kept in LDS
 };
 
+// LDS ring: outputs the ring must hold per lane.  After a drain fewer than 64 bytes (a multiple of gcd(64, fb_dst))
+// are pending, i.e. at most (64 - g) / fb_dst + 1 frames; up to `per_drain` more arrive before the next drain.
+static constexpr uint32_t ring_pending(uint32_t fb_dst)
+{
+    uint32_t g = 64, x = fb_dst;
+    while (x) { const uint32_t t = g % x; g = x; x = t; }
+    return (64 - g) / fb_dst + 1;
+}
+
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
-__global__ __launch_bounds__(64, (BlockGeom<T, CH>::WAVES_PER_SIMD))
+__global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
 void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
-                      const double* __restrict__ coef, const uint16_t* __restrict__ ramp_table,
+                      const uint32_t n_work, const double* __restrict__ coef, const uint16_t* __restrict__ ramp_table,
                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                       const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
-                      uint64_t* __restrict__ dbg)
+                      const uint32_t ring_entries, uint64_t* __restrict__ dbg)
 {
-    constexpr int BPW = BlockGeom<T, CH>::BPW, ROWS = BlockGeom<T, CH>::ROWS;
+    static_assert(T == 32, "two coefficient registers per lane hold taps k and k + 16 of a 32-tap row");
+    constexpr int BPW = BlockGeom<T, CH>::BPW, ROWS = BlockGeom<T, CH>::ROWS, MSG_SLOTS = BlockGeom<T, CH>::MSG_SLOTS;
     constexpr int FB_SRC = CH * SB, FB_DST = CH * DB;
-    constexpr int RING = BlockGeom<T, CH>::ring_entries(FB_DST);  // outputs the LDS ring holds per lane (power of two)
     constexpr int IN_BLOCKS = ((8 * FB_SRC + 15 + 15) / 16) | 1;   // 16-byte pieces per staged row, odd (bank spread)
     constexpr int IN_STRIDE = IN_BLOCKS * 16;
     constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
-    constexpr int MSG_SLOTS = 32;                                  // messages of the wave's output range kept in LDS
-    constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_MSG = OFF_RING + RING * 64 * 4;
+    // a wave's private LDS region (after the shared coefficient table): input stages, message table, output ring
+    constexpr uint32_t OFF_IN = 0, OFF_MSG = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_RING = OFF_MSG + MSG_SLOTS * 16;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const lds_u8_t lds = (lds_u8_t)smem;
-    // One wave per workgroup: staging, ring and write-back are private to the wave, so no workgroup barrier exists.
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid;
-    constexpr uint32_t wave = 0;
-    const const_f64_ptr_t coef_c = (const_f64_ptr_t)coef;
-    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0, st_smem = 0, st_fma = 0, st_fma0 = 0;
-    if constexpr (STAMP) st_mark = stamp_now();
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t ring_mask = ring_entries - 1;
+    const uint32_t coef_bytes = (uint32_t)L * T * 8;
+    const uint32_t wave_lds = OFF_RING + ring_entries * 256;
 
-    const SrcWork wk = work[blockIdx.x];
+    // ---- coefficient table -> LDS, once per workgroup (the only workgroup barrier of the kernel) ----
+    for (uint32_t i = tid; i < coef_bytes / 16; i += blockDim.x)
+        ((__attribute__((address_space(3))) u32x4*)(lds_u8_t)smem)[i] = ((const u32x4*)coef)[i];
+    __syncthreads();
+    const __attribute__((address_space(3))) double* coef_lds =
+        (const __attribute__((address_space(3))) double*)((lds_u8_t)smem + (lane & 15) * 8);     // + phase * T * 8
+    uint8_t* const wsmem = smem + coef_bytes + wave * wave_lds;       // this wave's region: staging, ring and
+    const lds_u8_t lds = (lds_u8_t)wsmem;                            // write-back are private to the wave
+    const int Mr = M % L;
+
+    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0;
+
+    for (uint32_t unit = blockIdx.x * n_waves + wave; unit < n_work; unit += gridDim.x * n_waves) {
+    if constexpr (STAMP) { st_wait = st_issue = st_drain = st_compute = 0; st_mark = stamp_now(); }
+    const SrcWork wk = work[unit];
     const SrcSeg seg = segs[wk.seg];
     const uint32_t n_blocks = wk.n_blocks;
-    const uint32_t bw = lane / CH;                       // block within the wave
+    const uint32_t bw = lane / CH;                       // block within the wave's unit
     const uint32_t c = lane - bw * CH;                   // this lane's channel
-    const uint32_t row = wave * BPW + bw;                // block within the workgroup
+    const uint32_t row = bw;
     const bool lane_valid = bw < BPW && row < n_blocks;
     const uint64_t blk = wk.first_block + row;
     const int64_t n_start = (int64_t)(blk * M_blk);      // absolute input frame at advance a = 0
-    const uint64_t m_start = blk * L_blk;                // absolute output frame at j = 0
     const int64_t row_g = seg.src_base + (n_start - T) * (int64_t)FB_SRC;   // byte offset of the frame at a_lin = 0
     // The stream start reads as zeros.  Blocks are at least T input frames long (planner), so only a block that
     // starts at input frame 0 reaches before the stream: its whole warm-up pass (advances a < 0) must be zeros.
     const bool first_block = n_start == 0;
 
-    // Messages (ramp parameters) of the wave's output range.  Lane 0's block starts the range: its message is found
-    // by bisection; the next MSG_SLOTS messages go to an LDS table, compacted and made relative to the wave's first
+    // Messages (ramp parameters) of the unit's output range.  Lane 0's block starts the range: its message is found
+    // by bisection; the next MSG_SLOTS messages go to an LDS table, compacted and made relative to the unit's first
     // output frame, so that the per-output path never issues a global load (it would have to wait for the staging
     // loads in flight).  A range with more messages than the table holds falls back to reading them from memory.
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const __attribute__((address_space(3))) u32x4_t* msg_tab = (const __attribute__((address_space(3))) u32x4_t*)(lds + OFF_MSG);
-    const uint64_t wave_m0 = (wk.first_block + wave * BPW) * (uint64_t)L_blk;
+    const __attribute__((address_space(3))) u32x4* msg_tab = (const __attribute__((address_space(3))) u32x4*)(lds + OFF_MSG);
+    const uint64_t wave_m0 = wk.first_block * (uint64_t)L_blk;
     uint32_t tab_lo;
     {
         uint32_t lo = seg.msg_begin, hi = seg.msg_end;
@@ -163,8 +171,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             if (msgs[mid].out0 <= wave_m0) lo = mid; else hi = mid;
         }
         tab_lo = lo;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the previous unit's table has been read
+        __builtin_amdgcn_wave_barrier();
         if (lane < (uint32_t)MSG_SLOTS) {
-            u32x4_t e = {0x7fffffffu, 0u, 0u, 0u};                 // past the segment: starts "never"
+            u32x4 e = {0x7fffffffu, 0u, 0u, 0u};                   // past the segment: starts "never"
             if (tab_lo + lane < seg.msg_end) {
                 const SegMsg m = msgs[tab_lo + lane];
                 e.x = (uint32_t)(int32_t)(int64_t)(m.out0 - wave_m0);
@@ -172,20 +182,20 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 e.z = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16);
                 e.w = m.flags;
             }
-            ((__attribute__((address_space(3))) u32x4_t*)(lds + OFF_MSG))[lane] = e;
+            ((__attribute__((address_space(3))) u32x4*)(lds + OFF_MSG))[lane] = e;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // this lane's message cursor, relative to its own block: output j is frame j - msg_rel0 of the message
-    const int32_t lane_off = (int32_t)(bw * L_blk);                // block's first output relative to the wave's
+    const int32_t lane_off = (int32_t)(bw * L_blk);                // block's first output relative to the unit's
     uint32_t mi = 0;                                                // index into the table (tab_lo + mi in memory)
     int32_t msg_rel0 = 0;
     uint32_t msg_n = 0x7fffffffu, msg_ramp = 0, msg_flags = 0;     // msg_ramp = start | end << 16
     auto load_msg = [&](uint32_t idx) __attribute__((always_inline)) {
         if (idx < (uint32_t)MSG_SLOTS) {
-            const u32x4_t e = msg_tab[idx];
+            const u32x4 e = msg_tab[idx];
             msg_rel0 = (int32_t)e.x - lane_off; msg_n = e.y; msg_ramp = e.z; msg_flags = e.w;
         } else {
             const SegMsg m = msgs[tab_lo + idx];
@@ -201,12 +211,12 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     int32_t evt_j = (msg_flags & OHGPU_FLAG_RAMP) ? 0 : msg_rel0 + (int32_t)msg_n;
 
     // ---- input staging: stage q holds advances [8q - T, 8q + 8 - T) of every row, as raw packed bytes.
-    // Thread `tid` moves pieces idx = it*256 + tid: piece `part` of row r = idx / IN_BLOCKS.
+    // Lane `lane` moves pieces idx = it*64 + lane: piece `part` of row r = idx / IN_BLOCKS.
     int64_t piece_g[IN_ITERS];       // unaligned byte offset of that row's frame at a_lin = 0
     int32_t piece_part[IN_ITERS];    // -1: nothing to move
 #pragma unroll
     for (int it = 0; it < IN_ITERS; it++) {
-        const uint32_t idx = it * 64 + tid;
+        const uint32_t idx = it * 64 + lane;
         const uint32_t r = idx / IN_BLOCKS;
         piece_g[it] = seg.src_base + ((int64_t)((wk.first_block + r) * M_blk) - T) * (int64_t)FB_SRC;
 #ifdef OHGPU_EXP_NODMA
@@ -225,10 +235,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 if (addr >= 0 && (uint64_t)addr + 16 <= src_arena_bytes) {
                     // LDS destination = wave-uniform base + lane*16
                     __builtin_amdgcn_global_load_lds((global_ptr_t)(src + addr),
-                                                     (lds_ptr_t)(smem + buf + (uint32_t)(it * 64) * 16), 16, 0, 0);
+                                                     (lds_ptr_t)(wsmem + buf + (uint32_t)(it * 64) * 16), 16, 0, 0);
                 } else {
                     // piece straddles an end of the arena: copy only the bytes that exist
-                    const lds_u8_t d = lds + buf + (uint32_t)(it * 64 + tid) * 16;
+                    const lds_u8_t d = lds + buf + (uint32_t)(it * 64 + lane) * 16;
                     for (int b = 0; b < 16; b++) {
                         const int64_t a1 = addr + b;
                         d[b] = (a1 >= 0 && (uint64_t)a1 < src_arena_bytes) ? src[a1] : (uint8_t)0;
@@ -244,8 +254,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // the ring, lays their bytes out in memory order and shifts the stream to the piece's first byte.  Four
     // neighbouring lanes write one whole line: every HBM write is a full, aligned line.
     const __attribute__((address_space(3))) uint32_t* ring = (const __attribute__((address_space(3))) uint32_t*)(lds + OFF_RING);
-    const int64_t wave_dst = seg.dst_base + (int64_t)((wk.first_block + wave * BPW) * L_blk) * FB_DST;   // first block of this wave
-    const uint32_t wave_rows = (wave * BPW >= n_blocks) ? 0u : (n_blocks - wave * BPW < (uint32_t)BPW ? n_blocks - wave * BPW : (uint32_t)BPW);
+    const int64_t wave_dst = seg.dst_base + (int64_t)(wk.first_block * L_blk) * FB_DST;   // first block of this unit
+    const uint32_t wave_rows = n_blocks < (uint32_t)BPW ? n_blocks : (uint32_t)BPW;
     uint32_t drained = 0;                                 // lines written so far (wave-uniform)
     auto drain = [&](int j_now) __attribute__((always_inline)) {
         constexpr int NS = (DB - 1 + 16 + DB - 1) / DB;   // subsamples that can overlap a 16-byte piece
@@ -265,11 +275,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #pragma unroll
                     for (int i = 0; i < NS; i++) {
                         const uint32_t q = q0 + i, jq = q / CH, cq = q - jq * CH;
-                        const uint32_t w = ring[(jq & (RING - 1)) * 64 + r * CH + cq];     // left-justified BE word, ramp applied
+                        const uint32_t w = ring[(jq & ring_mask) * 64 + r * CH + cq];      // left-justified BE word, ramp applied
                         // v = the DB bytes in memory order, first byte in the low bits
                         const uint32_t v = DST_LE ? (w >> (32 - 8 * DB))
                                                   : (__builtin_bswap32(w) & (DB == 4 ? 0xffffffffu : ((1u << (8 * (DB & 3))) - 1)));
-                        constexpr int dummy = 0; (void)dummy;
                         const int bp = i * DB;
                         const int dw = bp >> 2, sh = (bp & 3) * 8;
                         if (dw < 5) u[dw] |= v << sh;
@@ -294,8 +303,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const int total = (int)M_blk + T;         // advances a = a_lin - T for a_lin in [0, total)
     int j = 0;                                // outputs emitted so far (wave-uniform)
     int t = 0;                                // j * M
+    int p = 0;                                // phase of output j = t mod L (every block starts at phase 0)
     uint32_t in_off = OFF_IN;                 // LDS offset of this lane's subsample in the current stage's first frame
     const bool any_first = __any(first_block) != 0;
+    // coefficients of output j: cA = taps 0..15, cB = taps 16..31, tap k in lane (k & 15) of every 16-lane row
+    double cA = coef_lds[0], cB = coef_lds[16];
 
     issue_stage(0);
 
@@ -305,98 +317,63 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             const int a_lin = g * T + s;
             if (a_lin >= total) return;
             const int a = a_lin - T;
-            if constexpr ((s & 7) == 0) {
-                const int q = a_lin >> 3;
+            if constexpr ((s & 3) == 0) {
                 if constexpr (STAMP) { const uint64_t n = stamp_now(); st_compute += n - st_mark; st_mark = n; }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage q has landed (this wave issued all of it)
-                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
-                if ((q + 1) * 8 < total) issue_stage(q + 1);
-                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
+                if constexpr ((s & 7) == 0) {
+                    const int q = a_lin >> 3;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage q has landed (this wave issued all of it)
+                    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
+                    if ((q + 1) * 8 < total) issue_stage(q + 1);
+                    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
+                    in_off = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE + row * IN_STRIDE +
+                             (uint32_t)((row_g + (int64_t)q * 8 * FB_SRC) & 15) + c * SB;
+                }
                 drain(j);
                 if constexpr (STAMP) { const uint64_t n = stamp_now(); st_drain += n - st_mark; st_mark = n; }
-                in_off = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE + row * IN_STRIDE +
-                         (uint32_t)((row_g + (int64_t)q * 8 * FB_SRC) & 15) + c * SB;
             }
-            // Coefficients of this advance's first output: all four lines (T = 32) are requested at once, before the
-            // sample is unpacked, so that an output costs ONE scalar-cache round trip (hidden by the SIMD's other waves).
-            static_assert(T == 32, "this body holds one output's coefficients in four 16-SGPR lines");
-            const bool emits = t < L * (a + 1);
-            u32x16 q0, q1, q2, q3;
-            auto load_lines = [&](const_f64_ptr_t cp) __attribute__((always_inline)) {
-                asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\t"
-                             "s_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0"
-                             : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3) : "s"(cp));
-            };
-#ifdef OHGPU_EXP_NOCOEF
-            if (emits) load_lines(coef_c);
-#else
-            if (emits) load_lines(coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T);
-#endif
             // ---- advance: this channel's sample of frame (n_start + a) enters slot s ----
             win[s] = (double)lds_load_subsample<SB, SRC_LE>(lds + in_off + (s & 7) * FB_SRC);
             // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
-            if (emits) {
-                while (true) {
-                    if constexpr (STAMP) {
-                        uint64_t t0, t1;
-                        asm volatile("s_memtime %0" : "=s"(t0));
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(t0));
-                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
-                        st_smem += t1 - t0;
-                        st_fma0 = t1;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));   // the lines have landed
-                    double acc0 = 0.0, acc1 = 0.0;
+            while (t < L * (a + 1)) {
+                double acc0 = 0.0, acc1 = 0.0;
 #ifdef OHGPU_EXP_NOFMA
-                    acc0 = win[s] + coef_get(q0, 0) + coef_get(q1, 0) + coef_get(q2, 0) + coef_get(q3, 0);
-#elif defined(OHGPU_EXP_ACC4)
-                    double acc2 = 0.0, acc3 = 0.0;
-                    static_for([&](auto kc) __attribute__((always_inline)) {
-                        constexpr int k = 4 * decltype(kc)::value;
-                        const u32x16& qk = (k < 8) ? q0 : (k < 16) ? q1 : (k < 24) ? q2 : q3;
-                        acc0 = fma(coef_get(qk, k & 7), win[(s - k + 2 * T) % T], acc0);
-                        acc1 = fma(coef_get(qk, (k + 1) & 7), win[(s - (k + 1) + 2 * T) % T], acc1);
-                        acc2 = fma(coef_get(qk, (k + 2) & 7), win[(s - (k + 2) + 2 * T) % T], acc2);
-                        acc3 = fma(coef_get(qk, (k + 3) & 7), win[(s - (k + 3) + 2 * T) % T], acc3);
-                    }, std::make_integer_sequence<int, T / 4>{});
-                    acc0 += acc2; acc1 += acc3;
+                acc0 = win[s] + cA + cB;
 #else
-                    static_for([&](auto kc) __attribute__((always_inline)) {
-                        constexpr int k = 2 * decltype(kc)::value;
-                        const u32x16& qk = (k < 8) ? q0 : (k < 16) ? q1 : (k < 24) ? q2 : q3;
-                        acc0 = fma(coef_get(qk, k & 7), win[(s - k + 2 * T) % T], acc0);
-                        acc1 = fma(coef_get(qk, (k + 1) & 7), win[(s - (k + 1) + 2 * T) % T], acc1);
-                    }, std::make_integer_sequence<int, T / 2>{});
-#endif
-                    if constexpr (STAMP) {
-                        uint64_t t1;
-                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(acc0), "v"(acc1));
-                        st_fma += t1 - st_fma0;
+                static_for([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = 2 * decltype(kc)::value;
+                    if constexpr (k < 16) {
+                        fmac_bcast<k, k == 0>(acc0, cA, win[(s - k + 2 * T) % T]);
+                        fmac_bcast<k + 1, false>(acc1, cA, win[(s - (k + 1) + 2 * T) % T]);
+                    } else {
+                        fmac_bcast<k - 16, k == 16>(acc0, cB, win[(s - k + 2 * T) % T]);
+                        fmac_bcast<k - 15, false>(acc1, cB, win[(s - (k + 1) + 2 * T) % T]);
                     }
-                    uint32_t w = ((uint32_t)src_round_s24(acc0 + acc1)) << 8;      // left-justified BE word (a11)
-                    if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
-                        if (lane_valid && j >= evt_j) {
-                            while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
-                            if (msg_flags & OHGPU_FLAG_RAMP) {
-                                const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
-                                const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
-                                w = ramp_word(w, mult, 3, CH, c);
-                                evt_j = j + 1;
-                            } else {
-                                evt_j = msg_rel0 + (int32_t)msg_n;
-                            }
+                }, std::make_integer_sequence<int, T / 2>{});
+#endif
+                // the next output's coefficients (same advance or a later one): its phase is known now
+                p += Mr;
+                if (p >= L) p -= L;
+                {
+                    const __attribute__((address_space(3))) double* cp = coef_lds + (uint32_t)p * T;
+                    cA = cp[0]; cB = cp[16];
+                }
+                uint32_t w = ((uint32_t)src_round_s24(acc0 + acc1)) << 8;      // left-justified BE word (a11)
+                if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
+                    if (lane_valid && j >= evt_j) {
+                        while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
+                        if (msg_flags & OHGPU_FLAG_RAMP) {
+                            const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
+                            const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
+                            w = ramp_word(w, mult, 3, CH, c);
+                            evt_j = j + 1;
+                        } else {
+                            evt_j = msg_rel0 + (int32_t)msg_n;
                         }
                     }
-                    ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_RING))[((uint32_t)j & (RING - 1)) * 64 + tid] = w;
-                    j++;
-                    t += M;
-                    if (!(t < L * (a + 1))) break;
-#ifdef OHGPU_EXP_NOCOEF
-                    load_lines(coef_c);
-#else
-                    load_lines(coef_c + (size_t)__builtin_amdgcn_readfirstlane(t - L * a) * T);
-#endif
                 }
+                ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_RING))[((uint32_t)j & ring_mask) * 64 + lane] = w;
+                j++;
+                t += M;
             }
         }, std::make_integer_sequence<int, T>{});
         if (g == 0 && any_first) {                        // warm-up pass done: a stream's first block starts from silence
@@ -406,11 +383,13 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     }
     drain(j);
     if constexpr (STAMP) {
+        const uint64_t n = stamp_now(); st_drain += n - st_mark;
         if (dbg != nullptr && lane == 0) {
-            uint64_t* o = dbg + (size_t)blockIdx.x * 4;
-            o[0] = st_wait + (st_fma << 32); o[1] = st_issue + (st_smem << 32); o[2] = st_drain; o[3] = st_compute;
+            uint64_t* o = dbg + (size_t)unit * 4;
+            o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute;
         }
     }
+    }   // units
 }
 
 // ---- instantiations: (T, channels, source bytes, source LE, destination bytes, destination LE) ----
@@ -428,15 +407,31 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     X(32, 2, 2, true, 2, false)
 #endif
 
+// Launch shape: up to MAX_WAVES waves per workgroup (what the LDS left by the coefficient table allows), one
+// workgroup per CU, waves loop over the work units; a small batch is spread as one-wave workgroups instead.
+static void launch_shape(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32_t* grid, uint32_t* waves, uint32_t* lds)
+{
+    const SrcFastPlan& f = b->fast;
+    const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
+    uint32_t w = (f.n_work + cus - 1) / cus;
+    if (w < 1) w = 1;
+    if (w > f.max_waves) w = f.max_waves;
+    uint32_t g = (f.n_work + w - 1) / w;
+    if (g > cus) g = cus;
+    *grid = g; *waves = w; *lds = f.coef_lds_bytes + w * f.wave_lds_bytes;
+}
+
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
-static hipError_t launch_one(const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
+static hipError_t launch_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
 {
     auto kernel = src_block_kernel<T, CH, SB, SRC_LE, DB, DST_LE>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fast.lds_bytes);
+    uint32_t grid, waves, lds;
+    launch_shape(ctx, b, &grid, &waves, &lds);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(64), b->fast.lds_bytes, s,
-                       p.segs, p.msgs, p.work, p.coef, p.ramp_table, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
+                       p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_entries, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -449,55 +444,59 @@ bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, 
     return false;
 }
 
-// geometry the planner needs (must match the kernel's constexprs)
-void src_block_geometry(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t* rows, uint32_t* ring, uint32_t* lds_bytes)
+// Geometry the planner needs (must match the kernel's constexprs).  `out_per_drain` = the most outputs four
+// consecutive advances can emit (ceil(4L/M)).  Returns false when the layout does not fit the CU's LDS.
+bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
+                        uint32_t* rows, uint32_t* ring, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves)
 {
-    const uint32_t bpw = 64 / ch, r = bpw;
+    const uint32_t bpw = 64 / ch;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
     const uint32_t in_blocks = ((8 * fb_src + 15 + 15) / 16) | 1;
-    const uint32_t need = (63 + fb_dst - 1) / fb_dst + 9 + 1;
+    const uint32_t need = ring_pending(fb_dst) + out_per_drain;
     uint32_t rg = 8;
     while (rg < need) rg *= 2;
-    *rows = r;
+    if (rg > 64) return false;
+    *rows = bpw;
     *ring = rg;
-    *lds_bytes = 2 * r * in_blocks * 16 + rg * 64 * 4 + 32 * 16;
-    (void)T;
+    *coef_lds_bytes = L * T * 8;
+    *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + rg * 256;
+    const uint32_t budget = 160 * 1024;
+    if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
+    uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
+    if (w > 12) w = 12;
+    if (w < 4) return false;            // too few waves per CU to be worth it: the generic kernel takes the batch
+    *max_waves = w;
+    return true;
 }
 
 // Diagnostic only (OHGPU_STAMP_FILE=<path>): runs the stamped build of the S24LE->S24BE stereo kernel once, waits,
-// and writes per-wave {wait, issue, drain, compute} cycle sums as text.  Never used by the product path.
-static hipError_t launch_stamped(const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s, const char* path)
+// and writes per-unit {wait, issue, drain, compute} cycle sums as text.  Never used by the product path.
+static hipError_t launch_stamped(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s, const char* path)
 {
     auto kernel = src_block_kernel<32, 2, 3, true, 3, false, true>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fast.lds_bytes);
+    uint32_t grid, waves, lds;
+    launch_shape(ctx, b, &grid, &waves, &lds);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const size_t n = (size_t)b->fast.n_work * 4;
     uint64_t* d = nullptr;
     e = hipMalloc((void**)&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return e;
     hipMemsetAsync(d, 0, n * sizeof(uint64_t), s);
-    hipLaunchKernelGGL(kernel, dim3(b->fast.n_work), dim3(64), b->fast.lds_bytes, s,
-                       p.segs, p.msgs, p.work, p.coef, p.ramp_table, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, d);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
+                       p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_entries, d);
     e = hipStreamSynchronize(s);
     if (e == hipSuccess) {
         std::vector<uint64_t> h(n);
         e = hipMemcpy(h.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(path, "w")) {
             double sum[4] = {0, 0, 0, 0};
-            double smem = 0, fma = 0;
-            for (size_t i = 0; i < n; i += 4) {
-                smem += (double)(h[i + 1] >> 32);
-                h[i + 1] &= 0xffffffffull;
-                fma += (double)(h[i] >> 32);
-                h[i] &= 0xffffffffull;
+            for (size_t i = 0; i < n; i += 4)
                 for (int k = 0; k < 4; k++) sum[k] += (double)h[i + k];
-            }
-            const double waves = (double)n / 4;
-            int occ = -1;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)src_block_kernel<32, 2, 3, true, 3, false, false>, 64, b->fast.lds_bytes);
-            fprintf(f, "waves %.0f mean cycles per wave: wait %.0f issue %.0f drain %.0f compute %.0f (of which waiting for coefficient lines %.0f, inside the FMA blocks %.0f) | lds %u B, occupancy API %d WG/CU\n", waves,
-                    sum[0] / waves, sum[1] / waves, sum[2] / waves, sum[3] / waves, smem / waves, fma / waves, b->fast.lds_bytes, occ);
+            const double units = (double)n / 4;
+            fprintf(f, "units %.0f mean cycles per unit: wait %.0f issue %.0f drain %.0f compute %.0f | grid %u x %u waves, lds %u B\n",
+                    units, sum[0] / units, sum[1] / units, sum[2] / units, sum[3] / units, grid, waves, lds);
             fclose(f);
         }
     }
@@ -514,12 +513,12 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
     prm.ramp_table = ctx->d_ramp_table;
     if (const char* path = getenv("OHGPU_STAMP_FILE")) {
         if (b->fast.T == 32 && prm.channels == 2 && prm.sb == 3 && prm.src_le && prm.db == 3 && !prm.dst_le)
-            return launch_stamped(b, prm, s, path);
+            return launch_stamped(ctx, b, prm, s, path);
     }
     const uint32_t T = b->fast.T;
 #define X(t, c, s_, sl, d, dl)                                                                                            \
     if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
-        return launch_one<t, c, s_, sl, d, dl>(b, prm, s);
+        return launch_one<t, c, s_, sl, d, dl>(ctx, b, prm, s);
     OHGPU_BLOCK_KERNELS(X)
 #undef X
     return hipErrorInvalidValue;

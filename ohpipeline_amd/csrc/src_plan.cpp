@@ -69,8 +69,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint32_t dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
     if (!src_block_supported(T, ch, sb, src_le, db, dst_le)) return OHGPU_OK;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
-    uint32_t rows = 0, ring = 0, lds_bytes = 0;
-    src_block_geometry(T, ch, sb, db, &rows, &ring, &lds_bytes);
+    // the ring is drained every four advances: #{j : a <= floor(j*M/L) < a+4} <= ceil(4L/M) outputs arrive in between
+    const uint32_t out_per_drain = (4 * L + M - 1) / M;
+    uint32_t rows = 0, ring = 0, coef_lds = 0, wave_lds = 0, max_waves = 0;
+    if (!src_block_geometry(L, T, ch, sb, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
     uint32_t L_blk = L * ((128 + L - 1) / L);
     {
@@ -82,9 +84,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint64_t M_blk64 = (uint64_t)L_blk * M / L;
     if (M_blk64 + T > 32000 || M_blk64 < T) return OHGPU_OK;    // a block is at least one filter length of input
     const uint32_t M_blk = (uint32_t)M_blk64;
-    const uint32_t max_out_per_stage = (8 * L + M - 1) / M;      // #{j : a <= floor(j*M/L) < a+8} <= ceil(8L/M)
-    if (max_out_per_stage > 9) return OHGPU_OK;                  // the LDS ring is sized for <= 9 outputs per stage
-    if (lds_bytes > 160 * 1024) return OHGPU_OK;
     const uint32_t oc_log2 = 0;
     (void)fb_src; (void)gcd_u32;
 
@@ -171,7 +170,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.cpl = 1;
     f.n_work = (uint32_t)work.size();
     f.n_rem = rem.size();
-    f.lds_bytes = lds_bytes;
+    f.coef_lds_bytes = coef_lds;
+    f.wave_lds_bytes = wave_lds;
+    f.max_waves = max_waves;
+    f.ring_entries = ring;
     f.fast_out_frames = fast_frames;
     SrcFastParams& p = f.params;
     memset(&p, 0, sizeof(p));
