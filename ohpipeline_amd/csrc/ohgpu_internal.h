@@ -89,10 +89,11 @@ struct SrcFastPlan {
     uint32_t coef_lds_bytes = 0;  // the coefficient table's share of a workgroup's LDS
     uint32_t wave_lds_bytes = 0;  // per wave: input stages, message table, output ring
     uint32_t max_waves = 0;       // waves per workgroup the LDS allows (<= 12)
-    uint32_t ring_entries = 0;    // outputs the LDS ring holds per lane (power of two)
+    uint32_t ring_bytes = 0;      // bytes of packed output a block row's LDS ring holds
     void*    d_segs = nullptr;
     void*    d_msgs = nullptr;
     void*    d_work = nullptr;
+    void*    d_counter = nullptr; // uint32: units claimed so far by the running launch (zeroed before every launch)
     void*    d_rem = nullptr;     // DevSrcDesc[] the generic kernel finishes (block-unaligned heads and tails)
     size_t   n_rem = 0;
     uint64_t fast_out_frames = 0;
@@ -149,7 +150,7 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
-                        uint32_t* rows, uint32_t* ring, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);
+                        uint32_t* rows, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);
 
 // host helpers
 void build_ramp_table(uint16_t out[512]);

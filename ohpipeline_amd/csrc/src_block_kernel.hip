@@ -94,13 +94,26 @@ struct BlockGeom {
     static constexpr int MSG_SLOTS = 32;                // messages of a wave's output range kept in LDS
 };
 
-// LDS ring: outputs the ring must hold per lane.  After a drain fewer than 64 bytes (a multiple of gcd(64, fb_dst))
-// are pending, i.e. at most (64 - g) / fb_dst + 1 frames; up to `per_drain` more arrive before the next drain.
-static constexpr uint32_t ring_pending(uint32_t fb_dst)
+// Output ring: every block row owns `ring_bytes` of LDS that hold its packed output byte stream modulo ring_bytes.
+// ring_bytes is a multiple of the frame size (a frame never wraps) and of 16 (a 16-byte piece of a line never
+// wraps).  After a drain fewer than 64 bytes (a multiple of g = gcd(64, fb_dst)) are pending, and `out_per_drain`
+// more frames arrive before the next drain.  Rows are 4 bytes further apart so that they start in different banks.
+static constexpr uint32_t gcd_c(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
+static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain)
 {
-    uint32_t g = 64, x = fb_dst;
-    while (x) { const uint32_t t = g % x; g = x; x = t; }
-    return (64 - g) / fb_dst + 1;
+    const uint32_t unit = fb_dst * 16 / gcd_c(fb_dst, 16);
+    const uint32_t need = (64 - gcd_c(64, fb_dst)) + out_per_drain * fb_dst;
+    return unit * ((need + unit - 1) / unit);
+}
+
+// the DB bytes of a finished subsample -> LDS, at any byte position (v = the bytes in memory order, first byte low)
+template <int DB>
+__device__ __forceinline__ void lds_store_subsample(lds_u8_t q, uint32_t v)
+{
+    if constexpr (DB == 4) *(__attribute__((address_space(3))) uint32_t*)q = v;                  // 4-aligned by construction
+    else if constexpr (DB == 2) *(__attribute__((address_space(3))) uint16_t*)q = (uint16_t)v;   // 2-aligned
+    else if constexpr (DB == 3) { q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16); }
+    else q[0] = (uint8_t)v;
 }
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
@@ -109,7 +122,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                       const uint32_t n_work, const double* __restrict__ coef, const uint16_t* __restrict__ ramp_table,
                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                       const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
-                      const uint32_t ring_entries, uint64_t* __restrict__ dbg)
+                      const uint32_t ring_bytes, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
 {
     static_assert(T == 32, "two coefficient registers per lane hold taps k and k + 16 of a 32-tap row");
     constexpr int BPW = BlockGeom<T, CH>::BPW, ROWS = BlockGeom<T, CH>::ROWS, MSG_SLOTS = BlockGeom<T, CH>::MSG_SLOTS;
@@ -125,13 +138,15 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const uint32_t lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_waves = blockDim.x >> 6;
-    const uint32_t ring_mask = ring_entries - 1;
     const uint32_t coef_bytes = (uint32_t)L * T * 8;
-    const uint32_t wave_lds = OFF_RING + ring_entries * 256;
+    const uint32_t row_stride = ring_bytes + 4;                       // output ring: rows start in different banks
+    const uint32_t wave_lds = OFF_RING + ((ROWS * row_stride + 15) & ~15u);
 
-    // ---- coefficient table -> LDS, once per workgroup (the only workgroup barrier of the kernel) ----
-    for (uint32_t i = tid; i < coef_bytes / 16; i += blockDim.x)
-        ((__attribute__((address_space(3))) u32x4*)(lds_u8_t)smem)[i] = ((const u32x4*)coef)[i];
+    // ---- coefficient table -> LDS, once per workgroup (the only workgroup barrier of the kernel).  The Q28
+    // integers are scaled by 2^-28 on the way (exact): the accumulator is then in sample units, every partial sum
+    // is a multiple of 2^-28 below 2^25 (exact in fp64), and rounding is floor(sum + 0.5) with the 0.5 preloaded.
+    for (uint32_t i = tid; i < (uint32_t)L * T; i += blockDim.x)
+        ((__attribute__((address_space(3))) double*)(lds_u8_t)smem)[i] = coef[i] * (1.0 / 268435456.0);
     __syncthreads();
     const __attribute__((address_space(3))) double* coef_lds =
         (const __attribute__((address_space(3))) double*)((lds_u8_t)smem + (lane & 15) * 8);     // + phase * T * 8
@@ -141,7 +156,14 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 
     uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0;
 
-    for (uint32_t unit = blockIdx.x * n_waves + wave; unit < n_work; unit += gridDim.x * n_waves) {
+    // Work units: every wave starts on its own unit, then claims further ones from a counter, so that the waves of
+    // the whole grid finish together (waves sharing a SIMD run at very different speeds; a fixed share per wave
+    // left the chip a quarter idle).  The claim is issued at the start of a unit and consumed at its end.
+    const uint32_t first_claimed = gridDim.x * n_waves;
+    uint32_t unit = blockIdx.x * n_waves + wave;
+    while (unit < n_work) {
+    uint32_t claim = 0;
+    if (lane == 0) claim = atomicAdd(unit_counter, 1u);
     if constexpr (STAMP) { st_wait = st_issue = st_drain = st_compute = 0; st_mark = stamp_now(); }
     const SrcWork wk = work[unit];
     const SrcSeg seg = segs[wk.seg];
@@ -249,16 +271,17 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     };
 
     // ---- tail: the block's output is a byte stream of L_blk*FB_DST bytes that starts 64-byte aligned (planner).
-    // Whenever a 64-byte line of it is complete in the ring, the wave writes that line of all its blocks: lane l of
-    // pass `it` owns 16-byte piece (l & 3) of block (it*16 + l/4), gathers the <= NS subsamples that overlap it from
-    // the ring, lays their bytes out in memory order and shifts the stream to the piece's first byte.  Four
-    // neighbouring lanes write one whole line: every HBM write is a full, aligned line.
-    const __attribute__((address_space(3))) uint32_t* ring = (const __attribute__((address_space(3))) uint32_t*)(lds + OFF_RING);
+    // A finished subsample is ramped, packed and stored at its place in the row's byte ring.  Whenever a 64-byte
+    // line of the stream is complete, the wave writes that line of all its blocks: lane l of pass `it` copies
+    // 16-byte piece (l & 3) of block (it*16 + l/4) from the ring to memory.  Four neighbouring lanes write one whole
+    // line: every HBM write is a full, aligned line.
+    const uint32_t ring_lane = OFF_RING + row * row_stride + c * DB;     // this lane's subsample in the ring's frame 0
     const int64_t wave_dst = seg.dst_base + (int64_t)(wk.first_block * L_blk) * FB_DST;   // first block of this unit
     const uint32_t wave_rows = n_blocks < (uint32_t)BPW ? n_blocks : (uint32_t)BPW;
     uint32_t drained = 0;                                 // lines written so far (wave-uniform)
+    uint32_t line_pos = 0;                                // ring position of line `drained`
+    uint32_t ring_pos = 0;                                // ring position of frame j
     auto drain = [&](int j_now) __attribute__((always_inline)) {
-        constexpr int NS = (DB - 1 + 16 + DB - 1) / DB;   // subsamples that can overlap a 16-byte piece
         while (drained < (((uint32_t)j_now * FB_DST) >> 6)) {
 #pragma unroll
             for (int it = 0; it < (BPW * 4 + 63) / 64; it++) {
@@ -269,30 +292,18 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #else
                 if (r < wave_rows) {
 #endif
-                    const uint32_t b0 = drained * 64 + part * 16;          // first byte of the piece in the block's stream
-                    const uint32_t q0 = b0 / DB, delta = b0 - q0 * DB;     // first overlapping subsample, bytes to skip in it
-                    uint32_t u[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int i = 0; i < NS; i++) {
-                        const uint32_t q = q0 + i, jq = q / CH, cq = q - jq * CH;
-                        const uint32_t w = ring[(jq & ring_mask) * 64 + r * CH + cq];      // left-justified BE word, ramp applied
-                        // v = the DB bytes in memory order, first byte in the low bits
-                        const uint32_t v = DST_LE ? (w >> (32 - 8 * DB))
-                                                  : (__builtin_bswap32(w) & (DB == 4 ? 0xffffffffu : ((1u << (8 * (DB & 3))) - 1)));
-                        const int bp = i * DB;
-                        const int dw = bp >> 2, sh = (bp & 3) * 8;
-                        if (dw < 5) u[dw] |= v << sh;
-                        if (sh + 8 * DB > 32 && dw + 1 < 5) u[dw + 1] |= v >> (32 - sh);
-                    }
+                    uint32_t pos = line_pos + part * 16;
+                    if (pos >= ring_bytes) pos -= ring_bytes;
+                    const __attribute__((address_space(3))) uint32_t* q =
+                        (const __attribute__((address_space(3))) uint32_t*)(lds + OFF_RING + r * row_stride + pos);
                     u32x4 v4;
-                    v4.x = __builtin_amdgcn_alignbyte(u[1], u[0], delta);
-                    v4.y = __builtin_amdgcn_alignbyte(u[2], u[1], delta);
-                    v4.z = __builtin_amdgcn_alignbyte(u[3], u[2], delta);
-                    v4.w = __builtin_amdgcn_alignbyte(u[4], u[3], delta);
-                    *(u32x4*)(dst + wave_dst + (int64_t)((uint64_t)r * L_blk) * FB_DST + b0) = v4;
+                    v4.x = q[0]; v4.y = q[1]; v4.z = q[2]; v4.w = q[3];
+                    *(u32x4*)(dst + wave_dst + (int64_t)((uint64_t)r * L_blk) * FB_DST + drained * 64 + part * 16) = v4;
                 }
             }
             drained++;
+            line_pos += 64;
+            if (line_pos >= ring_bytes) line_pos -= ring_bytes;
         }
     };
 
@@ -335,7 +346,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             win[s] = (double)lds_load_subsample<SB, SRC_LE>(lds + in_off + (s & 7) * FB_SRC);
             // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
             while (t < L * (a + 1)) {
-                double acc0 = 0.0, acc1 = 0.0;
+                double acc0 = 0.5, acc1 = 0.0;                                 // round half up: floor(sum + 0.5)
 #ifdef OHGPU_EXP_NOFMA
                 acc0 = win[s] + cA + cB;
 #else
@@ -357,7 +368,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                     const __attribute__((address_space(3))) double* cp = coef_lds + (uint32_t)p * T;
                     cA = cp[0]; cB = cp[16];
                 }
-                uint32_t w = ((uint32_t)src_round_s24(acc0 + acc1)) << 8;      // left-justified BE word (a11)
+                int32_t y = (int32_t)floor(acc0 + acc1);
+                y = y > 8388607 ? 8388607 : (y < -8388608 ? -8388608 : y);
+                uint32_t w = (uint32_t)y << 8;                                  // left-justified BE word (a11)
                 if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
                     if (lane_valid && j >= evt_j) {
                         while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
@@ -371,7 +384,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                         }
                     }
                 }
-                ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_RING))[((uint32_t)j & ring_mask) * 64 + lane] = w;
+                // the DB bytes in memory order (first byte low) -> their place in the row's byte ring
+                lds_store_subsample<DB>(lds + ring_lane + ring_pos, DST_LE ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w));
+                ring_pos += FB_DST;
+                if (ring_pos == ring_bytes) ring_pos = 0;
                 j++;
                 t += M;
             }
@@ -389,6 +405,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute;
         }
     }
+    unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     }   // units
 }
 
@@ -429,9 +446,12 @@ static hipError_t launch_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const S
     launch_shape(ctx, b, &grid, &waves, &lds);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(b->fast.d_counter, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
                        p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_entries, (uint64_t*)nullptr);
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_bytes,
+                       (uint32_t*)b->fast.d_counter, (uint64_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -447,19 +467,16 @@ bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, 
 // Geometry the planner needs (must match the kernel's constexprs).  `out_per_drain` = the most outputs four
 // consecutive advances can emit (ceil(4L/M)).  Returns false when the layout does not fit the CU's LDS.
 bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
-                        uint32_t* rows, uint32_t* ring, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves)
+                        uint32_t* rows, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves)
 {
     const uint32_t bpw = 64 / ch;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
     const uint32_t in_blocks = ((8 * fb_src + 15 + 15) / 16) | 1;
-    const uint32_t need = ring_pending(fb_dst) + out_per_drain;
-    uint32_t rg = 8;
-    while (rg < need) rg *= 2;
-    if (rg > 64) return false;
+    const uint32_t rb = ring_bytes_for(fb_dst, out_per_drain);
     *rows = bpw;
-    *ring = rg;
+    *ring_bytes = rb;
     *coef_lds_bytes = L * T * 8;
-    *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + rg * 256;
+    *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + ((bpw * (rb + 4) + 15) & ~15u);
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
@@ -483,9 +500,11 @@ static hipError_t launch_stamped(const ohgpu_ctx* ctx, const ohgpu_batch* b, con
     e = hipMalloc((void**)&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return e;
     hipMemsetAsync(d, 0, n * sizeof(uint64_t), s);
+    hipMemsetAsync(b->fast.d_counter, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
                        p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_entries, d);
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_bytes,
+                       (uint32_t*)b->fast.d_counter, d);
     e = hipStreamSynchronize(s);
     if (e == hipSuccess) {
         std::vector<uint64_t> h(n);
@@ -497,6 +516,12 @@ static hipError_t launch_stamped(const ohgpu_ctx* ctx, const ohgpu_batch* b, con
             const double units = (double)n / 4;
             fprintf(f, "units %.0f mean cycles per unit: wait %.0f issue %.0f drain %.0f compute %.0f | grid %u x %u waves, lds %u B\n",
                     units, sum[0] / units, sum[1] / units, sum[2] / units, sum[3] / units, grid, waves, lds);
+            double mn = 1e30, mx = 0;
+            for (size_t u = 0; u < n / 4; u++) {
+                const double c = (double)(h[4 * u] + h[4 * u + 1] + h[4 * u + 2] + h[4 * u + 3]);
+                mn = c < mn ? c : mn; mx = c > mx ? c : mx;
+            }
+            fprintf(f, "cycles per unit: min %.0f max %.0f\n", mn, mx);
             fclose(f);
         }
     }

@@ -25,6 +25,7 @@ void free_src_fast(ohgpu_batch* b)
     if (f.d_msgs) hipFree(f.d_msgs);
     if (f.d_work) hipFree(f.d_work);
     if (f.d_rem) hipFree(f.d_rem);
+    if (f.d_counter) hipFree(f.d_counter);
     f = SrcFastPlan();
 }
 
@@ -164,6 +165,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
     if (err == OHGPU_OK) err = upload_vec(work, &f.d_work);
     if (err == OHGPU_OK) err = upload_vec(rem, &f.d_rem);
+    if (err == OHGPU_OK) err = upload_vec(std::vector<uint32_t>(1, 0u), &f.d_counter);
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
     f.enabled = true;
     f.T = T;
@@ -173,7 +175,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.coef_lds_bytes = coef_lds;
     f.wave_lds_bytes = wave_lds;
     f.max_waves = max_waves;
-    f.ring_entries = ring;
+    f.ring_bytes = ring;
     f.fast_out_frames = fast_frames;
     SrcFastParams& p = f.params;
     memset(&p, 0, sizeof(p));
