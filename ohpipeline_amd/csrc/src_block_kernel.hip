@@ -99,12 +99,20 @@ struct BlockGeom {
 // wraps).  After a drain fewer than 64 bytes (a multiple of g = gcd(64, fb_dst)) are pending, and `out_per_drain`
 // more frames arrive before the next drain.  Rows are 4 bytes further apart so that they start in different banks.
 static constexpr uint32_t gcd_c(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
-static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain)
+static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain, bool pair)
 {
-    const uint32_t unit = fb_dst * 16 / gcd_c(fb_dst, 16);
-    const uint32_t need = (64 - gcd_c(64, fb_dst)) + out_per_drain * fb_dst;
+    // pair mode (24-bit stereo): frames enter the ring two at a time, so one more frame can be waiting and the
+    // pending bytes are a multiple of gcd(64, 2 * fb_dst)
+    const uint32_t step = pair ? 2 * fb_dst : fb_dst;
+    const uint32_t unit = step * 16 / gcd_c(step, 16);
+    const uint32_t need = (64 - gcd_c(64, step)) + (out_per_drain + (pair ? 1 : 0)) * fb_dst;
     return unit * ((need + unit - 1) / unit);
 }
+#ifdef OHGPU_EXP_BYTERING
+static constexpr bool ring_pair_mode(uint32_t, uint32_t) { return false; }
+#else
+static constexpr bool ring_pair_mode(uint32_t ch, uint32_t db) { return ch == 2 && db == 3; }
+#endif
 
 // the DB bytes of a finished subsample -> LDS, at any byte position (v = the bytes in memory order, first byte low)
 template <int DB>
@@ -275,14 +283,24 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // line of the stream is complete, the wave writes that line of all its blocks: lane l of pass `it` copies
     // 16-byte piece (l & 3) of block (it*16 + l/4) from the ring to memory.  Four neighbouring lanes write one whole
     // line: every HBM write is a full, aligned line.
-    const uint32_t ring_lane = OFF_RING + row * row_stride + c * DB;     // this lane's subsample in the ring's frame 0
+    // 24-bit stereo ("pair mode"): the two channel lanes of a block pack two frames = 12 bytes = three aligned words
+    // between them (one lane swap, two byte permutes with per-lane selectors) and store them with ONE ds_write2_b32
+    // every second output: lane A words 0-1, lane B words 1-2 (word 1 twice, same value).  Byte stores would cost
+    // three LDS store instructions per output.  Other layouts store each subsample's bytes where they belong.
+    constexpr bool PAIR = ring_pair_mode(CH, DB);
+    constexpr uint32_t B0 = DST_LE ? 1 : 3, B1 = 2, B2 = DST_LE ? 3 : 1;      // byte of the left-justified word that is memory byte 0, 1, 2
+    const uint32_t ring_lane = OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB);   // this lane's place in the ring's frame (pair) 0
+    // selectors for v_perm_b32 {got (bytes 4-7), own (bytes 0-3)}: words 0/1 from the even frame, words 1/2 from the odd one
+    const uint32_t sel_lo = c == 0 ? (B0 | B1 << 8 | B2 << 16 | (4 + B0) << 24) : (B1 | B2 << 8 | (4 + B0) << 16 | (4 + B1) << 24);
+    const uint32_t sel_hi = c == 0 ? ((4 + B1) | (4 + B2) << 8 | B0 << 16 | B1 << 24) : ((4 + B2) | B0 << 8 | B1 << 16 | B2 << 24);
+    uint32_t w_even = 0;                                  // pair mode: the even output's word, waiting for its partner
     const int64_t wave_dst = seg.dst_base + (int64_t)(wk.first_block * L_blk) * FB_DST;   // first block of this unit
     const uint32_t wave_rows = n_blocks < (uint32_t)BPW ? n_blocks : (uint32_t)BPW;
     uint32_t drained = 0;                                 // lines written so far (wave-uniform)
     uint32_t line_pos = 0;                                // ring position of line `drained`
     uint32_t ring_pos = 0;                                // ring position of frame j
     auto drain = [&](int j_now) __attribute__((always_inline)) {
-        while (drained < (((uint32_t)j_now * FB_DST) >> 6)) {
+        while (drained < (((uint32_t)(PAIR ? (j_now & ~1) : j_now) * FB_DST) >> 6)) {
 #pragma unroll
             for (int it = 0; it < (BPW * 4 + 63) / 64; it++) {
                 const uint32_t piece = it * 64 + lane;
@@ -343,7 +361,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 if constexpr (STAMP) { const uint64_t n = stamp_now(); st_drain += n - st_mark; st_mark = n; }
             }
             // ---- advance: this channel's sample of frame (n_start + a) enters slot s ----
+#ifdef OHGPU_EXP_NOSAMPLE
+            win[s] = (double)(int)(lane + s);
+#else
             win[s] = (double)lds_load_subsample<SB, SRC_LE>(lds + in_off + (s & 7) * FB_SRC);
+#endif
             // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
             while (t < L * (a + 1)) {
                 double acc0 = 0.5, acc1 = 0.0;                                 // round half up: floor(sum + 0.5)
@@ -364,14 +386,20 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 // the next output's coefficients (same advance or a later one): its phase is known now
                 p += Mr;
                 if (p >= L) p -= L;
+#ifndef OHGPU_EXP_NOCOEF
                 {
                     const __attribute__((address_space(3))) double* cp = coef_lds + (uint32_t)p * T;
                     cA = cp[0]; cB = cp[16];
                 }
+#endif
                 int32_t y = (int32_t)floor(acc0 + acc1);
                 y = y > 8388607 ? 8388607 : (y < -8388608 ? -8388608 : y);
                 uint32_t w = (uint32_t)y << 8;                                  // left-justified BE word (a11)
+#ifdef OHGPU_EXP_NOEVT
+                if (j < 0) {
+#else
                 if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
+#endif
                     if (lane_valid && j >= evt_j) {
                         while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
                         if (msg_flags & OHGPU_FLAG_RAMP) {
@@ -384,10 +412,30 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                         }
                     }
                 }
-                // the DB bytes in memory order (first byte low) -> their place in the row's byte ring
-                lds_store_subsample<DB>(lds + ring_lane + ring_pos, DST_LE ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w));
-                ring_pos += FB_DST;
-                if (ring_pos == ring_bytes) ring_pos = 0;
+#ifdef OHGPU_EXP_NORING
+                if (w == 0x12345u) lds_store_subsample<DB>(lds + ring_lane + ring_pos, w);
+#else
+                if constexpr (PAIR) {
+                    if (j & 1) {
+                        // lane A needs B's even word, lane B needs A's odd word
+                        const uint32_t give = c == 0 ? w : w_even;
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                        const uint32_t lo = __builtin_amdgcn_perm(got, w_even, sel_lo);
+                        const uint32_t hi = __builtin_amdgcn_perm(got, w, sel_hi);
+                        __attribute__((address_space(3))) uint32_t* q = (__attribute__((address_space(3))) uint32_t*)(lds + ring_lane + ring_pos);
+                        q[0] = lo; q[1] = hi;
+                        ring_pos += 2 * FB_DST;
+                        if (ring_pos == ring_bytes) ring_pos = 0;
+                    } else {
+                        w_even = w;
+                    }
+                } else {
+                    // the DB bytes in memory order (first byte low) -> their place in the row's byte ring
+                    lds_store_subsample<DB>(lds + ring_lane + ring_pos, DST_LE ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w));
+                    ring_pos += FB_DST;
+                    if (ring_pos == ring_bytes) ring_pos = 0;
+                }
+#endif
                 j++;
                 t += M;
             }
@@ -472,7 +520,7 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     const uint32_t bpw = 64 / ch;
     const uint32_t fb_src = ch * sb, fb_dst = ch * db;
     const uint32_t in_blocks = ((8 * fb_src + 15 + 15) / 16) | 1;
-    const uint32_t rb = ring_bytes_for(fb_dst, out_per_drain);
+    const uint32_t rb = ring_bytes_for(fb_dst, out_per_drain, ring_pair_mode(ch, db));
     *rows = bpw;
     *ring_bytes = rb;
     *coef_lds_bytes = L * T * 8;
