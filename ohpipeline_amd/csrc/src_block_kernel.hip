@@ -46,6 +46,56 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S..
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- hand-issued LDS traffic of the per-output loop, with counted waits ----
+// hipcc waits for LDS data with `s_waitcnt lgkmcnt(0)`, which also waits for whatever was issued last -- here the
+// ring store of the previous output and the reads for the next one, i.e. a full LDS round trip per output with only
+// three waves per SIMD to hide it.  The loop's LDS operations are therefore issued from inline asm, invisible to the
+// compiler's wait insertion, in a fixed order per output (see the loop), and waited for by hand: a wave's LDS
+// operations complete in issue order, so `lgkmcnt(N)` retires all but the N youngest.  N must not exceed the number
+// of LDS operations issued after the awaited one on ANY path (a smaller N only waits longer).  Every statement has
+// a "memory" clobber so that compiler-issued LDS traffic (message table, drain) keeps its place between them, and
+// a wait names the awaited registers as "+v" so that no use can move above it.  No scalar memory operation may
+// be in flight in the loop (they share the counter and complete out of order): tools/inspect_kernel.sh checks that.
+__device__ __forceinline__ void lds_issue_f64(double& dst, uint32_t addr)
+{
+    asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_issue_f64_hi(double& dst, uint32_t addr)      // 16 doubles further on
+{
+    asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_issue_2xu32(uint64_t& dst, uint32_t addr)     // the aligned words at addr, addr + 4
+{
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_issue_store_2xu32(uint32_t addr, uint32_t lo, uint32_t hi)
+{
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(addr), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void lds_issue_store_u32(uint32_t addr, uint32_t v)
+{
+    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_issue_store_u16(uint32_t addr, uint32_t v)
+{
+    asm volatile("ds_write_b16 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(double& x)
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(double& x, uint64_t& y)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(uint64_t& y)
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(y) : "i"(N) : "memory");
+}
+
 // acc += (lane K of this lane's 16-lane row of cv) * x.  cv is only ever written by LDS loads (a VALU write would
 // need two wait states before a DPP read; the s_nop in front of each output's first tap covers moves the
 // compiler might insert anyway).
@@ -58,16 +108,19 @@ __device__ __forceinline__ void fmac_bcast(double& acc, const double cv, const d
         asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cv), "v"(x), "i"(K));
 }
 
-// one subsample (SB packed bytes at any byte alignment) from LDS -> S24 integer.  The LDS accepts unaligned
-// addresses but serialises such an access lane by lane (SQ_LDS_UNALIGNED_STALL was half of the kernel's time), so
-// the two ALIGNED words that hold the subsample are read (one ds_read2_b32) and shifted into place.
-template <int SB, bool LE>
-__device__ __forceinline__ int32_t lds_load_subsample(const __attribute__((address_space(3))) uint8_t* p)
+// One subsample (SB packed bytes at any byte alignment) from LDS.  The LDS accepts unaligned addresses but
+// serialises such an access lane by lane (SQ_LDS_UNALIGNED_STALL was half of the kernel's time), so the two ALIGNED
+// words that hold the subsample are read (one ds_read2_b32) and shifted into place when the sample enters the window.
+struct RawSubsample { uint64_t words; uint32_t shift; };
+__device__ __forceinline__ void lds_issue_subsample(RawSubsample& r, uint32_t lds_addr)
 {
-    const uint32_t a = (uint32_t)(uintptr_t)p;
-    const __attribute__((address_space(3))) uint32_t* q = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(a & ~3u);
-    const uint32_t lo = q[0], hi = q[1];
-    const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, a & 3u);                  // the 4 bytes that start at p
+    lds_issue_2xu32(r.words, lds_addr & ~3u);
+    r.shift = lds_addr & 3u;
+}
+template <int SB, bool LE>
+__device__ __forceinline__ int32_t unpack_subsample(const RawSubsample& r)          // -> S24 integer
+{
+    const uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(r.words >> 32), (uint32_t)r.words, r.shift);   // the 4 bytes that start at it
     if constexpr (SB == 3) {
         return LE ? ((int32_t)(w << 8)) >> 8 : ((int32_t)__builtin_bswap32(w)) >> 8;
     } else if constexpr (SB == 2) {
@@ -114,16 +167,6 @@ static constexpr bool ring_pair_mode(uint32_t, uint32_t) { return false; }
 static constexpr bool ring_pair_mode(uint32_t ch, uint32_t db) { return ch == 2 && db == 3; }
 #endif
 
-// the DB bytes of a finished subsample -> LDS, at any byte position (v = the bytes in memory order, first byte low)
-template <int DB>
-__device__ __forceinline__ void lds_store_subsample(lds_u8_t q, uint32_t v)
-{
-    if constexpr (DB == 4) *(__attribute__((address_space(3))) uint32_t*)q = v;                  // 4-aligned by construction
-    else if constexpr (DB == 2) *(__attribute__((address_space(3))) uint16_t*)q = (uint16_t)v;   // 2-aligned
-    else if constexpr (DB == 3) { q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16); }
-    else q[0] = (uint8_t)v;
-}
-
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
 __global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
 void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
@@ -148,7 +191,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t coef_bytes = (uint32_t)L * T * 8;
     const uint32_t row_stride = ring_bytes + 4;                       // output ring: rows start in different banks
-    const uint32_t wave_lds = OFF_RING + ((ROWS * row_stride + 15) & ~15u);
+    const uint32_t ring_area = (ROWS * row_stride + 15) & ~15u;
+    const uint32_t wave_lds = OFF_RING + ring_area + 512;            // + 8 bytes per lane that absorb pair mode's idle stores
 
     // ---- coefficient table -> LDS, once per workgroup (the only workgroup barrier of the kernel).  The Q28
     // integers are scaled by 2^-28 on the way (exact): the accumulator is then in sample units, every partial sum
@@ -156,8 +200,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     for (uint32_t i = tid; i < (uint32_t)L * T; i += blockDim.x)
         ((__attribute__((address_space(3))) double*)(lds_u8_t)smem)[i] = coef[i] * (1.0 / 268435456.0);
     __syncthreads();
-    const __attribute__((address_space(3))) double* coef_lds =
-        (const __attribute__((address_space(3))) double*)((lds_u8_t)smem + (lane & 15) * 8);     // + phase * T * 8
+    const uint32_t coef_lane = (uint32_t)(uintptr_t)((lds_u8_t)smem + (lane & 15) * 8);          // + phase * T * 8
     uint8_t* const wsmem = smem + coef_bytes + wave * wave_lds;       // this wave's region: staging, ring and
     const lds_u8_t lds = (lds_u8_t)wsmem;                            // write-back are private to the wave
     const int Mr = M % L;
@@ -288,12 +331,16 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // every second output: lane A words 0-1, lane B words 1-2 (word 1 twice, same value).  Byte stores would cost
     // three LDS store instructions per output.  Other layouts store each subsample's bytes where they belong.
     constexpr bool PAIR = ring_pair_mode(CH, DB);
+    static_assert(PAIR || DB == 2 || DB == 4, "a subsample is stored with one aligned LDS store");
     constexpr uint32_t B0 = DST_LE ? 1 : 3, B1 = 2, B2 = DST_LE ? 3 : 1;      // byte of the left-justified word that is memory byte 0, 1, 2
-    const uint32_t ring_lane = OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB);   // this lane's place in the ring's frame (pair) 0
+    const uint32_t wave_lds_addr = (uint32_t)(uintptr_t)lds;
+    const uint32_t ring_lane = wave_lds_addr + OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB);   // this lane's place in frame (pair) 0
+    const uint32_t idle_lane = wave_lds_addr + OFF_RING + ring_area + lane * 8;                          // where pair mode's idle stores go
     // selectors for v_perm_b32 {got (bytes 4-7), own (bytes 0-3)}: words 0/1 from the even frame, words 1/2 from the odd one
     const uint32_t sel_lo = c == 0 ? (B0 | B1 << 8 | B2 << 16 | (4 + B0) << 24) : (B1 | B2 << 8 | (4 + B0) << 16 | (4 + B1) << 24);
     const uint32_t sel_hi = c == 0 ? ((4 + B1) | (4 + B2) << 8 | B0 << 16 | B1 << 24) : ((4 + B2) | B0 << 8 | B1 << 16 | B2 << 24);
     uint32_t w_even = 0;                                  // pair mode: the even output's word, waiting for its partner
+    uint32_t st_addr = idle_lane, st_lo = 0, st_hi = 0;   // the store the NEXT output issues (this output's, or idle)
     const int64_t wave_dst = seg.dst_base + (int64_t)(wk.first_block * L_blk) * FB_DST;   // first block of this unit
     const uint32_t wave_rows = n_blocks < (uint32_t)BPW ? n_blocks : (uint32_t)BPW;
     uint32_t drained = 0;                                 // lines written so far (wave-uniform)
@@ -333,13 +380,28 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     int j = 0;                                // outputs emitted so far (wave-uniform)
     int t = 0;                                // j * M
     int p = 0;                                // phase of output j = t mod L (every block starts at phase 0)
-    uint32_t in_off = OFF_IN;                 // LDS offset of this lane's subsample in the current stage's first frame
+    uint32_t in_off = 0;                      // LDS address of this lane's subsample in the current stage's first frame
     const bool any_first = __any(first_block) != 0;
+    auto issue_store = [&]() __attribute__((always_inline)) {
+        if constexpr (PAIR) lds_issue_store_2xu32(st_addr, st_lo, st_hi);
+        else if constexpr (DB == 4) lds_issue_store_u32(st_addr, st_lo);
+        else lds_issue_store_u16(st_addr, st_lo);
+    };
     // coefficients of output j: cA = taps 0..15, cB = taps 16..31, tap k in lane (k & 15) of every 16-lane row
-    double cA = coef_lds[0], cB = coef_lds[16];
+    double cA, cB;
+    lds_issue_f64_hi(cB, coef_lane);
+    lds_issue_f64(cA, coef_lane);
+    RawSubsample raw;
 
     issue_stage(0);
 
+    // LDS operations of the loop, in issue order.  Per advance: R (raw sample).  Per output: S (the previous output's
+    // ring store; pair mode stores every second output and sends the other one to an idle slot so that the count is
+    // fixed), B' and A' (the next output's coefficient registers, each reloaded as soon as its 16 taps are done).
+    //     advance:  R  { W1  S  16 taps(cB)  B'  W2  unpack  16 taps(cA)  A'  round, ramp, pack }*
+    // W1 awaits cB: issued last output as B', followed at least by A'           -> lgkmcnt(1)
+    // W2 awaits cA and R: A' of last output / R are followed by S and B'         -> lgkmcnt(2)
+    // The newest sample is tap 0, used last, so its read has the first 16 taps to land.
     for (int g = 0; g * T < total; g++) {
         static_for([&](auto slot) __attribute__((always_inline)) {
             constexpr int s = decltype(slot)::value;
@@ -354,43 +416,67 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                     if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
                     if ((q + 1) * 8 < total) issue_stage(q + 1);
                     if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
-                    in_off = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE + row * IN_STRIDE +
+                    in_off = wave_lds_addr + OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE + row * IN_STRIDE +
                              (uint32_t)((row_g + (int64_t)q * 8 * FB_SRC) & 15) + c * SB;
                 }
+                issue_store();                                          // the last output's bytes must be in the ring
+                st_addr = idle_lane;
                 drain(j);
                 if constexpr (STAMP) { const uint64_t n = stamp_now(); st_drain += n - st_mark; st_mark = n; }
             }
             // ---- advance: this channel's sample of frame (n_start + a) enters slot s ----
 #ifdef OHGPU_EXP_NOSAMPLE
-            win[s] = (double)(int)(lane + s);
+            raw.words = lane + s; raw.shift = 0;
 #else
-            win[s] = (double)lds_load_subsample<SB, SRC_LE>(lds + in_off + (s & 7) * FB_SRC);
+            lds_issue_subsample(raw, in_off + (s & 7) * FB_SRC);
 #endif
+            if (!(t < L * (a + 1))) {                                   // no output needs it yet (warm-up, or M > L)
+                lds_wait<0>(raw.words);
+                win[s] = (double)unpack_subsample<SB, SRC_LE>(raw);
+            }
             // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
             while (t < L * (a + 1)) {
                 double acc0 = 0.5, acc1 = 0.0;                                 // round half up: floor(sum + 0.5)
+                p += Mr;                                                       // the next output's phase
+                if (p >= L) p -= L;
+                const uint32_t cp = coef_lane + (uint32_t)p * (T * 8);
+                lds_wait<1>(cB);
+#ifndef OHGPU_EXP_NORING
+                issue_store();
+#endif
 #ifdef OHGPU_EXP_NOFMA
-                acc0 = win[s] + cA + cB;
+                acc0 += cB;
 #else
                 static_for([&](auto kc) __attribute__((always_inline)) {
                     constexpr int k = 2 * decltype(kc)::value;
-                    if constexpr (k < 16) {
-                        fmac_bcast<k, k == 0>(acc0, cA, win[(s - k + 2 * T) % T]);
-                        fmac_bcast<k + 1, false>(acc1, cA, win[(s - (k + 1) + 2 * T) % T]);
-                    } else {
-                        fmac_bcast<k - 16, k == 16>(acc0, cB, win[(s - k + 2 * T) % T]);
-                        fmac_bcast<k - 15, false>(acc1, cB, win[(s - (k + 1) + 2 * T) % T]);
-                    }
-                }, std::make_integer_sequence<int, T / 2>{});
+                    fmac_bcast<k, k == 0>(acc0, cB, win[(s - (k + 16) + 2 * T) % T]);
+                    fmac_bcast<k + 1, false>(acc1, cB, win[(s - (k + 17) + 2 * T) % T]);
+                }, std::make_integer_sequence<int, 8>{});
 #endif
-                // the next output's coefficients (same advance or a later one): its phase is known now
-                p += Mr;
-                if (p >= L) p -= L;
-#ifndef OHGPU_EXP_NOCOEF
-                {
-                    const __attribute__((address_space(3))) double* cp = coef_lds + (uint32_t)p * T;
-                    cA = cp[0]; cB = cp[16];
-                }
+#ifdef OHGPU_EXP_NOCOEF
+                lds_issue_f64_hi(cB, coef_lane);
+#else
+                lds_issue_f64_hi(cB, cp);
+#endif
+#ifdef OHGPU_EXP_NORING
+                lds_wait<1>(cA, raw.words);
+#else
+                lds_wait<2>(cA, raw.words);
+#endif
+                win[s] = (double)unpack_subsample<SB, SRC_LE>(raw);
+#ifdef OHGPU_EXP_NOFMA
+                acc0 += cA + win[s];
+#else
+                static_for([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = 14 - 2 * decltype(kc)::value;           // taps 15 .. 0: the newest sample last
+                    fmac_bcast<k + 1, k == 14>(acc1, cA, win[(s - (k + 1) + 2 * T) % T]);
+                    fmac_bcast<k, false>(acc0, cA, win[(s - k + 2 * T) % T]);
+                }, std::make_integer_sequence<int, 8>{});
+#endif
+#ifdef OHGPU_EXP_NOCOEF
+                lds_issue_f64(cA, coef_lane);
+#else
+                lds_issue_f64(cA, cp);
 #endif
                 int32_t y = (int32_t)floor(acc0 + acc1);
                 y = y > 8388607 ? 8388607 : (y < -8388608 ? -8388608 : y);
@@ -412,30 +498,27 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                         }
                     }
                 }
-#ifdef OHGPU_EXP_NORING
-                if (w == 0x12345u) lds_store_subsample<DB>(lds + ring_lane + ring_pos, w);
-#else
+                // pack; the next output (or the end of the unit) issues the store
                 if constexpr (PAIR) {
                     if (j & 1) {
                         // lane A needs B's even word, lane B needs A's odd word
                         const uint32_t give = c == 0 ? w : w_even;
                         const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-                        const uint32_t lo = __builtin_amdgcn_perm(got, w_even, sel_lo);
-                        const uint32_t hi = __builtin_amdgcn_perm(got, w, sel_hi);
-                        __attribute__((address_space(3))) uint32_t* q = (__attribute__((address_space(3))) uint32_t*)(lds + ring_lane + ring_pos);
-                        q[0] = lo; q[1] = hi;
+                        st_lo = __builtin_amdgcn_perm(got, w_even, sel_lo);
+                        st_hi = __builtin_amdgcn_perm(got, w, sel_hi);
+                        st_addr = ring_lane + ring_pos;
                         ring_pos += 2 * FB_DST;
                         if (ring_pos == ring_bytes) ring_pos = 0;
                     } else {
                         w_even = w;
+                        st_addr = idle_lane;
                     }
                 } else {
-                    // the DB bytes in memory order (first byte low) -> their place in the row's byte ring
-                    lds_store_subsample<DB>(lds + ring_lane + ring_pos, DST_LE ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w));
+                    st_lo = DST_LE ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);       // the DB bytes in memory order, first byte low
+                    st_addr = ring_lane + ring_pos;
                     ring_pos += FB_DST;
                     if (ring_pos == ring_bytes) ring_pos = 0;
                 }
-#endif
                 j++;
                 t += M;
             }
@@ -445,6 +528,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
         }
     }
+    // the last output's store, then the lines it completes (LDS operations of a wave execute in order)
+    issue_store();
     drain(j);
     if constexpr (STAMP) {
         const uint64_t n = stamp_now(); st_drain += n - st_mark;
@@ -524,7 +609,7 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     *rows = bpw;
     *ring_bytes = rb;
     *coef_lds_bytes = L * T * 8;
-    *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + ((bpw * (rb + 4) + 15) & ~15u);
+    *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + ((bpw * (rb + 4) + 15) & ~15u) + 512;
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
