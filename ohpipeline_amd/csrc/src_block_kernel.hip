@@ -80,15 +80,20 @@ __device__ __forceinline__ void lds_issue_store_u16(uint32_t addr, uint32_t v)
 {
     asm volatile("ds_write_b16 %0, %1" : : "v"(addr), "v"(v) : "memory");
 }
+#ifdef OHGPU_EXP_NOWAIT
+#define OHGPU_WAIT_INSN "s_nop 0 ; %"
+#else
+#define OHGPU_WAIT_INSN "s_waitcnt lgkmcnt(%"
+#endif
 template <int N>
 __device__ __forceinline__ void lds_wait(double& x)
 {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "i"(N) : "memory");
+    asm volatile(OHGPU_WAIT_INSN "1)" : "+v"(x) : "i"(N) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lds_wait(double& x, uint64_t& y)
 {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "i"(N) : "memory");
+    asm volatile(OHGPU_WAIT_INSN "2)" : "+v"(x), "+v"(y) : "i"(N) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lds_wait(uint64_t& y)
@@ -161,11 +166,7 @@ static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain
     const uint32_t need = (64 - gcd_c(64, step)) + (out_per_drain + (pair ? 1 : 0)) * fb_dst;
     return unit * ((need + unit - 1) / unit);
 }
-#ifdef OHGPU_EXP_BYTERING
-static constexpr bool ring_pair_mode(uint32_t, uint32_t) { return false; }
-#else
 static constexpr bool ring_pair_mode(uint32_t ch, uint32_t db) { return ch == 2 && db == 3; }
-#endif
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
 __global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
