@@ -306,8 +306,9 @@ int ohgpu_pcm_batch_create(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n
             b->uniform = false;
         }
     }
-    const int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_msg_desc));
-    if (err != OHGPU_OK) { delete b; return err; }
+    int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_msg_desc));
+    if (err == OHGPU_OK) err = plan_pcm_line(ctx, b, descs, n);
+    if (err != OHGPU_OK) { if (b->d_descs) hipFree(b->d_descs); delete b; return err; }
     *out = b;
     return OHGPU_OK;
 }
@@ -318,7 +319,10 @@ int ohgpu_pcm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!batch || batch->kind != kBatchPcm) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_run: not a pcm batch");
     if (batch->n == 0) return OHGPU_OK;
     if (!dst_base || (!src_base && batch->src_bytes_touched)) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_run: null arena pointer");
-    OHGPU_HIP_TRY(launch_pcm_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    if (ctx->variant == 0 && batch->line.enabled)
+        OHGPU_HIP_TRY(launch_pcm_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    else
+        OHGPU_HIP_TRY(launch_pcm_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
     return OHGPU_OK;
 }
 
@@ -328,6 +332,7 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     if (!batch) return OHGPU_OK;
     if (batch->d_descs) hipFree(batch->d_descs);
     if (batch->kind == kBatchSrc) free_src_fast(batch);
+    if (batch->kind == kBatchPcm) free_pcm_line(batch);
     delete batch;
     return OHGPU_OK;
 }

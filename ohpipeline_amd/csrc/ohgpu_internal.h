@@ -99,6 +99,21 @@ struct SrcFastPlan {
     uint64_t fast_out_frames = 0;
 };
 
+// ---- line kernel of the PCM message path (csrc/pcm_line_kernel.hip) ----
+struct PcmChunk {             // one wave's share of a message: subsamples [q0, q0 + nq)
+    uint32_t msg, q0, nq, pad;
+};
+struct PcmMsgAux {            // x / d == umulhi(x, m) >> s for x < 2^31 (m == 0: d == 1)
+    uint32_t m_ch, s_ch;      // d = channels
+    uint32_t m_n1, s_n1;      // d = n_frames - 1
+};
+struct PcmLinePlan {
+    bool     enabled = false;
+    uint32_t n_chunks = 0;
+    void*    d_chunks = nullptr;
+    void*    d_aux = nullptr;
+};
+
 enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3 };
 
 }  // namespace ohgpu
@@ -129,6 +144,7 @@ struct ohgpu_batch {
     bool     uniform;             // every descriptor has the same format fields
     uint8_t  channels, src_bits, src_endian, dst_bits, dst_endian;
     ohgpu::SrcFastPlan fast;      // kBatchSrc only
+    ohgpu::PcmLinePlan line;      // kBatchPcm only
 };
 
 namespace ohgpu {
@@ -145,6 +161,9 @@ int set_error(int code, const char* fmt, ...);
 // kernels
 hipError_t launch_fmt_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n);
+void free_pcm_line(ohgpu_batch* b);
 hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* src_filter,
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Throughput of the PCM message path (unpack -> attenuate -> ramp|silence -> pack, no
+resampling) on one GPU: `streams` contiguous streams cut into 5 ms messages with a ramp-up / ramp-down schedule,
+inputs resident in HBM.  Prints one JSON line: GB/s over the algorithmic bytes (source read once + destination written
+once) against the 8 TB/s HBM peak.  Usage: python tools/bench_pcm.py [--variant 0|1] [--src-bits 24 --dst-bits 24 ...]
+With --check the output is compared with the CPU oracle on a few streams (test infrastructure, not the measured path)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=480000, help="frames per stream")
+    ap.add_argument("--msg-frames", type=int, default=240)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--src-bits", type=int, default=24)
+    ap.add_argument("--dst-bits", type=int, default=24)
+    ap.add_argument("--src-endian", choices=["big", "little"], default="big")
+    ap.add_argument("--dst-endian", choices=["big", "little"], default="big")
+    ap.add_argument("--attenuation", type=int, default=256)
+    ap.add_argument("--misalign", type=int, default=0, help="byte offset added to both arenas' stream starts")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+
+    from ohpipeline_amd import capi, hostmodel
+    ch, sb, db = a.channels, a.src_bits // 8, a.dst_bits // 8
+    n_msgs = (a.frames + a.msg_frames - 1) // a.msg_frames
+    first = np.arange(n_msgs, dtype=np.int64) * a.msg_frames
+    count = np.minimum(a.msg_frames, a.frames - first)
+    jps = 56448000 // 48000
+    sched = np.array(hostmodel.stream_ramp_schedule([int(c) * jps for c in count], 50 * 56448, 500 * 56448), dtype=np.int64)
+    d = np.zeros(a.streams * n_msgs, dtype=capi.MSG_DESC)
+    src_stream = a.frames * ch * sb + a.misalign
+    dst_stream = a.frames * ch * db + a.misalign
+    for s in range(a.streams):
+        sl = slice(s * n_msgs, (s + 1) * n_msgs)
+        d["src_offset"][sl] = s * src_stream + a.misalign + first * ch * sb
+        d["dst_offset"][sl] = s * dst_stream + a.misalign + first * ch * db
+        d["n_frames"][sl] = count
+        d["flags"][sl] = sched[:, 0]
+        d["ramp_start"][sl] = sched[:, 1]
+        d["ramp_end"][sl] = sched[:, 2]
+    d["attenuation"] = a.attenuation
+    d["channels"], d["src_bits"], d["dst_bits"] = ch, a.src_bits, a.dst_bits
+    d["src_endian"] = capi.ENDIAN_BIG if a.src_endian == "big" else capi.ENDIAN_LITTLE
+    d["dst_endian"] = capi.ENDIAN_BIG if a.dst_endian == "big" else capi.ENDIAN_LITTLE
+    src_bytes, dst_bytes = a.streams * src_stream, a.streams * dst_stream
+    rng = np.random.default_rng(1234)
+    src = rng.integers(0, 256, size=src_bytes, dtype=np.uint8)
+
+    ctx = capi.Context(0)
+    ctx.set_kernel_variant(a.variant)
+    d_src = ctx.upload(src)
+    d_dst = ctx.malloc(dst_bytes)
+    ctx.memset(d_dst, 0xEE, dst_bytes)
+    batch = ctx.pcm_batch(d, src_bytes, dst_bytes)
+    for _ in range(a.warmup):
+        ctx.pcm_run(batch, d_src, d_dst)
+    ctx.sync()
+    ev = [(ctx.event(), ctx.event()) for _ in range(a.steps)]
+    for k in range(a.steps):
+        ctx.record(ev[k][0])
+        ctx.pcm_run(batch, d_src, d_dst)
+        ctx.record(ev[k][1])
+    ctx.sync()
+    ms = sorted(ctx.elapsed_ms(e0, e1) for e0, e1 in ev)
+    avg = sum(ms) / len(ms)
+    algo = a.streams * a.frames * ch * (sb + db)
+    out = dict(metric="PCM message path GB/s", ms_avg=round(avg, 4), ms_min=round(ms[0], 4),
+               gbps=round(algo / avg / 1e6, 1), frac_of_8TBps=round(algo / avg / 1e6 / 8000.0, 4),
+               msamples_per_s=round(a.streams * a.frames / avg / 1e3, 1), algorithmic_bytes=algo,
+               config=dict(streams=a.streams, frames=a.frames, msg_frames=a.msg_frames, channels=ch, src_bits=a.src_bits,
+                           dst_bits=a.dst_bits, src_endian=a.src_endian, dst_endian=a.dst_endian,
+                           attenuation=a.attenuation, misalign=a.misalign, variant=a.variant, msgs=int(d.size)))
+    if a.check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ctypes as C
+        import oracle_lib as O
+        k = min(a.streams, 3) * n_msgs
+        part = np.ascontiguousarray(d[:k]).view(O.MSG_DESC) if d.dtype != O.MSG_DESC else np.ascontiguousarray(d[:k])
+        ref = np.full(dst_bytes, 0xEE, dtype=np.uint8)
+        rc = O.lib().ohp_msg_process_batch(part.ctypes.data_as(C.c_void_p), part.size, src.ctypes.data_as(C.c_void_p),
+                                            ref.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        got = ctx.download(d_dst, dst_bytes)
+        n = min(a.streams, 3) * dst_stream
+        out["check"] = "ok" if np.array_equal(got[:n], ref[:n]) else "MISMATCH"
+    print(json.dumps(out))
+    ctx.batch_destroy(batch)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
