@@ -100,18 +100,24 @@ struct SrcFastPlan {
 };
 
 // ---- line kernel of the PCM message path (csrc/pcm_line_kernel.hip) ----
-struct PcmChunk {             // one wave's share of a message: subsamples [q0, q0 + nq)
-    uint32_t msg, q0, nq, pad;
+struct PcmChunk {             // one wave's share of a message: subsamples [q0, q0 + nq); 64 bytes = one scalar load
+    uint64_t src_off, dst_off;    // byte offsets of the chunk's first source / destination byte in the arenas
+    uint32_t q0, nq;
+    uint32_t n_frames;            // of the whole message (ramp)
+    uint16_t ramp_start, ramp_end;
+    uint32_t attenuation;
+    uint8_t  channels, sb, db, flags;   // bytes per subsample; kChunk* bits
+    uint32_t m_ch, m_n1;          // x / d == umulhi(x, m) >> s for x < 2^31 (m == 0: d == 1); d = channels, n_frames - 1
+    uint8_t  s_ch, s_n1, pad8[2];
+    uint32_t plain_sel;           // v_perm_b32 selector of the plain path: source bytes -> destination bytes in memory order
+    uint32_t pad[2];
 };
-struct PcmMsgAux {            // x / d == umulhi(x, m) >> s for x < 2^31 (m == 0: d == 1)
-    uint32_t m_ch, s_ch;      // d = channels
-    uint32_t m_n1, s_n1;      // d = n_frames - 1
-};
+static_assert(sizeof(PcmChunk) == 64, "chunk record = one 64-byte scalar load");
+enum { kChunkRamp = 1, kChunkSilence = 2, kChunkZeroLsb = 4, kChunkSrcLe = 8, kChunkDstLe = 16 };
 struct PcmLinePlan {
     bool     enabled = false;
     uint32_t n_chunks = 0;
     void*    d_chunks = nullptr;
-    void*    d_aux = nullptr;
 };
 
 enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3 };

@@ -2,20 +2,22 @@
 // attenuate -> ramp | silence -> pack, any depth / byte order / channel count / alignment, line-coalesced.
 //
 // HBM-bound byte work (about 0.5 integer op per byte), so the design is about memory instructions, not arithmetic:
-//   * A message is cut into CHUNKS of <= 512 subsamples (host, at batch creation); one wave owns a chunk at a time.
+//   * A message is cut into CHUNKS of <= 512 subsamples (host, at batch creation), each described by one 64-byte
+//     record that a single scalar load fetches; one wave owns a chunk at a time.
 //   * In: the aligned 16-byte pieces that cover the chunk's source bytes go straight to LDS
 //     (global_load_lds_dwordx4, 64 pieces per instruction).  A piece always overlaps bytes the message owns, so it
 //     never leaves the page those bytes live in, whatever the arena's end looks like.
-//   * Transform: lane = subsample.  It reads the two aligned LDS words that hold its bytes, builds the reference's
-//     left-justified big-endian word, applies attenuation / ramp / silence with pcm_device.h's expressions, and stores
-//     the destination bytes in MEMORY order (first byte lowest) as one word in an LDS array.
-//   * Out: lane = aligned destination dword.  It reads the 2..4 consecutive words whose bytes fall into that dword,
-//     funnels them together and stores 4 bytes; 64 lanes write 256 contiguous bytes.  Only a chunk's first and last
-//     dword can be partial; those are written byte by byte (another message may own the other bytes).
+//   * Lane = aligned destination dword.  For each of the 1..4 subsamples whose bytes fall into it, the lane reads
+//     the two aligned LDS words that hold the source bytes, builds the reference's left-justified big-endian word,
+//     applies attenuation / ramp / silence with pcm_device.h's expressions and keeps the destination bytes in MEMORY
+//     order; it funnels them together and stores 4 bytes: 64 lanes write 256 contiguous bytes.  A subsample that
+//     straddles two dwords is transformed twice (cheaper than a second trip through LDS).  Only a chunk's first and
+//     last dword can be partial; those are written byte by byte (another message may own the other bytes).
 //   * The two integer divisions of the ramp (frame = subsample / channels, ramp = i * total / (frames - 1)) use
 //     per-message multipliers computed on the host (exact for operands < 2^31, which validation guarantees).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <vector>
 
 #include "ohgpu_internal.h"
@@ -51,37 +53,44 @@ __device__ __forceinline__ uint32_t ramp_index_magic(uint32_t ramp_start, int32_
     return idx < kRampTableCount - 1 ? idx : kRampTableCount - 1;
 }
 
-__global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const ohgpu_msg_desc* __restrict__ descs,
-                                                                  const PcmMsgAux* __restrict__ aux,
-                                                                  const PcmChunk* __restrict__ chunks, const uint32_t n_chunks,
+// SB / DB: bytes per source / destination subsample when the whole batch has one layout (immediates instead of
+// scalar registers in every shift and multiply), 0 = read them from each chunk's record.
+template <int SB, int DB>
+__global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChunk* __restrict__ chunks, const uint32_t n_chunks,
                                                                   const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                   const uint16_t* __restrict__ ramp_table)
 {
     __shared__ uint16_t s_ramp[kRampTableCount];
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kLineWaves][kInBytes];
-    __shared__ uint32_t s_w[kLineWaves][kChunkSub + 4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < kRampTableCount; i += blockDim.x) s_ramp[i] = ramp_table[i];
     __syncthreads();
     const __attribute__((address_space(3))) uint8_t* in = (const __attribute__((address_space(3))) uint8_t*)&s_in[wave][0];
-    __attribute__((address_space(3))) uint32_t* words = (__attribute__((address_space(3))) uint32_t*)&s_w[wave][0];
 
-    for (uint32_t chunk = blockIdx.x * kLineWaves + wave; chunk < n_chunks; chunk += gridDim.x * kLineWaves) {
-        const PcmChunk ck = chunks[chunk];
-        const ohgpu_msg_desc d = descs[ck.msg];
-        const uint32_t ch = d.channels, sb = d.src_bits >> 3, db = d.dst_bits >> 3;
-        const bool src_le = d.src_endian == OHGPU_ENDIAN_LITTLE && sb > 1;
-        const bool dst_le = d.dst_endian == OHGPU_ENDIAN_LITTLE;
-        const bool ramp = (d.flags & OHGPU_FLAG_RAMP) != 0;
-        const bool silence = (d.flags & OHGPU_FLAG_SILENCE) != 0;
-        const bool zero_lsb = (d.flags & OHGPU_FLAG_ZERO_LSB32) != 0 && db == 4;
-        const bool atten = d.attenuation != OHGPU_UNITY_ATTENUATION;
+    // A chunk record is one 64-byte scalar load and holds everything the chunk needs; the next chunk's record is
+    // requested before this chunk is processed, so only the input staging's latency is exposed per chunk (and hidden by
+    // the CU's other waves).
+    const uint32_t stride = gridDim.x * kLineWaves;
+    uint32_t chunk = blockIdx.x * kLineWaves + wave;
+    if (chunk >= n_chunks) return;
+    PcmChunk next = chunks[chunk];
+    while (true) {
+        const PcmChunk ck = next;
+        const uint32_t chunk_next = chunk + stride;
+        if (chunk_next < n_chunks) next = chunks[chunk_next];
+        const uint32_t ch = ck.channels, sb = SB ? SB : ck.sb, db = DB ? DB : ck.db;
+        const bool src_le = (ck.flags & kChunkSrcLe) != 0;
+        const bool dst_le = (ck.flags & kChunkDstLe) != 0;
+        const bool ramp = (ck.flags & kChunkRamp) != 0;
+        const bool silence = (ck.flags & kChunkSilence) != 0;
+        const bool zero_lsb = (ck.flags & kChunkZeroLsb) != 0;
+        const bool atten = ck.attenuation != OHGPU_UNITY_ATTENUATION;
         const uint32_t q0 = ck.q0, nq = ck.nq;
 
         // ---- in: aligned 16-byte pieces -> LDS ----
-        const uint64_t s_addr = (uint64_t)(uintptr_t)src + d.src_offset + (uint64_t)q0 * sb;   // first source byte
+        const uint64_t s_addr = (uint64_t)(uintptr_t)src + ck.src_off;                          // first source byte
         const uint32_t head = (uint32_t)s_addr & 15u;
         if (!silence) {
             const uint8_t* base = (const uint8_t*)(uintptr_t)(s_addr - head);
@@ -95,77 +104,84 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const ohgpu_m
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- transform: lane = subsample ----
-        PcmMsgAux ax;
-        if (ramp) ax = aux[ck.msg];
-        const int32_t total = (int32_t)((uint32_t)d.ramp_start - (uint32_t)d.ramp_end);
+        // ---- lane = aligned destination dword: transform the 1..4 subsamples whose bytes fall into it, funnel, store ----
+        const int32_t total = (int32_t)((uint32_t)ck.ramp_start - (uint32_t)ck.ramp_end);
         const uint32_t keep = db == 4 ? (zero_lsb ? 0xffffff00u : 0xffffffffu) : ~(0xffffffffu >> (8 * db));   // the db top bytes
-        for (uint32_t qb = 0; qb < nq; qb += 64) {
-            const uint32_t q = qb + lane;
-            if (q < nq) {
-                uint32_t w;
-                const uint32_t sub = q0 + q;                            // subsample index inside the message
-                if (silence) {
-                    w = silence_word((uint64_t)sub * sb, sb, ch);
-                } else {
-                    const uint32_t off = head + q * sb;
-                    const __attribute__((address_space(3))) uint32_t* a = (const __attribute__((address_space(3))) uint32_t*)(in + (off & ~3u));
-                    const uint32_t raw = __builtin_amdgcn_alignbyte(a[1], a[0], off & 3u);      // the 4 bytes that start at the subsample
-                    // left-justified big-endian word (load_be_word): BE bytes are already in order, LE bytes reversed
-                    w = src_le ? (raw << (32 - 8 * sb)) : (__builtin_bswap32(raw) & ~(sb == 4 ? 0u : (0xffffffffu >> (8 * sb))));
-                    if (atten) w = attenuate_word(w, d.attenuation);
-                    if (ramp) {
-                        const uint32_t frame = udiv_magic(sub, ax.m_ch, ax.s_ch);
-                        const uint32_t mult = s_ramp[ramp_index_magic(d.ramp_start, total, frame, d.n_frames, ax.m_n1, ax.s_n1)];
-                        w = ramp_word(w, mult, sb, ch, sub - frame * ch);
-                    }
+        // subsample q of the chunk -> its destination bytes in memory order, first byte lowest (0 past the end)
+        auto subsample = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t {
+            if (q >= nq) return 0u;
+            uint32_t w;
+            const uint32_t sub = q0 + q;                                // subsample index inside the message
+            if (silence) {
+                w = silence_word((uint64_t)sub * sb, sb, ch);
+            } else {
+                const uint32_t off = head + q * sb;
+                const __attribute__((address_space(3))) uint32_t* a = (const __attribute__((address_space(3))) uint32_t*)(in + (off & ~3u));
+                const uint32_t raw = __builtin_amdgcn_alignbyte(a[1], a[0], off & 3u);      // the 4 bytes that start at the subsample
+                // left-justified big-endian word (load_be_word): BE bytes are already in order, LE bytes reversed
+                w = src_le ? (raw << (32 - 8 * sb)) : (__builtin_bswap32(raw) & ~(sb == 4 ? 0u : (0xffffffffu >> (8 * sb))));
+                if (atten) w = attenuate_word(w, ck.attenuation);
+                if (ramp) {
+                    const uint32_t frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
+                    const uint32_t mult = s_ramp[ramp_index_magic(ck.ramp_start, total, frame, ck.n_frames, ck.m_n1, ck.s_n1)];
+                    w = ramp_word(w, mult, sb, ch, sub - frame * ch);
                 }
-                // destination bytes in memory order, first byte lowest (store_word)
-                w &= keep;
-                words[q] = dst_le ? (w >> (32 - 8 * db)) : __builtin_bswap32(w);
             }
-        }
-        if (lane < 4) words[nq + lane] = 0;                             // the gather reads up to 3 words past the end
-
-        // ---- out: lane = aligned destination dword ----
-        const uint64_t d_addr = (uint64_t)(uintptr_t)dst + d.dst_offset + (uint64_t)q0 * db;   // first destination byte
+            w &= keep;                                                  // store_word: the db top bytes ...
+            return dst_le ? (w >> (32 - 8 * db)) : __builtin_bswap32(w);   // ... in the requested byte order
+        };
+        // The common case -- no attenuation, ramp or silence -- is a fixed byte shuffle of the four bytes that start at
+        // the subsample: ONE v_perm_b32 with the selector the host put into the record (depth conversion, both byte
+        // orders, the zeroed low byte of 32-bit output).  Subsamples past the chunk's end read bytes that exist in the
+        // staging buffer and only ever land in byte positions the edge path does not store.
+        auto subsample_plain = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t off = head + q * sb;
+            const __attribute__((address_space(3))) uint32_t* a = (const __attribute__((address_space(3))) uint32_t*)(in + (off & ~3u));
+            return __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(a[1], a[0], off & 3u), ck.plain_sel);
+        };
+        const uint64_t d_addr = (uint64_t)(uintptr_t)dst + ck.dst_off;                          // first destination byte
         const uint32_t dhead = (uint32_t)d_addr & 3u;
         const uint32_t len = nq * db;
         const uint32_t n_dw = (dhead + len + 3u) >> 2;
         uint8_t* const obase = (uint8_t*)(uintptr_t)(d_addr - dhead);
-        for (uint32_t kb = 0; kb < n_dw; kb += 64) {
-            const uint32_t k = kb + lane;
-            if (k < n_dw) {
-                const int32_t pos = (int32_t)(k * 4) - (int32_t)dhead;  // stream position of the dword's first byte
-                const uint32_t upos = pos < 0 ? 0u : (uint32_t)pos;
-                uint32_t v;                                             // stream bytes [upos, upos + 4)
-                if (db == 3) {
-                    const uint32_t qa = __umulhi(upos, 0xAAAAAAABu) >> 1, o = upos - qa * 3;
-                    const uint32_t v0 = words[qa], v1 = words[qa + 1];
-                    // bytes {v0: 0..3, v1: 4..7}; stream = v0.b0 v0.b1 v0.b2 v1.b0 v1.b1 v1.b2
-                    const uint32_t sel = o == 0 ? 0x04020100u : (o == 1 ? 0x05040201u : 0x06050402u);
-                    v = __builtin_amdgcn_perm(v1, v0, sel);
-                } else if (db == 4) {
-                    const uint32_t qa = upos >> 2, o = upos & 3;
-                    v = __builtin_amdgcn_alignbyte(words[qa + 1], words[qa], o);
-                } else if (db == 2) {
-                    const uint32_t qa = upos >> 1, o = upos & 1;
-                    const uint32_t x = words[qa] | (words[qa + 1] << 16);
-                    v = __builtin_amdgcn_alignbyte(words[qa + 2], x, o);
-                } else {
-                    v = words[upos] | (words[upos + 1] << 8) | (words[upos + 2] << 16) | (words[upos + 3] << 24);
-                }
-                if (pos >= 0 && (uint32_t)pos + 4 <= len) {
-                    *(uint32_t*)(obase + (size_t)k * 4) = v;
-                } else {                                                // first / last dword of the chunk: only its own bytes
-                    const uint32_t skip = pos < 0 ? (uint32_t)(-pos) : 0u;   // v starts at stream byte upos = pos + skip
-                    for (uint32_t b = skip; b < 4; b++) {
-                        if ((uint32_t)(pos + (int32_t)b) < len) obase[(size_t)k * 4 + b] = (uint8_t)(v >> (8 * (b - skip)));
+        auto emit = [&](auto&& sub_fn) __attribute__((always_inline)) {
+            for (uint32_t kb = 0; kb < n_dw; kb += 64) {
+                const uint32_t k = kb + lane;
+                if (k < n_dw) {
+                    const int32_t pos = (int32_t)(k * 4) - (int32_t)dhead;  // stream position of the dword's first byte
+                    const uint32_t upos = pos < 0 ? 0u : (uint32_t)pos;
+                    uint32_t v;                                             // stream bytes [upos, upos + 4)
+                    if (db == 3) {
+                        const uint32_t qa = __umulhi(upos, 0xAAAAAAABu) >> 1, o = upos - qa * 3;
+                        const uint32_t v0 = sub_fn(qa), v1 = sub_fn(qa + 1);
+                        // bytes {v0: 0..3, v1: 4..7}; stream = v0.b0 v0.b1 v0.b2 v1.b0 v1.b1 v1.b2
+                        const uint32_t sel = o == 0 ? 0x04020100u : (o == 1 ? 0x05040201u : 0x06050402u);
+                        v = __builtin_amdgcn_perm(v1, v0, sel);
+                    } else if (db == 4) {
+                        const uint32_t qa = upos >> 2, o = upos & 3;
+                        v = sub_fn(qa);
+                        if (dhead != 0) v = __builtin_amdgcn_alignbyte(sub_fn(qa + 1), v, o);
+                    } else if (db == 2) {
+                        const uint32_t qa = upos >> 1, o = upos & 1;
+                        v = sub_fn(qa) | (sub_fn(qa + 1) << 16);
+                        if (dhead & 1) v = __builtin_amdgcn_alignbyte(sub_fn(qa + 2), v, o);
+                    } else {
+                        v = sub_fn(upos) | (sub_fn(upos + 1) << 8) | (sub_fn(upos + 2) << 16) | (sub_fn(upos + 3) << 24);
+                    }
+                    if (pos >= 0 && (uint32_t)pos + 4 <= len) {
+                        *(uint32_t*)(obase + (size_t)k * 4) = v;
+                    } else {                                                // first / last dword of the chunk: only its own bytes
+                        const uint32_t skip = pos < 0 ? (uint32_t)(-pos) : 0u;   // v starts at stream byte upos = pos + skip
+                        for (uint32_t b = skip; b < 4; b++) {
+                            if ((uint32_t)(pos + (int32_t)b) < len) obase[(size_t)k * 4 + b] = (uint8_t)(v >> (8 * (b - skip)));
+                        }
                     }
                 }
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the word array is reused by the next chunk
+        };
+        if (!(ramp || silence || atten)) emit(subsample_plain); else emit(subsample);
+        if (chunk_next >= n_chunks) break;
+        chunk = chunk_next;
     }
 }
 
@@ -182,7 +198,6 @@ static void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)            // x / d 
 void free_pcm_line(ohgpu_batch* b)
 {
     if (b->line.d_chunks) hipFree(b->line.d_chunks);
-    if (b->line.d_aux) hipFree(b->line.d_aux);
     b->line = PcmLinePlan();
 }
 
@@ -191,25 +206,45 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
     (void)ctx;
     b->line = PcmLinePlan();
     std::vector<PcmChunk> chunks;
-    std::vector<PcmMsgAux> aux(n);
     for (size_t i = 0; i < n; i++) {
         const ohgpu_msg_desc& d = descs[i];
         const uint64_t n_sub = (uint64_t)d.n_frames * d.channels;
         if (n_sub > 0xffffffffull) return OHGPU_OK;                     // the generic kernel takes such a batch
-        magic_u31(d.channels, &aux[i].m_ch, &aux[i].s_ch);
-        magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &aux[i].m_n1, &aux[i].s_n1);
         if ((d.flags & OHGPU_FLAG_RAMP) && n_sub >= (1ull << 31)) return OHGPU_OK;
+        PcmChunk c;
+        memset(&c, 0, sizeof(c));
+        const uint32_t sb = d.src_bits / 8, db = d.dst_bits / 8;
+        c.n_frames = d.n_frames;
+        c.ramp_start = d.ramp_start; c.ramp_end = d.ramp_end;
+        c.attenuation = d.attenuation;
+        c.channels = d.channels; c.sb = (uint8_t)sb; c.db = (uint8_t)db;
+        c.flags = (uint8_t)(((d.flags & OHGPU_FLAG_RAMP) ? kChunkRamp : 0) | ((d.flags & OHGPU_FLAG_SILENCE) ? kChunkSilence : 0) |
+                            (((d.flags & OHGPU_FLAG_ZERO_LSB32) && db == 4) ? kChunkZeroLsb : 0) |
+                            ((d.src_endian == OHGPU_ENDIAN_LITTLE && sb > 1) ? kChunkSrcLe : 0) |
+                            ((d.dst_endian == OHGPU_ENDIAN_LITTLE) ? kChunkDstLe : 0));
+        // plain path: memory byte m of the destination subsample <- byte of the 4 source bytes (0x0c = zero)
+        for (uint32_t m = 0; m < 4; m++) {
+            uint32_t selb = 0x0c;
+            if (m < db) {
+                const uint32_t j = (c.flags & kChunkDstLe) ? db - 1 - m : m;               // index from the most significant byte
+                if (j < sb && !((c.flags & kChunkZeroLsb) && j == 3)) selb = (c.flags & kChunkSrcLe) ? sb - 1 - j : j;
+            }
+            c.plain_sel |= selb << (8 * m);
+        }
+        uint32_t sh;
+        magic_u31(d.channels, &c.m_ch, &sh); c.s_ch = (uint8_t)sh;
+        magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &c.m_n1, &sh); c.s_n1 = (uint8_t)sh;
         for (uint64_t q0 = 0; q0 < n_sub; q0 += kChunkSub) {
-            PcmChunk c;
-            c.msg = (uint32_t)i; c.q0 = (uint32_t)q0; c.nq = (uint32_t)(n_sub - q0 < kChunkSub ? n_sub - q0 : kChunkSub); c.pad = 0;
+            c.q0 = (uint32_t)q0;
+            c.nq = (uint32_t)(n_sub - q0 < kChunkSub ? n_sub - q0 : kChunkSub);
+            c.src_off = d.src_offset + q0 * sb;
+            c.dst_off = d.dst_offset + q0 * db;
             chunks.push_back(c);
         }
     }
     if (chunks.empty() || chunks.size() > 0xffffffffull) return OHGPU_OK;
     hipError_t e = hipMalloc(&b->line.d_chunks, chunks.size() * sizeof(PcmChunk));
     if (e == hipSuccess) e = hipMemcpy(b->line.d_chunks, chunks.data(), chunks.size() * sizeof(PcmChunk), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&b->line.d_aux, aux.size() * sizeof(PcmMsgAux));
-    if (e == hipSuccess) e = hipMemcpy(b->line.d_aux, aux.data(), aux.size() * sizeof(PcmMsgAux), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         free_pcm_line(b);
         return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "chunk plan upload: %s", hipGetErrorString(e));
@@ -219,15 +254,26 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
     return OHGPU_OK;
 }
 
-hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+template <int SB, int DB>
+static hipError_t launch_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
 {
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     uint32_t grid = (b->line.n_chunks + kLineWaves - 1) / kLineWaves;
     if (grid > cus * 8) grid = cus * 8;                                 // 8 workgroups = 32 waves fill a CU
-    hipLaunchKernelGGL(pcm_line_kernel, dim3(grid), dim3(kLineWaves * 64), 0, s,
-                       (const ohgpu_msg_desc*)b->d_descs, (const PcmMsgAux*)b->line.d_aux, (const PcmChunk*)b->line.d_chunks,
-                       b->line.n_chunks, src, dst, ctx->d_ramp_table);
+    hipLaunchKernelGGL((pcm_line_kernel<SB, DB>), dim3(grid), dim3(kLineWaves * 64), 0, s,
+                       (const PcmChunk*)b->line.d_chunks, b->line.n_chunks, src, dst, ctx->d_ramp_table);
     return hipGetLastError();
+}
+
+hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    if (b->uniform) {
+        const uint32_t sb = b->src_bits / 8, db = b->dst_bits / 8;
+#define X(S, D) if (sb == S && db == D) return launch_line<S, D>(ctx, b, src, dst, s);
+        X(2, 2) X(2, 3) X(2, 4) X(3, 2) X(3, 3) X(3, 4) X(4, 2) X(4, 3) X(4, 4)
+#undef X
+    }
+    return launch_line<0, 0>(ctx, b, src, dst, s);
 }
 
 }  // namespace ohgpu

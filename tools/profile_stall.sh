@@ -6,13 +6,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH_ARGS="--steps 5 --warmup 2 --no-cpu $*"
+TARGET=${OHGPU_PROFILE_TARGET:-$R/bench.py}                      # e.g. tools/bench_pcm.py (then pass its own arguments)
+if [ "$TARGET" = "$R/bench.py" ]; then BENCH_ARGS="--steps 5 --warmup 2 --no-cpu $*"; else BENCH_ARGS="$*"; fi
 i=0
 while IFS= read -r SET; do
   [ -z "$SET" ] && continue
   i=$((i+1))
   echo "== pmc$i: $SET" | tee -a "$OUT/log.txt"
-  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- python3 "$R/bench.py" $BENCH_ARGS >> "$OUT/log.txt" 2>&1 || echo "pmc$i failed" | tee -a "$OUT/log.txt"
+  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- python3 "$TARGET" $BENCH_ARGS >> "$OUT/log.txt" 2>&1 || echo "pmc$i failed" | tee -a "$OUT/log.txt"
 done <<'SETS'
 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_TC_DATA_READ_REQ SQC_TC_STALL
@@ -26,7 +27,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "src_block_kernel" not in row["Kernel_Name"]: continue
+        if not any(k in row["Kernel_Name"] for k in ("src_block_kernel", "pcm_line_kernel", "pcm_msg_kernel")): continue
         tot[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
 with open(out + "/summary.txt", "w") as o:
     for k in sorted(tot):
