@@ -30,7 +30,7 @@ typedef const __attribute__((address_space(1))) void* global_ptr_t;
 
 constexpr uint32_t kChunkSub = 512;                                   // subsamples per chunk
 constexpr uint32_t kLineWaves = 4;                                    // waves per workgroup
-constexpr uint32_t kInBytes = ((15 + kChunkSub * 4 + 15) / 16) * 16 + 16;
+constexpr uint32_t kInBytes = ((15 + kChunkSub * 4 + 15) / 16) * 16 + 16;   // <= 3 staging instructions of 64 pieces
 
 // x / d for x < 2^31 with the host's multiplier (m == 0: d == 1)
 __device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t m, uint32_t s)
@@ -61,25 +61,52 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
                                                                   const uint16_t* __restrict__ ramp_table)
 {
     __shared__ uint16_t s_ramp[kRampTableCount];
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kLineWaves][kInBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kLineWaves][2][kInBytes];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (uint32_t i = tid; i < kRampTableCount; i += blockDim.x) s_ramp[i] = ramp_table[i];
     __syncthreads();
-    const __attribute__((address_space(3))) uint8_t* in = (const __attribute__((address_space(3))) uint8_t*)&s_in[wave][0];
 
-    // A chunk record is one 64-byte scalar load and holds everything the chunk needs; the next chunk's record is
-    // requested before this chunk is processed, so only the input staging's latency is exposed per chunk (and hidden by
-    // the CU's other waves).
+    // Software pipeline over the wave's chunks (chunk, chunk + stride, ...): while chunk i is processed, the input of
+    // chunk i+1 is on its way into the other LDS buffer and the record of chunk i+2 is being fetched (a record is one
+    // 64-byte scalar load and holds everything a chunk needs).  Returns the number of staging instructions issued.
     const uint32_t stride = gridDim.x * kLineWaves;
     uint32_t chunk = blockIdx.x * kLineWaves + wave;
     if (chunk >= n_chunks) return;
-    PcmChunk next = chunks[chunk];
+    auto stage_in = [&](const PcmChunk& c, uint32_t buf) __attribute__((always_inline)) -> uint32_t {
+        if (c.flags & kChunkSilence) return 0u;
+        const uint64_t s_addr = (uint64_t)(uintptr_t)src + c.src_off;      // first source byte
+        const uint32_t head = (uint32_t)s_addr & 15u;
+        const uint8_t* base = (const uint8_t*)(uintptr_t)(s_addr - head);
+        const uint32_t n_pieces = (head + c.nq * (SB ? SB : c.sb) + 15u) >> 4;
+        uint32_t issued = 0;
+        for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64, issued++) {
+            if (p0 + lane < n_pieces)                                   // LDS destination = wave-uniform base + lane * 16
+                __builtin_amdgcn_global_load_lds((global_ptr_t)(base + (size_t)(p0 + lane) * 16),
+                                                 (lds_ptr_t)(&s_in[wave][buf][0] + p0 * 16), 16, 0, 0);
+        }
+        return issued;
+    };
+    PcmChunk ck = chunks[chunk];
+    PcmChunk nx = ck;
+    bool has_nx = chunk + stride < n_chunks;
+    if (has_nx) nx = chunks[chunk + stride];
+    stage_in(ck, 0);
+    uint32_t buf = 0;
     while (true) {
-        const PcmChunk ck = next;
-        const uint32_t chunk_next = chunk + stride;
-        if (chunk_next < n_chunks) next = chunks[chunk_next];
+        // fetch the record after next, start the next chunk's input, then wait for this chunk's input only
+        const bool has_nn = has_nx && chunk + 2 * stride < n_chunks;
+        PcmChunk nn = nx;
+        if (has_nn) nn = chunks[chunk + 2 * stride];
+        const uint32_t k_nx = has_nx ? stage_in(nx, buf ^ 1) : 0u;
+        if (k_nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (k_nx == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (k_nx == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const __attribute__((address_space(3))) uint8_t* in = (const __attribute__((address_space(3))) uint8_t*)&s_in[wave][buf][0];
         const uint32_t ch = ck.channels, sb = SB ? SB : ck.sb, db = DB ? DB : ck.db;
         const bool src_le = (ck.flags & kChunkSrcLe) != 0;
         const bool dst_le = (ck.flags & kChunkDstLe) != 0;
@@ -88,21 +115,7 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
         const bool zero_lsb = (ck.flags & kChunkZeroLsb) != 0;
         const bool atten = ck.attenuation != OHGPU_UNITY_ATTENUATION;
         const uint32_t q0 = ck.q0, nq = ck.nq;
-
-        // ---- in: aligned 16-byte pieces -> LDS ----
-        const uint64_t s_addr = (uint64_t)(uintptr_t)src + ck.src_off;                          // first source byte
-        const uint32_t head = (uint32_t)s_addr & 15u;
-        if (!silence) {
-            const uint8_t* base = (const uint8_t*)(uintptr_t)(s_addr - head);
-            const uint32_t n_pieces = (head + nq * sb + 15u) >> 4;
-            for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64) {
-                if (p0 + lane < n_pieces)                               // LDS destination = wave-uniform base + lane * 16
-                    __builtin_amdgcn_global_load_lds((global_ptr_t)(base + (size_t)(p0 + lane) * 16),
-                                                     (lds_ptr_t)(&s_in[wave][0] + p0 * 16), 16, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t head = (uint32_t)((uint64_t)(uintptr_t)src + ck.src_off) & 15u;
 
         // ---- lane = aligned destination dword: transform the 1..4 subsamples whose bytes fall into it, funnel, store ----
         const int32_t total = (int32_t)((uint32_t)ck.ramp_start - (uint32_t)ck.ramp_end);
@@ -180,8 +193,10 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
             }
         };
         if (!(ramp || silence || atten)) emit(subsample_plain); else emit(subsample);
-        if (chunk_next >= n_chunks) break;
-        chunk = chunk_next;
+        if (!has_nx) break;
+        chunk += stride;
+        ck = nx; nx = nn; has_nx = has_nn;
+        buf ^= 1;
     }
 }
 
