@@ -76,9 +76,8 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
     if (chunk >= n_chunks) return;
     auto stage_in = [&](const PcmChunk& c, uint32_t buf) __attribute__((always_inline)) -> uint32_t {
         if (c.flags & kChunkSilence) return 0u;
-        const uint64_t s_addr = (uint64_t)(uintptr_t)src + c.src_off;      // first source byte
-        const uint32_t head = (uint32_t)s_addr & 15u;
-        const uint8_t* base = (const uint8_t*)(uintptr_t)(s_addr - head);
+        const uint32_t head = (uint32_t)((uint64_t)(uintptr_t)src + c.src_off) & 15u;        // first source byte's place in its piece
+        const uint8_t* base = src + (c.src_off - head);
         const uint32_t n_pieces = (head + c.nq * (SB ? SB : c.sb) + 15u) >> 4;
         uint32_t issued = 0;
         for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64, issued++) {
@@ -148,15 +147,14 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
         // orders, the zeroed low byte of 32-bit output).  Subsamples past the chunk's end read bytes that exist in the
         // staging buffer and only ever land in byte positions the edge path does not store.
         auto subsample_plain = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t {
-            const uint32_t off = head + q * sb;
+            const uint32_t off = head + __umul24(q, sb);   // q <= 514, sb <= 4
             const __attribute__((address_space(3))) uint32_t* a = (const __attribute__((address_space(3))) uint32_t*)(in + (off & ~3u));
             return __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(a[1], a[0], off & 3u), ck.plain_sel);
         };
-        const uint64_t d_addr = (uint64_t)(uintptr_t)dst + ck.dst_off;                          // first destination byte
-        const uint32_t dhead = (uint32_t)d_addr & 3u;
+        const uint32_t dhead = (uint32_t)((uint64_t)(uintptr_t)dst + ck.dst_off) & 3u;         // first destination byte's place in its dword
         const uint32_t len = nq * db;
         const uint32_t n_dw = (dhead + len + 3u) >> 2;
-        uint8_t* const obase = (uint8_t*)(uintptr_t)(d_addr - dhead);
+        uint8_t* const obase = dst + (ck.dst_off - dhead);             // (pointer arithmetic on the argument keeps the stores global, not flat)
         auto emit = [&](auto&& sub_fn) __attribute__((always_inline)) {
             for (uint32_t kb = 0; kb < n_dw; kb += 64) {
                 const uint32_t k = kb + lane;
@@ -165,7 +163,7 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
                     const uint32_t upos = pos < 0 ? 0u : (uint32_t)pos;
                     uint32_t v;                                             // stream bytes [upos, upos + 4)
                     if (db == 3) {
-                        const uint32_t qa = __umulhi(upos, 0xAAAAAAABu) >> 1, o = upos - qa * 3;
+                        const uint32_t qa = __umulhi(upos, 0xAAAAAAABu) >> 1, o = upos - __umul24(qa, 3u);
                         const uint32_t v0 = sub_fn(qa), v1 = sub_fn(qa + 1);
                         // bytes {v0: 0..3, v1: 4..7}; stream = v0.b0 v0.b1 v0.b2 v1.b0 v1.b1 v1.b2
                         const uint32_t sel = o == 0 ? 0x04020100u : (o == 1 ? 0x05040201u : 0x06050402u);

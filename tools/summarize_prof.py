@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = name.split("(")[0]
-    for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_msg_kernel_v1", "pcm_stream_kernel"):
+    for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_line_kernel", "pcm_msg_kernel_v1", "fmt_kernel_v1"):
         if k in name:
             return k
     return name[-60:]
@@ -21,6 +21,7 @@ def short(name):
 
 def main():
     tag = sys.argv[1]
+    what = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 5 --warmup 2 --no-cpu"   # the profiled command
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = {"tag": tag, "kernels": {}, "counters": {}}
     for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
@@ -42,7 +43,7 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1, sort_keys=True)
     with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as md:
-        md.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu` "
+        md.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 {what}` "
                  "plus one `--pmc` pass per counter set (tools/profile_bench.sh).\n\n## Kernel time (kernel trace)\n\n")
         md.write("| kernel | calls | avg us | median us | min us | max us |\n|---|---|---|---|---|---|\n")
         for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["calls"]):
@@ -65,7 +66,8 @@ def main():
                "write_size_kib": c["WRITE_SIZE"], "kernel_avg_us_trace": out["kernels"][dom]["avg_us"],
                "source": f"profiles/{tag}_summary.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes",
                "streams_per_gpu": 256, "frames_per_stream": 441000, "kernel_variant": 0}
-        json.dump(pmc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+        if dom == "src_block_kernel":                                  # bench.py reads this one for roofline.traffic
+            json.dump(pmc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
         out["hbm_traffic"] = pmc
     print(json.dumps(out, indent=1, sort_keys=True))
 
