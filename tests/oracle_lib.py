@@ -70,6 +70,11 @@ def build(force=False):
 _lib = None
 
 
+class FeedbackModel(C.Structure):
+    _fields_ = [("coeffs", C.c_void_p), ("samples", C.c_void_p), ("state_count", C.c_uint32),
+                ("data_descale_bits", C.c_uint32), ("coeff_format", C.c_uint32), ("scale_shift_for_output", C.c_int32)]
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -122,6 +127,12 @@ def lib():
         "ohp_src_coef_q28": (i32p, [vp]), "ohp_src_coef_f64": (f64p, [vp]),
         "ohp_src_sum_abs_max": (C.c_int64, [vp]), "ohp_src_f_stop": (C.c_double, [vp]),
         "ohp_src_out_frames": (C.c_uint64, [vp, C.c_uint64]),
+        "ohp_burgs_method": (None, [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
+        "ohp_flywheel_decimation_factor": (C.c_uint32, [C.c_uint32]),
+        "ohp_flywheel_coeff_overflow": (C.c_int16, [vp, C.c_uint32, C.c_uint32]),
+        "ohp_feedback_init": (None, [C.POINTER(FeedbackModel), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
+        "ohp_feedback_next_sample": (C.c_int32, [C.POINTER(FeedbackModel)]),
+        "ohp_flywheel_ramp": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
