@@ -184,6 +184,30 @@ int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
 int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
 
+/* ---- FlywheelRamper ----
+ * Replaces FlywheelRamperManager::Ramp (OpenHome/Media/FlywheelRamper.cpp:44-66; per channel FlywheelRamper::Initialise
+ * :176-226 = decimate, Burg's method :246-314, coefficient correction :333-372, and FeedbackModel::NextSample :449-487;
+ * rendering with sample hold :83-131) for a batch of starving streams: one descriptor = one stream's ramp request.
+ * Training audio is what FlywheelInput prepares (StarvationRamper.cpp:90-111, 159-186 = OHGPU_FMT_UNPACK_PLANAR):
+ * planar big-endian 32-bit, channel c at src_offset + c * channel_bytes; of each plane the LAST in_samples * 4 bytes
+ * are used (Initialise skips older audio, :189-194).  Output: interleaved big-endian 32-bit, what RenderChannels hands
+ * to IPcmProcessor::ProcessFragment(buf, channels, 4) in blocks of block_frames. */
+typedef struct ohgpu_flywheel_desc {     /* 48 bytes */
+    uint64_t src_offset;
+    uint64_t channel_bytes;         /* bytes per channel plane, >= in_samples * 4 */
+    uint64_t dst_offset;            /* out_frames * channels * 4 bytes are written here */
+    uint32_t in_samples;            /* Jiffies::ToSamples(training jiffies, rate); in_samples / decimation >= 4 */
+    uint32_t out_frames;            /* Jiffies::ToSamples(ramp jiffies, rate) */
+    uint32_t block_frames;          /* Jiffies::ToSamples(kMaxOutputJiffiesBlockSize = 1 ms, rate): the hold counter restarts per block */
+    uint32_t sample_rate;           /* decides the decimation factor (FlywheelRamper.cpp:316-331); <= 384000 */
+    uint32_t channels;              /* 1..10 (kMaxChannelCount) */
+    uint32_t reserved;
+} ohgpu_flywheel_desc;
+
+int ohgpu_flywheel_batch_create(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs, size_t n,
+                                uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
+int ohgpu_flywheel_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+
 /* ---- sample-rate converter (own specification; DESIGN.md "Resampler") ---- */
 /* Host-side filter design: Kaiser-windowed sinc, Q28 coefficients, coef_q28[p*T + k] = h[p + k*L].
  * Pass coef_q28 = NULL to query L, M only.  Capacity must be >= L*T. */

@@ -37,6 +37,11 @@ FMT_DESC = np.dtype([
     ("n_frames", "<u4"), ("kind", "u1"), ("channels", "u1"), ("src_bits", "u1"), ("dst_bits", "u1"),
     ("reserved", "u1", (8,))], align=False)
 
+FLYWHEEL_DESC = np.dtype([
+    ("src_offset", "<u8"), ("channel_bytes", "<u8"), ("dst_offset", "<u8"), ("in_samples", "<u4"),
+    ("out_frames", "<u4"), ("block_frames", "<u4"), ("sample_rate", "<u4"), ("channels", "<u4"),
+    ("reserved", "<u4")], align=False)
+
 # every symbol of include/ohgpu.h: name -> (restype, argtypes)
 _vp, _vpp = C.c_void_p, C.POINTER(C.c_void_p)
 _u64p = C.POINTER(C.c_uint64)
@@ -69,6 +74,8 @@ SYMBOLS = {
     "ohgpu_pcm_process_host": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
     "ohgpu_fmt_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_fmt_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ohgpu_flywheel_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
+    "ohgpu_flywheel_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_design": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp, C.c_size_t,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ohgpu_src_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vpp]),
@@ -246,6 +253,17 @@ class Context:
 
     def fmt_run(self, batch, d_src, d_dst, stream=None):
         check(lib().ohgpu_fmt_batch_run(self._h, batch, d_src, d_dst, stream))
+
+    def flywheel_batch(self, descs, src_arena_bytes, dst_arena_bytes):
+        d = np.ascontiguousarray(descs)
+        assert d.dtype == FLYWHEEL_DESC
+        b = C.c_void_p()
+        check(lib().ohgpu_flywheel_batch_create(self._h, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes,
+                                                dst_arena_bytes, C.byref(b)))
+        return b
+
+    def flywheel_run(self, batch, d_src, d_dst, stream=None):
+        check(lib().ohgpu_flywheel_batch_run(self._h, batch, d_src, d_dst, stream))
 
     def src_create(self, L, M, T, coef_q28):
         c = np.ascontiguousarray(coef_q28, dtype=np.int32)

@@ -333,6 +333,7 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     if (batch->d_descs) hipFree(batch->d_descs);
     if (batch->kind == kBatchSrc) free_src_fast(batch);
     if (batch->kind == kBatchPcm) free_pcm_line(batch);
+    if (batch->kind == kBatchFlywheel) free_flywheel(batch);
     delete batch;
     return OHGPU_OK;
 }
@@ -436,6 +437,59 @@ int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: null arena pointer");
     OHGPU_HIP_TRY(launch_fmt_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    return OHGPU_OK;
+}
+
+/* ---------------------------------------------------------------- FlywheelRamper (N1) */
+int ohgpu_flywheel_batch_create(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs, size_t n,
+                                uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
+{
+    CTX_GUARD("ohgpu_flywheel_batch_create");
+    if (!out || (n && !descs)) return set_error(OHGPU_ERR_INVALID, "ohgpu_flywheel_batch_create: null argument");
+    *out = nullptr;
+    if (n > 0x0fffffffull) return set_error(OHGPU_ERR_INVALID, "ohgpu_flywheel_batch_create: too many descriptors");
+    ohgpu_batch* b = new (std::nothrow) ohgpu_batch();
+    if (!b) return set_error(OHGPU_ERR_NOMEM, "ohgpu_flywheel_batch_create: out of host memory");
+    b->kind = kBatchFlywheel;
+    b->n = n;
+    b->src_arena_bytes = src_arena_bytes;
+    b->dst_arena_bytes = dst_arena_bytes;
+    for (size_t i = 0; i < n; i++) {
+        const ohgpu_flywheel_desc& d = descs[i];
+        int err = OHGPU_OK;
+        const uint32_t dec = (d.sample_rate == 192000 || d.sample_rate == 176400) ? 4 : ((d.sample_rate == 88200 || d.sample_rate == 96000) ? 2 : 1);
+        const uint64_t plane = d.channel_bytes, need = (uint64_t)d.in_samples * 4, out_bytes = (uint64_t)d.out_frames * d.channels * 4;
+        if (d.channels < 1 || d.channels > 10) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: channels %u outside 1..10", i, d.channels);
+        else if (d.sample_rate > 384000) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: sample rate %u above 384000", i, d.sample_rate);   // ASSERT, FlywheelRamper.cpp:178
+        else if (need > plane) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: %llu-byte planes hold fewer than %u samples", i, (unsigned long long)plane, d.in_samples);   // ASSERT, :180
+        else if (d.in_samples / dec < 4) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: %u training samples after decimation by %u (need 4)", i, d.in_samples, dec);
+        else if (d.in_samples > 65536) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: %u training samples (limit 65536)", i, d.in_samples);
+        else if (d.block_frames == 0 && d.out_frames != 0) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: block_frames is 0", i);
+        else if (d.src_offset > src_arena_bytes || plane * d.channels > src_arena_bytes - d.src_offset)
+            err = set_error(OHGPU_ERR_BOUNDS, "flywheel desc %zu: training audio beyond the %llu-byte source arena", i, (unsigned long long)src_arena_bytes);
+        else if (d.dst_offset > dst_arena_bytes || out_bytes > dst_arena_bytes - d.dst_offset)
+            err = set_error(OHGPU_ERR_BOUNDS, "flywheel desc %zu: writes up to %llu beyond the %llu-byte destination arena", i,
+                            (unsigned long long)(d.dst_offset + out_bytes), (unsigned long long)dst_arena_bytes);
+        if (err != OHGPU_OK) { delete b; return err; }
+        b->in_frames += d.in_samples;
+        b->out_frames += d.out_frames;
+        b->src_bytes_touched += need * d.channels;
+        b->dst_bytes_written += out_bytes;
+    }
+    int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_flywheel_desc));
+    if (err == OHGPU_OK) err = plan_flywheel(ctx, b, descs, n);
+    if (err != OHGPU_OK) { if (b->d_descs) hipFree(b->d_descs); delete b; return err; }
+    *out = b;
+    return OHGPU_OK;
+}
+
+int ohgpu_flywheel_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
+{
+    CTX_GUARD("ohgpu_flywheel_batch_run");
+    if (!batch || batch->kind != kBatchFlywheel) return set_error(OHGPU_ERR_INVALID, "ohgpu_flywheel_batch_run: not a flywheel batch");
+    if (batch->n == 0) return OHGPU_OK;
+    if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_flywheel_batch_run: null arena pointer");
+    OHGPU_HIP_TRY(launch_flywheel(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
     return OHGPU_OK;
 }
 

@@ -120,7 +120,15 @@ struct PcmLinePlan {
     void*    d_chunks = nullptr;
 };
 
-enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3 };
+// ---- FlywheelRamper (csrc/flywheel_kernel.hip) ----
+struct FlywheelLane { uint32_t req, channel; };      // one lane = one channel of one request
+struct FlywheelPlan {
+    uint32_t n_lanes = 0, lanes_padded = 0, max_count = 0;
+    void*    d_lanes = nullptr;
+    void*    d_work = nullptr;    // int16 [3][max_count][lanes_padded]: decimated input, per, pef of Burg's method
+};
+
+enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3, kBatchFlywheel = 4 };
 
 }  // namespace ohgpu
 
@@ -151,6 +159,7 @@ struct ohgpu_batch {
     uint8_t  channels, src_bits, src_endian, dst_bits, dst_endian;
     ohgpu::SrcFastPlan fast;      // kBatchSrc only
     ohgpu::PcmLinePlan line;      // kBatchPcm only
+    ohgpu::FlywheelPlan fly;      // kBatchFlywheel only
 };
 
 namespace ohgpu {
@@ -170,6 +179,9 @@ hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8
 hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n);
 void free_pcm_line(ohgpu_batch* b);
+int plan_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_flywheel_desc* descs, size_t n);
+void free_flywheel(ohgpu_batch* b);
+hipError_t launch_flywheel(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* src_filter,
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
