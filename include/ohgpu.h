@@ -207,6 +207,9 @@ typedef struct ohgpu_flywheel_desc {     /* 48 bytes */
 int ohgpu_flywheel_batch_create(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs, size_t n,
                                 uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
 int ohgpu_flywheel_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+/* Host-buffer convenience: H2D, run, D2H, sync (dst_host bytes that no request covers are preserved). */
+int ohgpu_flywheel_process_host(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs, size_t n,
+                                const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
 
 /* ---- sample-rate converter (own specification; DESIGN.md "Resampler") ---- */
 /* Host-side filter design: Kaiser-windowed sinc, Q28 coefficients, coef_q28[p*T + k] = h[p + k*L].

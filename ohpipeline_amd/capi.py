@@ -76,6 +76,7 @@ SYMBOLS = {
     "ohgpu_fmt_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_flywheel_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_flywheel_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ohgpu_flywheel_process_host": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
     "ohgpu_src_design": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp, C.c_size_t,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ohgpu_src_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vpp]),

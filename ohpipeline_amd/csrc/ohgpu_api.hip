@@ -493,6 +493,27 @@ int ohgpu_flywheel_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const voi
     return OHGPU_OK;
 }
 
+int ohgpu_flywheel_process_host(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs, size_t n,
+                                const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes)
+{
+    CTX_GUARD("ohgpu_flywheel_process_host");
+    ohgpu_batch* b = nullptr;
+    int err = ohgpu_flywheel_batch_create(ctx, descs, n, src_bytes, dst_bytes, &b);
+    if (err != OHGPU_OK) return err;
+    void *d_src = nullptr, *d_dst = nullptr;
+    err = ohgpu_malloc(ctx, src_bytes, &d_src);
+    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
+    if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
+    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);
+    if (err == OHGPU_OK) err = ohgpu_flywheel_batch_run(ctx, b, d_src, d_dst, nullptr);
+    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
+    if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
+    if (d_src) hipFree(d_src);
+    if (d_dst) hipFree(d_dst);
+    ohgpu_batch_destroy(ctx, b);
+    return err;
+}
+
 /* ---------------------------------------------------------------- sample-rate converter */
 int ohgpu_src_design(uint32_t rate_in, uint32_t rate_out, uint32_t taps_per_phase, double beta, double f_pass_hz,
                      int32_t* coef_q28, size_t coef_capacity, uint32_t* L, uint32_t* M)

@@ -9,8 +9,10 @@
 #include <vector>
 
 #include "../../ohpipeline_amd/host/Elements.h"
+#include "../../ohpipeline_amd/host/FlywheelRamper.h"
 #include "../../ohpipeline_amd/host/Msg.h"
 #include "../../ohpipeline_amd/host/SampleRateConverter.h"
+#include "../../oracle/ohp_flywheel.h"
 #include "../../oracle/ohp_pipeline.h"
 
 using namespace OpenHome;
@@ -401,6 +403,78 @@ private:
     std::vector<TByte> iInput;
 };
 
+// ------------------------------------------------------------------------------------------- FlywheelRamper (N1)
+// Driven the way Tests/TestFlywheelRamper.cpp:619-671 drives the original: a manager with (generation, ramp) jiffies, a
+// block of planar 32-bit audio, output collected by an IPcmProcessor -- here checked against the oracle, which the
+// reference's known-answer tests pin.
+class ProcessorBlocks : public IPcmProcessor {
+public:
+    void BeginBlock() override { iOpen = true; }
+    void ProcessFragment(const Brx& aData, TUint aNumChannels, TUint aSubsampleBytes) override
+    {
+        TEST(iOpen && aSubsampleBytes == 4);
+        iChannels = aNumChannels;
+        iBlockBytes.push_back(aData.Bytes());
+        iBuf.insert(iBuf.end(), aData.Ptr(), aData.Ptr() + aData.Bytes());
+    }
+    void ProcessSilence(const Brx&, TUint, TUint) override { TEST(false); }
+    void EndBlock() override { iOpen = false; }
+    void Flush() override {}
+    std::vector<TByte> iBuf;
+    std::vector<TUint> iBlockBytes;
+    TUint iChannels = 0;
+    TBool iOpen = false;
+};
+
+static void SuiteFlywheelGpu(MsgFactory& aFactory)
+{
+    const TUint kGenJiffies = Jiffies::kPerMs, kRampJiffies = 20 * Jiffies::kPerMs;   // StarvationRamper.cpp:374-375
+    const struct { TUint rate, channels; } cases[] = { {44100, 2}, {192000, 8}, {96000, 6}, {48000, 1} };
+    FlywheelRamperBatch batch(aFactory);
+    std::vector<ProcessorBlocks> sinks(4);
+    std::vector<std::vector<TByte>> inputs(4);
+    uint32_t x = 99;
+    for (int k = 0; k < 4; k++) {
+        const TUint rate = cases[k].rate, ch = cases[k].channels;
+        const TUint n = FlywheelRamper::SampleCount(rate, kGenJiffies) + (k == 1 ? 2 : 0);   // one request gets "slightly too much data"
+        std::vector<TByte>& in = inputs[k];
+        for (TUint c = 0; c < ch; c++) {
+            int32_t v = (int32_t)(0x20000000u + c * 0x01000000u);
+            for (TUint i = 0; i < n; i++) {
+                x = x * 1664525u + 1013904223u;
+                v += (int32_t)(x >> 8) - (1 << 23) - (int32_t)(i * 0x00040000u);          // a noisy, decaying run
+                in.push_back((TByte)((uint32_t)v >> 24)); in.push_back((TByte)((uint32_t)v >> 16));
+                in.push_back((TByte)((uint32_t)v >> 8)); in.push_back((TByte)v);
+            }
+        }
+        if (k == 0) {                                                                    // the drop-in shape: one manager, one Ramp()
+            FlywheelRamperManager manager(aFactory, sinks[0], kGenJiffies, kRampJiffies);
+            manager.Ramp(Brn(in.data(), (TUint)in.size()), rate, ch);
+        } else {
+            batch.Add(sinks[k], Brn(in.data(), (TUint)in.size()), rate, ch, kGenJiffies, kRampJiffies);
+        }
+    }
+    TEST(batch.Count() == 3);
+    batch.Run();
+    for (int k = 0; k < 4; k++) {
+        const TUint rate = cases[k].rate, ch = cases[k].channels;
+        const TUint inSamples = FlywheelRamper::SampleCount(rate, kGenJiffies), outFrames = FlywheelRamper::SampleCount(rate, kRampJiffies);
+        const TUint block = FlywheelRamper::SampleCount(rate, FlywheelRamperManager::kMaxOutputJiffiesBlockSize);
+        std::vector<TByte> want((size_t)outFrames * ch * 4);
+        TEST(ohp_flywheel_ramp(inputs[k].data(), inputs[k].size() / ch, inSamples, rate, ch, outFrames, block, want.data()) == 0);
+        TEST(sinks[k].iChannels == ch && sinks[k].iBuf.size() == want.size());
+        TEST(sinks[k].iBuf.size() == want.size() && memcmp(sinks[k].iBuf.data(), want.data(), want.size()) == 0);
+        TEST(sinks[k].iBlockBytes.size() == (outFrames + block - 1) / block);           // 1 ms blocks, FlywheelRamper.cpp:52-63
+        TEST(sinks[k].iBlockBytes.front() == block * ch * 4);
+    }
+    TEST(FlywheelRamper::DecimationFactor(176400) == 4 && FlywheelRamper::DecimationFactor(96000) == 2 && FlywheelRamper::DecimationFactor(44100) == 1);
+    ProcessorBlocks sink;
+    FlywheelRamperManager manager(aFactory, sink, kGenJiffies, kRampJiffies);
+    TByte few[8 * 4] = { 0 };
+    TEST_THROWS(manager.Ramp(Brn(few, sizeof few), 44100, 2), AssertionFailed);          // less than the generation period: ASSERT, :180
+    TEST_THROWS(manager.Ramp(Brn(few, sizeof few), 44100, 11), AssertionFailed);
+}
+
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
@@ -425,6 +499,7 @@ int main(int argc, char** argv)
             ramper.Run();
             SuiteSrcGpu src(f);
             src.Run();
+            SuiteFlywheelGpu(f);
         }
     }
     catch (const std::exception& e) {
