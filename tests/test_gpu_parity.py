@@ -128,6 +128,30 @@ def test_pcm_extremes_bit_exact(vctx):
     assert np.array_equal(run_pcm(vctx, descs, src, dp), oracle_pcm(descs, src, dp))
 
 
+@pytest.mark.parametrize("bits,dbits", list(itertools.product([8, 16, 24, 32], [8, 16, 24, 32])))
+def test_pcm_uniform_batches_every_depth_pair(vctx, bits, dbits):
+    """Uniform batches run the line kernel's depth-specialised instantiations: every (source, destination) depth, both
+    byte orders on both sides, 1/2/6 channels, ragged and multi-chunk messages, plain / ramped / silent / zero-LSB, every
+    byte misalignment of both arenas."""
+    rng = np.random.default_rng(bits * 100 + dbits)
+    for se, de, ch in itertools.product([LE, BE], [LE, BE], [1, 2, 6]):
+        rows, parts, sp, dp = [], [], 0, 0
+        for k, n in enumerate([1, 2, 5, 43, 171, 220, 700, 1537]):
+            pad = k % 5
+            nbytes = n * ch * bits // 8
+            parts.append(rng.integers(0, 256, size=pad + nbytes, dtype=np.uint8))
+            flags = [0, O.FLAG_RAMP, 0, O.FLAG_RAMP | O.FLAG_ZERO_LSB32, O.FLAG_SILENCE, 0, O.FLAG_RAMP, O.FLAG_ZERO_LSB32][k]
+            ramp = RAMPS[(k + ch) % len(RAMPS)]
+            rows.append((sp + pad, dp + (k % 4), n, ramp[0], ramp[1], 256, ch, bits, se, dbits, de, flags))
+            sp += pad + nbytes
+            dp += n * ch * dbits // 8 + 7
+        descs = np.array(rows, dtype=O.MSG_DESC)
+        src = np.concatenate(parts)
+        got, want = run_pcm(vctx, descs, src, dp), oracle_pcm(descs, src, dp)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"{bits}->{dbits} se={se} de={de} ch={ch}: {bad.size} mismatches, first at {bad[:5]}"
+
+
 def test_attenuation_all_s16_values(vctx):
     """a6 over every 16-bit value for att in {0,1,64,255,256} (floor semantics of the unsigned multiply/divide)."""
     vals = np.arange(65536, dtype=np.uint32)
