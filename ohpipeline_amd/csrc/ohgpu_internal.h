@@ -57,8 +57,10 @@ struct SrcWork {              // one workgroup's share: up to `rows` consecutive
     uint64_t first_block;     // absolute block index (block b covers outputs [b*L_blk, (b+1)*L_blk))
     uint32_t seg;
     uint32_t n_blocks;
+    uint32_t msg_first;       // index (in the SegMsg array) of the message that holds the unit's first output frame
+    uint32_t pad;
 };
-static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 16 && sizeof(SrcSeg) == 24, "plan layouts");
+static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 24 && sizeof(SrcSeg) == 24, "plan layouts");
 
 struct SrcFastParams {        // kernel argument block
     const SrcSeg*  segs;
@@ -71,19 +73,13 @@ struct SrcFastParams {        // kernel argument block
     uint64_t src_arena_bytes;
     uint32_t L, M;
     uint32_t L_blk, M_blk;    // outputs / inputs per block
-    uint32_t rows;            // blocks per workgroup
-    uint32_t cgn;             // lanes per block (channel groups)
-    uint32_t oc_log2;         // outputs per store stage = 1 << oc_log2
-    uint32_t in_blocks;       // 16-byte pieces per staged input row
-    uint32_t out_blocks;      // 16-byte pieces per staged output row
-    uint32_t channels, sb, db;
+    uint32_t channels, sb, db; // the batch's layout: selects the kernel instantiation
     uint32_t src_le, dst_le;
-    uint32_t ablate;          // timing experiments only (OHGPU_ABLATE env): 1 no stores, 2 no input DMA, 4 phase-0 coefficients, 8 no barriers
 };
 
 struct SrcFastPlan {
     bool     enabled = false;
-    uint32_t T = 0, cpl = 0;
+    uint32_t T = 0;               // taps per phase
     SrcFastParams params{};
     uint32_t n_work = 0;
     uint32_t coef_lds_bytes = 0;  // the coefficient table's share of a workgroup's LDS

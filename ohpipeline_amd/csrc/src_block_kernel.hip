@@ -231,20 +231,14 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // starts at input frame 0 reaches before the stream: its whole warm-up pass (advances a < 0) must be zeros.
     const bool first_block = n_start == 0;
 
-    // Messages (ramp parameters) of the unit's output range.  Lane 0's block starts the range: its message is found
-    // by bisection; the next MSG_SLOTS messages go to an LDS table, compacted and made relative to the unit's first
+    // Messages (ramp parameters) of the unit's output range.  Lane 0's block starts the range, in message
+    // wk.msg_first; that and the next MSG_SLOTS - 1 messages go to an LDS table, compacted and made relative to the unit's first
     // output frame, so that the per-output path never issues a global load (it would have to wait for the staging
     // loads in flight).  A range with more messages than the table holds falls back to reading them from memory.
     const __attribute__((address_space(3))) u32x4* msg_tab = (const __attribute__((address_space(3))) u32x4*)(lds + OFF_MSG);
     const uint64_t wave_m0 = wk.first_block * (uint64_t)L_blk;
-    uint32_t tab_lo;
+    const uint32_t tab_lo = wk.msg_first;                           // (the planner found it: no search here)
     {
-        uint32_t lo = seg.msg_begin, hi = seg.msg_end;
-        while (hi - lo > 1) {                                       // wave-uniform bisection
-            const uint32_t mid = (lo + hi) >> 1;
-            if (msgs[mid].out0 <= wave_m0) lo = mid; else hi = mid;
-        }
-        tab_lo = lo;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the previous unit's table has been read
         __builtin_amdgcn_wave_barrier();
         if (lane < (uint32_t)MSG_SLOTS) {
@@ -285,28 +279,36 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     int32_t evt_j = (msg_flags & OHGPU_FLAG_RAMP) ? 0 : msg_rel0 + (int32_t)msg_n;
 
     // ---- input staging: stage q holds advances [8q - T, 8q + 8 - T) of every row, as raw packed bytes.
-    // Lane `lane` moves pieces idx = it*64 + lane: piece `part` of row r = idx / IN_BLOCKS.
-    int64_t piece_g[IN_ITERS];       // unaligned byte offset of that row's frame at a_lin = 0
-    int32_t piece_part[IN_ITERS];    // -1: nothing to move
+    // Lane `lane` moves pieces idx = it*64 + lane: piece `part` of row r = idx / IN_BLOCKS.  A stage is 8 frames =
+    // a multiple of 16 bytes further on than the last, so a piece's (16-byte aligned) address just advances by that.
+    static_assert((8 * FB_SRC) % 16 == 0, "a stage advances every piece by a whole number of 16-byte pieces");
+    const int total = (int)M_blk + T;         // advances a = a_lin - T for a_lin in [0, total)
+    const int n_stages = (total + 7) >> 3;
+    int64_t piece_a[IN_ITERS];       // arena offset of this lane's piece of the NEXT stage to issue (16-byte aligned)
+    bool piece_on[IN_ITERS];         // this lane has a piece to move
+    bool unit_safe = true;           // every piece of every stage lies inside the arena: no per-piece checks
 #pragma unroll
     for (int it = 0; it < IN_ITERS; it++) {
         const uint32_t idx = it * 64 + lane;
         const uint32_t r = idx / IN_BLOCKS;
-        piece_g[it] = seg.src_base + ((int64_t)((wk.first_block + r) * M_blk) - T) * (int64_t)FB_SRC;
+        const int64_t g = seg.src_base + ((int64_t)((wk.first_block + r) * M_blk) - T) * (int64_t)FB_SRC;   // row's frame at a_lin = 0
+        piece_a[it] = (g & ~(int64_t)15) + 16 * (int64_t)(idx - r * IN_BLOCKS);
 #ifdef OHGPU_EXP_NODMA
-        piece_part[it] = -1; (void)n_blocks;
+        piece_on[it] = false; (void)n_blocks;
 #else
-        piece_part[it] = (r < n_blocks && r < (uint32_t)ROWS) ? (int32_t)(idx - r * IN_BLOCKS) : -1;
+        piece_on[it] = r < n_blocks && r < (uint32_t)ROWS;
 #endif
+        const int64_t last = piece_a[it] + (int64_t)(n_stages - 1) * (8 * FB_SRC);
+        if (piece_on[it] && (piece_a[it] < 0 || (uint64_t)last + 16 > src_arena_bytes)) unit_safe = false;
     }
+    unit_safe = __all(unit_safe) != 0;
     auto issue_stage = [&](int q) __attribute__((always_inline)) {
         const uint32_t buf = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
-        const int64_t shift = (int64_t)q * 8 * FB_SRC;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; it++) {
-            if (piece_part[it] >= 0) {
-                const int64_t addr = ((piece_g[it] + shift) & ~(int64_t)15) + 16 * (int64_t)piece_part[it];
-                if (addr >= 0 && (uint64_t)addr + 16 <= src_arena_bytes) {
+            if (piece_on[it]) {
+                const int64_t addr = piece_a[it];
+                if (unit_safe || (addr >= 0 && (uint64_t)addr + 16 <= src_arena_bytes)) {
                     // LDS destination = wave-uniform base + lane*16
                     __builtin_amdgcn_global_load_lds((global_ptr_t)(src + addr),
                                                      (lds_ptr_t)(wsmem + buf + (uint32_t)(it * 64) * 16), 16, 0, 0);
@@ -319,6 +321,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                     }
                 }
             }
+            piece_a[it] += 8 * FB_SRC;
         }
     };
 
@@ -377,11 +380,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #pragma unroll
     for (int s = 0; s < T; s++) win[s] = 0.0;
 
-    const int total = (int)M_blk + T;         // advances a = a_lin - T for a_lin in [0, total)
     int j = 0;                                // outputs emitted so far (wave-uniform)
     int t = 0;                                // j * M
     int p = 0;                                // phase of output j = t mod L (every block starts at phase 0)
     uint32_t in_off = 0;                      // LDS address of this lane's subsample in the current stage's first frame
+    const uint32_t in_base = wave_lds_addr + OFF_IN + row * IN_STRIDE + ((uint32_t)row_g & 15u) + c * SB;
     const bool any_first = __any(first_block) != 0;
     auto issue_store = [&]() __attribute__((always_inline)) {
         if constexpr (PAIR) lds_issue_store_2xu32(st_addr, st_lo, st_hi);
@@ -417,8 +420,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                     if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
                     if ((q + 1) * 8 < total) issue_stage(q + 1);
                     if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
-                    in_off = wave_lds_addr + OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE + row * IN_STRIDE +
-                             (uint32_t)((row_g + (int64_t)q * 8 * FB_SRC) & 15) + c * SB;
+                    in_off = in_base + (uint32_t)(q & 1) * ROWS * IN_STRIDE;   // (a stage shifts the row by whole pieces: same misalignment)
                 }
                 issue_store();                                          // the last output's bytes must be in the ring
                 st_addr = idle_lane;

@@ -12,12 +12,6 @@
 
 namespace ohgpu {
 
-static uint32_t gcd_u32(uint32_t a, uint32_t b)
-{
-    while (b) { const uint32_t t = a % b; a = b; b = t; }
-    return a;
-}
-
 void free_src_fast(ohgpu_batch* b)
 {
     SrcFastPlan& f = b->fast;
@@ -85,8 +79,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint64_t M_blk64 = (uint64_t)L_blk * M / L;
     if (M_blk64 + T > 32000 || M_blk64 < T) return OHGPU_OK;    // a block is at least one filter length of input
     const uint32_t M_blk = (uint32_t)M_blk64;
-    const uint32_t oc_log2 = 0;
-    (void)fb_src; (void)gcd_u32;
 
     // order messages by (stream, output position); a stream is identified by where its absolute frame 0 lives
     std::vector<uint32_t> order(n);
@@ -139,9 +131,13 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             sg.src_base = sbase; sg.dst_base = dbase; sg.msg_begin = msg_begin; sg.msg_end = (uint32_t)msgs.size();
             const uint32_t seg_index = (uint32_t)segs.size();
             segs.push_back(sg);
+            uint32_t mi = msg_begin;                      // message that holds the unit's first output frame
             for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
                 SrcWork w;
                 w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
+                while (mi + 1 < sg.msg_end && msgs[mi + 1].out0 <= bk * L_blk) mi++;
+                w.msg_first = mi;
+                w.pad = 0;
                 work.push_back(w);
             }
             fast_frames += (blk_hi - blk_lo) * L_blk;
@@ -169,7 +165,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
     f.enabled = true;
     f.T = T;
-    f.cpl = 1;
     f.n_work = (uint32_t)work.size();
     f.n_rem = rem.size();
     f.coef_lds_bytes = coef_lds;
@@ -185,7 +180,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     p.coef = flt->d_coef;
     p.src_arena_bytes = b->src_arena_bytes;
     p.L = L; p.M = M; p.L_blk = L_blk; p.M_blk = M_blk;
-    p.rows = rows; p.cgn = ch; p.oc_log2 = oc_log2;
     p.channels = ch; p.sb = sb; p.db = db;
     p.src_le = src_le;
     p.dst_le = dst_le;
