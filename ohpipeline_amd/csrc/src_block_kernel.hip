@@ -487,7 +487,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #ifdef OHGPU_EXP_NOEVT
                 if (j < 0) {
 #else
-                if (__any(j >= evt_j)) {                                        // message boundary or ramping somewhere in the wave
+                if (__builtin_expect(__any(j >= evt_j) != 0, 0)) {              // message boundary or ramping somewhere in the wave (rare: out of line)
 #endif
                     if (lane_valid && j >= evt_j) {
                         while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
@@ -617,6 +617,7 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
     if (w > 12) w = 12;
+    if (const char* e = getenv("OHGPU_EXP_MAX_WAVES")) { const uint32_t x = (uint32_t)atoi(e); if (x >= 4 && x < w) w = x; }   // occupancy experiments
     if (w < 4) return false;            // too few waves per CU to be worth it: the generic kernel takes the batch
     *max_waves = w;
     return true;
