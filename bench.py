@@ -132,7 +132,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 baseline v1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="compare the GPU output of the last step with the oracle")
+    ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per stream (the headline is stereo; 6 and 8 also run the block kernel)")
     args = ap.parse_args()
+    globals()["CHANNELS"] = args.channels
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -205,10 +207,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: {n_streams} independent stereo S24LE streams per GPU, 44.1->48 kHz, "
+            "config": {"workload": f"configs[2]: {n_streams} independent {'stereo' if CHANNELS == 2 else str(CHANNELS) + '-channel'} S24LE streams per GPU, 44.1->48 kHz, "
                                    f"{args.seconds:g} s each ({in_frames} frames), 5 ms output messages, "
                                    f"ramp up 50 ms / down 500 ms, S24 BE out",
-                       "streams_per_gpu": n_streams, "frames_per_stream": in_frames, "taps_per_phase": TAPS,
+                       "streams_per_gpu": n_streams, "channels": CHANNELS, "frames_per_stream": in_frames, "taps_per_phase": TAPS,
                        "msgs_per_step": int(info["n_msgs"]), "kernel_variant": args.variant,
                        "block_kernel_out_frames": plan["block_kernel_out_frames"], "generic_pieces": plan["generic_pieces"],
                        "sharding": f"streams x{world} ranks, no collective"},

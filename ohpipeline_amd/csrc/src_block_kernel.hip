@@ -85,6 +85,11 @@ __device__ __forceinline__ void lds_issue_store_u16(uint32_t addr, uint32_t v)
 #else
 #define OHGPU_WAIT_INSN "s_waitcnt lgkmcnt(%"
 #endif
+__device__ __forceinline__ void lds_issue_store_3xu8(uint32_t addr, uint32_t v)   // bytes 0, 1, 2 of v at addr, addr + 1, addr + 2
+{
+    asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8_d16_hi %0, %1 offset:2"
+                 : : "v"(addr), "v"(v), "v"(v >> 8) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void lds_wait(double& x)
 {
@@ -335,7 +340,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // every second output: lane A words 0-1, lane B words 1-2 (word 1 twice, same value).  Byte stores would cost
     // three LDS store instructions per output.  Other layouts store each subsample's bytes where they belong.
     constexpr bool PAIR = ring_pair_mode(CH, DB);
-    static_assert(PAIR || DB == 2 || DB == 4, "a subsample is stored with one aligned LDS store");
+    // LDS stores per output: one aligned store, or three byte stores for 24-bit output that is not stereo
+    constexpr int NS = (!PAIR && DB == 3) ? 3 : 1;
+    static_assert(DB >= 2 && DB <= 4, "destination depths 16 / 24 / 32 bit");
     constexpr uint32_t B0 = DST_LE ? 1 : 3, B1 = 2, B2 = DST_LE ? 3 : 1;      // byte of the left-justified word that is memory byte 0, 1, 2
     const uint32_t wave_lds_addr = (uint32_t)(uintptr_t)lds;
     const uint32_t ring_lane = wave_lds_addr + OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB);   // this lane's place in frame (pair) 0
@@ -389,6 +396,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     auto issue_store = [&]() __attribute__((always_inline)) {
         if constexpr (PAIR) lds_issue_store_2xu32(st_addr, st_lo, st_hi);
         else if constexpr (DB == 4) lds_issue_store_u32(st_addr, st_lo);
+        else if constexpr (DB == 3) lds_issue_store_3xu8(st_addr, st_lo);
         else lds_issue_store_u16(st_addr, st_lo);
     };
     // coefficients of output j: cA = taps 0..15, cB = taps 16..31, tap k in lane (k & 15) of every 16-lane row
@@ -404,7 +412,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // fixed), B' and A' (the next output's coefficient registers, each reloaded as soon as its 16 taps are done).
     //     advance:  R  { W1  S  16 taps(cB)  B'  W2  unpack  16 taps(cA)  A'  round, ramp, pack }*
     // W1 awaits cB: issued last output as B', followed at least by A'           -> lgkmcnt(1)
-    // W2 awaits cA and R: A' of last output / R are followed by S and B'         -> lgkmcnt(2)
+    // W2 awaits cA and R: A' of last output / R are followed by NS stores and B'  -> lgkmcnt(NS + 1)
     // The newest sample is tap 0, used last, so its read has the first 16 taps to land.
     for (int g = 0; g * T < total; g++) {
         static_for([&](auto slot) __attribute__((always_inline)) {
@@ -464,7 +472,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #ifdef OHGPU_EXP_NORING
                 lds_wait<1>(cA, raw.words);
 #else
-                lds_wait<2>(cA, raw.words);
+                lds_wait<NS + 1>(cA, raw.words);
 #endif
                 win[s] = (double)unpack_subsample<SB, SRC_LE>(raw);
 #ifdef OHGPU_EXP_NOFMA
@@ -519,6 +527,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 } else {
                     st_lo = DST_LE ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);       // the DB bytes in memory order, first byte low
                     st_addr = ring_lane + ring_pos;
+                    if constexpr (64 % CH != 0) st_addr = bw < (uint32_t)BPW ? st_addr : idle_lane;   // lanes beyond the last whole block
                     ring_pos += FB_DST;
                     if (ring_pos == ring_bytes) ring_pos = 0;
                 }
@@ -557,7 +566,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     X(32, 2, 3, true, 2, false)     \
     X(32, 2, 2, true, 3, false)     \
     X(32, 2, 2, true, 2, true)      \
-    X(32, 2, 2, true, 2, false)
+    X(32, 2, 2, true, 2, false)     \
+    X(32, 6, 3, true, 3, false)     \
+    X(32, 6, 3, false, 3, false)    \
+    X(32, 8, 3, true, 3, false)     \
+    X(32, 8, 3, false, 3, false)
 #endif
 
 // Launch shape: up to MAX_WAVES waves per workgroup (what the LDS left by the coefficient table allows), one

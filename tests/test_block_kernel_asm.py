@@ -40,7 +40,7 @@ def kernels():
                 if "Lb1EEEv" not in name:
                     found[name] = body
                 name = None
-    assert len(found) >= 8, "expected every instantiation in the assembly"
+    assert len(found) >= 12, "expected every instantiation in the assembly"
     return found
 
 
@@ -65,4 +65,5 @@ def test_every_output_has_its_counted_waits(kernels):
         assert taps % 32 == 0
         outputs = taps // 32                                  # unrolled output bodies
         assert sum("lgkmcnt(1)" in l for l in body) == outputs, name
-        assert sum("lgkmcnt(2)" in l for l in body) == outputs, name
+        # the second wait leaves the stores (one, or three byte stores) and one read in flight
+        assert sum("lgkmcnt(2)" in l or "lgkmcnt(4)" in l for l in body) == outputs, name

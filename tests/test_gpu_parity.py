@@ -324,6 +324,32 @@ def test_src_formats_bit_exact(vctx, rin, rout, T, ch, sbits, send, dbits, dend)
     vctx.src_destroy(h)
 
 
+@pytest.mark.parametrize("ch,send", [(6, LE), (6, BE), (8, LE), (8, BE)])
+def test_src_multichannel_block_kernel(ctx, ch, send):
+    """6- and 8-channel S24 streams (BASELINE config 4's layouts) on the block kernel: line-aligned streams so that
+    every stream's whole blocks take the tuned path, ramps included."""
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    in_frames, n_streams = 5880, 4                              # 6400 output frames = 40 blocks per stream
+    src = np.concatenate([W.noise_pcm(50 + s, in_frames, ch, 24, send) for s in range(n_streams)])
+    out_total = ref.out_frames(in_frames)
+    assert (out_total * ch * 3) % 64 == 0
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 30 * O.JIFFIES_PER_MS, 50 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, ch, 24, send, 24, BE, sched)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+    ctx.memset(d_dst, 0xA5, dbytes)
+    b = ctx.src_batch(h, descs, src.size, dbytes)
+    plan = ctx.src_plan(b)
+    assert plan["block_kernel_out_frames"] == n_streams * out_total and plan["generic_pieces"] == 0
+    ctx.src_run(b, d_src, d_dst)
+    got = ctx.download(d_dst, dbytes)
+    want = oracle_src(ref, descs, src, dbytes)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}"
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
 def test_src_chunked_streaming_equals_whole(vctx):
     """Cross-chunk state = (T-1 frames of history, phase): feeding windows with src_frame0 > 0 gives the same bytes."""
     h, ref = make_src(vctx, 44100, 48000, 32)
