@@ -64,9 +64,10 @@ __device__ __forceinline__ void lds_issue_f64_hi(double& dst, uint32_t addr)    
 {
     asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(dst) : "v"(addr) : "memory");
 }
-__device__ __forceinline__ void lds_issue_2xu32(uint64_t& dst, uint32_t addr)     // the aligned words at addr, addr + 4
+template <int DW>
+__device__ __forceinline__ void lds_issue_2xu32(uint64_t& dst, uint32_t addr)     // the aligned words at addr + 4*DW, addr + 4*DW + 4
 {
-    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(dst) : "v"(addr) : "memory");
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "i"(DW), "i"(DW + 1) : "memory");
 }
 __device__ __forceinline__ void lds_issue_store_2xu32(uint32_t addr, uint32_t lo, uint32_t hi)
 {
@@ -118,15 +119,13 @@ __device__ __forceinline__ void fmac_bcast(double& acc, const double cv, const d
         asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cv), "v"(x), "i"(K));
 }
 
-// One subsample (SB packed bytes at any byte alignment) from LDS.  The LDS accepts unaligned addresses but
+// One subsample (SB packed bytes at any byte alignment) from LDS.  The eight frames of a stage are FB_SRC bytes apart,
+// so frame s' sits at the same place in its dword as frame s' - P, P = 4 / gcd(4, FB_SRC): per stage P aligned base
+// addresses and P shift amounts are computed, and the read itself carries an immediate offset (no address arithmetic
+// per advance).  The LDS accepts unaligned addresses but
 // serialises such an access lane by lane (SQ_LDS_UNALIGNED_STALL was half of the kernel's time), so the two ALIGNED
 // words that hold the subsample are read (one ds_read2_b32) and shifted into place when the sample enters the window.
 struct RawSubsample { uint64_t words; uint32_t shift; };
-__device__ __forceinline__ void lds_issue_subsample(RawSubsample& r, uint32_t lds_addr)
-{
-    lds_issue_2xu32(r.words, lds_addr & ~3u);
-    r.shift = lds_addr & 3u;
-}
 template <int SB, bool LE>
 __device__ __forceinline__ int32_t unpack_subsample(const RawSubsample& r)          // -> S24 integer
 {
@@ -343,7 +342,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // LDS stores per output: one aligned store, or three byte stores for 24-bit output that is not stereo
     constexpr int NS = (!PAIR && DB == 3) ? 3 : 1;
     static_assert(DB >= 2 && DB <= 4, "destination depths 16 / 24 / 32 bit");
-    constexpr uint32_t B0 = DST_LE ? 1 : 3, B1 = 2, B2 = DST_LE ? 3 : 1;      // byte of the left-justified word that is memory byte 0, 1, 2
+    constexpr uint32_t B0 = DST_LE ? 0 : 2, B1 = 1, B2 = DST_LE ? 2 : 0;      // byte of the (right-justified) S24 value that is memory byte 0, 1, 2
     const uint32_t wave_lds_addr = (uint32_t)(uintptr_t)lds;
     const uint32_t ring_lane = wave_lds_addr + OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB);   // this lane's place in frame (pair) 0
     const uint32_t idle_lane = wave_lds_addr + OFF_RING + ring_area + lane * 8;                          // where pair mode's idle stores go
@@ -390,8 +389,13 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     int j = 0;                                // outputs emitted so far (wave-uniform)
     int t = 0;                                // j * M
     int p = 0;                                // phase of output j = t mod L (every block starts at phase 0)
-    uint32_t in_off = 0;                      // LDS address of this lane's subsample in the current stage's first frame
-    const uint32_t in_base = wave_lds_addr + OFF_IN + row * IN_STRIDE + ((uint32_t)row_g & 15u) + c * SB;
+    constexpr int PH = (FB_SRC % 4 == 0) ? 1 : ((FB_SRC % 2 == 0) ? 2 : 4);   // frames s' and s' + PH share their place in a dword
+    static_assert((FB_SRC * PH) % 4 == 0 && (8 % PH) == 0 && FB_SRC * 7 / 4 + 1 < 256, "immediate dword offsets of ds_read2_b32");
+    const uint32_t in_base = wave_lds_addr + OFF_IN + row * IN_STRIDE + ((uint32_t)row_g & 15u) + c * SB;   // frame 0 of buffer 0
+    uint32_t in_shift[PH];                    // byte position of frame p's subsample in its dword (the same in every stage)
+    uint32_t in_addr[PH];                     // aligned LDS address of frame p's dword in the current stage's buffer
+#pragma unroll
+    for (int ph = 0; ph < PH; ph++) { in_shift[ph] = (in_base + ph * FB_SRC) & 3u; in_addr[ph] = 0; }
     const bool any_first = __any(first_block) != 0;
     auto issue_store = [&]() __attribute__((always_inline)) {
         if constexpr (PAIR) lds_issue_store_2xu32(st_addr, st_lo, st_hi);
@@ -428,7 +432,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                     if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
                     if ((q + 1) * 8 < total) issue_stage(q + 1);
                     if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
-                    in_off = in_base + (uint32_t)(q & 1) * ROWS * IN_STRIDE;   // (a stage shifts the row by whole pieces: same misalignment)
+#pragma unroll
+                    for (int ph = 0; ph < PH; ph++)     // (a stage shifts the row by whole 16-byte pieces: same misalignment)
+                        in_addr[ph] = ((in_base + ph * FB_SRC) & ~3u) + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
                 }
                 issue_store();                                          // the last output's bytes must be in the ring
                 st_addr = idle_lane;
@@ -439,7 +445,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #ifdef OHGPU_EXP_NOSAMPLE
             raw.words = lane + s; raw.shift = 0;
 #else
-            lds_issue_subsample(raw, in_off + (s & 7) * FB_SRC);
+            {
+                constexpr int sp = s & 7, ph = sp % PH;                 // frame sp of the stage = frame ph + PH * k
+                lds_issue_2xu32<FB_SRC * (sp - ph) / 4>(raw.words, in_addr[ph]);
+                raw.shift = in_shift[ph];
+            }
 #endif
             if (!(t < L * (a + 1))) {                                   // no output needs it yet (warm-up, or M > L)
                 lds_wait<0>(raw.words);
@@ -491,7 +501,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #endif
                 int32_t y = (int32_t)floor(acc0 + acc1);
                 y = y > 8388607 ? 8388607 : (y < -8388608 ? -8388608 : y);
-                uint32_t w = (uint32_t)y << 8;                                  // left-justified BE word (a11)
+                // pair mode packs straight from the S24 value; the other layouts (and the ramp) use the left-justified word (a11)
+                uint32_t w = PAIR ? (uint32_t)y : (uint32_t)y << 8;
 #ifdef OHGPU_EXP_NOEVT
                 if (j < 0) {
 #else
@@ -502,7 +513,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                         if (msg_flags & OHGPU_FLAG_RAMP) {
                             const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
                             const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
-                            w = ramp_word(w, mult, 3, CH, c);
+                            w = PAIR ? ramp_word(w << 8, mult, 3, CH, c) >> 8 : ramp_word(w, mult, 3, CH, c);
                             evt_j = j + 1;
                         } else {
                             evt_j = msg_rel0 + (int32_t)msg_n;
