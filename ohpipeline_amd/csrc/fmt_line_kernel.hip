@@ -1,0 +1,203 @@
+// fmt_line_kernel.hip -- line-coalesced kernel of the layout-changing processors:
+//   a11  FlywheelInput::DoProcessFragment (StarvationRamper.cpp:117-186): packed BE interleaved -> planar BE 32-bit
+//   a13  Sender::DoProcessFragment (Av/Songcast/Sender.cpp:351-377): first two channels, at most 3 MSBs each
+//   a14  CodecFlac::CallbackWrite (Codec/Flac.cpp:379-417): planar host-endian TInt32 -> packed BE interleaved 8/16/24
+// All three are "gather source subsample f(q), shuffle its bytes, write destination subsample q", so they share the PCM
+// line kernel's structure (pcm_line_kernel.hip): a descriptor is cut into CHUNKS on the host, each described by one
+// 64-byte record; a wave stages the chunk's source bytes in LDS with 16-byte global->LDS loads (one run, or one run per
+// plane for a14), then lane = aligned destination dword: it reads the aligned LDS words that hold each contributing
+// subsample, shuffles them with ONE v_perm_b32 (selector from the record), funnels and stores 4 bytes; only a chunk's
+// first and last dword are written byte by byte.  The source subsample of destination subsample q is
+// (q / A) * B + C + (q % A) * D, with (A, B, C, D) from the record (q / A by an exact multiplier).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "ohgpu_internal.h"
+
+namespace ohgpu {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* global_ptr_t;
+
+constexpr uint32_t kFmtWaves = 4;
+constexpr uint32_t kFmtInBytes = 2304;                                 // staged source bytes per chunk (incl. alignment slack)
+constexpr uint32_t kFmtChunkSub = 512;                                 // destination subsamples per chunk
+
+__global__ __launch_bounds__(kFmtWaves * 64) void fmt_line_kernel(const FmtChunk* __restrict__ chunks, const uint32_t n_chunks,
+                                                                 const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kFmtWaves][kFmtInBytes];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const __attribute__((address_space(3))) uint8_t* in = (const __attribute__((address_space(3))) uint8_t*)&s_in[wave][0];
+    for (uint32_t chunk = blockIdx.x * kFmtWaves + wave; chunk < n_chunks; chunk += gridDim.x * kFmtWaves) {
+        const FmtChunk ck = chunks[chunk];
+        const uint32_t sb = ck.sb, db = ck.db, nq = ck.nq;
+        // ---- in: every run's aligned 16-byte pieces -> LDS (a piece always overlaps bytes the descriptor owns) ----
+        const uint32_t head = (uint32_t)((uint64_t)(uintptr_t)src + ck.src_off) & 15u;   // the same for every run (host checks)
+        const uint32_t n_pieces = (head + ck.run_bytes + 15u) >> 4;
+        for (uint32_t r = 0; r < ck.n_runs; r++) {
+            const uint8_t* base = src + (ck.src_off + (uint64_t)r * ck.run_src_stride - head);
+            for (uint32_t p0 = 0; p0 < n_pieces; p0 += 64) {
+                if (p0 + lane < n_pieces)                               // LDS destination = wave-uniform base + lane * 16
+                    __builtin_amdgcn_global_load_lds((global_ptr_t)(base + (size_t)(p0 + lane) * 16),
+                                                     (lds_ptr_t)(&s_in[wave][0] + r * ck.run_lds_stride + p0 * 16), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // destination subsample q -> its bytes in memory order (first byte lowest).  Past the chunk's end the lane
+        // reads bytes that exist in the staging buffer; they only land in byte positions the edge path does not store.
+        auto subsample = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t i = ck.m_a ? (__umulhi(q, ck.m_a) >> ck.s_a) : q;            // q / A
+            const uint32_t idx = __umul24(i, ck.map_b) + ck.map_c + __umul24(q - __umul24(i, ck.map_a), ck.map_d);
+            const uint32_t off = head + __umul24(idx, sb);
+            const __attribute__((address_space(3))) uint32_t* a = (const __attribute__((address_space(3))) uint32_t*)(in + (off & ~3u));
+            return __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(a[1], a[0], off & 3u), ck.sel);
+        };
+        const uint32_t dhead = (uint32_t)((uint64_t)(uintptr_t)dst + ck.dst_off) & 3u;
+        const uint32_t len = nq * db;
+        const uint32_t n_dw = (dhead + len + 3u) >> 2;
+        uint8_t* const obase = dst + (ck.dst_off - dhead);
+        for (uint32_t kb = 0; kb < n_dw; kb += 64) {
+            const uint32_t k = kb + lane;
+            if (k < n_dw) {
+                const int32_t pos = (int32_t)(k * 4) - (int32_t)dhead;  // stream position of the dword's first byte
+                const uint32_t upos = pos < 0 ? 0u : (uint32_t)pos;
+                uint32_t v;                                             // stream bytes [upos, upos + 4)
+                if (db == 3) {
+                    const uint32_t qa = __umulhi(upos, 0xAAAAAAABu) >> 1, o = upos - __umul24(qa, 3u);
+                    const uint32_t v0 = subsample(qa), v1 = subsample(qa + 1);
+                    const uint32_t sel = o == 0 ? 0x04020100u : (o == 1 ? 0x05040201u : 0x06050402u);
+                    v = __builtin_amdgcn_perm(v1, v0, sel);
+                } else if (db == 4) {
+                    const uint32_t qa = upos >> 2, o = upos & 3;
+                    v = subsample(qa);
+                    if (dhead != 0) v = __builtin_amdgcn_alignbyte(subsample(qa + 1), v, o);
+                } else if (db == 2) {
+                    const uint32_t qa = upos >> 1, o = upos & 1;
+                    v = subsample(qa) | (subsample(qa + 1) << 16);
+                    if (dhead & 1) v = __builtin_amdgcn_alignbyte(subsample(qa + 2), v, o);
+                } else {
+                    v = subsample(upos) | (subsample(upos + 1) << 8) | (subsample(upos + 2) << 16) | (subsample(upos + 3) << 24);
+                }
+                if (pos >= 0 && (uint32_t)pos + 4 <= len) {
+                    *(uint32_t*)(obase + (size_t)k * 4) = v;
+                } else {                                                // first / last dword of the chunk: only its own bytes
+                    const uint32_t skip = pos < 0 ? (uint32_t)(-pos) : 0u;
+                    for (uint32_t b = skip; b < 4; b++) {
+                        if ((uint32_t)(pos + (int32_t)b) < len) obase[(size_t)k * 4 + b] = (uint8_t)(v >> (8 * (b - skip)));
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the staging buffer is reused by the next chunk
+    }
+}
+
+// ---- host side ----
+static void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)            // x / d == umulhi(x, m) >> s for x < 2^31, d >= 2
+{
+    if (d <= 1) { *m = 0; *s = 0; return; }
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    *m = (uint32_t)(((1ull << (31 + l)) / d) + 1);
+    *s = l - 1;
+}
+
+void free_fmt_line(ohgpu_batch* b)
+{
+    if (b->fmtline.d_chunks) hipFree(b->fmtline.d_chunks);
+    b->fmtline = FmtLinePlan();
+}
+
+int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, size_t n)
+{
+    (void)ctx;
+    b->fmtline = FmtLinePlan();
+    std::vector<FmtChunk> chunks;
+    const uint32_t budget = kFmtInBytes - 32;                           // 15 bytes of head, rounding up to pieces, the +4 over-read
+    for (size_t i = 0; i < n; i++) {
+        const ohgpu_fmt_desc& d = descs[i];
+        if (d.n_frames == 0) continue;
+        const uint32_t ch = d.channels, sb = d.src_bits / 8;
+        FmtChunk c;
+        memset(&c, 0, sizeof(c));
+        uint32_t frames_per_chunk, sub_per_frame, sh;
+        if (d.kind == OHGPU_FMT_UNPACK_PLANAR) {                        // one chunk list per plane: q = frame
+            c.sb = (uint8_t)sb; c.db = 4; c.n_runs = 1;
+            c.map_a = 1; c.map_b = (uint16_t)ch; c.map_d = 0;
+            for (uint32_t m = 0; m < 4; m++) c.sel |= (m < sb ? m : 0x0cu) << (8 * m);     // left-justified, low bytes zero
+            sub_per_frame = 1;
+            frames_per_chunk = budget / (ch * sb) > 4 ? std::min<uint32_t>(kFmtChunkSub, budget / (ch * sb) - 4) : 0;   // (the lanes past the end read up to 3 frames on)
+        } else if (d.kind == OHGPU_FMT_SENDER_PACK) {                   // q = frame * out_ch + channel
+            const uint32_t out_ch = ch < 2 ? ch : 2, db = sb < 3 ? sb : 3;
+            c.sb = (uint8_t)sb; c.db = (uint8_t)db; c.n_runs = 1;
+            c.map_a = (uint16_t)out_ch; c.map_b = (uint16_t)ch; c.map_c = (uint16_t)(ch < 10 ? 0u : 8u); c.map_d = 1;
+            for (uint32_t m = 0; m < 4; m++) c.sel |= (m < db ? m : 0x0cu) << (8 * m);     // the db most significant bytes
+            sub_per_frame = out_ch;
+            frames_per_chunk = budget / (ch * sb) > 4 ? std::min<uint32_t>(kFmtChunkSub / out_ch, budget / (ch * sb) - 4) : 0;
+        } else {                                                        // FLAC: q = frame * ch + channel, one staged run per plane
+            const uint32_t db = d.dst_bits / 8;
+            if (d.src_plane_stride % 16 != 0 && ch > 1) return OHGPU_OK;   // planes would sit differently in their pieces: generic kernel
+            c.sb = 4; c.db = (uint8_t)db; c.n_runs = (uint16_t)ch;
+            c.map_a = (uint16_t)ch; c.map_b = 1; c.map_d = 0;                      // map_d set per chunk (run_lds_stride / 4)
+            for (uint32_t m = 0; m < 4; m++) c.sel |= (m < db ? db - 1 - m : 0x0cu) << (8 * m);   // BE bytes of the low db bytes of a LE word
+            sub_per_frame = ch;
+            frames_per_chunk = budget / ch > 80 ? std::min<uint32_t>(kFmtChunkSub / ch, (budget / ch - 64) / 4) : 0;   // ch runs of <= 4f + 62 bytes
+        }
+        if (frames_per_chunk == 0) return OHGPU_OK;                     // a frame does not fit the staging buffer: generic kernel
+        magic_u31(c.map_a, &c.m_a, &sh); c.s_a = (uint8_t)sh;
+        const uint32_t planes = d.kind == OHGPU_FMT_UNPACK_PLANAR ? ch : 1;
+        for (uint32_t p = 0; p < planes; p++) {
+            for (uint32_t f0 = 0; f0 < d.n_frames; f0 += frames_per_chunk) {
+                const uint32_t f = std::min<uint32_t>(frames_per_chunk, d.n_frames - f0);
+                FmtChunk k = c;
+                k.nq = f * sub_per_frame;
+                if (d.kind == OHGPU_FMT_UNPACK_PLANAR) {
+                    k.map_c = (uint16_t)p;
+                    k.src_off = d.src_offset + (uint64_t)f0 * ch * sb;
+                    k.run_bytes = f * ch * sb;
+                    k.dst_off = d.dst_offset + (uint64_t)p * d.dst_plane_stride + (uint64_t)f0 * 4;
+                } else if (d.kind == OHGPU_FMT_SENDER_PACK) {
+                    k.src_off = d.src_offset + (uint64_t)f0 * ch * sb;
+                    k.run_bytes = f * ch * sb;
+                    k.dst_off = d.dst_offset + (uint64_t)f0 * c.map_a * c.db;
+                } else {
+                    k.src_off = d.src_offset + (uint64_t)f0 * 4;
+                    k.run_bytes = f * 4;
+                    k.run_src_stride = d.src_plane_stride;
+                    k.run_lds_stride = (uint16_t)(((15 + f * 4 + 15) / 16) * 16 + 16);
+                    k.map_d = (uint16_t)(k.run_lds_stride / 4);
+                    k.dst_off = d.dst_offset + (uint64_t)f0 * ch * c.db;
+                }
+                chunks.push_back(k);
+            }
+        }
+    }
+    if (chunks.empty() || chunks.size() > 0xffffffffull) return OHGPU_OK;
+    hipError_t e = hipMalloc(&b->fmtline.d_chunks, chunks.size() * sizeof(FmtChunk));
+    if (e == hipSuccess) e = hipMemcpy(b->fmtline.d_chunks, chunks.data(), chunks.size() * sizeof(FmtChunk), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        free_fmt_line(b);
+        return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "chunk plan upload: %s", hipGetErrorString(e));
+    }
+    b->fmtline.n_chunks = (uint32_t)chunks.size();
+    b->fmtline.enabled = true;
+    return OHGPU_OK;
+}
+
+hipError_t launch_fmt_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
+    uint32_t grid = (b->fmtline.n_chunks + kFmtWaves - 1) / kFmtWaves;
+    if (grid > cus * 8) grid = cus * 8;
+    hipLaunchKernelGGL(fmt_line_kernel, dim3(grid), dim3(kFmtWaves * 64), 0, s,
+                       (const FmtChunk*)b->fmtline.d_chunks, b->fmtline.n_chunks, src, dst);
+    return hipGetLastError();
+}
+
+}  // namespace ohgpu

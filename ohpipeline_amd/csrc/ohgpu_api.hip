@@ -334,6 +334,7 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     if (batch->kind == kBatchSrc) free_src_fast(batch);
     if (batch->kind == kBatchPcm) free_pcm_line(batch);
     if (batch->kind == kBatchFlywheel) free_flywheel(batch);
+    if (batch->kind == kBatchFmt) free_fmt_line(batch);
     delete batch;
     return OHGPU_OK;
 }
@@ -424,8 +425,9 @@ int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n
         b->src_bytes_touched += nf ? src_hi - src_lo : 0;
         b->dst_bytes_written += nf ? dst_hi - dst_lo : 0;
     }
-    const int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_fmt_desc));
-    if (err != OHGPU_OK) { delete b; return err; }
+    int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_fmt_desc));
+    if (err == OHGPU_OK) err = plan_fmt_line(ctx, b, descs, n);
+    if (err != OHGPU_OK) { if (b->d_descs) hipFree(b->d_descs); delete b; return err; }
     *out = b;
     return OHGPU_OK;
 }
@@ -436,7 +438,10 @@ int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!batch || batch->kind != kBatchFmt) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: not a fmt batch");
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: null arena pointer");
-    OHGPU_HIP_TRY(launch_fmt_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    if (ctx->variant == 0 && batch->fmtline.enabled)
+        OHGPU_HIP_TRY(launch_fmt_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    else
+        OHGPU_HIP_TRY(launch_fmt_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
     return OHGPU_OK;
 }
 

@@ -116,6 +116,27 @@ struct PcmLinePlan {
     void*    d_chunks = nullptr;
 };
 
+// ---- line kernel of the layout-changing processors (csrc/fmt_line_kernel.hip) ----
+struct FmtChunk {             // 64 bytes = one scalar load
+    uint64_t src_off, dst_off;    // first source byte of run 0 / first destination byte
+    uint64_t run_src_stride;      // run r starts at src_off + r * run_src_stride (a14: one run per plane)
+    uint32_t nq;                  // destination subsamples
+    uint32_t run_bytes;           // source bytes per run
+    uint16_t n_runs;
+    uint16_t run_lds_stride;      // run r is staged run_lds_stride bytes after run r - 1
+    uint16_t map_a, map_b, map_c, map_d;   // source subsample of destination subsample q: (q / A) * B + C + (q % A) * D
+    uint32_t m_a;                 // q / A == umulhi(q, m_a) >> s_a (m_a == 0: A == 1)
+    uint32_t sel;                 // v_perm_b32 selector: source bytes -> destination bytes in memory order
+    uint8_t  s_a, sb, db, pad8;
+    uint32_t pad[2];
+};
+static_assert(sizeof(FmtChunk) == 64, "chunk record = one 64-byte scalar load");
+struct FmtLinePlan {
+    bool     enabled = false;
+    uint32_t n_chunks = 0;
+    void*    d_chunks = nullptr;
+};
+
 // ---- FlywheelRamper (csrc/flywheel_kernel.hip) ----
 struct FlywheelLane { uint32_t req, channel; };      // one lane = one channel of one request
 struct FlywheelPlan {
@@ -156,6 +177,7 @@ struct ohgpu_batch {
     ohgpu::SrcFastPlan fast;      // kBatchSrc only
     ohgpu::PcmLinePlan line;      // kBatchPcm only
     ohgpu::FlywheelPlan fly;      // kBatchFlywheel only
+    ohgpu::FmtLinePlan fmtline;   // kBatchFmt only
 };
 
 namespace ohgpu {
@@ -175,6 +197,9 @@ hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8
 hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n);
 void free_pcm_line(ohgpu_batch* b);
+int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, size_t n);
+void free_fmt_line(ohgpu_batch* b);
+hipError_t launch_fmt_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 int plan_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_flywheel_desc* descs, size_t n);
 void free_flywheel(ohgpu_batch* b);
 hipError_t launch_flywheel(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);

@@ -82,3 +82,51 @@ def test_flac_pack(ctx):
     with pytest.raises(capi.OhGpuError) as e:
         ctx.fmt_batch(d, 32, 32)
     assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_line_kernel_equals_byte_kernel_on_mixed_batches(ctx):
+    """The tuned kernel (variant 0) against the byte kernel (variant 1, the one the oracle tests above pin) on batches
+    that mix the three kinds, every depth, 1-10 channels, multi-chunk lengths and unaligned arena offsets."""
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        rows, src_parts, sp, dp = [], [], 0, 0
+        for k in range(40):
+            kind = [capi.FMT_UNPACK_PLANAR, capi.FMT_SENDER_PACK, capi.FMT_FLAC_PACK][int(rng.integers(0, 3))]
+            ch = int(rng.integers(1, 11))
+            n = int(rng.choice([1, 2, 7, 44, 240, 1000, 3000]))
+            pad = int(rng.integers(0, 9))
+            d = np.zeros(1, dtype=capi.FMT_DESC)
+            d["kind"], d["channels"], d["n_frames"] = kind, ch, n
+            if kind == capi.FMT_FLAC_PACK:
+                bits = int(rng.choice([8, 16, 24]))
+                stride = (n + int(rng.integers(0, 4))) * 4
+                if trial % 2 == 0:
+                    stride = (stride + 15) // 16 * 16                  # (other strides take the byte kernel: still must agree)
+                pad = (-sp) % 4 + 4 * (pad // 4)                      # TInt32 planes are 4-byte aligned
+                nbytes = ch * stride
+                d["src_bits"], d["dst_bits"], d["src_plane_stride"] = 32, bits, stride
+                out = n * ch * bits // 8
+            else:
+                sb = int(rng.integers(1, 5))
+                nbytes = n * ch * sb
+                d["src_bits"] = sb * 8
+                if kind == capi.FMT_UNPACK_PLANAR:
+                    stride = n * 4 + int(rng.integers(0, 3)) * 4
+                    d["dst_plane_stride"] = stride
+                    out = ch * stride
+                else:
+                    out = n * min(ch, 2) * min(sb, 3)
+            src_parts.append(rng.integers(0, 256, size=pad + nbytes, dtype=np.uint8))
+            d["src_offset"], d["dst_offset"] = sp + pad, dp + int(rng.integers(0, 4))
+            sp += pad + nbytes
+            dp += out + 8
+            rows.append(d)
+        descs = np.concatenate(rows)
+        src = np.concatenate(src_parts)
+        ctx.set_kernel_variant(0)
+        fast = run_fmt(ctx, descs, src, dp)
+        ctx.set_kernel_variant(1)
+        base = run_fmt(ctx, descs, src, dp)
+        ctx.set_kernel_variant(0)
+        bad = np.nonzero(fast != base)[0]
+        assert bad.size == 0, f"trial {trial}: {bad.size} mismatches, first at {bad[:5]}"
