@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (one thread) on a bounded sample of the streams")
     a = ap.parse_args()
 
     from ohpipeline_amd import capi, hostmodel
@@ -96,6 +97,21 @@ def main():
         got = ctx.download(d_dst, dst_bytes)
         n = min(a.streams, 3) * dst_stream
         out["check"] = "ok" if np.array_equal(got[:n], ref[:n]) else "MISMATCH"
+    if a.cpu:
+        import time
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ctypes as C
+        import oracle_lib as O
+        k = min(a.streams, 16) * n_msgs
+        part = np.ascontiguousarray(d[:k])
+        ref = np.zeros(dst_bytes, dtype=np.uint8)
+        t0 = time.perf_counter()
+        rc = O.lib().ohp_msg_process_batch(part.ctypes.data_as(C.c_void_p), part.size, src.ctypes.data_as(C.c_void_p),
+                                            ref.ctypes.data_as(C.c_void_p))
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        out["cpu_baseline"] = dict(value=round(min(a.streams, 16) * a.frames / dt / 1e6, 2), unit="Msamples/s", cores=1, kind="port",
+                                   sample=f"{min(a.streams, 16)} of the streams, one thread (gcc -O2 oracle, {dt:.2f} s)")
     print(json.dumps(out))
     ctx.batch_destroy(batch)
     ctx.close()
