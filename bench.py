@@ -133,8 +133,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="compare the GPU output of the last step with the oracle")
     ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per stream (the headline is stereo; 6 and 8 also run the block kernel)")
+    ap.add_argument("--rate-in", type=int, default=RATE_IN, help="input rate (the headline is 44100; 96000 with --taps 64 is config 4's other rate)")
+    ap.add_argument("--taps", type=int, default=TAPS, help="taps per phase")
     args = ap.parse_args()
     globals()["CHANNELS"] = args.channels
+    globals()["RATE_IN"] = args.rate_in
+    globals()["TAPS"] = args.taps
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,7 +211,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: {n_streams} independent {'stereo' if CHANNELS == 2 else str(CHANNELS) + '-channel'} S24LE streams per GPU, 44.1->48 kHz, "
+            "config": {"workload": f"configs[2]: {n_streams} independent {'stereo' if CHANNELS == 2 else str(CHANNELS) + '-channel'} S24LE streams per GPU, {RATE_IN / 1000:g}->48 kHz, "
                                    f"{args.seconds:g} s each ({in_frames} frames), 5 ms output messages, "
                                    f"ramp up 50 ms / down 500 ms, S24 BE out",
                        "streams_per_gpu": n_streams, "channels": CHANNELS, "frames_per_stream": in_frames, "taps_per_phase": TAPS,

@@ -56,13 +56,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // a "memory" clobber so that compiler-issued LDS traffic (message table, drain) keeps its place between them, and
 // a wait names the awaited registers as "+v" so that no use can move above it.  No scalar memory operation may
 // be in flight in the loop (they share the counter and complete out of order): tools/inspect_kernel.sh checks that.
-__device__ __forceinline__ void lds_issue_f64(double& dst, uint32_t addr)
+template <int BYTES>
+__device__ __forceinline__ void lds_issue_f64(double& dst, uint32_t addr)        // the double at addr + BYTES
 {
-    asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
-}
-__device__ __forceinline__ void lds_issue_f64_hi(double& dst, uint32_t addr)      // 16 doubles further on
-{
-    asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(dst) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(BYTES) : "memory");
 }
 template <int DW>
 __device__ __forceinline__ void lds_issue_2xu32(uint64_t& dst, uint32_t addr)     // the aligned words at addr + 4*DW, addr + 4*DW + 4
@@ -152,7 +149,7 @@ template <int T, int CH>
 struct BlockGeom {
     static constexpr int BPW = 64 / CH;                 // blocks per wave
     static constexpr int ROWS = BPW;
-    static constexpr int MAX_WAVES = 12;                // waves per workgroup (3 per SIMD: 168 VGPRs each)
+    static constexpr int MAX_WAVES = T <= 32 ? 12 : 8;  // waves per workgroup: 3 per SIMD (168 VGPRs each), 2 when the window is 64 deep
     static constexpr int MSG_SLOTS = 32;                // messages of a wave's output range kept in LDS
 };
 
@@ -180,7 +177,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                       const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
                       const uint32_t ring_bytes, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
 {
-    static_assert(T == 32, "two coefficient registers per lane hold taps k and k + 16 of a 32-tap row");
+    static_assert(T % 16 == 0 && T >= 32 && T <= 64, "T / 16 coefficient registers per lane: register r holds taps 16 r + (lane & 15)");
+    constexpr int NCR = T / 16;
     constexpr int BPW = BlockGeom<T, CH>::BPW, ROWS = BlockGeom<T, CH>::ROWS, MSG_SLOTS = BlockGeom<T, CH>::MSG_SLOTS;
     constexpr int FB_SRC = CH * SB, FB_DST = CH * DB;
     constexpr int IN_BLOCKS = ((8 * FB_SRC + 15 + 15) / 16) | 1;   // 16-byte pieces per staged row, odd (bank spread)
@@ -403,10 +401,12 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         else if constexpr (DB == 3) lds_issue_store_3xu8(st_addr, st_lo);
         else lds_issue_store_u16(st_addr, st_lo);
     };
-    // coefficients of output j: cA = taps 0..15, cB = taps 16..31, tap k in lane (k & 15) of every 16-lane row
-    double cA, cB;
-    lds_issue_f64_hi(cB, coef_lane);
-    lds_issue_f64(cA, coef_lane);
+    // coefficients of output j: register r = taps 16 r .. 16 r + 15, tap k in lane (k & 15) of every 16-lane row
+    double cf[NCR];
+    static_for([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = NCR - 1 - decltype(rc)::value;                  // issued in the order they are used: highest taps first
+        lds_issue_f64<r * 128>(cf[r], coef_lane);
+    }, std::make_integer_sequence<int, NCR>{});
     RawSubsample raw;
 
     issue_stage(0);
@@ -414,9 +414,12 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // LDS operations of the loop, in issue order.  Per advance: R (raw sample).  Per output: S (the previous output's
     // ring store; pair mode stores every second output and sends the other one to an idle slot so that the count is
     // fixed), B' and A' (the next output's coefficient registers, each reloaded as soon as its 16 taps are done).
-    //     advance:  R  { W1  S  16 taps(cB)  B'  W2  unpack  16 taps(cA)  A'  round, ramp, pack }*
-    // W1 awaits cB: issued last output as B', followed at least by A'           -> lgkmcnt(1)
-    // W2 awaits cA and R: A' of last output / R are followed by NS stores and B'  -> lgkmcnt(NS + 1)
+    //     advance:  R  { W  S  16 taps(c[NCR-1])  C'[NCR-1]   W  16 taps(c[NCR-2])  C'[NCR-2]  ...
+    //                      W  unpack  16 taps(c[0])  C'[0]   round, ramp, pack }*
+    // The first wait awaits c[NCR-1]: issued last output, followed at least by that output's other NCR - 1 reloads
+    //                                                                          -> lgkmcnt(NCR - 1)
+    // Every later wait awaits c[r] (and the last one R as well): followed by the rest of last output's reloads, this
+    // output's NS stores and the reloads already issued in this output                -> lgkmcnt(NCR - 1 + NS)
     // The newest sample is tap 0, used last, so its read has the first 16 taps to land.
     for (int g = 0; g * T < total; g++) {
         static_for([&](auto slot) __attribute__((always_inline)) {
@@ -461,44 +464,42 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 p += Mr;                                                       // the next output's phase
                 if (p >= L) p -= L;
                 const uint32_t cp = coef_lane + (uint32_t)p * (T * 8);
-                lds_wait<1>(cB);
+                static_for([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int r = NCR - 1 - decltype(rc)::value;          // highest taps (oldest samples) first, the newest sample last
+                    if constexpr (r == NCR - 1) {
+                        lds_wait<NCR - 1>(cf[r]);
 #ifndef OHGPU_EXP_NORING
-                issue_store();
+                        issue_store();
 #endif
-#ifdef OHGPU_EXP_NOFMA
-                acc0 += cB;
-#else
-                static_for([&](auto kc) __attribute__((always_inline)) {
-                    constexpr int k = 2 * decltype(kc)::value;
-                    fmac_bcast<k, k == 0>(acc0, cB, win[(s - (k + 16) + 2 * T) % T]);
-                    fmac_bcast<k + 1, false>(acc1, cB, win[(s - (k + 17) + 2 * T) % T]);
-                }, std::make_integer_sequence<int, 8>{});
-#endif
-#ifdef OHGPU_EXP_NOCOEF
-                lds_issue_f64_hi(cB, coef_lane);
-#else
-                lds_issue_f64_hi(cB, cp);
-#endif
+                    } else if constexpr (r == 0) {
 #ifdef OHGPU_EXP_NORING
-                lds_wait<1>(cA, raw.words);
+                        lds_wait<NCR - 1>(cf[0], raw.words);
 #else
-                lds_wait<NS + 1>(cA, raw.words);
+                        lds_wait<NCR - 1 + NS>(cf[0], raw.words);
 #endif
-                win[s] = (double)unpack_subsample<SB, SRC_LE>(raw);
-#ifdef OHGPU_EXP_NOFMA
-                acc0 += cA + win[s];
+                        win[s] = (double)unpack_subsample<SB, SRC_LE>(raw);
+                    } else {
+#ifdef OHGPU_EXP_NORING
+                        lds_wait<NCR - 1>(cf[r]);
 #else
-                static_for([&](auto kc) __attribute__((always_inline)) {
-                    constexpr int k = 14 - 2 * decltype(kc)::value;           // taps 15 .. 0: the newest sample last
-                    fmac_bcast<k + 1, k == 14>(acc1, cA, win[(s - (k + 1) + 2 * T) % T]);
-                    fmac_bcast<k, false>(acc0, cA, win[(s - k + 2 * T) % T]);
-                }, std::make_integer_sequence<int, 8>{});
+                        lds_wait<NCR - 1 + NS>(cf[r]);
+#endif
+                    }
+#ifdef OHGPU_EXP_NOFMA
+                    acc0 += cf[r] + (r == 0 ? win[s] : 0.0);
+#else
+                    static_for([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = 14 - 2 * decltype(kc)::value;       // taps 16 r + 15 .. 16 r
+                        fmac_bcast<k + 1, k == 14>(acc1, cf[r], win[(s - (16 * r + k + 1) + 2 * T) % T]);
+                        fmac_bcast<k, false>(acc0, cf[r], win[(s - (16 * r + k) + 2 * T) % T]);
+                    }, std::make_integer_sequence<int, 8>{});
 #endif
 #ifdef OHGPU_EXP_NOCOEF
-                lds_issue_f64(cA, coef_lane);
+                    lds_issue_f64<r * 128>(cf[r], coef_lane);
 #else
-                lds_issue_f64(cA, cp);
+                    lds_issue_f64<r * 128>(cf[r], cp);
 #endif
+                }, std::make_integer_sequence<int, NCR>{});
                 int32_t y = (int32_t)floor(acc0 + acc1);
                 y = y > 8388607 ? 8388607 : (y < -8388608 ? -8388608 : y);
                 // pair mode packs straight from the S24 value; the other layouts (and the ramp) use the left-justified word (a11)
@@ -581,7 +582,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     X(32, 6, 3, true, 3, false)     \
     X(32, 6, 3, false, 3, false)    \
     X(32, 8, 3, true, 3, false)     \
-    X(32, 8, 3, false, 3, false)
+    X(32, 8, 3, false, 3, false)    \
+    X(64, 2, 3, true, 3, false)     \
+    X(64, 8, 3, true, 3, false)
 #endif
 
 // Launch shape: up to MAX_WAVES waves per workgroup (what the LDS left by the coefficient table allows), one
@@ -640,7 +643,7 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
-    if (w > 12) w = 12;
+    if (w > (T <= 32 ? 12u : 8u)) w = T <= 32 ? 12u : 8u;
     if (const char* e = getenv("OHGPU_EXP_MAX_WAVES")) { const uint32_t x = (uint32_t)atoi(e); if (x >= 4 && x < w) w = x; }   // occupancy experiments
     if (w < 4) return false;            // too few waves per CU to be worth it: the generic kernel takes the batch
     *max_waves = w;

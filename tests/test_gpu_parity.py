@@ -350,6 +350,33 @@ def test_src_multichannel_block_kernel(ctx, ch, send):
     ctx.src_destroy(h)
 
 
+@pytest.mark.parametrize("ch", [2, 8])
+def test_src_decimate_by_two_block_kernel(ctx, ch):
+    """96 -> 48 kHz (L = 1, M = 2) with 64 taps: every second advance emits nothing, the window is 64 deep, the same
+    coefficient row serves every output.  BASELINE config 4's other rate, on the block kernel."""
+    h, ref = make_src(ctx, 96000, 48000, 64)
+    assert ref.L == 1 and ref.M == 2
+    in_frames, n_streams = 12800, 3
+    src = np.concatenate([W.noise_pcm(70 + s, in_frames, ch, 24, LE) for s in range(n_streams)])
+    out_total = ref.out_frames(in_frames)
+    assert out_total == 6400
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 30 * O.JIFFIES_PER_MS, 50 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, ch, 24, LE, 24, BE, sched)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+    ctx.memset(d_dst, 0xA5, dbytes)
+    b = ctx.src_batch(h, descs, src.size, dbytes)
+    plan = ctx.src_plan(b)
+    assert plan["block_kernel_out_frames"] == n_streams * out_total and plan["generic_pieces"] == 0
+    ctx.src_run(b, d_src, d_dst)
+    got = ctx.download(d_dst, dbytes)
+    want = oracle_src(ref, descs, src, dbytes)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}"
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
 def test_src_chunked_streaming_equals_whole(vctx):
     """Cross-chunk state = (T-1 frames of history, phase): feeding windows with src_frame0 > 0 gives the same bytes."""
     h, ref = make_src(vctx, 44100, 48000, 32)
