@@ -584,6 +584,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     X(32, 8, 3, true, 3, false)     \
     X(32, 8, 3, false, 3, false)    \
     X(64, 2, 3, true, 3, false)     \
+    X(64, 6, 3, true, 3, false)     \
     X(64, 8, 3, true, 3, false)
 #endif
 

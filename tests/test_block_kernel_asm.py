@@ -40,7 +40,7 @@ def kernels():
                 if "Lb1EEEv" not in name:
                     found[name] = body
                 name = None
-    assert len(found) >= 14, "expected every instantiation in the assembly"
+    assert len(found) >= 15, "expected every instantiation in the assembly"
     return found
 
 

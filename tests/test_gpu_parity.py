@@ -377,6 +377,35 @@ def test_src_decimate_by_two_block_kernel(ctx, ch):
     ctx.src_destroy(h)
 
 
+def test_src_config4_mix_runs_on_the_block_kernel(ctx):
+    """BASELINE config 4's deterministic mix -- rate in {44.1k, 96k} -> 48k, channels in {2, 6, 8}, S24, by stream id -- as
+    one batch per (filter, layout): every group is planned onto the block kernel and is bit-exact."""
+    filters = {44100: make_src(ctx, 44100, 48000, 32), 96000: make_src(ctx, 96000, 48000, 64)}
+    groups = {}
+    for sid in range(24):
+        groups.setdefault(((44100, 96000)[sid % 2], (2, 6, 8)[sid % 3]), []).append(sid)
+    assert len(groups) == 6
+    for (rate, ch), sids in groups.items():
+        h, ref = filters[rate]
+        in_frames = 5880 if rate == 44100 else 12800             # 6400 output frames either way
+        src = np.concatenate([W.noise_pcm(sid, in_frames, ch, 24, LE) for sid in sids])
+        n_msgs = (6400 + 239) // 240
+        sched = W.ramp_schedule(n_msgs, 240 * 1176, 30 * O.JIFFIES_PER_MS, 50 * O.JIFFIES_PER_MS)
+        descs, sbytes, dbytes, _, _ = W.src_stream_descs(len(sids), in_frames, ref.L, ref.M, 240, ch, 24, LE, 24, BE, sched)
+        assert int(descs["n_frames"].max()) * ch * 3 <= O.MAX_BYTES    # <= 9216-byte messages (Msg.h:117)
+        d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+        ctx.memset(d_dst, 0xA5, dbytes)
+        b = ctx.src_batch(h, descs, src.size, dbytes)
+        plan = ctx.src_plan(b)
+        assert plan["block_kernel_out_frames"] == len(sids) * 6400 and plan["generic_pieces"] == 0, (rate, ch, plan)
+        ctx.src_run(b, d_src, d_dst)
+        got = ctx.download(d_dst, dbytes)
+        assert np.array_equal(got, oracle_src(ref, descs, src, dbytes)), (rate, ch)
+        ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    for h, _ in filters.values():
+        ctx.src_destroy(h)
+
+
 def test_src_chunked_streaming_equals_whole(vctx):
     """Cross-chunk state = (T-1 frames of history, phase): feeding windows with src_frame0 > 0 gives the same bytes."""
     h, ref = make_src(vctx, 44100, 48000, 32)
