@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libohgpu.so")
 HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip"]
 HEADERS = ["ohgpu_internal.h", "pcm_device.h", os.path.join(ROOT, "include", "ohgpu.h")]
 ARCH = "gfx950"
+BLOCK_PARTS = 3                     # OHGPU_BLOCK_PARTS in csrc/src_block_kernel.hip
 
 
 def hipcc():
@@ -39,19 +40,46 @@ def is_stale():
 
 
 def build(force=False, verbose=False, save_temps=False):
+    """One object per source (compiled in parallel, kept under build/obj and reused while the source, the headers and the
+    flags are unchanged), then one link."""
     if not force and not is_stale():
         return LIB_PATH
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           *os.environ.get("OHGPU_EXTRA_FLAGS", "").split(),
-           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + _sources()
+    obj_dir = os.path.join(PKG, "build", "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             *os.environ.get("OHGPU_EXTRA_FLAGS", "").split(),
+             "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
     if save_temps:
-        tmp = os.path.join(PKG, "build")
-        os.makedirs(tmp, exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+        flags += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    headers = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    newest_header = max(os.path.getmtime(h) for h in headers if os.path.exists(h))
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+
+    def compile_one(job):
+        src, part = job
+        obj = os.path.join(obj_dir, f"{os.path.basename(src)}.{tag}.{part}.o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
+            return obj
+        cmd = [hipcc(), *flags, *([f"-DOHGPU_BLOCK_PART={part}"] if part else []), "-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd, cwd=PKG)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        # the block kernel's instantiations are compiled in BLOCK_PARTS parts (see the end of src_block_kernel.hip)
+        jobs = [(src, part) for src in _sources()
+                for part in (range(1, BLOCK_PARTS + 1) if os.path.basename(src) == "src_block_kernel.hip" else (0,))]
+        jobs.sort(key=lambda j: 0 if j[1] else 1)                # the long ones first
+        objs = list(ex.map(compile_one, jobs))
+    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd, cwd=PKG)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link, cwd=PKG)
     return LIB_PATH
 
 

@@ -567,10 +567,15 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 }
 
 // ---- instantiations: (T, channels, source bytes, source LE, destination bytes, destination LE) ----
+// The list is compiled in parts so that the build can run them side by side (ohpipeline_amd/build.py compiles this file
+// once per part with -DOHGPU_BLOCK_PART=k): part 1 also holds the host code and only DECLARES the other parts' kernels;
+// parts 2.. hold nothing but their kernels.  Without the macro (tools, tests) the file is one translation unit.
 #ifdef OHGPU_EXP_ONE_KERNEL
-#define OHGPU_BLOCK_KERNELS(X) X(32, 2, 3, true, 3, false)
+#define OHGPU_BLOCK_KERNELS_1(X) X(32, 2, 3, true, 3, false)
+#define OHGPU_BLOCK_KERNELS_2(X)
+#define OHGPU_BLOCK_KERNELS_3(X)
 #else
-#define OHGPU_BLOCK_KERNELS(X)      \
+#define OHGPU_BLOCK_KERNELS_1(X)    \
     X(32, 2, 3, true, 3, false)     \
     X(32, 2, 3, true, 3, true)      \
     X(32, 2, 3, false, 3, false)    \
@@ -578,16 +583,34 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     X(32, 2, 3, true, 2, false)     \
     X(32, 2, 2, true, 3, false)     \
     X(32, 2, 2, true, 2, true)      \
-    X(32, 2, 2, true, 2, false)     \
+    X(32, 2, 2, true, 2, false)
+#define OHGPU_BLOCK_KERNELS_2(X)    \
     X(32, 6, 3, true, 3, false)     \
     X(32, 6, 3, false, 3, false)    \
     X(32, 8, 3, true, 3, false)     \
-    X(32, 8, 3, false, 3, false)    \
+    X(32, 8, 3, false, 3, false)
+#define OHGPU_BLOCK_KERNELS_3(X)    \
     X(64, 2, 3, true, 3, false)     \
     X(64, 6, 3, true, 3, false)     \
     X(64, 8, 3, true, 3, false)
 #endif
+#define OHGPU_BLOCK_KERNELS(X) OHGPU_BLOCK_KERNELS_1(X) OHGPU_BLOCK_KERNELS_2(X) OHGPU_BLOCK_KERNELS_3(X)
+#define OHGPU_BLOCK_PARTS 3
 
+#define OHGPU_KERNEL_ARGS const SrcSeg*, const SegMsg*, const SrcWork*, uint32_t, const double*, const uint16_t*, const uint8_t*, \
+                          uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
+#define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_block_kernel<t, c, s_, sl, d, dl, false>(OHGPU_KERNEL_ARGS);
+#define X_DECLARE(t, c, s_, sl, d, dl) extern template __global__ void src_block_kernel<t, c, s_, sl, d, dl, false>(OHGPU_KERNEL_ARGS);
+#if defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 2
+OHGPU_BLOCK_KERNELS_2(X_DEFINE)
+#elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 3
+OHGPU_BLOCK_KERNELS_3(X_DEFINE)
+#elif defined(OHGPU_BLOCK_PART)
+OHGPU_BLOCK_KERNELS_2(X_DECLARE)
+OHGPU_BLOCK_KERNELS_3(X_DECLARE)
+#endif
+
+#if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
 // Launch shape: up to MAX_WAVES waves per workgroup (what the LDS left by the coefficient table allows), one
 // workgroup per CU, waves loop over the work units; a small batch is spread as one-wave workgroups instead.
 static void launch_shape(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32_t* grid, uint32_t* waves, uint32_t* lds)
@@ -713,5 +736,7 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
 #undef X
     return hipErrorInvalidValue;
 }
+
+#endif   // host code: part 1 (or the single translation unit)
 
 }  // namespace ohgpu
