@@ -99,15 +99,6 @@ __global__ __launch_bounds__(kFmtWaves * 64) void fmt_line_kernel(const FmtChunk
 }
 
 // ---- host side ----
-static void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)            // x / d == umulhi(x, m) >> s for x < 2^31, d >= 2
-{
-    if (d <= 1) { *m = 0; *s = 0; return; }
-    uint32_t l = 0;
-    while ((1ull << l) < d) l++;
-    *m = (uint32_t)(((1ull << (31 + l)) / d) + 1);
-    *s = l - 1;
-}
-
 void free_fmt_line(ohgpu_batch* b)
 {
     if (b->fmtline.d_chunks) hipFree(b->fmtline.d_chunks);

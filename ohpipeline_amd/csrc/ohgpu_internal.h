@@ -95,6 +95,17 @@ struct SrcFastPlan {
     uint64_t fast_out_frames = 0;
 };
 
+// x / d == umulhi(x, m) >> s for every x < 2^31 (d >= 2; m == 0 stands for d == 1): with 2^(l-1) < d <= 2^l and
+// m = floor(2^(31+l) / d) + 1 the error term x * (m * d - 2^(31+l)) stays below 2^(31+l).  Host side of the line kernels.
+inline void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)
+{
+    if (d <= 1) { *m = 0; *s = 0; return; }
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    *m = (uint32_t)(((1ull << (31 + l)) / d) + 1);
+    *s = l - 1;
+}
+
 // ---- line kernel of the PCM message path (csrc/pcm_line_kernel.hip) ----
 struct PcmChunk {             // one wave's share of a message: subsamples [q0, q0 + nq); 64 bytes = one scalar load
     uint64_t src_off, dst_off;    // byte offsets of the chunk's first source / destination byte in the arenas

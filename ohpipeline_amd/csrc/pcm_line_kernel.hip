@@ -199,15 +199,6 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
 }
 
 // ---- host side: chunk list and per-message multipliers ----
-static void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)            // x / d == umulhi(x, m) >> s for x < 2^31, d >= 2
-{
-    if (d <= 1) { *m = 0; *s = 0; return; }
-    uint32_t l = 0;
-    while ((1ull << l) < d) l++;                                        // 2^(l-1) < d <= 2^l
-    *m = (uint32_t)(((1ull << (31 + l)) / d) + 1);
-    *s = l - 1;
-}
-
 void free_pcm_line(ohgpu_batch* b)
 {
     if (b->line.d_chunks) hipFree(b->line.d_chunks);
