@@ -180,7 +180,11 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
                         v = sub_fn(upos) | (sub_fn(upos + 1) << 8) | (sub_fn(upos + 2) << 16) | (sub_fn(upos + 3) << 24);
                     }
                     if (pos >= 0 && (uint32_t)pos + 4 <= len) {
+#ifdef OHGPU_EXP_STORE_PLAIN
                         *(uint32_t*)(obase + (size_t)k * 4) = v;
+#else
+                        __builtin_nontemporal_store(v, (uint32_t*)(obase + (size_t)k * 4));   // written once, never read here
+#endif
                     } else {                                                // first / last dword of the chunk: only its own bytes
                         const uint32_t skip = pos < 0 ? (uint32_t)(-pos) : 0u;   // v starts at stream byte upos = pos + skip
                         for (uint32_t b = skip; b < 4; b++) {
