@@ -298,7 +298,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #ifdef OHGPU_EXP_NODMA
         piece_on[it] = false; (void)n_blocks;
 #else
-        piece_on[it] = r < n_blocks && r < (uint32_t)ROWS;
+        // a row whose first frame sits early in its piece does not reach into the last piece of the window
+        // (8 frames + the 7 bytes the aligned two-word reads may touch beyond the last subsample)
+        const uint32_t pieces_needed = (((uint32_t)g & 15u) + 8 * FB_SRC + 7 + 15) >> 4;
+        piece_on[it] = r < n_blocks && r < (uint32_t)ROWS && (idx - r * IN_BLOCKS) < pieces_needed;
 #endif
         const int64_t last = piece_a[it] + (int64_t)(n_stages - 1) * (8 * FB_SRC);
         if (piece_on[it] && (piece_a[it] < 0 || (uint64_t)last + 16 > src_arena_bytes)) unit_safe = false;
