@@ -89,7 +89,7 @@ struct SrcFastPlan {
     void*    d_segs = nullptr;
     void*    d_msgs = nullptr;
     void*    d_work = nullptr;
-    void*    d_counter = nullptr; // uint32: units claimed so far by the running launch (zeroed before every launch)
+    void*    d_counter = nullptr; // uint32[2]: units claimed / waves finished by the running launch; the kernel's last wave zeroes them
     void*    d_rem = nullptr;     // DevSrcDesc[] the generic kernel finishes (block-unaligned heads and tails)
     size_t   n_rem = 0;
     uint64_t fast_out_frames = 0;

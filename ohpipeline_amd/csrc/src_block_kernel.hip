@@ -574,6 +574,15 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     }
     unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     }   // units
+    // The counters reset themselves: a wave reports in after its last claim, and the last wave of the grid to do so
+    // zeroes both words for the next launch (no memset between launches; the batch owns the counters, one launch at a time).
+    if (lane == 0) {
+        const uint32_t waves_total = gridDim.x * n_waves;
+        if (atomicAdd(unit_counter + 1, 1u) == waves_total - 1) {
+            __hip_atomic_store(unit_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(unit_counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---- instantiations: (T, channels, source bytes, source LE, destination bytes, destination LE) ----
@@ -643,8 +652,6 @@ static hipError_t launch_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const S
     launch_shape(ctx, b, &grid, &waves, &lds);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(b->fast.d_counter, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
                        p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
                        p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_bytes,
@@ -698,7 +705,6 @@ static hipError_t launch_stamped(const ohgpu_ctx* ctx, const ohgpu_batch* b, con
     e = hipMalloc((void**)&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return e;
     hipMemsetAsync(d, 0, n * sizeof(uint64_t), s);
-    hipMemsetAsync(b->fast.d_counter, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
                        p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
                        p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_bytes,

@@ -161,7 +161,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
     if (err == OHGPU_OK) err = upload_vec(work, &f.d_work);
     if (err == OHGPU_OK) err = upload_vec(rem, &f.d_rem);
-    if (err == OHGPU_OK) err = upload_vec(std::vector<uint32_t>(1, 0u), &f.d_counter);
+    if (err == OHGPU_OK) err = upload_vec(std::vector<uint32_t>(2, 0u), &f.d_counter);   // {units claimed, waves finished}: zero between launches
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
     f.enabled = true;
     f.T = T;

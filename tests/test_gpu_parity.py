@@ -406,6 +406,24 @@ def test_src_config4_mix_runs_on_the_block_kernel(ctx):
         ctx.src_destroy(h)
 
 
+def test_src_batch_can_be_run_repeatedly(ctx):
+    """A batch is planned once and launched every period: the block kernel's work counters must be back at zero after
+    each launch (they reset themselves), so the second and third run write the same bytes as the first."""
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    in_frames, n_streams = 8820, 40                              # enough units for several claims per wave
+    src = np.concatenate([W.noise_pcm(200 + s, in_frames, 2, 24, LE) for s in range(n_streams)])
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, None)
+    want = oracle_src(ref, descs, src, dbytes)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+    b = ctx.src_batch(h, descs, src.size, dbytes)
+    for run in range(3):
+        ctx.memset(d_dst, 0xA5 + run, dbytes)
+        ctx.src_run(b, d_src, d_dst)
+        assert np.array_equal(ctx.download(d_dst, dbytes), want), f"run {run}"
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
 def test_src_chunked_streaming_equals_whole(vctx):
     """Cross-chunk state = (T-1 frames of history, phase): feeding windows with src_frame0 > 0 gives the same bytes."""
     h, ref = make_src(vctx, 44100, 48000, 32)
