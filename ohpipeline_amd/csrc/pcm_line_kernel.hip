@@ -53,6 +53,34 @@ __device__ __forceinline__ uint32_t ramp_index_magic(uint32_t ramp_start, int32_
     return idx < kRampTableCount - 1 ? idx : kRampTableCount - 1;
 }
 
+// ---- group path helpers: 4*N bytes at any byte address <-> an N-register vector (inline asm: the access is ONE
+// instruction whatever the alignment).  A load's result must not be touched before the caller's s_waitcnt vmcnt(0), which
+// names the vectors as "+v"; only then are they taken apart. ----
+template <int N> struct GroupVec;
+template <> struct GroupVec<2> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct GroupVec<3> { typedef uint32_t type __attribute__((ext_vector_type(3))); };
+template <> struct GroupVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+
+template <int N>
+__device__ __forceinline__ void group_load(typename GroupVec<N>::type& v, const uint8_t* p)
+{
+    if constexpr (N == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (N == 3) asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+}
+template <int NI, int NO>
+__device__ __forceinline__ void group_store(uint8_t* p, const typename GroupVec<NI>::type& in, const uint32_t (&sel)[4][2])
+{
+    const uint32_t i0 = in[0], i1 = in[1], i2 = NI > 2 ? in[2] : 0u, i3 = NI > 3 ? in[3 < NI ? 3 : 0] : 0u;
+    typename GroupVec<NO>::type o;
+#pragma unroll
+    for (int j = 0; j < NO; j++)
+        o[j] = __builtin_amdgcn_perm(i1, i0, sel[j][0]) | (NI > 2 ? __builtin_amdgcn_perm(i3, i2, sel[j][1]) : 0u);
+    if constexpr (NO == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(o) : "memory");
+    else if constexpr (NO == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(p), "v"(o) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(o) : "memory");
+}
+
 // SB / DB: bytes per source / destination subsample when the whole batch has one layout (immediates instead of
 // scalar registers in every shift and multiply), 0 = read them from each chunk's record.
 template <int SB, int DB>
@@ -74,8 +102,12 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
     const uint32_t stride = gridDim.x * kLineWaves;
     uint32_t chunk = blockIdx.x * kLineWaves + wave;
     if (chunk >= n_chunks) return;
+    auto is_plain = [](const PcmChunk& c) __attribute__((always_inline)) -> bool {
+        return !(c.flags & (kChunkRamp | kChunkSilence)) && c.attenuation == OHGPU_UNITY_ATTENUATION;
+    };
     auto stage_in = [&](const PcmChunk& c, uint32_t buf) __attribute__((always_inline)) -> uint32_t {
         if (c.flags & kChunkSilence) return 0u;
+        if (SB != 0 && is_plain(c)) return 0u;                         // plain chunks of a uniform batch never touch LDS (group path)
         const uint32_t head = (uint32_t)((uint64_t)(uintptr_t)src + c.src_off) & 15u;        // first source byte's place in its piece
         const uint8_t* base = src + (c.src_off - head);
         const uint32_t n_pieces = (head + c.nq * (SB ? SB : c.sb) + 15u) >> 4;
@@ -87,6 +119,8 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
         }
         return issued;
     };
+    uint32_t grp_sel[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};        // group path: selector of destination dword j over source dwords {2pr+1, 2pr}
+    uint32_t grp_for = 0xffffffffu;                                   // the per-subsample selector they were derived from
     PcmChunk ck = chunks[chunk];
     PcmChunk nx = ck;
     bool has_nx = chunk + stride < n_chunks;
@@ -99,6 +133,57 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
         PcmChunk nn = nx;
         if (has_nn) nn = chunks[chunk + 2 * stride];
         const uint32_t k_nx = has_nx ? stage_in(nx, buf ^ 1) : 0u;
+        if constexpr (SB != 0 && DB != 0) {
+            if (is_plain(ck)) {
+                // ---- plain chunk of a uniform batch: registers only.  Lane = GROUP of four subsamples: 4*SB source bytes
+                // (one unaligned 8/12/16-byte load: unaligned wide accesses run at full rate, tools/micro/unaligned_store.hip),
+                // a fixed byte shuffle (per destination dword: one v_perm_b32 per pair of source dwords, selectors derived
+                // from the record's per-subsample selector when the layout changes), 4*DB destination bytes (one store).
+                if (ck.plain_sel != grp_for) {
+                    grp_for = ck.plain_sel;
+#pragma unroll
+                    for (int j = 0; j < DB; j++)
+#pragma unroll
+                        for (int pr = 0; pr < 2; pr++) {
+                            uint32_t sel = 0;
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                const int B = 4 * j + t, qi = B / DB, m = B % DB;
+                                const uint32_t sbyte = (ck.plain_sel >> (8 * m)) & 0xffu;
+                                const uint32_t sidx = (uint32_t)(qi * SB) + sbyte;              // source byte of the group
+                                uint32_t code = 0x0c;                                            // zero
+                                if (sbyte != 0x0c && (sidx >> 3) == (uint32_t)pr) code = sidx & 7u;   // byte of {I[2pr+1], I[2pr]}
+                                sel |= code << (8 * t);
+                            }
+                            grp_sel[j][pr] = sel;
+                        }
+                }
+                const uint32_t n_grp = ck.nq >> 2;
+                const uint8_t* const sp = src + ck.src_off;
+                uint8_t* const dp = dst + ck.dst_off;
+                for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {
+                    typename GroupVec<SB>::type in_a = {}, in_b = {};
+                    const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
+                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
+                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
+                    if (ga < n_grp) group_store<SB, DB>(dp + (size_t)ga * (4 * DB), in_a, grp_sel);
+                    if (gb < n_grp) group_store<SB, DB>(dp + (size_t)gb * (4 * DB), in_b, grp_sel);
+                }
+                // the chunk's last 1..3 subsamples: byte by byte
+                const uint32_t tail0 = n_grp * 4, tail_bytes = (ck.nq - tail0) * DB;
+                if (lane < tail_bytes) {
+                    const uint32_t q = tail0 + lane / DB, m = lane % DB;
+                    const uint32_t sbyte = (ck.plain_sel >> (8 * m)) & 0xffu;
+                    dp[(size_t)q * DB + m] = sbyte == 0x0c ? (uint8_t)0 : sp[(size_t)q * SB + sbyte];
+                }
+                if (!has_nx) break;
+                chunk += stride;
+                ck = nx; nx = nn; has_nx = has_nn;
+                buf ^= 1;
+                continue;
+            }
+        }
         if (k_nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (k_nx == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if (k_nx == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
