@@ -30,6 +30,7 @@ typedef const __attribute__((address_space(1))) void* global_ptr_t;
 
 constexpr uint32_t kChunkSub = 512;                                   // subsamples per chunk
 constexpr uint32_t kLineWaves = 4;                                    // waves per workgroup
+constexpr uint32_t kGroupChunkSub = 4096;                             // subsamples per merged group-path chunk
 constexpr uint32_t kInBytes = ((15 + kChunkSub * 4 + 15) / 16) * 16 + 16;   // <= 3 staging instructions of 64 pieces
 
 // x / d for x < 2^31 with the host's multiplier (m == 0: d == 1)
@@ -299,6 +300,7 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
     (void)ctx;
     b->line = PcmLinePlan();
     std::vector<PcmChunk> chunks;
+    bool mergeable = false;                                             // the last chunk is a group-path chunk
     for (size_t i = 0; i < n; i++) {
         const ohgpu_msg_desc& d = descs[i];
         const uint64_t n_sub = (uint64_t)d.n_frames * d.channels;
@@ -327,6 +329,25 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
         uint32_t sh;
         magic_u31(d.channels, &c.m_ch, &sh); c.s_ch = (uint8_t)sh;
         magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &c.m_n1, &sh); c.s_n1 = (uint8_t)sh;
+        // Plain messages of a uniform batch run the group path, which needs no staging buffer: such a message is one chunk,
+        // and it is appended to the previous chunk when it continues it in both arenas (a stream's consecutive messages).
+        const bool group_path = b->uniform && sb >= 2 && sb <= 4 && db >= 2 && db <= 4 &&
+                                !(d.flags & (OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE)) && d.attenuation == OHGPU_UNITY_ATTENUATION;
+        if (group_path && n_sub > 0) {
+            if (!chunks.empty() && mergeable) {
+                PcmChunk& p = chunks.back();
+                if (p.flags == c.flags && p.plain_sel == c.plain_sel && (uint64_t)p.nq + n_sub <= kGroupChunkSub &&
+                    p.src_off + (uint64_t)p.nq * sb == d.src_offset && p.dst_off + (uint64_t)p.nq * db == d.dst_offset) {
+                    p.nq += (uint32_t)n_sub;
+                    continue;
+                }
+            }
+            c.q0 = 0; c.nq = (uint32_t)n_sub; c.src_off = d.src_offset; c.dst_off = d.dst_offset;
+            chunks.push_back(c);
+            mergeable = true;
+            continue;
+        }
+        mergeable = false;
         for (uint64_t q0 = 0; q0 < n_sub; q0 += kChunkSub) {
             c.q0 = (uint32_t)q0;
             c.nq = (uint32_t)(n_sub - q0 < kChunkSub ? n_sub - q0 : kChunkSub);
