@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
     };
     auto stage_in = [&](const PcmChunk& c, uint32_t buf) __attribute__((always_inline)) -> uint32_t {
         if (c.flags & kChunkSilence) return 0u;
-        if (SB != 0 && is_plain(c)) return 0u;                         // plain chunks of a uniform batch never touch LDS (group path)
+        if (SB != 0) return 0u;                                        // a uniform batch works in registers (group paths): nothing to stage
         const uint32_t head = (uint32_t)((uint64_t)(uintptr_t)src + c.src_off) & 15u;        // first source byte's place in its piece
         const uint8_t* base = src + (c.src_off - head);
         const uint32_t n_pieces = (head + c.nq * (SB ? SB : c.sb) + 15u) >> 4;
@@ -177,6 +177,89 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
                     const uint32_t q = tail0 + lane / DB, m = lane % DB;
                     const uint32_t sbyte = (ck.plain_sel >> (8 * m)) & 0xffu;
                     dp[(size_t)q * DB + m] = sbyte == 0x0c ? (uint8_t)0 : sp[(size_t)q * SB + sbyte];
+                }
+                if (!has_nx) break;
+                chunk += stride;
+                ck = nx; nx = nn; has_nx = has_nn;
+                buf ^= 1;
+                continue;
+            }
+            if (!(ck.flags & kChunkSilence)) {
+                // ---- attenuated and / or ramped chunk of a uniform batch: the same groups of four subsamples, each
+                // subsample taken out of the loaded registers (static positions), run through pcm_device.h's expressions and
+                // put back at its (static) place in the destination registers.
+                const bool src_le = (ck.flags & kChunkSrcLe) != 0, dst_le = (ck.flags & kChunkDstLe) != 0;
+                const bool ramp = (ck.flags & kChunkRamp) != 0, atten = ck.attenuation != OHGPU_UNITY_ATTENUATION;
+                const uint32_t keep = DB == 4 ? ((ck.flags & kChunkZeroLsb) ? 0xffffff00u : 0xffffffffu) : ~(0xffffffffu >> (8 * (DB & 3)));
+                const int32_t total = (int32_t)((uint32_t)ck.ramp_start - (uint32_t)ck.ramp_end);
+                auto transform = [&](uint32_t raw, uint32_t sub) __attribute__((always_inline)) -> uint32_t {
+                    uint32_t w = src_le ? (raw << (32 - 8 * SB)) : (__builtin_bswap32(raw) & ~(SB == 4 ? 0u : (0xffffffffu >> (8 * (SB & 3)))));
+                    if (atten) w = attenuate_word(w, ck.attenuation);
+                    if (ramp) {
+                        const uint32_t frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
+                        const uint32_t mult = s_ramp[ramp_index_magic(ck.ramp_start, total, frame, ck.n_frames, ck.m_n1, ck.s_n1)];
+                        w = ramp_word(w, mult, SB, ck.channels, sub - frame * ck.channels);
+                    }
+                    w &= keep;
+                    return dst_le ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);      // destination bytes in memory order, first byte low
+                };
+                const uint32_t n_grp = ck.nq >> 2;
+                const uint8_t* const sp = src + ck.src_off;
+                uint8_t* const dp = dst + ck.dst_off;
+                const bool stereo_even = ck.channels == 2 && (ck.q0 & 1) == 0;     // a group = two whole frames: two ramp look-ups, not four
+                auto ramp_mult = [&](uint32_t frame) __attribute__((always_inline)) -> uint32_t {
+                    return s_ramp[ramp_index_magic(ck.ramp_start, total, frame, ck.n_frames, ck.m_n1, ck.s_n1)];
+                };
+                auto do_group = [&](uint32_t g, const typename GroupVec<SB>::type& in) __attribute__((always_inline)) {
+                    uint32_t iw[5] = {in[0], in[1], SB > 2 ? in[2 < SB ? 2 : 0] : 0u, SB > 3 ? in[3 < SB ? 3 : 0] : 0u, 0u};
+                    uint32_t ow[5] = {0, 0, 0, 0, 0};
+                    uint32_t m_lo = 0, m_hi = 0;
+                    if (ramp && stereo_even) { const uint32_t f = (ck.q0 >> 1) + 2 * g; m_lo = ramp_mult(f); m_hi = ramp_mult(f + 1); }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int off = k * SB, o = k * DB;
+                        const uint32_t raw = (off & 3) ? __builtin_amdgcn_alignbyte(iw[(off >> 2) + 1], iw[off >> 2], off & 3) : iw[off >> 2];
+                        uint32_t w = src_le ? (raw << (32 - 8 * SB)) : (__builtin_bswap32(raw) & ~(SB == 4 ? 0u : (0xffffffffu >> (8 * (SB & 3)))));
+                        if (atten) w = attenuate_word(w, ck.attenuation);
+                        if (ramp) {
+                            if (stereo_even) {
+                                w = ramp_word(w, k < 2 ? m_lo : m_hi, SB, 2, (uint32_t)(k & 1));
+                            } else {
+                                const uint32_t sub = ck.q0 + 4 * g + k, frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
+                                w = ramp_word(w, ramp_mult(frame), SB, ck.channels, sub - frame * ck.channels);
+                            }
+                        }
+                        w &= keep;
+                        const uint32_t v = dst_le ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);   // destination bytes in memory order
+                        ow[o >> 2] |= v << (8 * (o & 3));
+                        if ((o & 3) + DB > 4) ow[(o >> 2) + 1] |= v >> (32 - 8 * (o & 3));
+                    }
+                    typename GroupVec<DB>::type out;
+#pragma unroll
+                    for (int j = 0; j < DB; j++) out[j] = ow[j];
+                    uint8_t* const op = dp + (size_t)g * (4 * DB);
+                    if constexpr (DB == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
+                    else if constexpr (DB == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
+                    else asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
+                };
+                for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {      // two groups per lane in flight
+                    const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
+                    typename GroupVec<SB>::type in_a = {}, in_b = {};
+                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
+                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
+                    if (ga < n_grp) do_group(ga, in_a);
+                    if (gb < n_grp) do_group(gb, in_b);
+                }
+                const uint32_t tail0 = n_grp * 4;                   // the chunk's last 1..3 subsamples, one lane each
+                if (lane < ck.nq - tail0) {
+                    const uint32_t q = tail0 + lane;
+                    uint32_t raw = 0;
+#pragma unroll
+                    for (int bq = 0; bq < SB; bq++) raw |= (uint32_t)sp[(size_t)q * SB + bq] << (8 * bq);
+                    const uint32_t v = transform(raw, ck.q0 + q);
+#pragma unroll
+                    for (int bq = 0; bq < DB; bq++) dp[(size_t)q * DB + bq] = (uint8_t)(v >> (8 * bq));
                 }
                 if (!has_nx) break;
                 chunk += stride;
@@ -331,8 +414,14 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
         magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &c.m_n1, &sh); c.s_n1 = (uint8_t)sh;
         // Plain messages of a uniform batch run the group path, which needs no staging buffer: such a message is one chunk,
         // and it is appended to the previous chunk when it continues it in both arenas (a stream's consecutive messages).
-        const bool group_path = b->uniform && sb >= 2 && sb <= 4 && db >= 2 && db <= 4 &&
-                                !(d.flags & (OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE)) && d.attenuation == OHGPU_UNITY_ATTENUATION;
+        const bool registers_only = b->uniform && sb >= 2 && sb <= 4 && db >= 2 && db <= 4 && !(d.flags & OHGPU_FLAG_SILENCE);
+        const bool group_path = registers_only && !(d.flags & OHGPU_FLAG_RAMP) && d.attenuation == OHGPU_UNITY_ATTENUATION;
+        if (registers_only && !group_path && n_sub > 0) {                // ramped / attenuated: one chunk per message, no staging
+            c.q0 = 0; c.nq = (uint32_t)n_sub; c.src_off = d.src_offset; c.dst_off = d.dst_offset;
+            chunks.push_back(c);
+            mergeable = false;
+            continue;
+        }
         if (group_path && n_sub > 0) {
             if (!chunks.empty() && mergeable) {
                 PcmChunk& p = chunks.back();

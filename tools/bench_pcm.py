@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--all-ramped", action="store_true", help="every message carries a ramp (worst case for RampApplicator, a7)")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (one thread) on a bounded sample of the streams")
     a = ap.parse_args()
@@ -52,6 +53,9 @@ def main():
         d["flags"][sl] = sched[:, 0]
         d["ramp_start"][sl] = sched[:, 1]
         d["ramp_end"][sl] = sched[:, 2]
+    if a.all_ramped:
+        d["flags"] = capi.FLAG_RAMP
+        d["ramp_start"], d["ramp_end"] = 16384, 3000
     d["attenuation"] = a.attenuation
     d["channels"], d["src_bits"], d["dst_bits"] = ch, a.src_bits, a.dst_bits
     d["src_endian"] = capi.ENDIAN_BIG if a.src_endian == "big" else capi.ENDIAN_LITTLE
@@ -83,7 +87,7 @@ def main():
                msamples_per_s=round(a.streams * a.frames / avg / 1e3, 1), algorithmic_bytes=algo,
                config=dict(streams=a.streams, frames=a.frames, msg_frames=a.msg_frames, channels=ch, src_bits=a.src_bits,
                            dst_bits=a.dst_bits, src_endian=a.src_endian, dst_endian=a.dst_endian,
-                           attenuation=a.attenuation, misalign=a.misalign, variant=a.variant, msgs=int(d.size)))
+                           attenuation=a.attenuation, all_ramped=a.all_ramped, misalign=a.misalign, variant=a.variant, msgs=int(d.size)))
     if a.check:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ctypes as C
