@@ -130,3 +130,58 @@ def test_line_kernel_equals_byte_kernel_on_mixed_batches(ctx):
         ctx.set_kernel_variant(0)
         bad = np.nonzero(fast != base)[0]
         assert bad.size == 0, f"trial {trial}: {bad.size} mismatches, first at {bad[:5]}"
+
+
+def test_config5_data_path_flac_planes_to_resampled_ramped_s24(ctx):
+    """BASELINE config 5 behind the (host-side) FLAC decoder: planar TInt32 blocks -> a14 pack (S24 BE interleaved) ->
+    resample 44.1 -> 48 kHz -> ramp -> S24 BE, device arena to device arena, against the oracle's composition."""
+    import workloads as W
+    rng = np.random.default_rng(21)
+    ch, n_in, n_streams = 2, 5880, 3                               # 5880 frames -> 6400 output frames per stream
+    planes = rng.integers(-(1 << 23), 1 << 23, size=(n_streams, ch, n_in), dtype=np.int64).astype(np.int32)
+    src_planes = planes.view(np.uint8).reshape(-1)
+    # stage 1 (a14): one descriptor per libFLAC block of 1152 frames, as CodecFlac::CallbackWrite sees them
+    blocks = []
+    for s_ in range(n_streams):
+        for f0 in range(0, n_in, 1152):
+            n = min(1152, n_in - f0)
+            d = np.zeros(1, dtype=capi.FMT_DESC)
+            d["kind"], d["channels"], d["src_bits"], d["dst_bits"], d["n_frames"] = capi.FMT_FLAC_PACK, ch, 32, 24, n
+            d["src_offset"] = (s_ * ch * n_in + f0) * 4
+            d["src_plane_stride"] = n_in * 4
+            d["dst_offset"] = (s_ * n_in + f0) * ch * 3
+            blocks.append(d)
+    fmt_descs = np.concatenate(blocks)
+    packed_bytes = n_streams * n_in * ch * 3
+    d_planes, d_packed = ctx.upload(src_planes), ctx.malloc(packed_bytes)
+    fb = ctx.fmt_batch(fmt_descs, src_planes.size, packed_bytes)
+    ctx.fmt_run(fb, d_planes, d_packed)
+    # stage 2: the packed arena is the resampler's source arena
+    L, M, coef = capi.src_design(44100, 48000, 32, 9.0, 20000.0)
+    ref = O.Src(44100, 48000, 32, 9.0, 20000.0)
+    h = ctx.src_create(L, M, 32, coef)
+    out_total = ref.out_frames(n_in)
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 20 * O.JIFFIES_PER_MS, 40 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, n_in, L, M, 240, ch, 24, O.ENDIAN_BIG, 24, O.ENDIAN_BIG, sched)
+    assert sbytes == packed_bytes
+    d_out = ctx.malloc(dbytes)
+    sbatch = ctx.src_batch(h, descs, packed_bytes, dbytes)
+    ctx.src_run(sbatch, d_packed, d_out)
+    got = ctx.download(d_out, dbytes)
+    # oracle: ohp_flac_pack per block, then the resampler model on its output
+    packed_ref = np.zeros(packed_bytes, dtype=np.uint8)
+    for s_ in range(n_streams):
+        for f0 in range(0, n_in, 1152):
+            n = min(1152, n_in - f0)
+            ptrs = (C.POINTER(C.c_int32) * ch)(*[planes[s_, c].ctypes.data_as(C.POINTER(C.c_int32)) for c in range(ch)])
+            nb = C.c_uint32(0)
+            out = packed_ref[(s_ * n_in + f0) * ch * 3:]
+            assert O.lib().ohp_flac_pack(ptrs, ch, f0, n, 24, out.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0 and nb.value == n * ch * 3
+    assert np.array_equal(ctx.download(d_packed, packed_bytes), packed_ref)
+    want = np.zeros(dbytes, dtype=np.uint8)
+    assert ref.process_batch(descs, packed_ref, want) == 0
+    assert np.array_equal(got, want)
+    ctx.batch_destroy(fb); ctx.batch_destroy(sbatch); ctx.src_destroy(h)
+    for p in (d_planes, d_packed, d_out):
+        ctx.free(p)
