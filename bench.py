@@ -209,6 +209,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "msubsamples_per_s": round(total_frames * CHANNELS / elapsed / 1e6, 3),   # frames x channels
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
