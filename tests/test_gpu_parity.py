@@ -152,6 +152,35 @@ def test_pcm_uniform_batches_every_depth_pair(vctx, bits, dbits):
         assert bad.size == 0, f"{bits}->{dbits} se={se} de={de} ch={ch}: {bad.size} mismatches, first at {bad[:5]}"
 
 
+@pytest.mark.parametrize("bits,dbits,ch", [(24, 24, 2), (16, 24, 2), (24, 16, 6), (32, 24, 2), (16, 16, 1), (24, 32, 8)])
+def test_pcm_contiguous_streams_of_mixed_messages(vctx, bits, dbits, ch):
+    """Back-to-back messages of one stream -- what the chunk planner merges -- with plain, ramped, silent and (16-bit)
+    attenuated messages of 1..3000 frames in random order, both byte orders, and a second stream that starts unaligned."""
+    rng = np.random.default_rng(bits + dbits + ch)
+    for se, de in itertools.product([LE, BE], [LE, BE]):
+        rows, parts, sp, dp = [], [], 3, 5
+        for stream in range(2):
+            for k in range(60):
+                n = int(rng.choice([1, 2, 3, 4, 5, 43, 220, 240, 1000, 3000]))
+                kind = int(rng.integers(0, 10))
+                flags = O.FLAG_RAMP if kind < 3 else (O.FLAG_SILENCE if kind == 3 else 0)
+                if kind == 4 and dbits == 32:
+                    flags |= O.FLAG_ZERO_LSB32
+                att = int(rng.choice([256, 256, 100, 0])) if bits == 16 else 256
+                ramp = RAMPS[int(rng.integers(0, len(RAMPS)))]
+                nbytes = n * ch * bits // 8
+                parts.append(rng.integers(0, 256, size=nbytes, dtype=np.uint8))
+                rows.append((sp, dp, n, ramp[0], ramp[1], att, ch, bits, se, dbits, de, flags))
+                sp += nbytes
+                dp += n * ch * dbits // 8
+            parts.append(rng.integers(0, 256, size=1, dtype=np.uint8)); sp += 1; dp += 1      # the next stream starts off by one
+        descs = np.array(rows, dtype=O.MSG_DESC)
+        src = np.concatenate([np.zeros(3, np.uint8)] + parts)
+        got, want = run_pcm(vctx, descs, src, dp), oracle_pcm(descs, src, dp)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"{bits}->{dbits} ch={ch} se={se} de={de}: {bad.size} mismatches, first at {bad[:5]}"
+
+
 def test_attenuation_all_s16_values(vctx):
     """a6 over every 16-bit value for att in {0,1,64,255,256} (floor semantics of the unsigned multiply/divide)."""
     vals = np.arange(65536, dtype=np.uint32)
@@ -420,6 +449,50 @@ def test_src_batch_can_be_run_repeatedly(ctx):
         ctx.memset(d_dst, 0xA5 + run, dbytes)
         ctx.src_run(b, d_src, d_dst)
         assert np.array_equal(ctx.download(d_dst, dbytes), want), f"run {run}"
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_src_block_kernel_irregular_message_tilings(ctx, seed):
+    """The block kernel under message layouts the bench never produces: messages of 1..700 frames in random order of
+    size (a unit then spans anything from 8 to more than 32 messages -- beyond the LDS message table), every message
+    ramped with its own endpoints or not at all, streams that start and end inside a block, some messages missing (the
+    output range falls into several segments), 64-byte aligned and unaligned stream bases."""
+    rng = np.random.default_rng(seed)
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    rows, src_parts, s_pos, d_pos = [], [], 0, 0
+    for stream in range(6):
+        in_frames = int(rng.integers(3000, 9000))
+        out_total = ref.out_frames(in_frames)
+        src_parts.append(W.noise_pcm(300 + 10 * seed + stream, in_frames, 2, 24, LE))
+        d_base = d_pos if stream % 2 else (d_pos + 63) // 64 * 64       # odd streams: whatever follows (the generic kernel's case)
+        m = 0
+        small = stream == seed % 6                                      # one stream of tiny messages: > 32 per unit
+        while m < out_total:
+            n = int(rng.integers(1, 9)) if small else int(rng.choice([1, 5, 43, 220, 240, 241, 700]))
+            n = min(n, out_total - m)
+            ramp = RAMPS[int(rng.integers(0, len(RAMPS)))]
+            flags = O.FLAG_RAMP if rng.random() < 0.6 else 0
+            if rng.random() > 0.03:                                     # (a few messages are simply not asked for)
+                rows.append((s_pos, 0, in_frames, m, d_base + m * 6, n, ramp[0], ramp[1], 256, 2, 24, LE, 24, BE, flags, [0] * 8))
+            m += n
+        s_pos += in_frames * 6
+        d_pos = d_base + out_total * 6 + int(rng.integers(0, 9))
+    descs = np.array(rows, dtype=O.SRC_MSG_DESC)
+    order = rng.permutation(descs.size)                                # the batch need not be sorted
+    descs = descs[order]
+    src = np.concatenate(src_parts)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(d_pos)
+    ctx.memset(d_dst, 0xA5, d_pos)
+    b = ctx.src_batch(h, descs, src.size, d_pos)
+    plan = ctx.src_plan(b)
+    assert plan["block_kernel_out_frames"] > 0 and plan["generic_pieces"] > 0     # both kernels take part
+    ctx.src_run(b, d_src, d_dst)
+    got = ctx.download(d_dst, d_pos)
+    want = oracle_src(ref, descs, src, d_pos)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"seed {seed}: {bad.size} mismatches, first {bad[:5]}"
     ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
     ctx.src_destroy(h)
 
