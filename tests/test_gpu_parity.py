@@ -497,6 +497,32 @@ def test_src_block_kernel_irregular_message_tilings(ctx, seed):
     ctx.src_destroy(h)
 
 
+def test_src_downsampling_block_kernel(ctx):
+    """48 -> 44.1 kHz (L = 147, M = 160): blocks of 32 phase periods (4704 outputs from 5120 inputs), some advances emit no
+    output, 220-frame messages; on the block kernel."""
+    h, ref = make_src(ctx, 48000, 44100, 32)
+    assert (ref.L, ref.M) == (147, 160)
+    in_frames, n_streams = 5120 * 3, 3
+    src = np.concatenate([W.noise_pcm(400 + s, in_frames, 2, 24, LE) for s in range(n_streams)])
+    out_total = ref.out_frames(in_frames)
+    assert out_total == 4704 * 3 and (out_total * 6) % 64 == 0
+    n_msgs = (out_total + 219) // 220
+    sched = W.ramp_schedule(n_msgs, 220 * 1280, 30 * O.JIFFIES_PER_MS, 50 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 220, 2, 24, LE, 24, BE, sched)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+    ctx.memset(d_dst, 0xA5, dbytes)
+    b = ctx.src_batch(h, descs, src.size, dbytes)
+    plan = ctx.src_plan(b)
+    assert plan["block_kernel_out_frames"] == n_streams * out_total, plan
+    ctx.src_run(b, d_src, d_dst)
+    got = ctx.download(d_dst, dbytes)
+    want = oracle_src(ref, descs, src, dbytes)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}"
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
 def test_src_chunked_streaming_equals_whole(vctx):
     """Cross-chunk state = (T-1 frames of history, phase): feeding windows with src_frame0 > 0 gives the same bytes."""
     h, ref = make_src(vctx, 44100, 48000, 32)
