@@ -701,7 +701,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
     hipStream_t s = pick_stream(ctx, stream);
-    const bool aligned = (((uintptr_t)src_base & 15u) | ((uintptr_t)dst_base & 63u)) == 0;
+    const bool aligned = ((uintptr_t)src_base & 15u) == 0;          // the staging loads move aligned 16-byte pieces of the arena
     if (ctx->variant == 0 && batch->fast.enabled && aligned) {
         // whole phase-aligned blocks on the block kernel, block-unaligned heads/tails on the generic one
         OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));

@@ -115,7 +115,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         }
         const uint64_t m_begin = d0.out_frame0, m_end = next_out;
         uint64_t blk_lo = (m_begin + L_blk - 1) / L_blk, blk_hi = m_end / L_blk;
-        bool fast_ok = !zero_len && blk_hi > blk_lo && (dbase % 64 == 0);   // output lines are written whole
+        // (a stream whose output does not start on a 64-byte boundary is written with unaligned 16-byte stores: they run at
+        // the aligned rate -- tools/micro/unaligned_store.hip -- only the lines are then no longer whole)
+        bool fast_ok = !zero_len && blk_hi > blk_lo;
         if (fast_ok) {
             // every whole block's history must be present in the windows the caller declared (they were validated
             // per message; the block reads nothing a message of the block does not itself need)

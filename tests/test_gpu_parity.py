@@ -523,6 +523,26 @@ def test_src_downsampling_block_kernel(ctx):
     ctx.src_destroy(h)
 
 
+def test_src_block_kernel_takes_streams_at_any_destination_alignment(ctx):
+    """The destination of a stream need not start on a 64-byte line for its whole blocks to run on the block kernel."""
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    in_frames = 5880                                               # 6400 output frames = 40 whole blocks
+    src = np.concatenate([W.noise_pcm(500 + s, in_frames, 2, 24, LE) for s in range(4)])
+    descs, sbytes, dbytes, out_total, n_msgs = W.src_stream_descs(4, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, None)
+    shift = np.repeat(np.array([1, 7, 32, 63], dtype=np.uint64), n_msgs) + np.repeat(np.arange(4, dtype=np.uint64) * 64, n_msgs)
+    descs["dst_offset"] += shift
+    dbytes += 4 * 64 + 64
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+    ctx.memset(d_dst, 0xA5, dbytes)
+    b = ctx.src_batch(h, descs, src.size, dbytes)
+    plan = ctx.src_plan(b)
+    assert plan["block_kernel_out_frames"] == 4 * out_total and plan["generic_pieces"] == 0, plan
+    ctx.src_run(b, d_src, d_dst)
+    assert np.array_equal(ctx.download(d_dst, dbytes), oracle_src(ref, descs, src, dbytes))
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
 def test_src_chunked_streaming_equals_whole(vctx):
     """Cross-chunk state = (T-1 frames of history, phase): feeding windows with src_frame0 > 0 gives the same bytes."""
     h, ref = make_src(vctx, 44100, 48000, 32)
