@@ -111,8 +111,31 @@ void free_fmt_line(ohgpu_batch* b)
 
 int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, size_t n)
 {
-    (void)ctx;
     b->fmtline = FmtLinePlan();
+    // A batch of Songcast packs that drop no channel (mono / stereo senders) is a plain depth conversion, big-endian to
+    // big-endian: exactly the PCM line kernel's register-only group path.
+    {
+        bool as_pcm = n > 0;
+        for (size_t i = 0; i < n && as_pcm; i++)
+            as_pcm = descs[i].kind == OHGPU_FMT_SENDER_PACK && descs[i].channels <= 2 && descs[i].src_bits >= 16 &&
+                     descs[i].src_bits == descs[0].src_bits && descs[i].channels == descs[0].channels;
+        if (as_pcm) {
+            std::vector<ohgpu_msg_desc> msgs(n);
+            const uint8_t sbits = descs[0].src_bits, dbits = sbits < 24 ? sbits : 24;
+            for (size_t i = 0; i < n; i++) {
+                ohgpu_msg_desc& m = msgs[i];
+                memset(&m, 0, sizeof(m));
+                m.src_offset = descs[i].src_offset; m.dst_offset = descs[i].dst_offset; m.n_frames = descs[i].n_frames;
+                m.ramp_start = m.ramp_end = OHGPU_RAMP_MAX; m.attenuation = OHGPU_UNITY_ATTENUATION;
+                m.channels = descs[i].channels; m.src_bits = sbits; m.dst_bits = dbits;
+                m.src_endian = m.dst_endian = OHGPU_ENDIAN_BIG;
+            }
+            b->uniform = true;
+            b->channels = descs[0].channels; b->src_bits = sbits; b->dst_bits = dbits;
+            b->src_endian = b->dst_endian = OHGPU_ENDIAN_BIG;
+            return plan_pcm_line(ctx, b, msgs.data(), n);                // -> b->line; ohgpu_fmt_batch_run launches it
+        }
+    }
     std::vector<FmtChunk> chunks;
     const uint32_t budget = kFmtInBytes - 32;                           // 15 bytes of head, rounding up to pieces, the +4 over-read
     for (size_t i = 0; i < n; i++) {

@@ -334,7 +334,7 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     if (batch->kind == kBatchSrc) free_src_fast(batch);
     if (batch->kind == kBatchPcm) free_pcm_line(batch);
     if (batch->kind == kBatchFlywheel) free_flywheel(batch);
-    if (batch->kind == kBatchFmt) free_fmt_line(batch);
+    if (batch->kind == kBatchFmt) { free_fmt_line(batch); free_pcm_line(batch); }
     delete batch;
     return OHGPU_OK;
 }
@@ -438,7 +438,9 @@ int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!batch || batch->kind != kBatchFmt) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: not a fmt batch");
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: null arena pointer");
-    if (ctx->variant == 0 && batch->fmtline.enabled)
+    if (ctx->variant == 0 && batch->line.enabled)                       // stereo Songcast packs planned onto the PCM line kernel
+        OHGPU_HIP_TRY(launch_pcm_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    else if (ctx->variant == 0 && batch->fmtline.enabled)
         OHGPU_HIP_TRY(launch_fmt_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
     else
         OHGPU_HIP_TRY(launch_fmt_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
