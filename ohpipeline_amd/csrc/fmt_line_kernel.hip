@@ -102,6 +102,99 @@ __global__ __launch_bounds__(kFmtWaves * 64) void fmt_line_kernel(const FmtChunk
     }
 }
 
+// ---- register-only kernels for the two stereo cases that dominate in practice (the generic kernel above serves the
+// rest): no LDS, one or two wide loads per lane, byte permutes with COMPILE-TIME selectors, wide stores.  A chunk is a
+// whole descriptor here; record fields: src_off, dst_off, nq = frames, run_src_stride = the plane stride. ----
+typedef uint32_t fv2 __attribute__((ext_vector_type(2)));
+typedef uint32_t fv3 __attribute__((ext_vector_type(3)));
+typedef uint32_t fv4 __attribute__((ext_vector_type(4)));
+
+// selector of v_perm_b32 {hi (bytes 4-7), lo (bytes 0-3)} that takes `n` bytes from byte `first` on, low to high, zero above
+static constexpr uint32_t sel_bytes(int first, int n)
+{
+    uint32_t s = 0;
+    for (int t = 0; t < 4; t++) s |= (uint32_t)(t < n ? first + t : 0x0c) << (8 * t);
+    return s;
+}
+
+// a11, stereo: lane = four frames = 8*SB interleaved source bytes -> four left-justified big-endian words per plane
+template <int SB>
+__global__ __launch_bounds__(256) void unpack_stereo_kernel(const FmtChunk* __restrict__ chunks, const uint32_t n_chunks,
+                                                            const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t chunk = wave; chunk < n_chunks; chunk += gridDim.x * 4) {
+        const FmtChunk ck = chunks[chunk];
+        const uint8_t* sp = src + ck.src_off;
+        uint8_t* p0 = dst + ck.dst_off;
+        uint8_t* p1 = p0 + ck.run_src_stride;
+        const uint32_t n_grp = ck.nq >> 2;
+        for (uint32_t g = lane; g < n_grp; g += 64) {
+            uint32_t in[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint8_t* a = sp + (size_t)g * (8 * SB);
+            if constexpr (SB == 2) { fv4 v; asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(a) : "memory"); in[0] = v.x; in[1] = v.y; in[2] = v.z; in[3] = v.w; }
+            else if constexpr (SB == 3) { fv3 v, w; asm volatile("global_load_dwordx3 %0, %2, off\n\tglobal_load_dwordx3 %1, %2, off offset:12\n\ts_waitcnt vmcnt(0)" : "=&v"(v), "=&v"(w) : "v"(a) : "memory"); in[0] = v.x; in[1] = v.y; in[2] = v.z; in[3] = w.x; in[4] = w.y; in[5] = w.z; }
+            else { fv4 v, w; asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)" : "=&v"(v), "=&v"(w) : "v"(a) : "memory"); in[0] = v.x; in[1] = v.y; in[2] = v.z; in[3] = v.w; in[4] = w.x; in[5] = w.y; in[6] = w.z; in[7] = w.w; }
+            fv4 o0, o1;
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int sidx = (2 * f + c) * SB, d = sidx >> 2;                 // first source byte, its dword
+                    const uint32_t w = __builtin_amdgcn_perm(in[d + 1 < 8 ? d + 1 : 7], in[d], sel_bytes(sidx & 3, SB));
+                    if (c == 0) o0[f] = w; else o1[f] = w;
+                }
+            }
+            asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p0 + (size_t)g * 16), "v"(o0) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p1 + (size_t)g * 16), "v"(o1) : "memory");
+        }
+        const uint32_t f0 = n_grp * 4;                                                // the last 1..3 frames, byte by byte
+        if (lane < (ck.nq - f0) * 8) {
+            const uint32_t f = f0 + lane / 8, c = (lane >> 2) & 1, b = lane & 3;
+            (c ? p1 : p0)[(size_t)f * 4 + b] = b < (uint32_t)SB ? sp[((size_t)f * 2 + c) * SB + b] : (uint8_t)0;
+        }
+    }
+}
+
+// a14, stereo: lane = two frames = two TInt32 of each plane -> four DB-byte big-endian subsamples, interleaved
+template <int DB>
+__global__ __launch_bounds__(256) void flac_stereo_kernel(const FmtChunk* __restrict__ chunks, const uint32_t n_chunks,
+                                                          const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (uint32_t chunk = wave; chunk < n_chunks; chunk += gridDim.x * 4) {
+        const FmtChunk ck = chunks[chunk];
+        const uint8_t* s0 = src + ck.src_off;
+        const uint8_t* s1 = s0 + ck.run_src_stride;
+        uint8_t* dp = dst + ck.dst_off;
+        const uint32_t n_grp = ck.nq >> 1;
+        for (uint32_t g = lane; g < n_grp; g += 64) {
+            fv2 a, b;
+            asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(a), "=&v"(b) : "v"(s0 + (size_t)g * 8), "v"(s1 + (size_t)g * 8) : "memory");
+            const uint32_t x[4] = {a.x, b.x, a.y, b.y};                               // frame 0: ch 0, ch 1; frame 1: ch 0, ch 1
+            uint32_t ow[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int o = k * DB;
+                const uint32_t v = __builtin_bswap32(x[k]) >> (8 * (4 - DB));        // the low DB bytes, most significant first
+                ow[o >> 2] |= v << (8 * (o & 3));
+                if ((o & 3) + DB > 4) ow[(o >> 2) + 1] |= v >> (32 - 8 * (o & 3));
+            }
+            uint8_t* op = dp + (size_t)g * (4 * DB);
+            if constexpr (DB == 1) asm volatile("global_store_dword %0, %1, off nt" : : "v"(op), "v"(ow[0]) : "memory");
+            else if constexpr (DB == 2) { fv2 o = {ow[0], ow[1]}; asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(op), "v"(o) : "memory"); }
+            else { fv3 o = {ow[0], ow[1], ow[2]}; asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(op), "v"(o) : "memory"); }
+        }
+        if ((ck.nq & 1) && lane < 2 * DB) {                                           // an odd last frame, byte by byte
+            const uint32_t f = ck.nq - 1, c = lane / DB, b = lane % DB;
+            const uint32_t xv = *(const uint32_t*)((c ? s1 : s0) + (size_t)f * 4);
+            dp[((size_t)f * 2 + c) * DB + b] = (uint8_t)(xv >> (8 * (DB - 1 - b)));
+        }
+    }
+}
+
 // ---- host side ----
 void free_fmt_line(ohgpu_batch* b)
 {
@@ -134,6 +227,40 @@ int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, s
             b->channels = descs[0].channels; b->src_bits = sbits; b->dst_bits = dbits;
             b->src_endian = b->dst_endian = OHGPU_ENDIAN_BIG;
             return plan_pcm_line(ctx, b, msgs.data(), n);                // -> b->line; ohgpu_fmt_batch_run launches it
+        }
+    }
+    // Uniform stereo batches of a11 (16/24/32-bit) or a14 take the register-only kernels: one record per descriptor.
+    {
+        const uint8_t kind = n ? descs[0].kind : 0;
+        bool grp = n > 0 && (kind == OHGPU_FMT_UNPACK_PLANAR || kind == OHGPU_FMT_FLAC_PACK);
+        for (size_t i = 0; i < n && grp; i++) {
+            const ohgpu_fmt_desc& d = descs[i];
+            grp = d.kind == kind && d.channels == 2 && d.src_bits == descs[0].src_bits && d.dst_bits == descs[0].dst_bits &&
+                  (kind == OHGPU_FMT_FLAC_PACK || d.src_bits >= 16);
+        }
+        if (grp) {
+            std::vector<FmtChunk> recs;
+            for (size_t i = 0; i < n; i++) {
+                const ohgpu_fmt_desc& d = descs[i];
+                if (d.n_frames == 0) continue;
+                FmtChunk c;
+                memset(&c, 0, sizeof(c));
+                c.src_off = d.src_offset; c.dst_off = d.dst_offset; c.nq = d.n_frames;
+                c.run_src_stride = kind == OHGPU_FMT_FLAC_PACK ? d.src_plane_stride : d.dst_plane_stride;
+                recs.push_back(c);
+            }
+            if (recs.empty()) return OHGPU_OK;
+            hipError_t e = hipMalloc(&b->fmtline.d_chunks, recs.size() * sizeof(FmtChunk));
+            if (e == hipSuccess) e = hipMemcpy(b->fmtline.d_chunks, recs.data(), recs.size() * sizeof(FmtChunk), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                free_fmt_line(b);
+                return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "record upload: %s", hipGetErrorString(e));
+            }
+            b->fmtline.n_chunks = (uint32_t)recs.size();
+            b->fmtline.group_kind = kind;
+            b->fmtline.group_bytes = (uint8_t)((kind == OHGPU_FMT_FLAC_PACK ? descs[0].dst_bits : descs[0].src_bits) / 8);
+            b->fmtline.enabled = true;
+            return OHGPU_OK;
         }
     }
     std::vector<FmtChunk> chunks;
@@ -213,6 +340,20 @@ hipError_t launch_fmt_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     uint32_t grid = (b->fmtline.n_chunks + kFmtWaves - 1) / kFmtWaves;
     if (grid > cus * 8) grid = cus * 8;
+    const FmtChunk* recs = (const FmtChunk*)b->fmtline.d_chunks;
+    const uint32_t nr = b->fmtline.n_chunks;
+    if (b->fmtline.group_kind == OHGPU_FMT_UNPACK_PLANAR) {
+        if (b->fmtline.group_bytes == 2) hipLaunchKernelGGL(unpack_stereo_kernel<2>, dim3(grid), dim3(256), 0, s, recs, nr, src, dst);
+        else if (b->fmtline.group_bytes == 3) hipLaunchKernelGGL(unpack_stereo_kernel<3>, dim3(grid), dim3(256), 0, s, recs, nr, src, dst);
+        else hipLaunchKernelGGL(unpack_stereo_kernel<4>, dim3(grid), dim3(256), 0, s, recs, nr, src, dst);
+        return hipGetLastError();
+    }
+    if (b->fmtline.group_kind == OHGPU_FMT_FLAC_PACK) {
+        if (b->fmtline.group_bytes == 1) hipLaunchKernelGGL(flac_stereo_kernel<1>, dim3(grid), dim3(256), 0, s, recs, nr, src, dst);
+        else if (b->fmtline.group_bytes == 2) hipLaunchKernelGGL(flac_stereo_kernel<2>, dim3(grid), dim3(256), 0, s, recs, nr, src, dst);
+        else hipLaunchKernelGGL(flac_stereo_kernel<3>, dim3(grid), dim3(256), 0, s, recs, nr, src, dst);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(fmt_line_kernel, dim3(grid), dim3(kFmtWaves * 64), 0, s,
                        (const FmtChunk*)b->fmtline.d_chunks, b->fmtline.n_chunks, src, dst);
     return hipGetLastError();

@@ -144,6 +144,8 @@ struct FmtChunk {             // 64 bytes = one scalar load
 static_assert(sizeof(FmtChunk) == 64, "chunk record = one 64-byte scalar load");
 struct FmtLinePlan {
     bool     enabled = false;
+    uint8_t  group_kind = 0;      // OHGPU_FMT_UNPACK_PLANAR / _FLAC_PACK: a uniform stereo batch on the register-only kernels
+    uint8_t  group_bytes = 0;     // its source (a11) / destination (a14) bytes per subsample
     uint32_t n_chunks = 0;
     void*    d_chunks = nullptr;
 };

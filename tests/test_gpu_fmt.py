@@ -33,7 +33,8 @@ def run_fmt(ctx, descs, src, dst_bytes):
 def test_flywheel_unpack_planar(ctx):
     """a11: packed BE interleaved 1/2/3/4 bytes -> planar 4-byte BE left-justified (StarvationRamper.cpp:117-186)."""
     rng = np.random.default_rng(3)
-    for sb, ch, n in [(1, 2, 44), (2, 2, 44), (3, 2, 44), (4, 2, 44), (3, 8, 192), (2, 10, 7), (3, 1, 1)]:
+    for sb, ch, n in [(1, 2, 44), (2, 2, 44), (3, 2, 44), (4, 2, 44), (3, 8, 192), (2, 10, 7), (3, 1, 1),
+                      (3, 2, 45), (2, 2, 3), (4, 2, 1), (3, 2, 1027), (2, 2, 4098)]:      # stereo kernels: tails of 1..3 frames
         src = rng.integers(0, 256, size=n * ch * sb, dtype=np.uint8)
         stride = n * 4 + 8
         d = np.zeros(1, dtype=capi.FMT_DESC)
@@ -64,7 +65,8 @@ def test_sender_pack(ctx):
 def test_flac_pack(ctx):
     """a14: planar TInt32 -> packed BE interleaved 8/16/24; 32-bit is unsupported as in the reference (Flac.cpp:379-417)."""
     rng = np.random.default_rng(5)
-    for bits, ch, n in [(8, 2, 100), (16, 2, 4096), (24, 2, 4096), (24, 6, 1152), (16, 1, 17)]:
+    for bits, ch, n in [(8, 2, 100), (16, 2, 4096), (24, 2, 4096), (24, 6, 1152), (16, 1, 17),
+                        (24, 2, 4097), (8, 2, 1), (16, 2, 3), (24, 2, 2)]:                 # stereo kernel: odd last frame
         planes = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(ch, n + 3), dtype=np.int64).astype(np.int32)
         src = planes.view(np.uint8).reshape(-1)
         d = np.zeros(1, dtype=capi.FMT_DESC)
