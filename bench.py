@@ -226,7 +226,12 @@ def main():
                          "frac": round(achieved_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
                          "kernel": "fused resample+ramp+pack", "kernel_avg_ms": round(kernel_avg_ms, 4),
                          "algorithmic_bytes_per_launch": int(algorithmic_bytes),
-                         "bytes_per_input_frame": round(bytes_per_in_frame, 4)},
+                         "bytes_per_input_frame": round(bytes_per_in_frame, 4),
+                         # the pipe that actually bounds this kernel: 2*T*channels*L/M fp64 flop per input frame
+                         # on the vector (= matrix) fp64 pipe, 78.6 TFLOP/s dense on MI355X
+                         "fp64_tflops": round(frames_per_step * 2.0 * TAPS * CHANNELS * work["L"] / work["M"] / (kernel_avg_ms * 1e-3) / 1e12, 2),
+                         "fp64_peak_tflops": 78.6,
+                         "fp64_frac": round(frames_per_step * 2.0 * TAPS * CHANNELS * work["L"] / work["M"] / (kernel_avg_ms * 1e-3) / 1e12 / 78.6, 4)},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
