@@ -11,8 +11,10 @@
 #include "../../ohpipeline_amd/host/Elements.h"
 #include "../../ohpipeline_amd/host/FlywheelRamper.h"
 #include "../../ohpipeline_amd/host/Msg.h"
+#include "../../ohpipeline_amd/host/RampGenerator.h"
 #include "../../ohpipeline_amd/host/SampleRateConverter.h"
 #include "../../oracle/ohp_flywheel.h"
+#include "../../oracle/ohp_oracle.h"
 #include "../../oracle/ohp_pipeline.h"
 
 using namespace OpenHome;
@@ -475,6 +477,83 @@ static void SuiteFlywheelGpu(MsgFactory& aFactory)
     TEST_THROWS(manager.Ramp(Brn(few, sizeof few), 44100, 11), AssertionFailed);
 }
 
+// ------------------------------------------------------------------------------------------- starvation ramp (a11 + N1 + a12 + a7)
+// What StarvationRamper does when its upstream runs dry (StarvationRamper.cpp:590-640): FlywheelInput::Prepare on the
+// recent audio, RampGenerator::Start, then the generated messages flow downstream and are read like any other audio.
+static void SuiteStarvationRampGpu(MsgFactory& aFactory)
+{
+    const TUint kTraining = Jiffies::kPerMs, kRampDown = 20 * Jiffies::kPerMs;         // :374-375
+    const struct { TUint rate, channels, bits; } cases[] = { {44100, 2, 24}, {48000, 2, 16}, {96000, 6, 32}, {44100, 1, 8} };
+    uint32_t x = 4242;
+    for (const auto& cs : cases) {
+        const TUint frameBytes = cs.channels * cs.bits / 8;
+        // 3 ms of recent audio as three messages (big-endian, as the pipeline holds it), a slow decaying tone plus noise
+        std::deque<MsgAudio*> recent;
+        std::vector<TByte> all;
+        const TUint framesPerMsg = Jiffies::ToSamples(Jiffies::kPerMs, cs.rate);
+        for (TUint m = 0; m < 3; m++) {
+            std::vector<TByte> data((size_t)framesPerMsg * frameBytes);
+            for (TUint f = 0; f < framesPerMsg; f++) {
+                for (TUint c = 0; c < cs.channels; c++) {
+                    x = x * 1664525u + 1013904223u;
+                    int32_t v = (int32_t)(0x30000000 - (int32_t)((m * framesPerMsg + f) * 0x00080000u)) + (int32_t)(x >> 10) - (1 << 21);
+                    for (TUint b = 0; b < cs.bits / 8; b++) data[(size_t)f * frameBytes + c * (cs.bits / 8) + b] = (TByte)((uint32_t)v >> (24 - 8 * b));
+                }
+            }
+            all.insert(all.end(), data.begin(), data.end());
+            recent.push_back(aFactory.CreateMsgAudioPcm(Brn(data.data(), (TUint)data.size()), cs.channels, cs.rate, cs.bits, AudioDataEndian::Big, 0));
+        }
+        FlywheelInput input(aFactory, kTraining);
+        const Brx& planar = input.Prepare(recent, kTraining, cs.rate, cs.bits, cs.channels);
+        const TUint inSamples = Jiffies::ToSamples(kTraining, cs.rate);
+        TEST(recent.empty() && planar.Bytes() == inSamples * 4 * cs.channels);
+        // oracle a11 on the newest millisecond
+        std::vector<TByte> wantPlanar(planar.Bytes());
+        std::vector<uint32_t> pos(cs.channels, 0);
+        const TByte* newest = all.data() + all.size() - (size_t)inSamples * frameBytes;
+        TEST(ohp_flywheel_unpack(newest, inSamples * frameBytes, cs.channels, cs.bits / 8, wantPlanar.data(), inSamples * 4, pos.data()) == 0);
+        TEST(memcmp(planar.Ptr(), wantPlanar.data(), wantPlanar.size()) == 0);
+
+        RampGenerator gen(aFactory, kTraining, kRampDown);
+        const TUint startRamp = Ramp::kMax;
+        gen.Start(planar, cs.rate, cs.channels, cs.bits, startRamp);
+        // oracle: flywheel -> a12 pack, then every 1 ms message read with the ramp the host algebra gave it
+        const TUint outFrames = Jiffies::ToSamples(kRampDown, cs.rate), block = Jiffies::ToSamples(Jiffies::kPerMs, cs.rate);
+        std::vector<TByte> ramp32((size_t)outFrames * cs.channels * 4), packed((size_t)outFrames * frameBytes);
+        TEST(ohp_flywheel_ramp(wantPlanar.data(), inSamples * 4, inSamples, cs.rate, cs.channels, outFrames, block, ramp32.data()) == 0);
+        uint32_t packedBytes = 0;
+        TEST(ohp_rampgen_pack(ramp32.data(), (uint32_t)ramp32.size(), cs.bits, packed.data(), &packedBytes) == 0 && packedBytes == packed.size());
+        PlayableBatch batch(aFactory);
+        std::vector<ProcessorPcmBufTest> sinks((outFrames + block - 1) / block);
+        std::vector<ohp_msg_desc> descs;
+        Msg* msg = nullptr;
+        TUint n = 0, frames = 0, lastEnd = startRamp;
+        while (gen.TryGetAudio(msg)) {
+            MsgAudioPcm* pcm = dynamic_cast<MsgAudioPcm*>(msg);
+            TEST(pcm != nullptr && n < sinks.size());
+            TEST(pcm->Ramp().IsEnabled() && pcm->Ramp().Direction() == Ramp::EDown && pcm->Ramp().Start() == lastEnd);
+            lastEnd = pcm->Ramp().End();
+            MsgPlayable* playable = pcm->CreatePlayable();
+            ohp_msg_desc d;
+            memset(&d, 0, sizeof(d));
+            d.src_offset = (uint64_t)frames * frameBytes; d.dst_offset = d.src_offset; d.n_frames = playable->Bytes() / frameBytes;
+            d.ramp_start = (uint16_t)playable->Ramp().Start(); d.ramp_end = (uint16_t)playable->Ramp().End(); d.attenuation = 256;
+            d.channels = (uint8_t)cs.channels; d.src_bits = d.dst_bits = (uint8_t)cs.bits; d.src_endian = d.dst_endian = OHP_ENDIAN_BIG;
+            d.flags = OHP_FLAG_RAMP;
+            descs.push_back(d);
+            frames += d.n_frames;
+            batch.Add(playable, sinks[n++]);
+        }
+        TEST(frames == outFrames && lastEnd == Ramp::kMin);                      // the whole 20 ms, down to silence
+        batch.Run();
+        std::vector<TByte> got, want(packed.size());
+        for (TUint i = 0; i < n; i++) got.insert(got.end(), sinks[i].Ptr(), sinks[i].Ptr() + sinks[i].Buf().Bytes());
+        TEST(ohp_msg_process_batch(descs.data(), descs.size(), packed.data(), want.data()) == 0);
+        TEST(got.size() == want.size() && memcmp(got.data(), want.data(), want.size()) == 0);
+        TEST(!gen.TryGetAudio(msg));
+    }
+}
+
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
@@ -500,6 +579,7 @@ int main(int argc, char** argv)
             SuiteSrcGpu src(f);
             src.Run();
             SuiteFlywheelGpu(f);
+            SuiteStarvationRampGpu(f);
         }
     }
     catch (const std::exception& e) {
