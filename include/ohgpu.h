@@ -211,6 +211,76 @@ int ohgpu_flywheel_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const voi
 int ohgpu_flywheel_process_host(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs, size_t n,
                                 const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
 
+/* ---- Songcast sender frames ----
+ * Replaces, for a batch of 5 ms packets of many streams, what Sender::SendPendingAudio (Av/Songcast/Sender.cpp:307-321)
+ * and OhmSenderDriver::SendAudio (Av/Songcast/OhmSender.cpp:418-480) do per packet on the pipeline thread:
+ *   MsgPlayable::Read of every pending message (attenuation, ramp; Msg.cpp:2646-2653)      the fragment's ramp fields
+ *   Sender::DoProcessFragment (Sender.cpp:351-377): first two channels, <= 3 bytes each      fused into the same pass
+ *   OhmMsgAudio::ReinitialiseFields + Serialise (OhmMsg.cpp:203-223, 363-413),
+ *   OhmHeader::Externalise (Ohm.cpp:44-52), OhmMsgAudio::GetStreamHeader (OhmMsg.cpp:225-241)  the frame header kernel
+ * Each frame is written to dst_base + dst_offset as the datagram OhmMsgAudio::SendableBuffer hands to the socket:
+ *   "Ohm " 01 03 <total:2> | 32 <flags> <samples:2> <frame:4> <network ts:4> <media latency:4> <media ts:4> <sample start:8>
+ *   | <samples total:8> <sample rate:4> <bit rate:4> <volume offset:2> <bit depth> <channels> 00 <codec len> <codec> | audio
+ * (big endian).  Sending it, resend history and timestamping stay with the host. */
+#define OHGPU_OHM_FLAG_HALT        0x01u   /* OhmMsgAudio::kFlagHalt .. kFlagResent, OhmMsg.h:67-70 */
+#define OHGPU_OHM_FLAG_LOSSLESS    0x02u
+#define OHGPU_OHM_FLAG_TIMESTAMPED 0x04u   /* the frame also gets kFlagTimestamped2 (OhmMsg.cpp:211) */
+#define OHGPU_OHM_FLAG_RESENT      0x08u
+#define OHGPU_OHM_MAX_CODEC_BYTES  29u     /* OhmMsgAudio::kMaxCodecBytes */
+#define OHGPU_OHM_MAX_AUDIO_BYTES  5760u   /* OhmMsgAudio::kMaxSampleBytes */
+
+typedef struct ohgpu_ohm_stream {   /* 64 bytes: what Sender::ProcessMsg(MsgDecodedStream*) (Sender.cpp:217-242) fixes for a stream */
+    uint64_t samples_total;         /* TrackLength / Jiffies::PerSample */
+    uint32_t sample_rate;
+    uint32_t bit_rate;
+    int16_t  volume_offset;         /* OhmSenderDriver::SetAudioFormat passes 0 */
+    uint8_t  src_channels;          /* 1..10: the pipeline's channel count; the wire carries min(channels, 2), taken from
+                                       channel 0, or channel 8 when there are >= 10 (Sender::FirstChannelToSend) */
+    uint8_t  src_bits;              /* 8/16/24/32: the pipeline's depth; the wire carries min(bits, 24) */
+    uint8_t  codec_bytes;           /* 0..29 */
+    uint8_t  codec[29];
+    uint8_t  reserved[14];
+} ohgpu_ohm_stream;
+
+typedef struct ohgpu_ohm_fragment { /* 24 bytes: one pending message's MsgPlayable read into the frame (Sender.cpp:312-316) */
+    uint64_t src_offset;            /* packed big-endian interleaved audio at the stream's src_channels / src_bits */
+    uint32_t n_frames;
+    uint16_t ramp_start;
+    uint16_t ramp_end;
+    uint16_t attenuation;           /* 256 = unity; other values only on 16-bit audio */
+    uint8_t  flags;                 /* OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE */
+    uint8_t  reserved[5];
+} ohgpu_ohm_fragment;
+
+typedef struct ohgpu_ohm_frame_desc {   /* 48 bytes: one OhmSenderDriver::SendAudio */
+    uint64_t dst_offset;            /* the datagram starts here; ohgpu_ohm_frame_layout gives its size */
+    uint64_t sample_start;          /* iSampleStart */
+    uint32_t stream;                /* index into streams[] */
+    uint32_t frame;                 /* iFrame */
+    uint32_t network_timestamp;
+    uint32_t media_latency;         /* iLatencyOhm */
+    uint32_t media_timestamp;       /* 0 from this sender (OhmMsg.cpp:217) */
+    uint32_t first_fragment;        /* fragments[first_fragment .. first_fragment + n_fragments) make up the audio, in order */
+    uint16_t n_fragments;
+    uint8_t  flags;                 /* OHGPU_OHM_FLAG_* */
+    uint8_t  reserved[5];
+} ohgpu_ohm_frame_desc;
+
+/* Sizes of a frame of `samples` sample instants: the header (8 + 50 + codec_bytes) and the whole datagram. */
+int ohgpu_ohm_frame_layout(const ohgpu_ohm_stream* stream, uint32_t samples, uint32_t* header_bytes, uint32_t* frame_bytes);
+/* OHGPU_ERR_INVALID where the reference asserts: more audio than OhmMsgAudio::kMaxSampleBytes in a frame (Sender.cpp:364),
+ * a codec name over 29 bytes; OHGPU_ERR_UNSUPPORTED for ramped/silent/attenuated fragments of more than 8 channels. */
+int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size_t n_streams,
+                           const ohgpu_ohm_frame_desc* frames, size_t n_frames,
+                           const ohgpu_ohm_fragment* fragments, size_t n_fragments,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
+int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+/* Host-buffer convenience: H2D, run, D2H, sync (dst_host bytes that no frame covers are preserved). */
+int ohgpu_ohm_process_host(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size_t n_streams,
+                           const ohgpu_ohm_frame_desc* frames, size_t n_frames,
+                           const ohgpu_ohm_fragment* fragments, size_t n_fragments,
+                           const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
+
 /* ---- sample-rate converter (own specification; DESIGN.md "Resampler") ---- */
 /* Host-side filter design: Kaiser-windowed sinc, Q28 coefficients, coef_q28[p*T + k] = h[p + k*L].
  * Pass coef_q28 = NULL to query L, M only.  Capacity must be >= L*T. */

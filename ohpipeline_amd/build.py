@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libohgpu.so")
 
-HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip"]
+HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "ohm_frame_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip"]
 HEADERS = ["ohgpu_internal.h", "pcm_device.h", os.path.join(ROOT, "include", "ohgpu.h")]
 ARCH = "gfx950"
 BLOCK_PARTS = 3                     # OHGPU_BLOCK_PARTS in csrc/src_block_kernel.hip

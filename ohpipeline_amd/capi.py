@@ -42,6 +42,20 @@ FLYWHEEL_DESC = np.dtype([
     ("out_frames", "<u4"), ("block_frames", "<u4"), ("sample_rate", "<u4"), ("channels", "<u4"),
     ("reserved", "<u4")], align=False)
 
+OHM_FLAG_HALT, OHM_FLAG_LOSSLESS, OHM_FLAG_TIMESTAMPED, OHM_FLAG_RESENT = 1, 2, 4, 8
+OHM_STREAM = np.dtype([
+    ("samples_total", "<u8"), ("sample_rate", "<u4"), ("bit_rate", "<u4"), ("volume_offset", "<i2"),
+    ("src_channels", "u1"), ("src_bits", "u1"), ("codec_bytes", "u1"), ("codec", "u1", (29,)),
+    ("reserved", "u1", (14,))], align=False)
+OHM_FRAGMENT = np.dtype([
+    ("src_offset", "<u8"), ("n_frames", "<u4"), ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
+    ("flags", "u1"), ("reserved", "u1", (5,))], align=False)
+OHM_FRAME_DESC = np.dtype([
+    ("dst_offset", "<u8"), ("sample_start", "<u8"), ("stream", "<u4"), ("frame", "<u4"), ("network_timestamp", "<u4"),
+    ("media_latency", "<u4"), ("media_timestamp", "<u4"), ("first_fragment", "<u4"), ("n_fragments", "<u2"),
+    ("flags", "u1"), ("reserved", "u1", (5,))], align=False)
+assert OHM_STREAM.itemsize == 64 and OHM_FRAGMENT.itemsize == 24 and OHM_FRAME_DESC.itemsize == 48
+
 # every symbol of include/ohgpu.h: name -> (restype, argtypes)
 _vp, _vpp = C.c_void_p, C.POINTER(C.c_void_p)
 _u64p = C.POINTER(C.c_uint64)
@@ -77,6 +91,10 @@ SYMBOLS = {
     "ohgpu_flywheel_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_flywheel_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_flywheel_process_host": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
+    "ohgpu_ohm_frame_layout": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ohgpu_ohm_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
+    "ohgpu_ohm_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ohgpu_ohm_process_host": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
     "ohgpu_src_design": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp, C.c_size_t,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ohgpu_src_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vpp]),
@@ -265,6 +283,17 @@ class Context:
 
     def flywheel_run(self, batch, d_src, d_dst, stream=None):
         check(lib().ohgpu_flywheel_batch_run(self._h, batch, d_src, d_dst, stream))
+
+    def ohm_batch(self, streams, frames, fragments, src_arena_bytes, dst_arena_bytes):
+        st, fr, fg = np.ascontiguousarray(streams), np.ascontiguousarray(frames), np.ascontiguousarray(fragments)
+        assert st.dtype == OHM_STREAM and fr.dtype == OHM_FRAME_DESC and fg.dtype == OHM_FRAGMENT
+        b = C.c_void_p()
+        check(lib().ohgpu_ohm_batch_create(self._h, st.ctypes.data_as(C.c_void_p), st.size, fr.ctypes.data_as(C.c_void_p), fr.size,
+                                           fg.ctypes.data_as(C.c_void_p), fg.size, src_arena_bytes, dst_arena_bytes, C.byref(b)))
+        return b
+
+    def ohm_run(self, batch, d_src, d_dst, stream=None):
+        check(lib().ohgpu_ohm_batch_run(self._h, batch, d_src, d_dst, stream))
 
     def src_create(self, L, M, T, coef_q28):
         c = np.ascontiguousarray(coef_q28, dtype=np.int32)

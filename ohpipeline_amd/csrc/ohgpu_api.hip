@@ -335,6 +335,7 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     if (batch->kind == kBatchPcm) free_pcm_line(batch);
     if (batch->kind == kBatchFlywheel) free_flywheel(batch);
     if (batch->kind == kBatchFmt) { free_fmt_line(batch); free_pcm_line(batch); }
+    if (batch->kind == kBatchOhm) free_ohm(ctx, batch);
     delete batch;
     return OHGPU_OK;
 }

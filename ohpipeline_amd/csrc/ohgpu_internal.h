@@ -158,7 +158,24 @@ struct FlywheelPlan {
     void*    d_work = nullptr;    // int16 [3][max_count][lanes_padded]: decimated input, per, pef of Burg's method
 };
 
-enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3, kBatchFlywheel = 4 };
+// ---- Songcast sender frames (csrc/ohm_frame_kernel.hip) ----
+struct OhmFrameRec {              // 48 bytes: the 36 per-frame header bytes as nine big-endian words, and where they go
+    uint64_t dst_off;
+    uint32_t w[9];
+    uint32_t stream;              // index of the 64-byte stream record: bytes [0, n) = OhmMsgAudio::GetStreamHeader, byte 63 = n
+};
+struct OhmPlan {
+    ohgpu_batch* direct = nullptr;         // pcm batch: fragments of mono/stereo streams, source -> frames (ramp + depth in one pass)
+    ohgpu_batch* select = nullptr;         // fmt batch: plain fragments of wider streams, source -> frames (channel select)
+    ohgpu_batch* stage = nullptr;          // pcm batch: ramped / silent fragments of wider streams, source -> scratch
+    ohgpu_batch* select_staged = nullptr;  // fmt batch: scratch -> frames
+    void*    d_scratch = nullptr;
+    void*    d_frames = nullptr;           // OhmFrameRec[n_frames]
+    void*    d_streams = nullptr;          // 64 bytes per stream
+    uint32_t n_frames = 0;
+};
+
+enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3, kBatchFlywheel = 4, kBatchOhm = 5 };
 
 }  // namespace ohgpu
 
@@ -191,6 +208,7 @@ struct ohgpu_batch {
     ohgpu::PcmLinePlan line;      // kBatchPcm only
     ohgpu::FlywheelPlan fly;      // kBatchFlywheel only
     ohgpu::FmtLinePlan fmtline;   // kBatchFmt only
+    ohgpu::OhmPlan ohm;           // kBatchOhm only
 };
 
 namespace ohgpu {
@@ -230,5 +248,6 @@ int  design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, do
 int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n,
                    const std::vector<DevSrcDesc>& dev);
 void free_src_fast(ohgpu_batch* b);
+void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b);
 
 }  // namespace ohgpu

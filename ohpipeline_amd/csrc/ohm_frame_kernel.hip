@@ -1,0 +1,301 @@
+// ohm_frame_kernel.hip -- Songcast sender frames: the C ABI's ohgpu_ohm_* entry points.
+//
+// A frame = header + audio.  The audio of every fragment is an ordinary message for the kernels that already exist:
+//   mono / stereo streams: one PCM message (ramp, attenuation, 32 -> 24 bit) written straight into the frame -- the
+//     Sender's pack of such a stream IS the depth conversion (Sender.cpp:351-377 keeps min(bytes, 3) leading bytes);
+//   wider streams: the Sender pack's channel select (fmt_line_kernel), after a PCM pass into a scratch arena when the
+//     fragment is ramped, attenuated or silent (what MsgPlayable::Read would have applied first, Msg.cpp:2753-2786).
+// What is new here is the header: 36 per-frame bytes (OhmHeader + the per-frame part of OhmMsgAudio::Serialise,
+// OhmMsg.cpp:363-413) and the per-stream 22 + codec bytes (GetStreamHeader, :225-241), written by 32 lanes per frame.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ohgpu_internal.h"
+
+namespace ohgpu {
+
+static constexpr uint32_t kPerFrameHeader = 36;        // OhmHeader::kHeaderBytes (8) + kPerFrameBytes (28), OhmMsg.cpp:368
+static constexpr uint32_t kStreamFixed = 22;           // GetStreamHeader without the codec name
+static constexpr uint32_t kLanesPerFrame = 32;
+
+__global__ void __launch_bounds__(256)
+ohm_header_kernel(const OhmFrameRec* __restrict__ frames, uint32_t n_frames, const uint8_t* __restrict__ streams,
+                  uint8_t* __restrict__ dst)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = t / kLanesPerFrame, lane = t % kLanesPerFrame;
+    if (f >= n_frames) return;
+    const OhmFrameRec& r = frames[f];
+    const uint8_t* s = streams + (size_t)r.stream * 64;
+    const uint32_t header_bytes = kPerFrameHeader + s[63];
+    uint8_t* out = dst + r.dst_off;
+    for (uint32_t b = lane; b < header_bytes; b += kLanesPerFrame) {
+        uint32_t v;
+        if (b < kPerFrameHeader) v = (r.w[b >> 2] >> (8u * (3u - (b & 3u)))) & 0xffu;
+        else v = s[b - kPerFrameHeader];
+        out[b] = (uint8_t)v;
+    }
+}
+
+static inline void put_be(uint8_t* p, uint64_t v, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * (n - 1 - i)));
+}
+
+void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b)
+{
+    OhmPlan& p = b->ohm;
+    ohgpu_batch_destroy(ctx, p.direct);
+    ohgpu_batch_destroy(ctx, p.select);
+    ohgpu_batch_destroy(ctx, p.stage);
+    ohgpu_batch_destroy(ctx, p.select_staged);
+    if (p.d_scratch) hipFree(p.d_scratch);
+    if (p.d_frames) hipFree(p.d_frames);
+    if (p.d_streams) hipFree(p.d_streams);
+    p = OhmPlan();
+}
+
+static int check_stream(const ohgpu_ohm_stream& s, size_t i)
+{
+    if (s.src_channels < 1 || s.src_channels > 10)
+        return set_error(OHGPU_ERR_INVALID, "ohm stream %zu: channels %u outside 1..10", i, s.src_channels);
+    if (!(s.src_bits == 8 || s.src_bits == 16 || s.src_bits == 24 || s.src_bits == 32))
+        return set_error(OHGPU_ERR_INVALID, "ohm stream %zu: bit depth %u (must be 8/16/24/32)", i, s.src_bits);
+    if (s.codec_bytes > OHGPU_OHM_MAX_CODEC_BYTES)                     // Bws<kMaxCodecBytes>, OhmMsg.h:66
+        return set_error(OHGPU_ERR_INVALID, "ohm stream %zu: codec name of %u bytes (limit 29)", i, s.codec_bytes);
+    return OHGPU_OK;
+}
+
+static inline uint32_t wire_channels(const ohgpu_ohm_stream& s) { return s.src_channels < 2 ? s.src_channels : 2; }
+static inline uint32_t wire_bytes(const ohgpu_ohm_stream& s) { return s.src_bits / 8 < 3 ? s.src_bits / 8 : 3; }
+
+}  // namespace ohgpu
+
+using namespace ohgpu;
+
+extern "C" {
+
+int ohgpu_ohm_frame_layout(const ohgpu_ohm_stream* stream, uint32_t samples, uint32_t* header_bytes, uint32_t* frame_bytes)
+{
+    if (!stream) return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_frame_layout: null stream");
+    const int err = check_stream(*stream, 0);
+    if (err != OHGPU_OK) return err;
+    const uint32_t hb = kPerFrameHeader + kStreamFixed + stream->codec_bytes;
+    const uint64_t audio = (uint64_t)samples * wire_channels(*stream) * wire_bytes(*stream);
+    if (audio > OHGPU_OHM_MAX_AUDIO_BYTES)
+        return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_frame_layout: %u samples need %llu audio bytes (OhmMsgAudio::kMaxSampleBytes is 5760)",
+                         samples, (unsigned long long)audio);
+    if (header_bytes) *header_bytes = hb;
+    if (frame_bytes) *frame_bytes = hb + (uint32_t)audio;
+    return OHGPU_OK;
+}
+
+int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size_t n_streams,
+                           const ohgpu_ohm_frame_desc* frames, size_t n_frames,
+                           const ohgpu_ohm_fragment* fragments, size_t n_fragments,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
+{
+    if (!ctx) return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_create: null context");
+    OHGPU_HIP_TRY(hipSetDevice(ctx->device));
+    if (!out || (n_streams && !streams) || (n_frames && !frames) || (n_fragments && !fragments))
+        return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_create: null argument");
+    *out = nullptr;
+    if (n_frames > 0x03ffffffull || n_fragments > 0xffffffffull || n_streams > 0xffffffffull)
+        return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_create: too many descriptors");
+    for (size_t i = 0; i < n_streams; i++) {
+        const int err = check_stream(streams[i], i);
+        if (err != OHGPU_OK) return err;
+    }
+
+    std::vector<OhmFrameRec> recs(n_frames);
+    std::vector<uint8_t> stream_recs(n_streams * 64, 0);
+    for (size_t i = 0; i < n_streams; i++) {                          // OhmMsgAudio::GetStreamHeader, OhmMsg.cpp:225-241
+        const ohgpu_ohm_stream& s = streams[i];
+        uint8_t* p = &stream_recs[i * 64];
+        put_be(p, s.samples_total, 8);
+        put_be(p + 8, s.sample_rate, 4);
+        put_be(p + 12, s.bit_rate, 4);
+        put_be(p + 16, (uint16_t)s.volume_offset, 2);
+        p[18] = (uint8_t)(s.src_bits < 24 ? s.src_bits : 24);          // Sender.cpp:226
+        p[19] = (uint8_t)wire_channels(s);                             // Sender.cpp:235
+        p[20] = 0;                                                     // kReserved
+        p[21] = s.codec_bytes;
+        memcpy(p + 22, s.codec, s.codec_bytes);
+        p[63] = (uint8_t)(kStreamFixed + s.codec_bytes);
+    }
+
+    std::vector<ohgpu_msg_desc> direct, stage;
+    std::vector<ohgpu_fmt_desc> select, select_staged;
+    uint64_t scratch_bytes = 0, in_frames = 0, src_touched = 0, dst_written = 0;
+    for (size_t f = 0; f < n_frames; f++) {
+        const ohgpu_ohm_frame_desc& fr = frames[f];
+        if (fr.stream >= n_streams) return set_error(OHGPU_ERR_INVALID, "ohm frame %zu: stream %u of %zu", f, fr.stream, n_streams);
+        if (fr.flags & ~(OHGPU_OHM_FLAG_HALT | OHGPU_OHM_FLAG_LOSSLESS | OHGPU_OHM_FLAG_TIMESTAMPED | OHGPU_OHM_FLAG_RESENT))
+            return set_error(OHGPU_ERR_INVALID, "ohm frame %zu: unknown flag bits 0x%x", f, fr.flags);
+        if ((uint64_t)fr.first_fragment + fr.n_fragments > n_fragments)
+            return set_error(OHGPU_ERR_INVALID, "ohm frame %zu: fragments [%u, +%u) of %zu", f, fr.first_fragment, fr.n_fragments, n_fragments);
+        const ohgpu_ohm_stream& s = streams[fr.stream];
+        const uint32_t ch = s.src_channels, wch = wire_channels(s), wb = wire_bytes(s);
+        const uint32_t header_bytes = kPerFrameHeader + kStreamFixed + s.codec_bytes;
+        uint64_t samples = 0;
+        for (uint32_t g = 0; g < fr.n_fragments; g++) samples += fragments[fr.first_fragment + g].n_frames;
+        const uint64_t audio_bytes = samples * wch * wb;
+        if (audio_bytes > OHGPU_OHM_MAX_AUDIO_BYTES)                   // ASSERT(iAudioBuf->BytesRemaining() >= totalBytesToCopy), Sender.cpp:364
+            return set_error(OHGPU_ERR_INVALID, "ohm frame %zu: %llu audio bytes (OhmMsgAudio::kMaxSampleBytes is 5760)", f, (unsigned long long)audio_bytes);
+        const uint64_t frame_bytes = header_bytes + audio_bytes;
+        if (fr.dst_offset > dst_arena_bytes || frame_bytes > dst_arena_bytes - fr.dst_offset)
+            return set_error(OHGPU_ERR_BOUNDS, "ohm frame %zu: writes [%llu, +%llu) beyond the %llu-byte destination arena", f,
+                             (unsigned long long)fr.dst_offset, (unsigned long long)frame_bytes, (unsigned long long)dst_arena_bytes);
+        // ---- header: OhmHeader::Externalise (Ohm.cpp:44-52) then OhmMsgAudio::Serialise (OhmMsg.cpp:385-411) ----
+        OhmFrameRec& r = recs[f];
+        uint32_t flags = fr.flags;
+        if (flags & OHGPU_OHM_FLAG_TIMESTAMPED) flags |= 0x10u;        // kFlagTimestamped2: iTimestamped2 = iTimestamped, OhmMsg.cpp:211
+        r.dst_off = fr.dst_offset;
+        r.stream = fr.stream;
+        r.w[0] = 0x4f686d20u;                                          // "Ohm "
+        r.w[1] = (1u << 24) | (3u << 16) | (uint32_t)frame_bytes;      // kMajor, kMsgTypeAudio, iBytes
+        r.w[2] = (50u << 24) | (flags << 16) | (uint32_t)samples;      // kHeaderBytes, flags, iSamples
+        r.w[3] = fr.frame;
+        r.w[4] = fr.network_timestamp;
+        r.w[5] = fr.media_latency;
+        r.w[6] = fr.media_timestamp;
+        r.w[7] = (uint32_t)(fr.sample_start >> 32);
+        r.w[8] = (uint32_t)fr.sample_start;
+        // ---- audio: one message per fragment ----
+        uint64_t at = fr.dst_offset + header_bytes;
+        for (uint32_t g = 0; g < fr.n_fragments; g++) {
+            const ohgpu_ohm_fragment& fg = fragments[fr.first_fragment + g];
+            const size_t gi = (size_t)fr.first_fragment + g;
+            if (fg.flags & ~(OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE))
+                return set_error(OHGPU_ERR_INVALID, "ohm fragment %zu: unknown flag bits 0x%x", gi, fg.flags);
+            const bool plain = !(fg.flags & (OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE)) && fg.attenuation == OHGPU_UNITY_ATTENUATION;
+            const uint64_t src_bytes = (uint64_t)fg.n_frames * ch * (s.src_bits / 8);
+            ohgpu_msg_desc m;
+            memset(&m, 0, sizeof(m));
+            m.src_offset = fg.src_offset;
+            m.n_frames = fg.n_frames;
+            m.ramp_start = fg.ramp_start;
+            m.ramp_end = fg.ramp_end;
+            m.attenuation = fg.attenuation;
+            m.channels = (uint8_t)ch;
+            m.src_bits = s.src_bits;
+            m.src_endian = OHGPU_ENDIAN_BIG;
+            m.dst_endian = OHGPU_ENDIAN_BIG;
+            m.flags = fg.flags;
+            ohgpu_fmt_desc p;
+            memset(&p, 0, sizeof(p));
+            p.dst_offset = at;
+            p.n_frames = fg.n_frames;
+            p.kind = OHGPU_FMT_SENDER_PACK;
+            p.channels = (uint8_t)ch;
+            p.src_bits = s.src_bits;
+            if (fg.n_frames == 0) {
+                // nothing to write
+            } else if (ch <= 2) {
+                m.dst_offset = at;
+                m.dst_bits = (uint8_t)(wb * 8);
+                direct.push_back(m);
+            } else if (plain) {
+                p.src_offset = fg.src_offset;
+                select.push_back(p);
+            } else {
+                if (ch > OHGPU_MAX_CHANNELS)
+                    return set_error(OHGPU_ERR_UNSUPPORTED, "ohm fragment %zu: ramp / silence / attenuation on %u channels (MsgPlayable carries at most 8)", gi, ch);
+                m.dst_offset = scratch_bytes;
+                m.dst_bits = s.src_bits;
+                stage.push_back(m);
+                p.src_offset = scratch_bytes;
+                select_staged.push_back(p);
+                scratch_bytes += (src_bytes + 63) & ~63ull;
+            }
+            in_frames += fg.n_frames;
+            if (!(fg.flags & OHGPU_FLAG_SILENCE)) src_touched += src_bytes;
+            at += (uint64_t)fg.n_frames * wch * wb;
+        }
+        dst_written += frame_bytes;
+    }
+
+    ohgpu_batch* b = new (std::nothrow) ohgpu_batch();
+    if (!b) return set_error(OHGPU_ERR_NOMEM, "ohgpu_ohm_batch_create: out of host memory");
+    b->kind = kBatchOhm;
+    b->n = n_frames;
+    b->src_arena_bytes = src_arena_bytes;
+    b->dst_arena_bytes = dst_arena_bytes;
+    b->in_frames = b->out_frames = in_frames;
+    b->src_bytes_touched = src_touched;
+    b->dst_bytes_written = dst_written;
+    OhmPlan& plan = b->ohm;
+    plan.n_frames = (uint32_t)n_frames;
+    int err = OHGPU_OK;
+    auto dev_copy = [&](void** d, const void* h, size_t bytes) -> int {
+        if (bytes == 0) return OHGPU_OK;
+        hipError_t e = hipMalloc(d, bytes);
+        if (e == hipErrorOutOfMemory) return set_error(OHGPU_ERR_NOMEM, "ohgpu_ohm_batch_create: out of device memory");
+        OHGPU_HIP_TRY(e);
+        if (h) OHGPU_HIP_TRY(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        return OHGPU_OK;
+    };
+    if (!direct.empty()) err = ohgpu_pcm_batch_create(ctx, direct.data(), direct.size(), src_arena_bytes, dst_arena_bytes, &plan.direct);
+    if (err == OHGPU_OK && !select.empty())
+        err = ohgpu_fmt_batch_create(ctx, select.data(), select.size(), src_arena_bytes, dst_arena_bytes, &plan.select);
+    if (err == OHGPU_OK && !stage.empty())
+        err = ohgpu_pcm_batch_create(ctx, stage.data(), stage.size(), src_arena_bytes, scratch_bytes, &plan.stage);
+    if (err == OHGPU_OK && !select_staged.empty())
+        err = ohgpu_fmt_batch_create(ctx, select_staged.data(), select_staged.size(), scratch_bytes, dst_arena_bytes, &plan.select_staged);
+    if (err == OHGPU_OK) err = dev_copy(&plan.d_scratch, nullptr, scratch_bytes);
+    if (err == OHGPU_OK) err = dev_copy(&plan.d_frames, recs.data(), recs.size() * sizeof(OhmFrameRec));
+    if (err == OHGPU_OK) err = dev_copy(&plan.d_streams, stream_recs.data(), stream_recs.size());
+    if (err != OHGPU_OK) { free_ohm(ctx, b); delete b; return err; }
+    *out = b;
+    return OHGPU_OK;
+}
+
+int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
+{
+    if (!ctx) return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_run: null context");
+    OHGPU_HIP_TRY(hipSetDevice(ctx->device));
+    if (!batch || batch->kind != kBatchOhm) return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_run: not a Songcast frame batch");
+    if (batch->n == 0) return OHGPU_OK;
+    if (!dst_base || (!src_base && batch->src_bytes_touched)) return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_run: null arena pointer");
+    const OhmPlan& p = batch->ohm;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int err = OHGPU_OK;
+    if (p.direct) err = ohgpu_pcm_batch_run(ctx, p.direct, src_base, dst_base, s);
+    if (err == OHGPU_OK && p.select) err = ohgpu_fmt_batch_run(ctx, p.select, src_base, dst_base, s);
+    if (err == OHGPU_OK && p.stage) err = ohgpu_pcm_batch_run(ctx, p.stage, src_base, p.d_scratch, s);
+    if (err == OHGPU_OK && p.select_staged) err = ohgpu_fmt_batch_run(ctx, p.select_staged, p.d_scratch, dst_base, s);
+    if (err != OHGPU_OK) return err;
+    const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame;
+    const uint32_t blocks = (p.n_frames + frames_per_block - 1) / frames_per_block;
+    hipLaunchKernelGGL(ohm_header_kernel, dim3(blocks), dim3(threads), 0, s,
+                       (const OhmFrameRec*)p.d_frames, p.n_frames, (const uint8_t*)p.d_streams, (uint8_t*)dst_base);
+    OHGPU_HIP_TRY(hipGetLastError());
+    return OHGPU_OK;
+}
+
+int ohgpu_ohm_process_host(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size_t n_streams,
+                           const ohgpu_ohm_frame_desc* frames, size_t n_frames,
+                           const ohgpu_ohm_fragment* fragments, size_t n_fragments,
+                           const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes)
+{
+    ohgpu_batch* b = nullptr;
+    int err = ohgpu_ohm_batch_create(ctx, streams, n_streams, frames, n_frames, fragments, n_fragments, src_bytes, dst_bytes, &b);
+    if (err != OHGPU_OK) return err;
+    void *d_src = nullptr, *d_dst = nullptr;
+    err = ohgpu_malloc(ctx, src_bytes, &d_src);
+    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
+    if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
+    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);   // bytes no frame covers stay as given
+    if (err == OHGPU_OK) err = ohgpu_ohm_batch_run(ctx, b, d_src, d_dst, nullptr);
+    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
+    if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
+    if (d_src) ohgpu_free(ctx, d_src);
+    if (d_dst) ohgpu_free(ctx, d_dst);
+    ohgpu_batch_destroy(ctx, b);
+    return err;
+}
+
+}  // extern "C"

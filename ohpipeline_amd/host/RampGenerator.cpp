@@ -95,7 +95,11 @@ RampGenerator::RampGenerator(MsgFactory& aFactory, TUint aInputJiffies, TUint aR
 
 RampGenerator::~RampGenerator()
 {
-    ASSERT(iQueue.empty());                              // :227
+    // the reference asserts the queue was drained (:227); a destructor must not throw, so undelivered messages are released
+    while (!iQueue.empty()) {
+        iQueue.front()->RemoveRef();
+        iQueue.pop_front();
+    }
 }
 
 void RampGenerator::Start(const Brx& aRecentAudio, TUint aSampleRate, TUint aNumChannels, TUint aBitDepth, TUint aCurrentRampValue)

@@ -59,11 +59,10 @@ class Playable(C.Structure):
 
 def build(force=False):
     """Compile the oracle with its own Makefile (gcc -O2)."""
-    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("ohp_oracle.c", "ohp_pipeline.c", "ohp_oracle.h", "ohp_pipeline.h")]
-    stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
+    stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
 
@@ -73,6 +72,29 @@ _lib = None
 class FeedbackModel(C.Structure):
     _fields_ = [("coeffs", C.c_void_p), ("samples", C.c_void_p), ("state_count", C.c_uint32),
                 ("data_descale_bits", C.c_uint32), ("coeff_format", C.c_uint32), ("scale_shift_for_output", C.c_int32)]
+
+
+class OhmAudio(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("msg_type", "msg_bytes", "halt", "lossless", "timestamped", "timestamped2", "resent",
+                                          "samples", "frame", "network_timestamp", "media_latency", "media_timestamp")] + \
+               [("sample_start", C.c_uint64), ("samples_total", C.c_uint64), ("sample_rate", C.c_uint32), ("bit_rate", C.c_uint32),
+                ("volume_offset", C.c_int32), ("bit_depth", C.c_uint32), ("channels", C.c_uint32), ("codec_bytes", C.c_uint32),
+                ("codec", C.c_uint8 * 32), ("audio_offset", C.c_uint32), ("audio_bytes", C.c_uint32)]
+
+
+class SenderFragment(C.Structure):
+    _fields_ = [("msg", C.c_uint32), ("playable", Playable)]
+
+
+class SenderPacket(C.Structure):
+    _fields_ = [("first_fragment", C.c_uint32), ("n_fragments", C.c_uint32)]
+
+
+class OhmDriver(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("bytes_per_sample", C.c_uint32), ("lossless", C.c_uint32), ("latency_ms", C.c_uint32),
+                ("latency_ohm", C.c_uint32), ("timestamp_multiplier", C.c_uint32), ("sample_start", C.c_uint64),
+                ("samples_total", C.c_uint64), ("frame", C.c_uint32), ("first_frame", C.c_uint32), ("send", C.c_uint32),
+                ("stream_header", C.c_uint8 * 88), ("stream_header_bytes", C.c_uint32)]
 
 
 def lib():
@@ -133,6 +155,18 @@ def lib():
         "ohp_feedback_init": (None, [C.POINTER(FeedbackModel), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
         "ohp_feedback_next_sample": (C.c_int32, [C.POINTER(FeedbackModel)]),
         "ohp_flywheel_ramp": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+        "ohp_ohm_stream_header": (C.c_int, [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, vp, C.c_uint32]),
+        "ohp_ohm_audio_frame": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                          vp, C.c_uint32, vp, C.c_uint32]),
+        "ohp_ohm_audio_parse": (C.c_int, [vp, C.c_uint32, C.POINTER(OhmAudio)]),
+        "ohp_sender_packetise": (C.c_int, [C.POINTER(MsgAudio), C.c_uint32, C.c_int, C.POINTER(SenderFragment), C.c_uint32, u32p,
+                                           C.POINTER(SenderPacket), C.c_uint32, u32p]),
+        "ohp_ohm_driver_init": (None, [C.POINTER(OhmDriver), C.c_uint32]),
+        "ohp_ohm_driver_set_track_position": (None, [C.POINTER(OhmDriver), C.c_uint64, C.c_uint64]),
+        "ohp_ohm_driver_set_audio_format": (C.c_int, [C.POINTER(OhmDriver), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                      vp, C.c_uint32, C.c_uint64]),
+        "ohp_ohm_driver_send_audio": (C.c_int, [C.POINTER(OhmDriver), vp, C.c_uint32, C.c_int, vp, C.c_uint32]),
+        "ohp_ohm_driver_stream_interrupted": (None, [C.POINTER(OhmDriver)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -232,3 +266,68 @@ class Src:
                 self.h = None
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------ Songcast sender (oracle/ohp_songcast.h)
+def ohm_stream_header(samples_total, sample_rate, bit_rate, volume_offset, bit_depth, channels, codec=b""):
+    buf = np.zeros(88, dtype=np.uint8)
+    c = np.frombuffer(bytes(codec) or b"\0", dtype=np.uint8).copy()
+    n = lib().ohp_ohm_stream_header(_ptr(buf), buf.size, samples_total, sample_rate, bit_rate, volume_offset, bit_depth,
+                                    channels, _ptr(c), len(codec))
+    return n, buf[:max(n, 0)].copy()
+
+
+def ohm_audio_frame(flags, samples, frame, network_timestamp, media_latency, sample_start, stream_header, audio):
+    out = np.zeros(8192, dtype=np.uint8)
+    sh = np.ascontiguousarray(np.frombuffer(bytes(stream_header), dtype=np.uint8))
+    au = np.ascontiguousarray(np.frombuffer(bytes(audio) or b"\0", dtype=np.uint8))
+    n = lib().ohp_ohm_audio_frame(_ptr(out), out.size, flags, samples, frame, network_timestamp, media_latency, sample_start,
+                                  _ptr(sh), sh.size, _ptr(au), len(bytes(audio)))
+    return n, out[:max(n, 0)].copy()
+
+
+def ohm_audio_parse(datagram):
+    d = np.ascontiguousarray(np.frombuffer(bytes(datagram), dtype=np.uint8))
+    out = OhmAudio()
+    err = lib().ohp_ohm_audio_parse(_ptr(d), d.size, C.byref(out))
+    return err, out
+
+
+def sender_packetise(msgs, flush=True):
+    """msgs: list of MsgAudio.  Returns (err, [SenderFragment], [SenderPacket])."""
+    arr = (MsgAudio * max(len(msgs), 1))(*msgs)
+    cap = 16 * len(msgs) + 64
+    frags, packs = (SenderFragment * cap)(), (SenderPacket * cap)()
+    nf, npk = C.c_uint32(0), C.c_uint32(0)
+    err = lib().ohp_sender_packetise(arr, len(msgs), 1 if flush else 0, frags, cap, C.byref(nf), packs, cap, C.byref(npk))
+    return err, list(frags[:nf.value]), list(packs[:npk.value])
+
+
+def songcast_datagrams(driver, msgs, audio, flush=True, halt_last=False):
+    """The reference's Sender + OhmSenderDriver over messages msgs[i] (MsgAudio) whose DecodedAudio is audio[i] (uint8 array,
+    None for silence): packetise, read every fragment's playable (attenuation, ramp), Sender pack, frame.  Returns the list
+    of datagrams (uint8 arrays) in send order."""
+    err, frags, packs = sender_packetise(msgs, flush)
+    assert err == 0, err
+    out = []
+    for k, pk in enumerate(packs):
+        payload = []
+        for f in frags[pk.first_fragment:pk.first_fragment + pk.n_fragments]:
+            a = None if audio[f.msg] is None else np.array(audio[f.msg], dtype=np.uint8)    # Read attenuates in place: work on a copy
+            e, pcm, _ = playable_read(f.playable, a)
+            assert e == 0, e
+            if pcm.size == 0:
+                continue
+            packed = np.zeros(pcm.size, dtype=np.uint8)
+            nb = C.c_uint32(0)
+            assert lib().ohp_sender_pack(_ptr(pcm), pcm.size, f.playable.channels, f.playable.bit_depth // 8, _ptr(packed), C.byref(nb)) == 0
+            payload.append(packed[:nb.value])
+        au = np.concatenate(payload) if payload else np.zeros(0, dtype=np.uint8)
+        buf = np.zeros(8192, dtype=np.uint8)
+        aptr = np.ascontiguousarray(au if au.size else np.zeros(1, dtype=np.uint8))
+        n = lib().ohp_ohm_driver_send_audio(C.byref(driver), _ptr(aptr), au.size, 1 if (halt_last and k == len(packs) - 1) else 0,
+                                            _ptr(buf), buf.size)
+        assert n >= 0, n
+        if n > 0:
+            out.append(buf[:n].copy())
+    return out

@@ -50,6 +50,26 @@ def test_struct_layouts_match_header(tmp_path):
     assert out[6] == capi.SRC_MSG_DESC.fields["flags"][1] == 55
 
 
+def test_songcast_struct_layouts_match_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ohgpu.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ohgpu_ohm_stream), sizeof(ohgpu_ohm_fragment),'
+                   'sizeof(ohgpu_ohm_frame_desc), offsetof(ohgpu_ohm_stream, codec), offsetof(ohgpu_ohm_fragment, flags),'
+                   'offsetof(ohgpu_ohm_frame_desc, first_fragment), offsetof(ohgpu_ohm_frame_desc, flags),'
+                   'sizeof(ohgpu_flywheel_desc));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == capi.OHM_STREAM.itemsize == 64
+    assert out[1] == capi.OHM_FRAGMENT.itemsize == 24
+    assert out[2] == capi.OHM_FRAME_DESC.itemsize == 48
+    assert out[3] == capi.OHM_STREAM.fields["codec"][1] == 21
+    assert out[4] == capi.OHM_FRAGMENT.fields["flags"][1] == 18
+    assert out[5] == capi.OHM_FRAME_DESC.fields["first_fragment"][1] == 36
+    assert out[6] == capi.OHM_FRAME_DESC.fields["flags"][1] == 42
+    assert out[7] == capi.FLYWHEEL_DESC.itemsize == 48
+
+
 def test_ramp_table_equals_reference_data():
     """The table the DEVICE uses (generated in host_design.cpp) equals RampArray.h:7-74 entry for entry."""
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "ramp_table_q15.json")))["values"]
