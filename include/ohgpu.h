@@ -239,7 +239,9 @@ typedef struct ohgpu_ohm_stream {   /* 64 bytes: what Sender::ProcessMsg(MsgDeco
     uint8_t  src_bits;              /* 8/16/24/32: the pipeline's depth; the wire carries min(bits, 24) */
     uint8_t  codec_bytes;           /* 0..29 */
     uint8_t  codec[29];
-    uint8_t  reserved[14];
+    uint8_t  src_endian;            /* 0 or OHGPU_ENDIAN_BIG: audio as DecodedAudio stores it (always big endian in the
+                                       reference); OHGPU_ENDIAN_LITTLE: codec output not yet swapped (row a1 fused in) */
+    uint8_t  reserved[13];
 } ohgpu_ohm_stream;
 
 typedef struct ohgpu_ohm_fragment { /* 24 bytes: one pending message's MsgPlayable read into the frame (Sender.cpp:312-316) */

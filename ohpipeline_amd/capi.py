@@ -46,7 +46,7 @@ OHM_FLAG_HALT, OHM_FLAG_LOSSLESS, OHM_FLAG_TIMESTAMPED, OHM_FLAG_RESENT = 1, 2, 
 OHM_STREAM = np.dtype([
     ("samples_total", "<u8"), ("sample_rate", "<u4"), ("bit_rate", "<u4"), ("volume_offset", "<i2"),
     ("src_channels", "u1"), ("src_bits", "u1"), ("codec_bytes", "u1"), ("codec", "u1", (29,)),
-    ("reserved", "u1", (14,))], align=False)
+    ("src_endian", "u1"), ("reserved", "u1", (13,))], align=False)
 OHM_FRAGMENT = np.dtype([
     ("src_offset", "<u8"), ("n_frames", "<u4"), ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
     ("flags", "u1"), ("reserved", "u1", (5,))], align=False)

@@ -64,6 +64,8 @@ static int check_stream(const ohgpu_ohm_stream& s, size_t i)
         return set_error(OHGPU_ERR_INVALID, "ohm stream %zu: channels %u outside 1..10", i, s.src_channels);
     if (!(s.src_bits == 8 || s.src_bits == 16 || s.src_bits == 24 || s.src_bits == 32))
         return set_error(OHGPU_ERR_INVALID, "ohm stream %zu: bit depth %u (must be 8/16/24/32)", i, s.src_bits);
+    if (!(s.src_endian == 0 || s.src_endian == OHGPU_ENDIAN_BIG || s.src_endian == OHGPU_ENDIAN_LITTLE))
+        return set_error(OHGPU_ERR_INVALID, "ohm stream %zu: endian %u", i, s.src_endian);
     if (s.codec_bytes > OHGPU_OHM_MAX_CODEC_BYTES)                     // Bws<kMaxCodecBytes>, OhmMsg.h:66
         return set_error(OHGPU_ERR_INVALID, "ohm stream %zu: codec name of %u bytes (limit 29)", i, s.codec_bytes);
     return OHGPU_OK;
@@ -171,7 +173,8 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
             const size_t gi = (size_t)fr.first_fragment + g;
             if (fg.flags & ~(OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE))
                 return set_error(OHGPU_ERR_INVALID, "ohm fragment %zu: unknown flag bits 0x%x", gi, fg.flags);
-            const bool plain = !(fg.flags & (OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE)) && fg.attenuation == OHGPU_UNITY_ATTENUATION;
+            const bool little = s.src_endian == OHGPU_ENDIAN_LITTLE && s.src_bits > 8;
+            const bool plain = !(fg.flags & (OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE)) && fg.attenuation == OHGPU_UNITY_ATTENUATION && !little;
             const uint64_t src_bytes = (uint64_t)fg.n_frames * ch * (s.src_bits / 8);
             ohgpu_msg_desc m;
             memset(&m, 0, sizeof(m));
@@ -182,7 +185,7 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
             m.attenuation = fg.attenuation;
             m.channels = (uint8_t)ch;
             m.src_bits = s.src_bits;
-            m.src_endian = OHGPU_ENDIAN_BIG;
+            m.src_endian = little ? OHGPU_ENDIAN_LITTLE : OHGPU_ENDIAN_BIG;
             m.dst_endian = OHGPU_ENDIAN_BIG;
             m.flags = fg.flags;
             ohgpu_fmt_desc p;

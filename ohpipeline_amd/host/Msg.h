@@ -23,6 +23,7 @@
 
 #include <atomic>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "OhTypes.h"
@@ -36,6 +37,7 @@ namespace Media {
 
 enum class AudioDataEndian { Invalid, Little, Big };     // Msg.h:107-112
 enum class AudioFormat { Pcm, Dsd, Undefined };
+enum class Multiroom { Allowed, Forbidden };              // Msg.h:584-588
 
 class MsgMode; class MsgTrack; class MsgDrain; class MsgDelay; class MsgEncodedStream; class MsgStreamSegment;
 class MsgAudioEncoded; class MsgMetaText; class MsgStreamInterrupted; class MsgHalt; class MsgFlush; class MsgWait;
@@ -168,6 +170,13 @@ public:
     TUint64 iTrackLength = 0, iSampleStart = 0;
     TBool iLossless = true, iSeekable = false, iLive = false;
     AudioFormat iFormat = AudioFormat::Pcm;
+    Media::Multiroom iMultiroom = Media::Multiroom::Allowed;
+    std::string iCodecName;
+    TUint BitRate() const { return iBitRate; }
+    TUint64 TrackLength() const { return iTrackLength; }             // jiffies
+    TBool Lossless() const { return iLossless; }
+    Media::Multiroom Multiroom() const { return iMultiroom; }
+    Brn CodecName() const { return Brn((const TByte*)iCodecName.data(), (TUint)iCodecName.size()); }
     TUint StreamId() const { return iStreamId; }
     TUint BitDepth() const { return iBitDepth; }
     TUint SampleRate() const { return iSampleRate; }

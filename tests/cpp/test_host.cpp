@@ -3,6 +3,7 @@
 // messages, elements pulled through a suite that acts as the upstream element, results inspected through an
 // IPcmProcessor.  `test_host cpu` runs the control-plane checks (no GPU); `test_host gpu` also reads audio through the
 // C ABI and compares the bytes with the CPU oracle.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -13,9 +14,11 @@
 #include "../../ohpipeline_amd/host/Msg.h"
 #include "../../ohpipeline_amd/host/RampGenerator.h"
 #include "../../ohpipeline_amd/host/SampleRateConverter.h"
+#include "../../ohpipeline_amd/host/Sender.h"
 #include "../../oracle/ohp_flywheel.h"
 #include "../../oracle/ohp_oracle.h"
 #include "../../oracle/ohp_pipeline.h"
+#include "../../oracle/ohp_songcast.h"
 
 using namespace OpenHome;
 using namespace OpenHome::Media;
@@ -554,6 +557,215 @@ static void SuiteStarvationRampGpu(MsgFactory& aFactory)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------- Songcast sender (N3)
+// Messages pushed at the Sender element the way the pipeline does (Sender.cpp:117-123); the datagrams it hands to the sink
+// are compared with the oracle's Sender + OhmSenderDriver + OhmMsgAudio fed the same messages.
+namespace {
+
+struct DatagramCollector : public Av::IOhmDatagramSink {
+    std::vector<std::vector<TByte>> grams;
+    void Send(const Brx& aDatagram) override { grams.emplace_back(aDatagram.Ptr(), aDatagram.Ptr() + aDatagram.Bytes()); }
+};
+
+struct SongcastStream {
+    TUint rate, channels, bits;
+    AudioDataEndian endian;
+    const char* codec;
+    TUint latencyMs;
+    TUint64 sampleStart, trackLengthJiffies;
+    // what was pushed, for the oracle
+    std::vector<ohp_msg_audio> msgs;
+    std::vector<std::vector<TByte>> audio;               // big endian, empty for silence
+    DatagramCollector sink;
+};
+
+// Pushes a MsgDecodedStream and n audio messages (some ramped across message boundaries, some silence) at aSender and
+// records the same messages for the oracle.
+void FeedStream(MsgFactory& aFactory, Av::Sender& aSender, SongcastStream& aStream, TUint aMsgs, uint32_t& aSeed)
+{
+    DecodedStreamInfo info;
+    info.iBitDepth = aStream.bits; info.iSampleRate = aStream.rate; info.iNumChannels = aStream.channels;
+    info.iBitRate = aStream.rate * aStream.bits * aStream.channels;
+    info.iTrackLength = aStream.trackLengthJiffies; info.iSampleStart = aStream.sampleStart;
+    info.iLossless = true; info.iCodecName = aStream.codec;
+    aSender.Push(aFactory.CreateMsgDecodedStream(info));
+    const TUint frameBytes = aStream.channels * aStream.bits / 8;
+    TUint rampRemaining = 0, rampValue = Ramp::kMax;
+    Ramp::EDirection rampDir = Ramp::ENone;
+    auto record = [&](MsgAudio* aMsg, const std::vector<TByte>& aBigEndian, TUint aOffsetBytes, TBool aSilence) {
+        ohp_msg_audio m;
+        if (aSilence) {
+            uint32_t j = aMsg->Jiffies();
+            TEST(ohp_msg_audio_init_silence(&m, &j, aStream.rate, aStream.bits, aStream.channels) == 0 && j == aMsg->Jiffies());
+        }
+        else {
+            TEST(ohp_msg_audio_init_pcm(&m, (uint32_t)aBigEndian.size(), aStream.channels, aStream.rate, aStream.bits) == 0);
+            m.offset_jiffies = (aOffsetBytes / frameBytes) * Jiffies::PerSample(aStream.rate);
+            m.size_jiffies = aMsg->Jiffies();
+        }
+        m.ramp.start = aMsg->Ramp().Start(); m.ramp.end = aMsg->Ramp().End();
+        m.ramp.direction = (uint32_t)aMsg->Ramp().Direction(); m.ramp.enabled = aMsg->Ramp().IsEnabled() ? 1 : 0;
+        aStream.msgs.push_back(m);
+        aStream.audio.push_back(aSilence ? std::vector<TByte>() : aBigEndian);
+    };
+    for (TUint k = 0; k < aMsgs; k++) {
+        aSeed = aSeed * 1664525u + 1013904223u;
+        const TUint maxFrames = std::min(aStream.rate / 60, DecodedAudio::kMaxBytes / frameBytes);
+        const TUint frames = 1 + (aSeed >> 8) % maxFrames;
+        const TUint kind = (aSeed >> 3) % 9;
+        MsgAudio* msg;
+        std::vector<TByte> be;
+        const TBool silence = (kind == 0);
+        if (silence) {
+            TUint jiffies = frames * Jiffies::PerSample(aStream.rate);
+            msg = aFactory.CreateMsgSilence(jiffies, aStream.rate, aStream.bits, aStream.channels);
+        }
+        else {
+            std::vector<TByte> data((size_t)frames * frameBytes);
+            for (auto& b : data) { aSeed = aSeed * 1664525u + 1013904223u; b = (TByte)(aSeed >> 24); }
+            be.resize(data.size());
+            TEST(ohp_construct_pcm(data.data(), (uint32_t)data.size(), aStream.bits,
+                                   aStream.endian == AudioDataEndian::Little ? OHP_ENDIAN_LITTLE : OHP_ENDIAN_BIG, be.data()) == 0);
+            msg = aFactory.CreateMsgAudioPcm(Brn(data.data(), (TUint)data.size()), aStream.channels, aStream.rate, aStream.bits, aStream.endian, 0);
+        }
+        if (rampRemaining == 0 && kind == 1) {           // start a ~12 ms ramp down, then one back up: they cross message boundaries
+            rampRemaining = (aStream.rate / 83) * Jiffies::PerSample(aStream.rate);        // whole samples, so every split lands on one
+            rampDir = (rampValue == Ramp::kMax) ? Ramp::EDown : Ramp::EUp;
+        }
+        if (rampRemaining > 0) {
+            if (msg->Jiffies() > rampRemaining) {        // the ramp ends inside this message: what Ramper / Stopper do
+                MsgAudio* rest = msg->Split(rampRemaining);
+                MsgAudio* split = nullptr;
+                rampValue = msg->SetRamp(rampValue, rampRemaining, rampDir, split);
+                TEST(split == nullptr && rampRemaining == 0);
+                const TUint firstBytes = (TUint)((TUint64)msg->Jiffies() / Jiffies::PerSample(aStream.rate)) * frameBytes;
+                record(msg, be, 0, silence);
+                aSender.Push(msg);
+                record(rest, be, firstBytes, silence);
+                aSender.Push(rest);
+                continue;
+            }
+            MsgAudio* split = nullptr;
+            rampValue = msg->SetRamp(rampValue, rampRemaining, rampDir, split);
+            TEST(split == nullptr);
+        }
+        record(msg, be, 0, silence);
+        aSender.Push(msg);
+    }
+}
+
+// The oracle's datagrams for what FeedStream recorded.
+std::vector<std::vector<TByte>> OracleDatagrams(const SongcastStream& aStream, bool aFlush)
+{
+    std::vector<std::vector<TByte>> out;
+    ohp_ohm_driver d;
+    ohp_ohm_driver_init(&d, aStream.latencyMs);
+    const TUint64 samplesTotal = aStream.trackLengthJiffies / Jiffies::PerSample(aStream.rate);
+    ohp_ohm_driver_set_track_position(&d, samplesTotal, aStream.sampleStart);
+    const TUint wireCh = aStream.channels < 2 ? aStream.channels : 2, wireBits = aStream.bits < 24 ? aStream.bits : 24;
+    TEST(ohp_ohm_driver_set_audio_format(&d, aStream.rate, aStream.rate * aStream.bits * aStream.channels, wireCh, wireBits, 1,
+                                         (const uint8_t*)aStream.codec, (uint32_t)strlen(aStream.codec), aStream.sampleStart) == 0);
+    std::vector<ohp_sender_fragment> frags(aStream.msgs.size() * 8 + 64);
+    std::vector<ohp_sender_packet> packs(aStream.msgs.size() * 8 + 64);
+    uint32_t nf = 0, np = 0;
+    TEST(ohp_sender_packetise(aStream.msgs.data(), (uint32_t)aStream.msgs.size(), aFlush ? 1 : 0, frags.data(), (uint32_t)frags.size(), &nf,
+                              packs.data(), (uint32_t)packs.size(), &np) == 0);
+    for (uint32_t k = 0; k < np; k++) {
+        std::vector<TByte> payload;
+        for (uint32_t g = 0; g < packs[k].n_fragments; g++) {
+            const ohp_sender_fragment& f = frags[packs[k].first_fragment + g];
+            if (f.playable.size_bytes == 0) continue;
+            std::vector<TByte> audio = aStream.audio[f.msg];                          // Read attenuates in place: a copy
+            std::vector<TByte> pcm(f.playable.size_bytes), packed(f.playable.size_bytes);
+            uint32_t n_frags = 0, bytes = 0, packedBytes = 0;
+            TEST(ohp_playable_read(&f.playable, audio.empty() ? nullptr : audio.data(), pcm.data(), (uint32_t)pcm.size(), nullptr, 0, &n_frags, &bytes) == 0);
+            TEST(ohp_sender_pack(pcm.data(), bytes, f.playable.channels, f.playable.bit_depth / 8, packed.data(), &packedBytes) == 0);
+            payload.insert(payload.end(), packed.begin(), packed.begin() + packedBytes);
+        }
+        std::vector<TByte> gram(8192);
+        const bool halt = aFlush && k == np - 1;                                        // ProcessMsg(MsgQuit*) sends with aHalt = true
+        const int n = ohp_ohm_driver_send_audio(&d, payload.empty() ? gram.data() : payload.data(), (uint32_t)payload.size(), halt ? 1 : 0,
+                                                gram.data(), (uint32_t)gram.size());
+        TEST(n >= 0);
+        if (n > 0) { gram.resize((size_t)n); out.push_back(gram); }
+    }
+    return out;
+}
+
+} // namespace
+
+static void SuiteSongcastSenderControl(MsgFactory& aControl)
+{   // no GPU: the packetiser and the driver's counters against the oracle; nothing is read
+    SongcastStream s = { 44100, 2, 16, AudioDataEndian::Big, "FLAC", 100, 1000, 0, {}, {}, {} };
+    s.trackLengthJiffies = (TUint64)Jiffies::kPerSecond * 60;
+    Av::Sender sender(aControl, s.sink, s.latencyMs);
+    sender.SetBatching(0);                                // never run the device
+    uint32_t seed = 99;
+    FeedStream(aControl, sender, s, 50, seed);
+    std::vector<ohp_sender_fragment> frags(1024);
+    std::vector<ohp_sender_packet> packs(1024);
+    uint32_t nf = 0, np = 0;
+    TEST(ohp_sender_packetise(s.msgs.data(), (uint32_t)s.msgs.size(), 0, frags.data(), 1024, &nf, packs.data(), 1024, &np) == 0);
+    uint64_t samples = 0; uint32_t sent = 0;
+    for (uint32_t k = 0; k < np; k++) {
+        uint32_t bytes = 0;
+        for (uint32_t g = 0; g < packs[k].n_fragments; g++) bytes += frags[packs[k].first_fragment + g].playable.size_bytes;
+        samples += bytes / 4;
+        sent += bytes ? 1 : 0;
+    }
+    TEST(np > 20 && sender.Driver().Frame() == sent && sender.Driver().SampleStart() == s.sampleStart + samples);
+    TEST(s.sink.grams.empty());
+    TByte b[4] = { 0 };
+    TEST_THROWS(sender.Push(aControl.CreateMsgAudioPcm(Brn(b, 4), 2, 44100, 16, AudioDataEndian::Big, 0)->CreatePlayable()), AssertionFailed);   // Sender.cpp:264-268
+}
+
+static void SuiteSongcastSenderGpu(MsgFactory& aFactory)
+{
+    SongcastStream streams[] = {
+        { 48000, 2, 24, AudioDataEndian::Big, "FLAC", 100, 0, 0, {}, {}, {} },
+        { 44100, 2, 16, AudioDataEndian::Little, "WAV", 250, 123456, 0, {}, {}, {} },
+        { 96000, 2, 32, AudioDataEndian::Big, "", 50, 7, 0, {}, {}, {} },
+        { 48000, 6, 24, AudioDataEndian::Big, "PCM", 100, 0, 0, {}, {}, {} },
+        { 44100, 1, 24, AudioDataEndian::Little, "ALAC", 100, 1ull << 33, 0, {}, {}, {} },
+        { 48000, 8, 16, AudioDataEndian::Little, "AIFF", 100, 0, 0, {}, {}, {} },
+    };
+    uint32_t seed = 2024;
+    // ---- each stream through its own Sender, the device running after every packet (the reference's cadence) ----
+    {
+        SongcastStream& s = streams[0];
+        s.trackLengthJiffies = (TUint64)Jiffies::kPerSecond * 200;
+        Av::Sender sender(aFactory, s.sink, s.latencyMs);
+        FeedStream(aFactory, sender, s, 30, seed);
+        sender.Push(aFactory.CreateMsgQuit());
+        const auto want = OracleDatagrams(s, true);
+        TEST(s.sink.grams.size() == want.size() && !want.empty());
+        for (size_t i = 0; i < want.size() && i < s.sink.grams.size(); i++) TEST(s.sink.grams[i] == want[i]);
+    }
+    // ---- all streams sharing one device pass ----
+    Av::OhmFrameBatch batch(aFactory);
+    std::vector<Av::Sender*> senders;
+    for (auto& s : streams) {
+        s.msgs.clear(); s.audio.clear(); s.sink.grams.clear();
+        s.trackLengthJiffies = (TUint64)Jiffies::kPerSecond * 300;
+        senders.push_back(new Av::Sender(aFactory, s.sink, s.latencyMs, &batch));
+        FeedStream(aFactory, *senders.back(), s, 40, seed);
+        senders.back()->Push(aFactory.CreateMsgQuit());
+    }
+    TEST(batch.Count() > 100 && streams[1].sink.grams.empty());
+    batch.Run();
+    TEST(batch.Count() == 0);
+    for (auto& s : streams) {
+        const auto want = OracleDatagrams(s, true);
+        TEST(s.sink.grams.size() == want.size() && !want.empty());
+        size_t bad = 0;
+        for (size_t i = 0; i < want.size() && i < s.sink.grams.size(); i++) bad += (s.sink.grams[i] == want[i]) ? 0 : 1;
+        TEST(bad == 0);
+        if (bad) printf("  stream %u Hz %u ch %u bit: %zu of %zu datagrams differ\n", s.rate, s.channels, s.bits, bad, want.size());
+    }
+    for (auto* p : senders) delete p;
+}
+
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
@@ -570,6 +782,7 @@ int main(int argc, char** argv)
             ProcessorPcmBufTest sink;
             TEST_THROWS(p->Read(sink), AssertionFailed);      // no GPU context: reading audio fails loudly, no CPU fallback
             p->RemoveRef();
+            SuiteSongcastSenderControl(control);
         }
         if (gpu) {
             MsgFactory f(0);
@@ -580,6 +793,7 @@ int main(int argc, char** argv)
             src.Run();
             SuiteFlywheelGpu(f);
             SuiteStarvationRampGpu(f);
+            SuiteSongcastSenderGpu(f);
         }
     }
     catch (const std::exception& e) {
