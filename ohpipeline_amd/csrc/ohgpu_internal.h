@@ -159,10 +159,11 @@ struct FlywheelPlan {
 };
 
 // ---- Songcast sender frames (csrc/ohm_frame_kernel.hip) ----
-struct OhmFrameRec {              // 48 bytes: the 36 per-frame header bytes as nine big-endian words, and where they go
+struct OhmFrameRec {              // 48 bytes: the 36 per-frame header bytes in wire order, and where they go
     uint64_t dst_off;
     uint32_t w[9];
-    uint32_t stream;              // index of the 64-byte stream record: bytes [0, n) = OhmMsgAudio::GetStreamHeader, byte 63 = n
+    uint32_t stream_and_bytes;    // bits 0..23: index of the 64-byte stream record (bytes [0, n) = OhmMsgAudio::GetStreamHeader);
+                                  // bits 24..31: the whole header's size, 36 + n
 };
 struct OhmPlan {
     ohgpu_batch* direct = nullptr;         // pcm batch: fragments of mono/stereo streams, source -> frames (ramp + depth in one pass)

@@ -6,7 +6,7 @@
 //   wider streams: the Sender pack's channel select (fmt_line_kernel), after a PCM pass into a scratch arena when the
 //     fragment is ramped, attenuated or silent (what MsgPlayable::Read would have applied first, Msg.cpp:2753-2786).
 // What is new here is the header: 36 per-frame bytes (OhmHeader + the per-frame part of OhmMsgAudio::Serialise,
-// OhmMsg.cpp:363-413) and the per-stream 22 + codec bytes (GetStreamHeader, :225-241), written by 32 lanes per frame.
+// OhmMsg.cpp:363-413) and the per-stream 22 + codec bytes (GetStreamHeader, :225-241), written by 16 lanes per frame.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -19,24 +19,50 @@ namespace ohgpu {
 
 static constexpr uint32_t kPerFrameHeader = 36;        // OhmHeader::kHeaderBytes (8) + kPerFrameBytes (28), OhmMsg.cpp:368
 static constexpr uint32_t kStreamFixed = 22;           // GetStreamHeader without the codec name
-static constexpr uint32_t kLanesPerFrame = 32;
+static constexpr uint32_t kLanesPerFrame = 16;
+static constexpr uint32_t kFramesPerGroup = 4;         // frames each 16-lane group writes, their loads issued together
 
+// 16 lanes per frame, one (unaligned) dword store each per 64 header bytes: the record already holds the 36 per-frame
+// bytes in wire order and the stream record the rest, so this is a two-source copy.  A header that is not a whole
+// number of dwords ends in byte stores.  The kernel is latency bound (record -> stream record -> store), hence the
+// header size travelling in the frame record and several frames in flight per lane.
 __global__ void __launch_bounds__(256)
 ohm_header_kernel(const OhmFrameRec* __restrict__ frames, uint32_t n_frames, const uint8_t* __restrict__ streams,
                   uint8_t* __restrict__ dst)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t f = t / kLanesPerFrame, lane = t % kLanesPerFrame;
-    if (f >= n_frames) return;
-    const OhmFrameRec& r = frames[f];
-    const uint8_t* s = streams + (size_t)r.stream * 64;
-    const uint32_t header_bytes = kPerFrameHeader + s[63];
-    uint8_t* out = dst + r.dst_off;
-    for (uint32_t b = lane; b < header_bytes; b += kLanesPerFrame) {
-        uint32_t v;
-        if (b < kPerFrameHeader) v = (r.w[b >> 2] >> (8u * (3u - (b & 3u)))) & 0xffu;
-        else v = s[b - kPerFrameHeader];
-        out[b] = (uint8_t)v;
+    const uint32_t group = t / kLanesPerFrame, lane = t % kLanesPerFrame;
+    uint32_t v[kFramesPerGroup][2], hb[kFramesPerGroup];
+    uint64_t off[kFramesPerGroup];
+#pragma unroll
+    for (uint32_t k = 0; k < kFramesPerGroup; k++) {
+        const uint32_t f = group * kFramesPerGroup + k;
+        hb[k] = 0;
+        if (f >= n_frames) continue;
+        const OhmFrameRec& r = frames[f];
+        const uint32_t sh = r.stream_and_bytes;
+        hb[k] = sh >> 24;
+        off[k] = r.dst_off;
+        const uint8_t* s = streams + (size_t)(sh & 0xffffffu) * 64;
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t w = lane + i * kLanesPerFrame;
+            v[k][i] = 0;
+            if (w * 4 < hb[k]) v[k][i] = (w < kPerFrameHeader / 4) ? r.w[w] : *(const uint32_t*)(s + (w * 4 - kPerFrameHeader));
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kFramesPerGroup; k++) {
+        uint8_t* out = dst + off[k];
+#pragma unroll
+        for (uint32_t i = 0; i < 2; i++) {
+            const uint32_t w = lane + i * kLanesPerFrame;
+            if (w * 4 + 4 <= hb[k]) {
+                __builtin_memcpy(out + w * 4, &v[k][i], 4);
+            } else if (w * 4 < hb[k]) {
+                for (uint32_t b = w * 4; b < hb[k]; b++) out[b] = (uint8_t)(v[k][i] >> (8u * (b & 3u)));
+            }
+        }
     }
 }
 
@@ -105,7 +131,7 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
     if (!out || (n_streams && !streams) || (n_frames && !frames) || (n_fragments && !fragments))
         return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_create: null argument");
     *out = nullptr;
-    if (n_frames > 0x03ffffffull || n_fragments > 0xffffffffull || n_streams > 0xffffffffull)
+    if (n_frames > 0x03ffffffull || n_fragments > 0xffffffffull || n_streams > 0x00ffffffull)
         return set_error(OHGPU_ERR_INVALID, "ohgpu_ohm_batch_create: too many descriptors");
     for (size_t i = 0; i < n_streams; i++) {
         const int err = check_stream(streams[i], i);
@@ -156,16 +182,20 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
         uint32_t flags = fr.flags;
         if (flags & OHGPU_OHM_FLAG_TIMESTAMPED) flags |= 0x10u;        // kFlagTimestamped2: iTimestamped2 = iTimestamped, OhmMsg.cpp:211
         r.dst_off = fr.dst_offset;
-        r.stream = fr.stream;
-        r.w[0] = 0x4f686d20u;                                          // "Ohm "
-        r.w[1] = (1u << 24) | (3u << 16) | (uint32_t)frame_bytes;      // kMajor, kMsgTypeAudio, iBytes
-        r.w[2] = (50u << 24) | (flags << 16) | (uint32_t)samples;      // kHeaderBytes, flags, iSamples
-        r.w[3] = fr.frame;
-        r.w[4] = fr.network_timestamp;
-        r.w[5] = fr.media_latency;
-        r.w[6] = fr.media_timestamp;
-        r.w[7] = (uint32_t)(fr.sample_start >> 32);
-        r.w[8] = (uint32_t)fr.sample_start;
+        r.stream_and_bytes = fr.stream | (header_bytes << 24);
+        uint8_t* h = (uint8_t*)r.w;                                    // the 36 bytes in wire order
+        memcpy(h, "Ohm ", 4);
+        h[4] = 1;                                                      // kMajor
+        h[5] = 3;                                                      // kMsgTypeAudio
+        put_be(h + 6, frame_bytes, 2);                                 // iBytes = kHeaderBytes + the rest
+        h[8] = 50;                                                     // OhmMsgAudio::kHeaderBytes
+        h[9] = (uint8_t)flags;
+        put_be(h + 10, samples, 2);
+        put_be(h + 12, fr.frame, 4);
+        put_be(h + 16, fr.network_timestamp, 4);
+        put_be(h + 20, fr.media_latency, 4);
+        put_be(h + 24, fr.media_timestamp, 4);
+        put_be(h + 28, fr.sample_start, 8);
         // ---- audio: one message per fragment ----
         uint64_t at = fr.dst_offset + header_bytes;
         for (uint32_t g = 0; g < fr.n_fragments; g++) {
@@ -271,7 +301,7 @@ int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (err == OHGPU_OK && p.stage) err = ohgpu_pcm_batch_run(ctx, p.stage, src_base, p.d_scratch, s);
     if (err == OHGPU_OK && p.select_staged) err = ohgpu_fmt_batch_run(ctx, p.select_staged, p.d_scratch, dst_base, s);
     if (err != OHGPU_OK) return err;
-    const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame;
+    const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame * kFramesPerGroup;
     const uint32_t blocks = (p.n_frames + frames_per_block - 1) / frames_per_block;
     hipLaunchKernelGGL(ohm_header_kernel, dim3(blocks), dim3(threads), 0, s,
                        (const OhmFrameRec*)p.d_frames, p.n_frames, (const uint8_t*)p.d_streams, (uint8_t*)dst_base);
