@@ -130,19 +130,26 @@ private:
 };
 
 // ---- the message types a PCM element has to recognise; only the audio ones carry behaviour here ----
+enum class Latency { NotSupported, Internal, External }; // Msg.h:366-371
+
 class ModeInfo {
 public:
     TBool iRampPauseResumeLong = true;                   // ModeInfo::RampPauseResumeLong()
+    Latency iLatencyMode = Latency::NotSupported;
     TBool RampPauseResumeLong() const { return iRampPauseResumeLong; }
+    Latency LatencyMode() const { return iLatencyMode; }
+    void SetLatencyMode(Latency aLatencyMode) { iLatencyMode = aLatencyMode; }
 };
 
 class MsgMode : public Msg {
 public:
-    explicit MsgMode(const ModeInfo& aInfo) : iInfo(aInfo) {}
+    explicit MsgMode(const ModeInfo& aInfo, const std::string& aMode = std::string()) : iInfo(aInfo), iMode(aMode) {}
     const ModeInfo& Info() const { return iInfo; }
+    const std::string& Mode() const { return iMode; }
     Msg* Process(IMsgProcessor& aProcessor) override { return aProcessor.ProcessMsg(this); }
 private:
     ModeInfo iInfo;
+    std::string iMode;
 };
 
 #define OH_TRIVIAL_MSG(Name)                                                                              \
@@ -152,17 +159,43 @@ private:
     }
 OH_TRIVIAL_MSG(MsgTrack);
 OH_TRIVIAL_MSG(MsgDrain);
-OH_TRIVIAL_MSG(MsgDelay);
-OH_TRIVIAL_MSG(MsgEncodedStream);
 OH_TRIVIAL_MSG(MsgStreamSegment);
 OH_TRIVIAL_MSG(MsgAudioEncoded);
 OH_TRIVIAL_MSG(MsgMetaText);
 OH_TRIVIAL_MSG(MsgStreamInterrupted);
 OH_TRIVIAL_MSG(MsgHalt);
-OH_TRIVIAL_MSG(MsgFlush);
 OH_TRIVIAL_MSG(MsgWait);
 OH_TRIVIAL_MSG(MsgAudioDsd);
 OH_TRIVIAL_MSG(MsgQuit);
+
+class MsgDelay : public Msg {                            // Msg.h:470-487
+public:
+    explicit MsgDelay(TUint aRemainingJiffies = 0) : iRemainingJiffies(aRemainingJiffies) {}
+    TUint RemainingJiffies() const { return iRemainingJiffies; }
+    Msg* Process(IMsgProcessor& aProcessor) override { return aProcessor.ProcessMsg(this); }
+private:
+    TUint iRemainingJiffies;
+};
+
+class MsgEncodedStream : public Msg {                    // Msg.h:603-650 (the one field the PCM path reads)
+public:
+    enum class Format { Encoded, Pcm, Dsd };
+    explicit MsgEncodedStream(Format aFormat = Format::Encoded) : iFormat(aFormat) {}
+    Format StreamFormat() const { return iFormat; }
+    Msg* Process(IMsgProcessor& aProcessor) override { return aProcessor.ProcessMsg(this); }
+private:
+    Format iFormat;
+};
+
+class MsgFlush : public Msg {                            // Msg.h:749-763
+public:
+    static const TUint kIdInvalid = 0;
+    explicit MsgFlush(TUint aId = kIdInvalid) : iId(aId) {}
+    TUint Id() const { return iId; }
+    Msg* Process(IMsgProcessor& aProcessor) override { return aProcessor.ProcessMsg(this); }
+private:
+    TUint iId;
+};
 
 class DecodedStreamInfo {                                // Msg.h:1062-1110 (the fields the PCM path reads)
 public:
@@ -323,6 +356,14 @@ public:
     MsgSilence* CreateMsgSilence(TUint& aSizeJiffies, TUint aSampleRate, TUint aBitDepth, TUint aChannels);
     MsgHalt* CreateMsgHalt();
     MsgQuit* CreateMsgQuit();
+    MsgTrack* CreateMsgTrack() { return new MsgTrack(); }
+    MsgDrain* CreateMsgDrain() { return new MsgDrain(); }
+    MsgDelay* CreateMsgDelay(TUint aRemainingJiffies) { return new MsgDelay(aRemainingJiffies); }
+    MsgEncodedStream* CreateMsgEncodedStream(MsgEncodedStream::Format aFormat = MsgEncodedStream::Format::Encoded) { return new MsgEncodedStream(aFormat); }
+    MsgMetaText* CreateMsgMetaText() { return new MsgMetaText(); }
+    MsgStreamInterrupted* CreateMsgStreamInterrupted() { return new MsgStreamInterrupted(); }
+    MsgFlush* CreateMsgFlush(TUint aId) { return new MsgFlush(aId); }
+    MsgWait* CreateMsgWait() { return new MsgWait(); }
     ohgpu_ctx* Gpu() const;
 private:
     ohgpu_ctx* iCtx;

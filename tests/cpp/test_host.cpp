@@ -7,8 +7,10 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <vector>
 
+#include "../../ohpipeline_amd/host/DecodedAudioAggregator.h"
 #include "../../ohpipeline_amd/host/Elements.h"
 #include "../../ohpipeline_amd/host/FlywheelRamper.h"
 #include "../../ohpipeline_amd/host/Msg.h"
@@ -766,6 +768,196 @@ static void SuiteSongcastSenderGpu(MsgFactory& aFactory)
     for (auto* p : senders) delete p;
 }
 
+// ------------------------------------------------------------------------------------------- batch builder (N4, first half)
+// Tests/TestDecodedAudioAggregator.cpp restated: the suite is the downstream element and inspects what comes out.
+namespace {
+
+class SuiteDecodedAudioAggregator : public IPipelineElementDownstream, private IMsgProcessor {
+    static const TUint kSampleRate = 44100, kChannels = 2, kBitDepth = 16;     // TestDecodedAudioAggregator.cpp:95-98
+    enum EMsgType { ENone, EMsgMode, EMsgTrack, EMsgDrain, EMsgEncodedStream, EMsgDecodedStream, EMsgAudioPcm, EMsgHalt, EMsgFlush, EMsgWait, EMsgQuit, EMsgOther };
+public:
+    explicit SuiteDecodedAudioAggregator(MsgFactory& aFactory) : iFactory(aFactory) {}
+    void Run()
+    {
+        TestStreamSuccessful(); TestNoDataAfterDecodedStream(); TestShortStream(); TestTrackEncodedStreamTrack();
+        TestPcmIsExpectedSize(); TestRawPcmNotAggregated(); TestCodecControllerChunks();
+    }
+private:
+    void Push(Msg* aMsg) override { iReceived.push_back(aMsg); }
+    void Setup()
+    {
+        for (auto* m : iReceived) m->RemoveRef();
+        iReceived.clear();
+        iAggregator.reset(new DecodedAudioAggregator(*this));
+        iTrackOffset = 0; iTrackOffsetBytes = 0; iJiffies = 0; iLast = ENone;
+    }
+    void Queue(Msg* aMsg) { iAggregator->Push(aMsg); }
+    void PullNext(EMsgType aExpected)
+    {
+        TEST(!iReceived.empty());
+        if (iReceived.empty()) return;
+        Msg* msg = iReceived.front();
+        iReceived.pop_front();
+        msg = msg->Process(*this);
+        msg->RemoveRef();
+        TEST(iLast == aExpected);
+    }
+    void PullNext(EMsgType aExpected, TUint64 aExpectedJiffies)
+    {
+        const TUint64 start = iJiffies;
+        PullNext(aExpected);
+        TEST(iJiffies - start == aExpectedJiffies);
+    }
+    MsgDecodedStream* CreateDecodedStream()
+    {
+        DecodedStreamInfo info;
+        info.iBitRate = 256; info.iBitDepth = kBitDepth; info.iSampleRate = kSampleRate; info.iNumChannels = kChannels; info.iCodecName = "Dummy";
+        return iFactory.CreateMsgDecodedStream(info);
+    }
+    MsgAudioPcm* CreateAudio(TUint aBytes, TUint aSampleRate = kSampleRate, TUint aBitDepth = kBitDepth, TUint aNumChannels = kChannels)
+    {
+        std::vector<TByte> data(aBytes, 0x7f);
+        MsgAudioPcm* audio = iFactory.CreateMsgAudioPcm(Brn(data.data(), aBytes), aNumChannels, aSampleRate, aBitDepth, AudioDataEndian::Little, iTrackOffset);
+        const TUint samples = aBytes / (aNumChannels * (aBitDepth / 8));
+        iTrackOffset += (TUint64)samples * (Jiffies::kPerSecond / aSampleRate);
+        iTrackOffsetBytes += aBytes;
+        return audio;
+    }
+    void StartStream()
+    {
+        Queue(iFactory.CreateMsgTrack());          PullNext(EMsgTrack);
+        Queue(iFactory.CreateMsgEncodedStream());  PullNext(EMsgEncodedStream);
+        Queue(CreateDecodedStream());              PullNext(EMsgDecodedStream);
+    }
+    void TestStreamSuccessful()
+    {   // :426-448
+        Setup();
+        const TUint kMaxMsgBytes = DecodedAudio::kMaxBytes, kAudioBytes = DecodedAudio::kMaxBytes * 5;
+        StartStream();
+        while (iTrackOffsetBytes < kAudioBytes) Queue(CreateAudio(kMaxMsgBytes));
+        for (int i = 0; i < 5; i++) PullNext(EMsgAudioPcm);
+        TEST(iTrackOffsetBytes == kAudioBytes && iJiffies == iTrackOffset && iReceived.empty());
+    }
+    void TestNoDataAfterDecodedStream()
+    {   // :450-464
+        Setup();
+        StartStream();
+        Queue(iFactory.CreateMsgTrack()); PullNext(EMsgTrack);
+        TEST(iJiffies == iTrackOffset);
+    }
+    void TestShortStream()
+    {   // :466-481
+        Setup();
+        StartStream();
+        Queue(CreateAudio(DecodedAudio::kMaxBytes));
+        PullNext(EMsgAudioPcm);
+        TEST(iJiffies == iTrackOffset);
+    }
+    void TestTrackEncodedStreamTrack()
+    {   // :483-502
+        Setup();
+        Queue(iFactory.CreateMsgTrack()); PullNext(EMsgTrack);
+        Queue(iFactory.CreateMsgTrack()); PullNext(EMsgTrack);
+        Queue(iFactory.CreateMsgEncodedStream()); PullNext(EMsgEncodedStream);
+        Queue(iFactory.CreateMsgTrack()); PullNext(EMsgTrack);
+    }
+    void TestPcmIsExpectedSize()
+    {   // :504-546
+        Setup();
+        const TUint kMaxMsgBytes = 64, kSamplesPerMsg = 16;
+        const TUint kAudioBytes = DecodedAudio::kMaxBytes - (DecodedAudio::kMaxBytes % kMaxMsgBytes);
+        const TUint64 kJiffiesPerMsg = (TUint64)(Jiffies::kPerSecond / kSampleRate) * kSamplesPerMsg;
+        const TUint kMaxDecodedBufferedJiffies = Jiffies::kPerMs * 5;
+        const TUint kRemainderJiffies = (TUint)(kMaxDecodedBufferedJiffies % kJiffiesPerMsg);
+        const TUint64 kExpectedJiffiesPerMsg = kMaxDecodedBufferedJiffies - kRemainderJiffies + kJiffiesPerMsg;
+        TEST(kMaxDecodedBufferedJiffies % kJiffiesPerMsg != 0);
+        StartStream();
+        while (iTrackOffsetBytes < kAudioBytes) Queue(CreateAudio(kMaxMsgBytes));
+        Queue(iFactory.CreateMsgEncodedStream());       // flush out remaining audio
+        while (iJiffies < iTrackOffset - kMaxDecodedBufferedJiffies) PullNext(EMsgAudioPcm, kExpectedJiffiesPerMsg);
+        if (iJiffies < iTrackOffset) PullNext(EMsgAudioPcm, iTrackOffset - iJiffies);
+        PullNext(EMsgEncodedStream);
+        TEST(iTrackOffsetBytes == kAudioBytes && iJiffies == iTrackOffset);
+    }
+    void TestRawPcmNotAggregated()
+    {   // :548-567
+        Setup();
+        ModeInfo info;
+        info.SetLatencyMode(Latency::Internal);
+        Queue(iFactory.CreateMsgMode(info));
+        Queue(iFactory.CreateMsgTrack());
+        Queue(iFactory.CreateMsgEncodedStream(MsgEncodedStream::Format::Pcm));
+        DecodedStreamInfo ds;
+        ds.iBitDepth = 32; ds.iSampleRate = 48000; ds.iNumChannels = 2;
+        Queue(iFactory.CreateMsgDecodedStream(ds));
+        Queue(CreateAudio(8, 48000, 32, 2));             // one sample for 32-bit stereo
+        PullNext(EMsgMode); PullNext(EMsgTrack); PullNext(EMsgEncodedStream); PullNext(EMsgDecodedStream);
+        PullNext(EMsgAudioPcm);
+        TEST(iJiffies == Jiffies::PerSample(48000) && iJiffies == iTrackOffset);
+    }
+    void TestCodecControllerChunks()
+    {   // CodecController::OutputAudioPcm, CodecController.cpp:799-826: a codec's block leaves in pieces of at most
+        // iMaxOutputJiffies (whole samples), the track offset running through; then the aggregator sees them
+        Setup();
+        const TUint kMaxOutputJiffies = 2 * Jiffies::kPerMs;
+        CodecController controller(iFactory, *iAggregator, kMaxOutputJiffies);
+        controller.OutputDecodedStream(1411200, 16, 44100, 2, Brn((const TByte*)"WAV", 3), 0, 0, true);
+        PullNext(EMsgDecodedStream);
+        TEST(controller.MaxOutputBytes() == Jiffies::ToSamples(kMaxOutputJiffies, 44100) * 4);            // 88 samples
+        std::vector<TByte> block(4000 * 4, 0x11);                                                          // 4000 samples in one call
+        const TUint64 out = controller.OutputAudioPcm(Brn(block.data(), (TUint)block.size()), 2, 44100, 16, AudioDataEndian::Little, 0);
+        TEST(out == (TUint64)4000 * Jiffies::PerSample(44100));
+        TEST_THROWS(controller.OutputAudioPcm(Brn(block.data(), 16), 2, 48000, 16, AudioDataEndian::Little, 0), AssertionFailed);
+        TEST(controller.OutputAudioPcm(Brn(block.data(), 0), 2, 44100, 16, AudioDataEndian::Little, 0) == 0);
+        Queue(iFactory.CreateMsgQuit());
+        // 88-sample pieces aggregate to 3 x 88 = 264 samples >= kMaxJiffies (5 ms less one 7350 Hz sample = 212.8 samples at 44.1 kHz)
+        TUint64 total = 0; TUint n = 0;
+        while (iReceived.size() > 1) {
+            const TUint64 before = iJiffies;
+            PullNext(EMsgAudioPcm);
+            const TUint64 got = iJiffies - before;
+            total += got; n++;
+            if (iReceived.size() > 1) TEST(got == (TUint64)264 * Jiffies::PerSample(44100));
+        }
+        PullNext(EMsgQuit);
+        TEST(total == out && n == (4000 + 263) / 264);
+        TEST_THROWS(controller.OutputDecodedStream(0, 16, 44101, 2, Brn(), 0, 0, true), CodecStreamFeatureUnsupported);
+    }
+private: // IMsgProcessor
+    Msg* ProcessMsg(MsgMode* aMsg) override { iLast = EMsgMode; return aMsg; }
+    Msg* ProcessMsg(MsgTrack* aMsg) override { iLast = EMsgTrack; return aMsg; }
+    Msg* ProcessMsg(MsgDrain* aMsg) override { iLast = EMsgDrain; return aMsg; }
+    Msg* ProcessMsg(MsgDelay* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgEncodedStream* aMsg) override { iLast = EMsgEncodedStream; return aMsg; }
+    Msg* ProcessMsg(MsgStreamSegment* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgAudioEncoded* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgMetaText* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgStreamInterrupted* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgHalt* aMsg) override { iLast = EMsgHalt; return aMsg; }
+    Msg* ProcessMsg(MsgFlush* aMsg) override { iLast = EMsgFlush; return aMsg; }
+    Msg* ProcessMsg(MsgWait* aMsg) override { iLast = EMsgWait; return aMsg; }
+    Msg* ProcessMsg(MsgDecodedStream* aMsg) override { iLast = EMsgDecodedStream; return aMsg; }
+    Msg* ProcessMsg(MsgAudioPcm* aMsg) override
+    {
+        iLast = EMsgAudioPcm;
+        TEST(aMsg->TrackOffset() == iJiffies);           // aggregated messages keep the running track offset
+        iJiffies += aMsg->Jiffies();
+        return aMsg;
+    }
+    Msg* ProcessMsg(MsgAudioDsd* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgSilence* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgPlayable* aMsg) override { iLast = EMsgOther; return aMsg; }
+    Msg* ProcessMsg(MsgQuit* aMsg) override { iLast = EMsgQuit; return aMsg; }
+private:
+    MsgFactory& iFactory;
+    std::unique_ptr<DecodedAudioAggregator> iAggregator;
+    std::deque<Msg*> iReceived;
+    TUint64 iTrackOffset = 0, iTrackOffsetBytes = 0, iJiffies = 0;
+    EMsgType iLast = ENone;
+};
+
+} // namespace
+
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
@@ -783,6 +975,8 @@ int main(int argc, char** argv)
             TEST_THROWS(p->Read(sink), AssertionFailed);      // no GPU context: reading audio fails loudly, no CPU fallback
             p->RemoveRef();
             SuiteSongcastSenderControl(control);
+            SuiteDecodedAudioAggregator aggregator(control);
+            aggregator.Run();
         }
         if (gpu) {
             MsgFactory f(0);
