@@ -197,7 +197,14 @@ private:
     TUint iId;
 };
 
-class DecodedStreamInfo {                                // Msg.h:1062-1110 (the fields the PCM path reads)
+class IStreamHandler {                                   // Msg.h:556-575 (the one call the PCM path makes)
+public:
+    static const TUint kStreamIdInvalid = 0;             // IPipelineIdProvider::kStreamIdInvalid
+    virtual ~IStreamHandler() {}
+    virtual void NotifyStarving(const Brx& aMode, TUint aStreamId, TBool aStarving) = 0;
+};
+
+class DecodedStreamInfo {                              // Msg.h:1062-1110 (the fields the PCM path reads)
 public:
     TUint iStreamId = 0, iBitRate = 0, iBitDepth = 0, iSampleRate = 0, iNumChannels = 0;
     TUint64 iTrackLength = 0, iSampleStart = 0;
@@ -205,6 +212,8 @@ public:
     AudioFormat iFormat = AudioFormat::Pcm;
     Media::Multiroom iMultiroom = Media::Multiroom::Allowed;
     std::string iCodecName;
+    IStreamHandler* iStreamHandler = nullptr;
+    IStreamHandler* StreamHandler() const { return iStreamHandler; }
     TUint BitRate() const { return iBitRate; }
     TUint64 TrackLength() const { return iTrackLength; }             // jiffies
     TBool Lossless() const { return iLossless; }
@@ -351,6 +360,7 @@ public:
     explicit MsgFactory(int aDevice = 0);
     ~MsgFactory();
     MsgMode* CreateMsgMode(const ModeInfo& aInfo);
+    MsgMode* CreateMsgMode(const ModeInfo& aInfo, const std::string& aMode) { return new MsgMode(aInfo, aMode); }
     MsgDecodedStream* CreateMsgDecodedStream(const DecodedStreamInfo& aInfo);
     MsgAudioPcm* CreateMsgAudioPcm(const Brx& aData, TUint aChannels, TUint aSampleRate, TUint aBitDepth, AudioDataEndian aEndian, TUint64 aTrackOffset);
     MsgSilence* CreateMsgSilence(TUint& aSizeJiffies, TUint aSampleRate, TUint aBitDepth, TUint aChannels);

@@ -4,10 +4,13 @@
 // IPcmProcessor.  `test_host cpu` runs the control-plane checks (no GPU); `test_host gpu` also reads audio through the
 // C ABI and compares the bytes with the CPU oracle.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../ohpipeline_amd/host/DecodedAudioAggregator.h"
@@ -17,6 +20,7 @@
 #include "../../ohpipeline_amd/host/RampGenerator.h"
 #include "../../ohpipeline_amd/host/SampleRateConverter.h"
 #include "../../ohpipeline_amd/host/Sender.h"
+#include "../../ohpipeline_amd/host/StarvationRamper.h"
 #include "../../oracle/ohp_flywheel.h"
 #include "../../oracle/ohp_oracle.h"
 #include "../../oracle/ohp_pipeline.h"
@@ -958,6 +962,448 @@ private:
 
 } // namespace
 
+// ------------------------------------------------------------------------------------------- batch builder (N4, second half)
+// Tests/TestStarvationRamper.cpp restated (the PCM cases): the suite is the upstream element (its Pull blocks until the
+// test has queued a message), the stream handler and the observer; messages pulled from the StarvationRamper are
+// inspected one by one.  Cases that starve need the device (FlywheelInput / RampGenerator run there).
+namespace {
+
+class SuiteStarvationRamper : private IPipelineElementUpstream, private IMsgProcessor, private IStreamHandler,
+                              private IStarvationRamperObserver {
+    static const TUint kMaxAudioBuffer = Jiffies::kPerMs * 100;          // TestStarvationRamper.cpp:25-33
+    static const TUint kRampUpDuration = Jiffies::kPerMs * 50;
+    static const TUint kSampleRateDefault = 48000, kBitDepthDefault = 16, kNumChannels = 2;
+    static const TUint kAudioPcmBytesDefault = 960;                       // 5 ms of 48k, 16-bit stereo
+    enum EMsgType { ENone, EMsgMode, EMsgTrack, EMsgDrain, EMsgDelay, EMsgEncodedStream, EMsgMetaText, EMsgStreamInterrupted,
+                    EMsgDecodedStream, EMsgAudioPcm, EMsgAudioDsd, EMsgSilence, EMsgHalt, EMsgFlush, EMsgWait, EMsgQuit };
+    typedef StarvationRamper::State State;
+public:
+    explicit SuiteStarvationRamper(MsgFactory& aFactory) : iFactory(aFactory) {}
+    void RunControl()
+    {   // no starvation in these: nothing is read, no device needed
+        Run(&SuiteStarvationRamper::TestMsgsPassWhenRunning);
+        Run(&SuiteStarvationRamper::TestBlocksWhenHasMaxAudio);
+        Run(&SuiteStarvationRamper::TestNoRampAroundHalt);
+        Run(&SuiteStarvationRamper::TestFlush);
+        Run(&SuiteStarvationRamper::TestPruneMsgsNotReqdDownstream);
+    }
+    void RunGpu()
+    {
+        Run(&SuiteStarvationRamper::TestRampBeforeDrain);
+        Run(&SuiteStarvationRamper::TestRampsAroundStarvation);
+        Run(&SuiteStarvationRamper::TestNotifyStarvingAroundStarvation);
+        Run(&SuiteStarvationRamper::TestReportsBuffering);
+        Run(&SuiteStarvationRamper::TestDrainAllAudio);
+        Run(&SuiteStarvationRamper::TestAllSampleRates);
+    }
+private:
+    void Run(void (SuiteStarvationRamper::*aTest)()) { Setup(); (this->*aTest)(); TearDown(); }
+    void Setup()
+    {
+        iStreamId = UINT32_MAX; iTrackOffset = 0; iJiffies = 0;
+        iRampingUp = iRampingDown = iBuffering = false;
+        iLastRampPos = Ramp::kMax; iNextStreamId = 1; iStarving = false; iStarvingStreamId = IStreamHandler::kStreamIdInvalid;
+        iSampleRate = kSampleRateDefault; iBitDepth = kBitDepthDefault; iLastPulledMsg = ENone;
+        iPcmData.assign(kAudioPcmBytesDefault, 0);                         // left = 0x7f7f, right = 0x0000
+        for (size_t i = 0; i < iPcmData.size(); i += 4) { iPcmData[i] = 0x7f; iPcmData[i + 1] = 0x7f; }
+        (void)iMsgAvailable.Clear();
+        iStarvationRamper = new StarvationRamper(iFactory, *this, *this, kMaxAudioBuffer, kRampUpDuration, 10);
+    }
+    void TearDown()
+    {
+        delete iStarvationRamper;
+        for (auto* m : iPendingMsgs) m->RemoveRef();
+        iPendingMsgs.clear();
+    }
+private: // from IPipelineElementUpstream
+    Msg* Pull() override
+    {
+        iMsgAvailable.Wait();
+        std::lock_guard<std::mutex> lock(iPendingMsgLock);
+        Msg* msg = iPendingMsgs.front();
+        iPendingMsgs.pop_front();
+        return msg;
+    }
+private: // from IStreamHandler / IStarvationRamperObserver
+    void NotifyStarving(const Brx& aMode, TUint aStreamId, TBool aStarving) override
+    {
+        TEST(aMode.Bytes() == 9 && memcmp(aMode.Ptr(), "DummyMode", 9) == 0);
+        iStarving = aStarving;
+        iStarvingStreamId = aStreamId;
+    }
+    void NotifyStarvationRamperBuffering(TBool aBuffering) override { iBuffering = aBuffering; }
+private: // from IMsgProcessor
+    Msg* ProcessMsg(MsgMode* aMsg) override { iLastPulledMsg = EMsgMode; return aMsg; }
+    Msg* ProcessMsg(MsgTrack* aMsg) override { iLastPulledMsg = EMsgTrack; return aMsg; }
+    Msg* ProcessMsg(MsgDrain* aMsg) override { iLastPulledMsg = EMsgDrain; return aMsg; }
+    Msg* ProcessMsg(MsgDelay* aMsg) override { iLastPulledMsg = EMsgDelay; return aMsg; }
+    Msg* ProcessMsg(MsgEncodedStream* aMsg) override { iLastPulledMsg = EMsgEncodedStream; return aMsg; }
+    Msg* ProcessMsg(MsgStreamSegment* aMsg) override { ASSERTS(); return aMsg; }
+    Msg* ProcessMsg(MsgAudioEncoded* aMsg) override { ASSERTS(); return aMsg; }
+    Msg* ProcessMsg(MsgMetaText* aMsg) override { iLastPulledMsg = EMsgMetaText; return aMsg; }
+    Msg* ProcessMsg(MsgStreamInterrupted* aMsg) override { iLastPulledMsg = EMsgStreamInterrupted; return aMsg; }
+    Msg* ProcessMsg(MsgHalt* aMsg) override { iLastPulledMsg = EMsgHalt; return aMsg; }
+    Msg* ProcessMsg(MsgFlush* aMsg) override { iLastPulledMsg = EMsgFlush; return aMsg; }
+    Msg* ProcessMsg(MsgWait* aMsg) override { iLastPulledMsg = EMsgWait; return aMsg; }
+    Msg* ProcessMsg(MsgDecodedStream* aMsg) override { iLastPulledMsg = EMsgDecodedStream; return aMsg; }
+    Msg* ProcessMsg(MsgAudioPcm* aMsg) override
+    {   // ProcessAudio, :323-346
+        iLastPulledMsg = EMsgAudioPcm;
+        iJiffies += aMsg->Jiffies();
+        const Media::Ramp& ramp = aMsg->Ramp();
+        if (iRampingDown) {
+            TEST(ramp.Direction() == Ramp::EDown);
+            TEST(ramp.Start() == iLastRampPos);
+            if (ramp.End() == Ramp::kMin) iRampingDown = false;
+        }
+        else if (iRampingUp) {
+            TEST(ramp.Direction() == Ramp::EUp);
+            TEST(ramp.Start() == iLastRampPos);
+            if (ramp.End() == Ramp::kMax) iRampingUp = false;
+        }
+        else {
+            TEST(ramp.Direction() == Ramp::ENone);
+        }
+        iLastRampPos = ramp.End();
+        return aMsg;
+    }
+    Msg* ProcessMsg(MsgAudioDsd* aMsg) override { iLastPulledMsg = EMsgAudioDsd; return aMsg; }
+    Msg* ProcessMsg(MsgSilence* aMsg) override { iLastPulledMsg = EMsgSilence; return aMsg; }
+    Msg* ProcessMsg(MsgPlayable* aMsg) override { ASSERTS(); return aMsg; }
+    Msg* ProcessMsg(MsgQuit* aMsg) override { iLastPulledMsg = EMsgQuit; return aMsg; }
+private:
+    void AddPending(Msg* aMsg)
+    {
+        { std::lock_guard<std::mutex> lock(iPendingMsgLock); iPendingMsgs.push_back(aMsg); }
+        iMsgAvailable.Signal();
+    }
+    size_t PendingCount() { std::lock_guard<std::mutex> lock(iPendingMsgLock); return iPendingMsgs.size(); }
+    void PullNext(TBool aWait = true)
+    {
+        if (aWait && !iRampingDown) {
+            // no ramping => we expect a msg to be available: poll until the StarvationRamper has pulled something
+            int retries = 1000;
+            while (iStarvationRamper->IsEmpty() && retries-- > 0) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        Msg* msg = iStarvationRamper->Pull();
+        msg = msg->Process(*this);
+        msg->RemoveRef();
+    }
+    void PullNext(EMsgType aExpectedMsg, TBool aWait = true)
+    {
+        PullNext(aWait);
+        if (iLastPulledMsg != aExpectedMsg) printf("  expected msg type %d, got %d\n", (int)aExpectedMsg, (int)iLastPulledMsg);
+        TEST(iLastPulledMsg == aExpectedMsg);
+    }
+    Msg* CreateMode() { return iFactory.CreateMsgMode(ModeInfo(), "DummyMode"); }
+    Msg* CreateDecodedStream()
+    {
+        DecodedStreamInfo info;
+        info.iStreamId = iNextStreamId; info.iBitRate = 100; info.iBitDepth = iBitDepth; info.iSampleRate = iSampleRate;
+        info.iNumChannels = kNumChannels; info.iCodecName = "notARealCodec"; info.iTrackLength = 1ull << 38; info.iStreamHandler = this;
+        return iFactory.CreateMsgDecodedStream(info);
+    }
+    Msg* CreateAudio()
+    {
+        MsgAudioPcm* audio = iFactory.CreateMsgAudioPcm(Brn(iPcmData.data(), (TUint)iPcmData.size()), kNumChannels, iSampleRate, iBitDepth,
+                                                        AudioDataEndian::Big, iTrackOffset);
+        iTrackOffset += audio->Jiffies();
+        return audio;
+    }
+    void Quit(TBool aRampDown = true)
+    {
+        iRampingDown = aRampDown;   // in case Pull() is called before StarvationRamper pulls the Halt below (causing SR to start a ramp down)
+        AddPending(iFactory.CreateMsgHalt());
+        AddPending(iFactory.CreateMsgQuit());
+        do { PullNext(); } while (iLastPulledMsg != EMsgQuit);
+    }
+private:
+    void TestMsgsPassWhenRunning()
+    {   // :511-546 without its DSD leg
+        AddPending(CreateMode());
+        AddPending(iFactory.CreateMsgDelay(Jiffies::kPerMs * 20));
+        AddPending(iFactory.CreateMsgDrain());
+        AddPending(CreateDecodedStream());
+        AddPending(CreateAudio());
+        PullNext(EMsgMode); PullNext(EMsgDelay); PullNext(EMsgDrain); PullNext(EMsgDecodedStream);
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        TUint size = Jiffies::kPerMs * 3;
+        AddPending(iFactory.CreateMsgSilence(size, 44100, 8, 2));
+        do { PullNext(EMsgSilence); } while (!iStarvationRamper->IsEmpty());
+        AddPending(iFactory.CreateMsgHalt());
+        AddPending(iFactory.CreateMsgQuit());
+        PullNext(EMsgHalt);
+        PullNext(EMsgQuit);
+    }
+    void TestBlocksWhenHasMaxAudio()
+    {   // :548-578
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        PullNext(EMsgMode);
+        PullNext(EMsgDecodedStream);
+        do { AddPending(CreateAudio()); } while (iTrackOffset < kMaxAudioBuffer);
+        AddPending(CreateAudio());
+        int retries = 100;
+        while (retries-- > 0) {                           // wait for expected number of pending msgs to be pulled
+            if (PendingCount() == 1) break;                // 1 == the MsgAudioPcm that doesn't yet fit into SR
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));      // long enough for it to be pulled if SR were running
+        TEST(PendingCount() == 1);
+        do { PullNext(EMsgAudioPcm); } while (iJiffies < iTrackOffset);    // (the reference polls pending/IsEmpty, which has a window)
+        TEST(PendingCount() == 0 && iStarvationRamper->IsEmpty());
+        AddPending(iFactory.CreateMsgQuit());
+        PullNext(EMsgQuit);
+    }
+    void TestNoRampAroundHalt()
+    {   // :580-604
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        AddPending(CreateAudio());
+        AddPending(CreateAudio());
+        AddPending(iFactory.CreateMsgHalt());
+        PullNext(EMsgMode);
+        PullNext(EMsgDecodedStream);
+        do { PullNext(EMsgAudioPcm); } while (iJiffies < iTrackOffset);
+        PullNext(EMsgHalt);
+        AddPending(CreateAudio());
+        AddPending(CreateAudio());
+        AddPending(iFactory.CreateMsgQuit());
+        do { PullNext(EMsgAudioPcm); } while (iJiffies < iTrackOffset);
+        PullNext(EMsgQuit);
+    }
+    void TestRampBeforeDrain()
+    {   // :606-632
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        AddPending(CreateAudio());
+        AddPending(CreateAudio());
+        AddPending(iFactory.CreateMsgDrain());
+        PullNext(EMsgMode);
+        PullNext(EMsgDecodedStream);
+        do { PullNext(EMsgAudioPcm); } while (iJiffies < iTrackOffset);
+        // ramp down then Halt should be generated before Drain is passed on
+        iRampingDown = true;
+        do { PullNext(EMsgAudioPcm); } while (iRampingDown);
+        PullNext(EMsgHalt);
+        PullNext(EMsgDrain);
+        AddPending(iFactory.CreateMsgQuit());
+        PullNext(EMsgQuit);
+    }
+    void TestRampsAroundStarvation()
+    {   // :634-690
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        do { AddPending(CreateAudio()); } while (iTrackOffset < StarvationRamper::kTrainingJiffies);
+        PullNext(EMsgMode);
+        PullNext(EMsgDecodedStream);
+        do { PullNext(EMsgAudioPcm); } while (iJiffies < iTrackOffset);
+        iRampingDown = true;
+        iJiffies = 0;
+        while (iRampingDown) PullNext(EMsgAudioPcm);
+        TEST(iJiffies == StarvationRamper::kRampDownJiffies);
+        PullNext(EMsgHalt, false);
+        TEST(iStarvationRamper->CurrentState() == State::RampingUp);
+        // ramps up once audio is available, ramp up takes kRampUpDuration
+        iRampingUp = true;
+        iJiffies = 0;
+        const TUint64 trackOffsetStart = iTrackOffset;
+        do { AddPending(CreateAudio()); } while (iTrackOffset - trackOffsetStart < kRampUpDuration);
+        while (iRampingUp) PullNext(EMsgAudioPcm);
+        TEST(iJiffies == kRampUpDuration);
+        TEST(iStarvationRamper->CurrentState() == State::Running);
+        if (!iStarvationRamper->IsEmpty()) PullNext(EMsgAudioPcm);          // clear any split msg at the end of the ramp up
+        // ramps down after < kMaxAudioBuffer of prior audio, ramp down takes StarvationRamper::kRampDownJiffies
+        AddPending(CreateDecodedStream());
+        PullNext(EMsgDecodedStream);
+        AddPending(CreateAudio());
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        iRampingDown = true;
+        iJiffies = 0;
+        while (iRampingDown) PullNext(EMsgAudioPcm);
+        TEST(iJiffies == StarvationRamper::kRampDownJiffies);
+        PullNext(EMsgHalt, false);
+        TEST(iStarvationRamper->CurrentState() == State::RampingUp);
+        Quit();
+    }
+    void TestNotifyStarvingAroundStarvation()
+    {   // :692-724
+        TEST(!iStarving);
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        PullNext(EMsgMode);
+        PullNext(EMsgDecodedStream);
+        TEST(!iStarving);
+        AddPending(CreateAudio());
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        iRampingDown = true;
+        PullNext(EMsgAudioPcm);
+        TEST(iStarving && iStarvingStreamId == iNextStreamId);
+        while (iRampingDown) PullNext(EMsgAudioPcm);
+        TEST(iStarving);
+        PullNext(EMsgHalt, false);
+        iRampingUp = true;
+        AddPending(CreateAudio());
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        TEST(!iStarving);
+        Quit();
+    }
+    void TestReportsBuffering()
+    {   // :726-781
+        TEST(iBuffering);
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        PullNext(EMsgMode);
+        TEST(iBuffering);
+        PullNext(EMsgDecodedStream);
+        TEST(iBuffering);
+        AddPending(CreateAudio());
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        TEST(!iBuffering);
+        iRampingDown = true;
+        while (iRampingDown) { PullNext(EMsgAudioPcm); TEST(iBuffering); }
+        PullNext(EMsgHalt, false);
+        AddPending(CreateAudio());
+        iRampingUp = true;
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        TEST(!iBuffering);
+        iRampingUp = false;
+        iRampingDown = true;
+        PullNext(EMsgAudioPcm);
+        TEST(iBuffering);
+        AddPending(CreateDecodedStream());
+        do { PullNext(); } while (iLastPulledMsg != EMsgDecodedStream);
+        iRampingDown = false;
+        TEST(iBuffering);
+        AddPending(CreateAudio());
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        TEST(!iBuffering);
+        AddPending(CreateDecodedStream());
+        AddPending(CreateAudio());
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));       // short wait to allow StarvationRamper to pull the above msgs
+        PullNext(EMsgDecodedStream);
+        do { PullNext(EMsgAudioPcm); } while (!iStarvationRamper->IsEmpty());
+        TEST(!iBuffering);
+        Quit();
+    }
+    void TestFlush()
+    {   // :783-809
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        for (TUint i = 0; i < 50; i++) AddPending(CreateAudio());
+        const TUint kFlushId = 42;
+        AddPending(iFactory.CreateMsgFlush(kFlushId));
+        PullNext(EMsgMode);
+        PullNext(EMsgDecodedStream);
+        PullNext(EMsgAudioPcm);
+        iJiffies = 0;
+        iStarvationRamper->Flush(kFlushId);
+        TEST(iStarvationRamper->CurrentState() == State::RampingDown);
+        iRampingDown = true;
+        do { PullNext(EMsgAudioPcm); } while (iJiffies < StarvationRamper::kRampDownJiffies);
+        TEST(iJiffies == StarvationRamper::kRampDownJiffies);
+        TEST(iStarvationRamper->CurrentState() == State::Flushing);
+        iRampingDown = false;
+        PullNext(EMsgHalt);
+        TEST(iStarvationRamper->IsEmpty());
+        TEST(iStarvationRamper->CurrentState() == State::Halted);
+        Quit(false);
+    }
+    void TestDrainAllAudio()
+    {   // :811-858 without the DSD message
+        AddPending(CreateMode());
+        AddPending(CreateDecodedStream());
+        do { AddPending(CreateAudio()); } while (iTrackOffset < StarvationRamper::kTrainingJiffies);
+        PullNext(EMsgMode);
+        PullNext(EMsgDecodedStream);
+        do { PullNext(EMsgAudioPcm); } while (iJiffies < iTrackOffset);
+        AddPending(CreateAudio());
+        AddPending(CreateDecodedStream());
+        TUint size = Jiffies::kPerMs * 5;
+        AddPending(iFactory.CreateMsgSilence(size, 44100, 8, 2));
+        AddPending(iFactory.CreateMsgHalt());
+        AddPending(iFactory.CreateMsgDrain());
+        TEST(!iStarvationRamper->Draining());
+        iJiffies = 0;
+        iStarvationRamper->DrainAllAudio();
+        TEST(!iStarvationRamper->Draining());
+        TEST(iStarvationRamper->StartDrainPending());
+        iRampingDown = true;
+        do {
+            PullNext(EMsgAudioPcm);
+            TEST(!iStarvationRamper->StartDrainPending());
+            TEST(iStarvationRamper->Draining());
+        } while (iJiffies < StarvationRamper::kRampDownJiffies);
+        TEST(iJiffies == StarvationRamper::kRampDownJiffies);
+        iRampingDown = false;
+        PullNext(EMsgHalt);
+        TEST(iStarvationRamper->Draining());
+        PullNext(EMsgDecodedStream);
+        PullNext(EMsgHalt);
+        TEST(!iStarvationRamper->StartDrainPending() && iStarvationRamper->Draining());
+        PullNext(EMsgDrain);
+        TEST(!iStarvationRamper->StartDrainPending() && !iStarvationRamper->Draining());
+        Quit(false);
+    }
+    void TestAllSampleRates()
+    {   // :860-914
+        const TUint kSampleRates[] = { 7350, 8000, 11025, 12000, 14700, 16000, 22050, 24000, 29400, 32000, 44100, 48000, 88200, 96000, 176400, 192000 };
+        const TUint kBitDepths[] = { 8, 16, 24, 32 };
+        for (TUint bits : kBitDepths) {
+            iBitDepth = bits;
+            const TUint byteDepth = bits / 8;
+            const TUint samples = DecodedAudio::kMaxBytes / (byteDepth * kNumChannels);
+            iPcmData.assign((size_t)samples * byteDepth * kNumChannels, 0);
+            for (TUint j = 0; j < samples; j++) for (TUint k = 0; k < byteDepth; k++) iPcmData[(size_t)j * byteDepth * 2 + k] = 0x7f;
+            for (TUint rate : kSampleRates) {
+                iSampleRate = rate;
+                iTrackOffset = 0;
+                iJiffies = 0;
+                AddPending(CreateMode());
+                AddPending(CreateDecodedStream());
+                do { AddPending(CreateAudio()); } while (iTrackOffset < StarvationRamper::kTrainingJiffies);
+                PullNext(EMsgMode);
+                PullNext(EMsgDecodedStream);
+                do { PullNext(EMsgAudioPcm); } while (iJiffies < iTrackOffset);
+                iRampingDown = true;
+                iJiffies = 0;
+                while (iRampingDown) PullNext(EMsgAudioPcm);
+                TUint expected = StarvationRamper::kRampDownJiffies;
+                Jiffies::RoundDown(expected, iSampleRate);
+                TEST(iJiffies == expected);
+                PullNext(EMsgHalt, false);
+            }
+        }
+        Quit();
+    }
+    void TestPruneMsgsNotReqdDownstream()
+    {   // :916-930
+        AddPending(iFactory.CreateMsgTrack());
+        AddPending(iFactory.CreateMsgDelay(Jiffies::kPerMs * 20));
+        AddPending(CreateDecodedStream());
+        AddPending(iFactory.CreateMsgMetaText());
+        AddPending(iFactory.CreateMsgWait());
+        AddPending(iFactory.CreateMsgHalt());
+        PullNext(EMsgDelay);
+        PullNext(EMsgDecodedStream);
+        PullNext(EMsgHalt);
+        Quit(false);
+    }
+private:
+    MsgFactory& iFactory;
+    StarvationRamper* iStarvationRamper = nullptr;
+    std::mutex iPendingMsgLock;
+    Semaphore iMsgAvailable;
+    std::deque<Msg*> iPendingMsgs;
+    EMsgType iLastPulledMsg = ENone;
+    TBool iRampingUp = false, iRampingDown = false, iBuffering = false, iStarving = false;
+    TUint iStreamId = 0, iLastRampPos = 0, iNextStreamId = 1, iStarvingStreamId = 0, iSampleRate = 0, iBitDepth = 0;
+    TUint64 iTrackOffset = 0, iJiffies = 0;
+    std::vector<TByte> iPcmData;
+};
+
+} // namespace
+
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
@@ -977,6 +1423,8 @@ int main(int argc, char** argv)
             SuiteSongcastSenderControl(control);
             SuiteDecodedAudioAggregator aggregator(control);
             aggregator.Run();
+            SuiteStarvationRamper starvation(control);
+            starvation.RunControl();
         }
         if (gpu) {
             MsgFactory f(0);
@@ -988,6 +1436,9 @@ int main(int argc, char** argv)
             SuiteFlywheelGpu(f);
             SuiteStarvationRampGpu(f);
             SuiteSongcastSenderGpu(f);
+            SuiteStarvationRamper starvation(f);
+            starvation.RunControl();
+            starvation.RunGpu();
         }
     }
     catch (const std::exception& e) {
