@@ -611,7 +611,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #define OHGPU_BLOCK_KERNELS_3(X)    \
     X(64, 2, 3, true, 3, false)     \
     X(64, 6, 3, true, 3, false)     \
-    X(64, 8, 3, true, 3, false)
+    X(64, 8, 3, true, 3, false)     \
+    X(32, 2, 2, false, 3, false)    \
+    X(32, 2, 2, false, 2, false)
 #endif
 #define OHGPU_BLOCK_KERNELS(X) OHGPU_BLOCK_KERNELS_1(X) OHGPU_BLOCK_KERNELS_2(X) OHGPU_BLOCK_KERNELS_3(X)
 #define OHGPU_BLOCK_PARTS 3
