@@ -168,6 +168,7 @@ static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain
     return unit * ((need + unit - 1) / unit);
 }
 static constexpr bool ring_pair_mode(uint32_t ch, uint32_t db) { return ch == 2 && db == 3; }
+static constexpr uint32_t kRampLdsBytes = 1024;         // RampArray.h's 512 Q15 multipliers, kept after the coefficient table
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
 __global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
@@ -192,7 +193,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const uint32_t lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_waves = blockDim.x >> 6;
-    const uint32_t coef_bytes = (uint32_t)L * T * 8;
+    const uint32_t table_bytes = (uint32_t)L * T * 8;
+    const uint32_t coef_bytes = table_bytes + kRampLdsBytes;          // the shared part: coefficient table, then the ramp table
     const uint32_t row_stride = ring_bytes + 4;                       // output ring: rows start in different banks
     const uint32_t ring_area = (ROWS * row_stride + 15) & ~15u;
     const uint32_t wave_lds = OFF_RING + ring_area + 512;            // + 8 bytes per lane that absorb pair mode's idle stores
@@ -202,6 +204,12 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // is a multiple of 2^-28 below 2^25 (exact in fp64), and rounding is floor(sum + 0.5) with the 0.5 preloaded.
     for (uint32_t i = tid; i < (uint32_t)L * T; i += blockDim.x)
         ((__attribute__((address_space(3))) double*)(lds_u8_t)smem)[i] = coef[i] * (1.0 / 268435456.0);
+    // the 512 ramp multipliers too: a ramped output looks its multiplier up here, not in memory (a global load in the
+    // per-output path waits, with vmcnt(0), for every staging load in flight)
+    const __attribute__((address_space(3))) uint16_t* const ramp_lds =
+        (const __attribute__((address_space(3))) uint16_t*)((lds_u8_t)smem + table_bytes);
+    for (uint32_t i = tid; i < kRampLdsBytes / 4; i += blockDim.x)
+        ((__attribute__((address_space(3))) uint32_t*)((lds_u8_t)smem + table_bytes))[i] = ((const uint32_t*)ramp_table)[i];
     __syncthreads();
     const uint32_t coef_lane = (uint32_t)(uintptr_t)((lds_u8_t)smem + (lane & 15) * 8);          // + phase * T * 8
     uint8_t* const wsmem = smem + coef_bytes + wave * wave_lds;       // this wave's region: staging, ring and
@@ -523,7 +531,11 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                         while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
                         if (msg_flags & OHGPU_FLAG_RAMP) {
                             const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
+#ifdef OHGPU_EXP_RAMP_GLOBAL
                             const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
+#else
+                            const uint32_t mult = ramp_lds[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
+#endif
                             w = PAIR ? ramp_word(w << 8, mult, 3, CH, c) >> 8 : ramp_word(w, mult, 3, CH, c);
                             evt_j = j + 1;
                         } else {
@@ -681,7 +693,7 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     const uint32_t rb = ring_bytes_for(fb_dst, out_per_drain, ring_pair_mode(ch, db));
     *rows = bpw;
     *ring_bytes = rb;
-    *coef_lds_bytes = L * T * 8;
+    *coef_lds_bytes = L * T * 8 + kRampLdsBytes;
     *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + ((bpw * (rb + 4) + 15) & ~15u) + 512;
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
