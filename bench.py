@@ -157,7 +157,8 @@ def main():
     in_frames = int(round(args.seconds * RATE_IN))
     work = build_workload(capi, rank * n_streams, n_streams, in_frames)
 
-    ctx = capi.Context(local_rank if world > 1 else 0)
+    # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal) the ranks share what there is
+    ctx = capi.Context(local_rank % max(capi.device_count(), 1) if world > 1 else 0)
     ctx.set_kernel_variant(args.variant)
     h = ctx.src_create(work["L"], work["M"], TAPS, work["coef"])
     d_src = ctx.upload(work["src"])

@@ -150,6 +150,12 @@ def ramp_table():
     return np.frombuffer(out, dtype=np.uint16).copy()
 
 
+def device_count():
+    """GPUs visible to the process (ohgpu_device_count); 0 without one."""
+    n = lib().ohgpu_device_count()
+    return max(int(n), 0)
+
+
 def src_design(rate_in, rate_out, taps_per_phase=32, beta=9.0, f_pass=20000.0):
     """Returns (L, M, coef_q28[L*T]) from the library's own host-side filter design."""
     L_, M_ = C.c_uint32(0), C.c_uint32(0)
