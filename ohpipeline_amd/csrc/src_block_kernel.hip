@@ -216,7 +216,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const lds_u8_t lds = (lds_u8_t)wsmem;                            // write-back are private to the wave
     const int Mr = M % L;
 
-    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0;
+    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0, st_setup = 0, st_warm = 0;
 
     // Work units: every wave starts on its own unit, then claims further ones from a counter, so that the waves of
     // the whole grid finish together (waves sharing a SIMD run at very different speeds; a fixed share per wave
@@ -226,7 +226,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     while (unit < n_work) {
     uint32_t claim = 0;
     if (lane == 0) claim = atomicAdd(unit_counter, 1u);
-    if constexpr (STAMP) { st_wait = st_issue = st_drain = st_compute = 0; st_mark = stamp_now(); }
+    if constexpr (STAMP) { st_wait = st_issue = st_drain = st_compute = st_setup = st_warm = 0; st_mark = stamp_now(); }
     const SrcWork wk = work[unit];
     const SrcSeg seg = segs[wk.seg];
     const uint32_t n_blocks = wk.n_blocks;
@@ -282,8 +282,17 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         }
     };
     if (lane_valid) {
-        load_msg(0);
-        while ((uint32_t)(0 - msg_rel0) >= msg_n) load_msg(++mi);   // first message that holds this block's output 0
+        // first message that holds this block's output 0: the last table entry that starts at or before it.  Counted
+        // over the whole table at once (32 pipelined broadcast reads, one wait): walking there entry by entry cost the
+        // last block of a unit some twenty dependent LDS round trips (a quarter of the unit's set-up time).
+#ifndef OHGPU_EXP_MSG_WALK
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int idx = 0; idx < MSG_SLOTS; idx++) cnt += ((int32_t)msg_tab[idx].x <= lane_off) ? 1u : 0u;
+        mi = cnt ? cnt - 1 : 0;
+#endif
+        load_msg(mi);
+        while ((uint32_t)(0 - msg_rel0) >= msg_n) load_msg(++mi);   // (beyond the table: the range has more than MSG_SLOTS messages)
     }
     // first output index at which this lane needs the slow path: always while ramping, else at the message's end
     int32_t evt_j = (msg_flags & OHGPU_FLAG_RAMP) ? 0 : msg_rel0 + (int32_t)msg_n;
@@ -439,6 +448,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // Every later wait awaits c[r] (and the last one R as well): followed by the rest of last output's reloads, this
     // output's NS stores and the reloads already issued in this output                -> lgkmcnt(NCR - 1 + NS)
     // The newest sample is tap 0, used last, so its read has the first 16 taps to land.
+    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_setup = n - st_mark; st_mark = n; }     // unit set-up: descriptors, message table, first stage issued
     for (int g = 0; g * T < total; g++) {
         static_for([&](auto slot) __attribute__((always_inline)) {
             constexpr int s = decltype(slot)::value;
@@ -569,6 +579,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 t += M;
             }
         }, std::make_integer_sequence<int, T>{});
+        if constexpr (STAMP) {
+            if (g == 0) { st_warm = st_wait + st_issue + st_drain + st_compute; st_wait = st_issue = st_drain = st_compute = 0; }   // the warm-up pass, whole
+        }
         if (g == 0 && any_first) {                        // warm-up pass done: a stream's first block starts from silence
 #pragma unroll
             for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
@@ -580,8 +593,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     if constexpr (STAMP) {
         const uint64_t n = stamp_now(); st_drain += n - st_mark;
         if (dbg != nullptr && lane == 0) {
-            uint64_t* o = dbg + (size_t)unit * 4;
-            o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute;
+            uint64_t* o = dbg + (size_t)unit * 6;
+            o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute; o[4] = st_setup; o[5] = st_warm;
         }
     }
     unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
@@ -714,7 +727,7 @@ static hipError_t launch_stamped(const ohgpu_ctx* ctx, const ohgpu_batch* b, con
     launch_shape(ctx, b, &grid, &waves, &lds);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const size_t n = (size_t)b->fast.n_work * 4;
+    const size_t n = (size_t)b->fast.n_work * 6;
     uint64_t* d = nullptr;
     e = hipMalloc((void**)&d, n * sizeof(uint64_t));
     if (e != hipSuccess) return e;
@@ -728,15 +741,15 @@ static hipError_t launch_stamped(const ohgpu_ctx* ctx, const ohgpu_batch* b, con
         std::vector<uint64_t> h(n);
         e = hipMemcpy(h.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost);
         if (FILE* f = fopen(path, "w")) {
-            double sum[4] = {0, 0, 0, 0};
-            for (size_t i = 0; i < n; i += 4)
-                for (int k = 0; k < 4; k++) sum[k] += (double)h[i + k];
-            const double units = (double)n / 4;
-            fprintf(f, "units %.0f mean cycles per unit: wait %.0f issue %.0f drain %.0f compute %.0f | grid %u x %u waves, lds %u B\n",
-                    units, sum[0] / units, sum[1] / units, sum[2] / units, sum[3] / units, grid, waves, lds);
+            double sum[6] = {0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < n; i += 6)
+                for (int k = 0; k < 6; k++) sum[k] += (double)h[i + k];
+            const double units = (double)n / 6;
+            fprintf(f, "units %.0f mean ticks per unit: set-up %.0f warm-up pass %.0f | then wait %.0f issue %.0f drain %.0f compute %.0f | grid %u x %u waves, lds %u B\n",
+                    units, sum[4] / units, sum[5] / units, sum[0] / units, sum[1] / units, sum[2] / units, sum[3] / units, grid, waves, lds);
             double mn = 1e30, mx = 0;
-            for (size_t u = 0; u < n / 4; u++) {
-                const double c = (double)(h[4 * u] + h[4 * u + 1] + h[4 * u + 2] + h[4 * u + 3]);
+            for (size_t u = 0; u < n / 6; u++) {
+                const double c = (double)(h[6 * u] + h[6 * u + 1] + h[6 * u + 2] + h[6 * u + 3] + h[6 * u + 4] + h[6 * u + 5]);
                 mn = c < mn ? c : mn; mx = c > mx ? c : mx;
             }
             fprintf(f, "cycles per unit: min %.0f max %.0f\n", mn, mx);

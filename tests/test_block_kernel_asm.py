@@ -68,13 +68,21 @@ def test_no_scratch_and_no_valu_exec_writes(kernels):
         assert not any(re.match(r"^\s*v_cmpx", l) for l in body), name
 
 
+def main_loop(body):
+    """From the first output's first counted wait (the last one before the first tap) to the end of the kernel."""
+    first_tap = next(i for i, l in enumerate(body) if "v_fmac_f64_dpp" in l)
+    start = max(i for i in range(first_tap) if re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", body[i]))
+    return body[start:]
+
+
 def test_every_output_has_its_counted_waits(kernels):
     for name, body in kernels.items():
         T = int(re.search(r"src_block_kernelILi(\d+)E", name).group(1))
         taps = sum("v_fmac_f64_dpp" in l for l in body)
         assert taps % T == 0
         outputs = taps // T                                   # unrolled output bodies
-        counted = sum(1 for l in body if re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l))
+        loop = main_loop(body)                                # (the unit's set-up has compiler-counted waits of its own)
+        counted = sum(1 for l in loop if re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l))
         # one wait per coefficient register (T / 16 of them) per output body, each leaving younger operations in flight
         assert counted == outputs * (T // 16), (name, counted, outputs)
 
@@ -86,6 +94,7 @@ def test_lds_traffic_keeps_the_order_the_counts_assume(kernels):
     for name, body in kernels.items():
         T = int(re.search(r"src_block_kernelILi(\d+)E", name).group(1))
         ncr = T // 16
+        body = main_loop(body)
         waits = [i for i, l in enumerate(body) if re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l)]
         assert waits
         for i in waits:
