@@ -35,6 +35,8 @@ def make_messages(rng, rate, bits, ch, n_msgs, ramps=True, silence=True, attenua
             audio.append(rng.integers(0, 256, frames * ch * bits // 8, dtype=np.uint8))
             if ramps and kind in (1, 2, 3):
                 a, b = sorted(int(v) for v in rng.integers(0, O.RAMP_MAX + 1, 2))
+                if a == b:                                                 # a ramp that goes nowhere is not a valid Ramp (Msg.cpp:745-782)
+                    a, b = (a - 1, b) if a > 0 else (a, b + 1)
                 m.ramp = O.Ramp(b, a, O.RAMP_DOWN, 1) if kind == 1 else O.Ramp(a, b, O.RAMP_UP, 1)
             elif ramps and kind == 4:
                 m.ramp = O.Ramp(0, 0, O.RAMP_MUTE, 1)                      # MsgAudioPcm::CreatePlayable -> MsgPlayableSilence

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Randomised soak of the GPU paths against the oracle with seeds the test suite does not use (run on the GPU box; not part
+of the suite because of its length).  Usage: python tools/soak.py [--minutes 3]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=3.0)
+    a = ap.parse_args()
+    import test_gpu_parity as P
+    import test_gpu_songcast as S
+    from ohpipeline_amd import capi
+    ctx = capi.Context(0)
+    deadline = time.time() + a.minutes * 60
+    seed, counts = 1000, {"src_tilings": 0, "songcast": 0, "pcm_matrix": 0}
+    formats = [(48000, 24, 2), (44100, 16, 2), (96000, 32, 2), (44100, 24, 1), (48000, 24, 6), (48000, 32, 8), (44100, 16, 6), (48000, 8, 2), (192000, 24, 2)]
+    while time.time() < deadline:
+        seed += 1
+        P.test_src_block_kernel_irregular_message_tilings(ctx, seed)
+        counts["src_tilings"] += 1
+        rng = np.random.default_rng(seed)
+        w = S.Workload()
+        for k in range(int(rng.integers(1, 12))):
+            rate, bits, ch = formats[int(rng.integers(0, len(formats)))]
+            w.add_stream(rng, rate, bits, ch, int(rng.integers(1, 30)), codec=bytes(rng.integers(65, 91, int(rng.integers(0, 30)), dtype=np.uint8)),
+                         latency_ms=int(rng.integers(0, 500)), sample_start=int(rng.integers(0, 1 << 40)), samples_total=int(rng.integers(0, 1 << 40)),
+                         halt_last=bool(rng.integers(0, 2)), gap=int(rng.integers(0, 9)), attenuate=True)
+        out, want = w.run(ctx)
+        S.check(out, want, w.expected)
+        counts["songcast"] += 1
+        descs, src, dst_bytes = P.matrix_descs(rng, [8, 16, 24, 32], [1, 2, 3, 6, 8], [1, 2, 7, 43, 220, 1000], [P.LE, P.BE],
+                                               [(8, P.BE), (16, P.BE), (24, P.BE), (32, P.BE), (16, P.LE), (24, P.LE), (32, P.LE)])
+        got = P.run_pcm(ctx, descs, src, dst_bytes)
+        wantp = P.oracle_pcm(descs, src, dst_bytes)
+        assert np.array_equal(got, wantp), f"pcm matrix seed {seed}"
+        counts["pcm_matrix"] += 1
+    print("soak ok:", counts, "seeds", 1001, "..", seed)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
