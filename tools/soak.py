@@ -17,12 +17,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=3.0)
     a = ap.parse_args()
+    import test_gpu_flywheel as F
+    import test_gpu_fmt as M
     import test_gpu_parity as P
     import test_gpu_songcast as S
     from ohpipeline_amd import capi
     ctx = capi.Context(0)
     deadline = time.time() + a.minutes * 60
-    seed, counts = 1000, {"src_tilings": 0, "songcast": 0, "pcm_matrix": 0}
+    seed, counts = 1000, {"src_tilings": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
+    real_rng = np.random.default_rng
     formats = [(48000, 24, 2), (44100, 16, 2), (96000, 32, 2), (44100, 24, 1), (48000, 24, 6), (48000, 32, 8), (44100, 16, 6), (48000, 8, 2), (192000, 24, 2)]
     while time.time() < deadline:
         seed += 1
@@ -44,6 +47,15 @@ def main():
         wantp = P.oracle_pcm(descs, src, dst_bytes)
         assert np.array_equal(got, wantp), f"pcm matrix seed {seed}"
         counts["pcm_matrix"] += 1
+        if seed % 10 == 0:                                   # the suites' own randomised tests, reseeded
+            np.random.default_rng = lambda s0=None, _k=seed: real_rng(None if s0 is None else int(s0) + 7919 * _k)
+            try:
+                F.test_flywheel_batch_matches_oracle(ctx)
+                M.test_line_kernel_equals_byte_kernel_on_mixed_batches(ctx)
+            finally:
+                np.random.default_rng = real_rng
+            counts["flywheel"] += 1
+            counts["fmt_mixed"] += 1
     print("soak ok:", counts, "seeds", 1001, "..", seed)
     ctx.close()
 
