@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -139,7 +140,13 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
                 while (mi + 1 < sg.msg_end && msgs[mi + 1].out0 <= bk * L_blk) mi++;
                 w.msg_first = mi;
-                w.pad = 0;
+                // cost class, for the order below: a wave that meets a ramped message goes through the per-output ramp path
+                // for all of its lanes, which makes such a unit two to three times as long as a plain one
+                const uint64_t u_lo = bk * L_blk, u_hi = (bk + w.n_blocks) * L_blk;
+                bool ramped = false;
+                for (uint32_t m = mi; m < sg.msg_end && msgs[m].out0 < u_hi && !ramped; m++)
+                    ramped = (msgs[m].flags & OHGPU_FLAG_RAMP) && msgs[m].out0 + msgs[m].n > u_lo;
+                w.pad = ramped ? 1u : 0u;
                 work.push_back(w);
             }
             fast_frames += (blk_hi - blk_lo) * L_blk;
@@ -158,6 +165,11 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         i = e;
     }
     if (work.empty()) return OHGPU_OK;
+    // Longest first: the waves claim units in this order, and the kernel ends when the last unit does.  With the ramped
+    // units where the streams put them (each stream's fade-out is its last units) the launch ended on a few long units
+    // with most of the chip idle.
+    if (!getenv("OHGPU_EXP_PLAN_ORDER"))                   // (experiments: keep the stream order)
+        std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) { return x.pad > y.pad; });
 
     int err = upload_vec(segs, &f.d_segs);
     if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
