@@ -51,8 +51,11 @@ struct SegMsg {               // ramp parameters of one output message, 24 bytes
     uint16_t ramp_start;
     uint16_t ramp_end;
     uint8_t  flags;
-    uint8_t  pad[7];
+    uint8_t  s_n1;            // x / (n - 1) == umulhi(x, m_n1) >> s_n1 for x < 2^31 (m_n1 == 0: n - 1 <= 1): the ramp's division
+    uint8_t  pad[2];
+    uint32_t m_n1;
 };
+static_assert(sizeof(SegMsg) == 24, "SegMsg");
 struct SrcWork {              // one workgroup's share: up to `rows` consecutive blocks of one segment
     uint64_t first_block;     // absolute block index (block b covers outputs [b*L_blk, (b+1)*L_blk))
     uint32_t seg;

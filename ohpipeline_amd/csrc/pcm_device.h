@@ -50,6 +50,27 @@ __device__ __forceinline__ uint32_t ramp_index(uint32_t ramp_start, int32_t tota
     return idx < kRampTableCount - 1 ? idx : kRampTableCount - 1;    // std::min(kRampArrayCount-1, ...)
 }
 
+// x / d for x < 2^31 with the host's multiplier (m == 0: d == 1)
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t m, uint32_t s)
+{
+    return m ? (__umulhi(x, m) >> s) : x;
+}
+
+// ramp_index (pcm_device.h) with the division by (n_frames - 1) replaced by the exact multiplier
+__device__ __forceinline__ uint32_t ramp_index_magic(uint32_t ramp_start, int32_t total, uint32_t i, uint32_t n_frames,
+                                                     uint32_t m, uint32_t s)
+{
+    uint32_t ramp = ramp_start;
+    if (n_frames != 1) {
+        const int32_t prod = (int32_t)i * total;                       // TInt arithmetic, Msg.cpp:835
+        const uint32_t mag = udiv_magic((uint32_t)(prod < 0 ? -prod : prod), m, s);
+        ramp = ramp_start - (uint32_t)(prod < 0 ? -(int32_t)mag : (int32_t)mag);   // C division truncates toward zero
+    }
+    ramp &= 0xffffu;
+    const uint32_t idx = (kRampMax - ramp + (1u << 4)) >> 5;
+    return idx < kRampTableCount - 1 ? idx : kRampTableCount - 1;
+}
+
 // RampApplicator::GetNextSample, the per-subsample part (Msg.cpp:840-895): top 16 bits * Q15 >> 15
 // (arithmetic shift), low byte(s) zeroed; 8-bit keeps one byte; 32-bit 6-channel gets channel<<4.
 __device__ __forceinline__ uint32_t ramp_word(uint32_t w, uint32_t mult, uint32_t sb, uint32_t channels, uint32_t c)

@@ -33,27 +33,6 @@ constexpr uint32_t kLineWaves = 4;                                    // waves p
 constexpr uint32_t kGroupChunkSub = 4096;                             // subsamples per merged group-path chunk
 constexpr uint32_t kInBytes = ((15 + kChunkSub * 4 + 15) / 16) * 16 + 16;   // <= 3 staging instructions of 64 pieces
 
-// x / d for x < 2^31 with the host's multiplier (m == 0: d == 1)
-__device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t m, uint32_t s)
-{
-    return m ? (__umulhi(x, m) >> s) : x;
-}
-
-// ramp_index (pcm_device.h) with the division by (n_frames - 1) replaced by the exact multiplier
-__device__ __forceinline__ uint32_t ramp_index_magic(uint32_t ramp_start, int32_t total, uint32_t i, uint32_t n_frames,
-                                                     uint32_t m, uint32_t s)
-{
-    uint32_t ramp = ramp_start;
-    if (n_frames != 1) {
-        const int32_t prod = (int32_t)i * total;                       // TInt arithmetic, Msg.cpp:835
-        const uint32_t mag = udiv_magic((uint32_t)(prod < 0 ? -prod : prod), m, s);
-        ramp = ramp_start - (uint32_t)(prod < 0 ? -(int32_t)mag : (int32_t)mag);   // C division truncates toward zero
-    }
-    ramp &= 0xffffu;
-    const uint32_t idx = (kRampMax - ramp + (1u << 4)) >> 5;
-    return idx < kRampTableCount - 1 ? idx : kRampTableCount - 1;
-}
-
 // ---- group path helpers: 4*N bytes at any byte address <-> an N-register vector (inline asm: the access is ONE
 // instruction whatever the alignment).  A load's result must not be touched before the caller's s_waitcnt vmcnt(0), which
 // names the vectors as "+v"; only then are they taken apart. ----

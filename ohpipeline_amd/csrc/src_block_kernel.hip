@@ -186,7 +186,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     constexpr int IN_STRIDE = IN_BLOCKS * 16;
     constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
     // a wave's private LDS region (after the shared coefficient table): input stages, message table, output ring
-    constexpr uint32_t OFF_IN = 0, OFF_MSG = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_RING = OFF_MSG + MSG_SLOTS * 16;
+    constexpr uint32_t OFF_IN = 0, OFF_MSG = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_MSGM = OFF_MSG + MSG_SLOTS * 16, OFF_RING = OFF_MSGM + MSG_SLOTS * 4;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -252,15 +252,18 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the previous unit's table has been read
         __builtin_amdgcn_wave_barrier();
         if (lane < (uint32_t)MSG_SLOTS) {
+            uint32_t em = 0;
             u32x4 e = {0x7fffffffu, 0u, 0u, 0u};                   // past the segment: starts "never"
             if (tab_lo + lane < seg.msg_end) {
                 const SegMsg m = msgs[tab_lo + lane];
                 e.x = (uint32_t)(int32_t)(int64_t)(m.out0 - wave_m0);
                 e.y = m.n;
                 e.z = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16);
-                e.w = m.flags;
+                e.w = (uint32_t)m.flags | ((uint32_t)m.s_n1 << 8);
+                em = m.m_n1;
             }
             ((__attribute__((address_space(3))) u32x4*)(lds + OFF_MSG))[lane] = e;
+            ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_MSGM))[lane] = em;    // the ramp's exact multiplier, read only when ramping
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -270,15 +273,18 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const int32_t lane_off = (int32_t)(bw * L_blk);                // block's first output relative to the unit's
     uint32_t mi = 0;                                                // index into the table (tab_lo + mi in memory)
     int32_t msg_rel0 = 0;
-    uint32_t msg_n = 0x7fffffffu, msg_ramp = 0, msg_flags = 0;     // msg_ramp = start | end << 16
+    uint32_t msg_n = 0x7fffffffu, msg_ramp = 0, msg_flags = 0;     // msg_ramp = start | end << 16; msg_flags = flags | division shift << 8
+    uint32_t msg_m = 0;                                             // x / (msg_n - 1) == umulhi(x, msg_m) >> shift
     auto load_msg = [&](uint32_t idx) __attribute__((always_inline)) {
         if (idx < (uint32_t)MSG_SLOTS) {
             const u32x4 e = msg_tab[idx];
             msg_rel0 = (int32_t)e.x - lane_off; msg_n = e.y; msg_ramp = e.z; msg_flags = e.w;
+            if (msg_flags & OHGPU_FLAG_RAMP) msg_m = ((const __attribute__((address_space(3))) uint32_t*)(lds + OFF_MSGM))[idx];
         } else {
             const SegMsg m = msgs[tab_lo + idx];
             msg_rel0 = (int32_t)(int64_t)(m.out0 - wave_m0) - lane_off;
-            msg_n = m.n; msg_ramp = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16); msg_flags = m.flags;
+            msg_n = m.n; msg_ramp = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16); msg_flags = (uint32_t)m.flags | ((uint32_t)m.s_n1 << 8);
+            msg_m = m.m_n1;
         }
     };
     if (lane_valid) {
@@ -544,7 +550,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #ifdef OHGPU_EXP_RAMP_GLOBAL
                             const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
 #else
-                            const uint32_t mult = ramp_lds[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
+                            const uint32_t mult = ramp_lds[ramp_index_magic(rs, (int32_t)(rs - re), (uint32_t)(j - msg_rel0), msg_n, msg_m, (msg_flags >> 8) & 31u)];
 #endif
                             w = PAIR ? ramp_word(w << 8, mult, 3, CH, c) >> 8 : ramp_word(w, mult, 3, CH, c);
                             evt_j = j + 1;
@@ -707,7 +713,7 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     *rows = bpw;
     *ring_bytes = rb;
     *coef_lds_bytes = L * T * 8 + kRampLdsBytes;
-    *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + ((bpw * (rb + 4) + 15) & ~15u) + 512;
+    *wave_lds_bytes = 2 * bpw * in_blocks * 16 + 32 * 16 + 32 * 4 + ((bpw * (rb + 4) + 15) & ~15u) + 512;
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;

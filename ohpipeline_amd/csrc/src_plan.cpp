@@ -128,6 +128,11 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 SegMsg sm;
                 memset(&sm, 0, sizeof(sm));
                 sm.out0 = d.out_frame0; sm.n = d.n_frames; sm.ramp_start = d.ramp_start; sm.ramp_end = d.ramp_end; sm.flags = d.flags;
+                if (d.flags & OHGPU_FLAG_RAMP) {            // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
+                    uint32_t sh = 0;
+                    magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &sm.m_n1, &sh);
+                    sm.s_n1 = (uint8_t)sh;
+                }
                 msgs.push_back(sm);
             }
             SrcSeg sg;
