@@ -174,7 +174,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // units where the streams put them (each stream's fade-out is its last units) the launch ended on a few long units
     // with most of the chip idle.
     if (!getenv("OHGPU_EXP_PLAN_ORDER"))                   // (experiments: keep the stream order)
-        std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) { return x.pad > y.pad; });
+        std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {     // ramped first, partly filled units last
+            return (x.pad ? 3u : 1u) * x.n_blocks > (y.pad ? 3u : 1u) * y.n_blocks;
+        });
 
     int err = upload_vec(segs, &f.d_segs);
     if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
