@@ -443,6 +443,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     RawSubsample raw;
 
     issue_stage(0);
+    issue_stage(1);                                       // (both buffers: the warm-up below runs two stages ahead)
 
     // LDS operations of the loop, in issue order.  Per advance: R (raw sample).  Per output: S (the previous output's
     // ring store; pair mode stores every second output and sends the other one to an idle slot so that the count is
@@ -454,8 +455,44 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // Every later wait awaits c[r] (and the last one R as well): followed by the rest of last output's reloads, this
     // output's NS stores and the reloads already issued in this output                -> lgkmcnt(NCR - 1 + NS)
     // The newest sample is tap 0, used last, so its read has the first 16 taps to land.
-    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_setup = n - st_mark; st_mark = n; }     // unit set-up: descriptors, message table, first stage issued
-    for (int g = 0; g * T < total; g++) {
+    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_setup = n - st_mark; st_mark = n; }     // unit set-up: descriptors, message table, first stages issued
+    // ---- warm-up: the T advances before the block's first output only fill the window.  Nothing overlaps the staging
+    // loads here, so their latency is what this pass costs: it runs TWO stages ahead (stages 0 and 1 were issued together,
+    // stage q + 2 goes into the buffer stage q has just been read from), which halves the number of exposed waits; the
+    // main loop then continues one stage ahead, from its second pass.  Four sample reads per LDS round trip.
+    static_for([&](auto stage) __attribute__((always_inline)) {
+        constexpr int q = decltype(stage)::value;
+        if constexpr ((q & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stages q and q + 1 have landed
+#pragma unroll
+        for (int ph = 0; ph < PH; ph++)
+            in_addr[ph] = ((in_base + ph * FB_SRC) & ~3u) + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
+        static_for([&](auto half) __attribute__((always_inline)) {
+            constexpr int h = decltype(half)::value;
+            RawSubsample r4[4];
+            static_for([&](auto k4) __attribute__((always_inline)) {
+                constexpr int sp = 4 * h + decltype(k4)::value, ph = sp % PH;
+#ifdef OHGPU_EXP_NOSAMPLE
+                r4[sp & 3].words = lane + sp;
+                r4[sp & 3].shift = 0;
+#else
+                lds_issue_2xu32<FB_SRC * (sp - ph) / 4>(r4[sp & 3].words, in_addr[ph]);
+                r4[sp & 3].shift = in_shift[ph];
+#endif
+            }, std::make_integer_sequence<int, 4>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r4[0].words), "+v"(r4[1].words), "+v"(r4[2].words), "+v"(r4[3].words) : : "memory");
+#pragma unroll
+            for (int k = 0; k < 4; k++) win[8 * q + 4 * h + k] = (double)unpack_subsample<SB, SRC_LE>(r4[k]);
+        }, std::make_integer_sequence<int, 2>{});
+        if constexpr (q + 2 <= T / 8) {
+            if ((q + 2) * 8 < total) issue_stage(q + 2);               // into the buffer just read (its reads have been waited for)
+        }
+    }, std::make_integer_sequence<int, T / 8>{});
+    if (any_first) {                                      // a stream's first block starts from silence
+#pragma unroll
+        for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
+    }
+    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_warm = n - st_mark; st_mark = n; }
+    for (int g = 1; g * T < total; g++) {
         static_for([&](auto slot) __attribute__((always_inline)) {
             constexpr int s = decltype(slot)::value;
             const int a_lin = g * T + s;
@@ -585,13 +622,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 t += M;
             }
         }, std::make_integer_sequence<int, T>{});
-        if constexpr (STAMP) {
-            if (g == 0) { st_warm = st_wait + st_issue + st_drain + st_compute; st_wait = st_issue = st_drain = st_compute = 0; }   // the warm-up pass, whole
-        }
-        if (g == 0 && any_first) {                        // warm-up pass done: a stream's first block starts from silence
-#pragma unroll
-            for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
-        }
     }
     // the last output's store, then the lines it completes (LDS operations of a wave execute in order)
     issue_store();
