@@ -168,11 +168,22 @@ struct OhmFrameRec {              // 48 bytes: the 36 per-frame header bytes in 
     uint32_t stream_and_bytes;    // bits 0..23: index of the 64-byte stream record (bytes [0, n) = OhmMsgAudio::GetStreamHeader);
                                   // bits 24..31: the whole header's size, 36 + n
 };
+struct OhmSelRec {               // 48 bytes: one fragment of a stream of more than two channels that carries a ramp or an attenuation
+    uint64_t src_off, dst_off;
+    uint32_t n_frames;
+    uint32_t m_n1;                // x / (n_frames - 1) == umulhi(x, m_n1) >> s_n1 for x < 2^31 (m_n1 == 0: n_frames - 1 <= 1)
+    uint16_t ramp_start, ramp_end, attenuation;
+    uint8_t  channels, sb, first_ch, flags, s_n1, little;
+    uint8_t  pad[12];
+};
+static_assert(sizeof(OhmSelRec) == 48, "OhmSelRec");
 struct OhmPlan {
     ohgpu_batch* direct = nullptr;         // pcm batch: fragments of mono/stereo streams, source -> frames (ramp + depth in one pass)
     ohgpu_batch* select = nullptr;         // fmt batch: plain fragments of wider streams, source -> frames (channel select)
     ohgpu_batch* stage = nullptr;          // pcm batch: ramped / silent fragments of wider streams, source -> scratch
     ohgpu_batch* select_staged = nullptr;  // fmt batch: scratch -> frames
+    void*    d_selr = nullptr;             // OhmSelRec[n_selr]: ramped / attenuated fragments of wider streams, one pass
+    uint32_t n_selr = 0;
     void*    d_scratch = nullptr;
     void*    d_frames = nullptr;           // OhmFrameRec[n_frames]
     void*    d_streams = nullptr;          // 64 bytes per stream

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ohgpu_internal.h"
+#include "pcm_device.h"
 
 namespace ohgpu {
 
@@ -66,6 +67,32 @@ ohm_header_kernel(const OhmFrameRec* __restrict__ frames, uint32_t n_frames, con
     }
 }
 
+// Ramped / attenuated fragments of streams with more than two channels: what MsgPlayablePcm::ReadBlock (attenuation, then
+// RampApplicator; Msg.cpp:2736-2786) and Sender::DoProcessFragment (two channels, <= 3 leading bytes; Sender.cpp:351-377)
+// do to the two channels that go on the wire, in one pass: a wave per fragment, a lane per wire subsample.
+__global__ void __launch_bounds__(256)
+ohm_select_ramp_kernel(const OhmSelRec* __restrict__ recs, uint32_t n_recs, const uint16_t* __restrict__ ramp_table,
+                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+{
+    const uint32_t lane = threadIdx.x & 63, waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_recs; i += waves) {
+        const OhmSelRec r = recs[i];
+        const uint32_t sb = r.sb, wb = sb < 3 ? sb : 3;
+        const int32_t total = (int32_t)r.ramp_start - (int32_t)r.ramp_end;
+        for (uint32_t q = lane; q < r.n_frames * 2; q += 64) {
+            const uint32_t f = q >> 1, c = r.first_ch + (q & 1);
+            const uint8_t* p = src + r.src_off + ((size_t)f * r.channels + c) * sb;
+            uint32_t w = 0;                                              // left-justified, most significant byte first
+            for (uint32_t k = 0; k < sb; k++) w |= (uint32_t)p[r.little ? sb - 1 - k : k] << (24 - 8 * k);
+            if (r.attenuation != OHGPU_UNITY_ATTENUATION) w = attenuate_word(w, r.attenuation);
+            if (r.flags & OHGPU_FLAG_RAMP)
+                w = ramp_word(w, ramp_table[ramp_index_magic(r.ramp_start, total, f, r.n_frames, r.m_n1, r.s_n1)], sb, r.channels, c);
+            uint8_t* o = dst + r.dst_off + (size_t)q * wb;
+            for (uint32_t k = 0; k < wb; k++) o[k] = (uint8_t)(w >> (24 - 8 * k));
+        }
+    }
+}
+
 static inline void put_be(uint8_t* p, uint64_t v, uint32_t n)
 {
     for (uint32_t i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * (n - 1 - i)));
@@ -79,6 +106,7 @@ void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b)
     ohgpu_batch_destroy(ctx, p.stage);
     ohgpu_batch_destroy(ctx, p.select_staged);
     if (p.d_scratch) hipFree(p.d_scratch);
+    if (p.d_selr) hipFree(p.d_selr);
     if (p.d_frames) hipFree(p.d_frames);
     if (p.d_streams) hipFree(p.d_streams);
     p = OhmPlan();
@@ -157,6 +185,7 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
 
     std::vector<ohgpu_msg_desc> direct, stage;
     std::vector<ohgpu_fmt_desc> select, select_staged;
+    std::vector<OhmSelRec> selr;
     uint64_t scratch_bytes = 0, in_frames = 0, src_touched = 0, dst_written = 0;
     for (size_t f = 0; f < n_frames; f++) {
         const ohgpu_ohm_frame_desc& fr = frames[f];
@@ -234,9 +263,32 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
             } else if (plain) {
                 p.src_offset = fg.src_offset;
                 select.push_back(p);
+            } else if (!(fg.flags & OHGPU_FLAG_SILENCE)) {
+                // ramp / attenuation on a wider stream: one pass over the two channels that go on the wire
+                if (ch > OHGPU_MAX_CHANNELS)
+                    return set_error(OHGPU_ERR_UNSUPPORTED, "ohm fragment %zu: ramp / attenuation on %u channels (MsgPlayable carries at most 8)", gi, ch);
+                if (fg.ramp_start > OHGPU_RAMP_MAX || fg.ramp_end > OHGPU_RAMP_MAX)
+                    return set_error(OHGPU_ERR_INVALID, "ohm fragment %zu: ramp [%u..%u] beyond Ramp::kMax", gi, fg.ramp_start, fg.ramp_end);
+                if ((fg.flags & OHGPU_FLAG_RAMP) && fg.n_frames > 131071u)      // i*iTotalRamp is TInt arithmetic (Msg.cpp:835)
+                    return set_error(OHGPU_ERR_INVALID, "ohm fragment %zu: ramped fragment of %u frames overflows the reference's TInt ramp product", gi, fg.n_frames);
+                if (fg.attenuation != OHGPU_UNITY_ATTENUATION && s.src_bits != 16)  // ASSERT(iBitDepth == 16), Msg.cpp:2741
+                    return set_error(OHGPU_ERR_UNSUPPORTED, "ohm fragment %zu: attenuation %u on %u-bit audio (16-bit only)", gi, fg.attenuation, s.src_bits);
+                if (fg.src_offset > src_arena_bytes || src_bytes > src_arena_bytes - fg.src_offset)
+                    return set_error(OHGPU_ERR_BOUNDS, "ohm fragment %zu: reads [%llu, +%llu) beyond the %llu-byte source arena", gi,
+                                     (unsigned long long)fg.src_offset, (unsigned long long)src_bytes, (unsigned long long)src_arena_bytes);
+                OhmSelRec sr;
+                memset(&sr, 0, sizeof(sr));
+                sr.src_off = fg.src_offset; sr.dst_off = at; sr.n_frames = fg.n_frames;
+                sr.ramp_start = fg.ramp_start; sr.ramp_end = fg.ramp_end; sr.attenuation = fg.attenuation;
+                sr.channels = (uint8_t)ch; sr.sb = (uint8_t)(s.src_bits / 8); sr.first_ch = (uint8_t)(ch < 10 ? 0 : 8);
+                sr.flags = fg.flags; sr.little = little ? 1 : 0;
+                uint32_t sh = 0;
+                magic_u31(fg.n_frames > 1 ? fg.n_frames - 1 : 1, &sr.m_n1, &sh);
+                sr.s_n1 = (uint8_t)sh;
+                selr.push_back(sr);
             } else {
                 if (ch > OHGPU_MAX_CHANNELS)
-                    return set_error(OHGPU_ERR_UNSUPPORTED, "ohm fragment %zu: ramp / silence / attenuation on %u channels (MsgPlayable carries at most 8)", gi, ch);
+                    return set_error(OHGPU_ERR_UNSUPPORTED, "ohm fragment %zu: silence on %u channels (MsgPlayable carries at most 8)", gi, ch);
                 m.dst_offset = scratch_bytes;
                 m.dst_bits = s.src_bits;
                 stage.push_back(m);
@@ -279,6 +331,8 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
     if (err == OHGPU_OK && !select_staged.empty())
         err = ohgpu_fmt_batch_create(ctx, select_staged.data(), select_staged.size(), scratch_bytes, dst_arena_bytes, &plan.select_staged);
     if (err == OHGPU_OK) err = dev_copy(&plan.d_scratch, nullptr, scratch_bytes);
+    if (err == OHGPU_OK) err = dev_copy(&plan.d_selr, selr.data(), selr.size() * sizeof(OhmSelRec));
+    plan.n_selr = (uint32_t)selr.size();
     if (err == OHGPU_OK) err = dev_copy(&plan.d_frames, recs.data(), recs.size() * sizeof(OhmFrameRec));
     if (err == OHGPU_OK) err = dev_copy(&plan.d_streams, stream_recs.data(), stream_recs.size());
     if (err != OHGPU_OK) { free_ohm(ctx, b); delete b; return err; }
@@ -301,6 +355,12 @@ int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (err == OHGPU_OK && p.stage) err = ohgpu_pcm_batch_run(ctx, p.stage, src_base, p.d_scratch, s);
     if (err == OHGPU_OK && p.select_staged) err = ohgpu_fmt_batch_run(ctx, p.select_staged, p.d_scratch, dst_base, s);
     if (err != OHGPU_OK) return err;
+    if (p.n_selr) {
+        const uint32_t blocks = (p.n_selr + 3) / 4 < 4096u ? (p.n_selr + 3) / 4 : 4096u;
+        hipLaunchKernelGGL(ohm_select_ramp_kernel, dim3(blocks), dim3(256), 0, s, (const OhmSelRec*)p.d_selr, p.n_selr,
+                           (const uint16_t*)ctx->d_ramp_table, (const uint8_t*)src_base, (uint8_t*)dst_base);
+        OHGPU_HIP_TRY(hipGetLastError());
+    }
     const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame * kFramesPerGroup;
     const uint32_t blocks = (p.n_frames + frames_per_block - 1) / frames_per_block;
     hipLaunchKernelGGL(ohm_header_kernel, dim3(blocks), dim3(threads), 0, s,

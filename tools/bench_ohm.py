@@ -51,7 +51,7 @@ def main():
     ctx = capi.Context(0)
     rng = np.random.default_rng(1)
     cases = [("stereo S24 plain", 2, 24, False), ("stereo S32 -> S24 plain", 2, 32, False), ("stereo S24 ramped", 2, 24, True),
-             ("6-channel S24 plain (channel select)", 6, 24, False), ("6-channel S24 ramped (staged)", 6, 24, True)]
+             ("6-channel S24 plain (channel select)", 6, 24, False), ("6-channel S24 ramped (select + ramp in one pass)", 6, 24, True)]
     for name, ch, bits, ramped in cases:
         streams, frames, frags, src_bytes, dst_bytes = build(capi, a.streams, a.packets, a.samples, ch, bits, ramped)
         src = rng.integers(0, 256, size=src_bytes, dtype=np.uint8)
