@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = name.split("(")[0]
-    for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_line_kernel", "pcm_msg_kernel_v1", "fmt_line_kernel", "fmt_kernel_v1", "flywheel_kernel", "ohm_header_kernel",
+    for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_line_kernel", "pcm_msg_kernel_v1", "fmt_line_kernel", "fmt_kernel_v1", "flywheel_kernel", "ohm_header_kernel", "ohm_select_ramp_kernel",
               "unpack_stereo_kernel", "flac_stereo_kernel"):
         if k in name:
             return k
