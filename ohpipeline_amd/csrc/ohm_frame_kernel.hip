@@ -72,7 +72,7 @@ ohm_header_kernel(const OhmFrameRec* __restrict__ frames, uint32_t n_frames, con
 // do to the two channels that go on the wire, in one pass: a wave per fragment, a lane per wire subsample.
 __global__ void __launch_bounds__(256)
 ohm_select_ramp_kernel(const OhmSelRec* __restrict__ recs, uint32_t n_recs, const uint16_t* __restrict__ ramp_table,
-                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+                       const uint8_t* __restrict__ src, uint64_t src_arena_bytes, uint8_t* __restrict__ dst)
 {
     const uint32_t lane = threadIdx.x & 63, waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_recs; i += waves) {
@@ -81,9 +81,16 @@ ohm_select_ramp_kernel(const OhmSelRec* __restrict__ recs, uint32_t n_recs, cons
         const int32_t total = (int32_t)r.ramp_start - (int32_t)r.ramp_end;
         for (uint32_t q = lane; q < r.n_frames * 2; q += 64) {
             const uint32_t f = q >> 1, c = r.first_ch + (q & 1);
-            const uint8_t* p = src + r.src_off + ((size_t)f * r.channels + c) * sb;
+            const uint64_t at = r.src_off + ((uint64_t)f * r.channels + c) * sb;
+            const uint8_t* p = src + at;
             uint32_t w = 0;                                              // left-justified, most significant byte first
-            for (uint32_t k = 0; k < sb; k++) w |= (uint32_t)p[r.little ? sb - 1 - k : k] << (24 - 8 * k);
+            if (at + 4 <= src_arena_bytes) {                             // one (unaligned) dword load; the bytes beyond the subsample are dropped
+                uint32_t v;
+                __builtin_memcpy(&v, p, 4);
+                w = r.little ? (v << (32 - 8 * sb)) : (__builtin_bswap32(v) & (0xffffffffu << (32 - 8 * sb)));
+            } else {
+                for (uint32_t k = 0; k < sb; k++) w |= (uint32_t)p[r.little ? sb - 1 - k : k] << (24 - 8 * k);
+            }
             if (r.attenuation != OHGPU_UNITY_ATTENUATION) w = attenuate_word(w, r.attenuation);
             if (r.flags & OHGPU_FLAG_RAMP)
                 w = ramp_word(w, ramp_table[ramp_index_magic(r.ramp_start, total, f, r.n_frames, r.m_n1, r.s_n1)], sb, r.channels, c);
@@ -358,7 +365,7 @@ int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (p.n_selr) {
         const uint32_t blocks = (p.n_selr + 3) / 4 < 4096u ? (p.n_selr + 3) / 4 : 4096u;
         hipLaunchKernelGGL(ohm_select_ramp_kernel, dim3(blocks), dim3(256), 0, s, (const OhmSelRec*)p.d_selr, p.n_selr,
-                           (const uint16_t*)ctx->d_ramp_table, (const uint8_t*)src_base, (uint8_t*)dst_base);
+                           (const uint16_t*)ctx->d_ramp_table, (const uint8_t*)src_base, batch->src_arena_bytes, (uint8_t*)dst_base);
         OHGPU_HIP_TRY(hipGetLastError());
     }
     const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame * kFramesPerGroup;
