@@ -724,6 +724,37 @@ static void SuiteSongcastSenderControl(MsgFactory& aControl)
     TEST(s.sink.grams.empty());
     TByte b[4] = { 0 };
     TEST_THROWS(sender.Push(aControl.CreateMsgAudioPcm(Brn(b, 4), 2, 44100, 16, AudioDataEndian::Big, 0)->CreatePlayable()), AssertionFailed);   // Sender.cpp:264-268
+
+    // the messages that cut a packet short, and what they do to the frame counter
+    std::vector<TByte> ms(48 * 4, 0x11);                                               // 1 ms of 48 kHz 16-bit stereo
+    auto audio = [&]() { return aControl.CreateMsgAudioPcm(Brn(ms.data(), (TUint)ms.size()), 2, 48000, 16, AudioDataEndian::Big, 0); };
+    DatagramCollector sink2;
+    Av::Sender s2(aControl, sink2, 50);
+    s2.SetBatching(0);
+    TEST_THROWS(s2.Push(audio()), AssertionFailed);                                    // audio before any MsgDecodedStream: ASSERT(iSampleRate != 0), Sender.cpp:246
+    DecodedStreamInfo info;
+    info.iBitDepth = 16; info.iSampleRate = 48000; info.iNumChannels = 2; info.iSampleStart = 7;
+    s2.Push(aControl.CreateMsgDecodedStream(info));
+    TEST(s2.Driver().Frame() == 0 && s2.Driver().SampleStart() == 7);                  // SetAudioFormat: iSampleStart (OhmSender.cpp:334); nothing pending, nothing sent
+    for (int k = 0; k < 3; k++) s2.Push(audio());                                      // 3 ms pending: below a packet
+    TEST(s2.Driver().Frame() == 0);
+    s2.Push(aControl.CreateMsgHalt());                                                 // SendPendingAudio(true): the 3 ms leave as a (halt) frame, Sender.cpp:196-201
+    TEST(s2.Driver().Frame() == 1 && s2.Driver().SampleStart() == 7 + 3 * 48);
+    s2.Push(aControl.CreateMsgHalt());                                                 // nothing pending, but a halt frame is still sent (samples == 0 && aHalt), OhmSender.cpp:434
+    TEST(s2.Driver().Frame() == 2 && s2.Driver().SampleStart() == 7 + 3 * 48);
+    s2.Push(audio());
+    s2.Push(aControl.CreateMsgStreamInterrupted());                                    // pending audio out, then the gap receivers resync on (:187-193, OhmSender.cpp:482-488)
+    TEST(s2.Driver().Frame() == 3 + 250);
+    for (int k = 0; k < 12; k++) s2.Push(audio());                                     // 12 ms: two whole packets, 2 ms left pending
+    TEST(s2.Driver().Frame() == 3 + 250 + 2);
+    s2.Push(aControl.CreateMsgTrack());                                                // SendPendingAudio(): the 2 ms go out, Sender.cpp:146-152
+    TEST(s2.Driver().Frame() == 3 + 250 + 3);
+    info.iMultiroom = Multiroom::Forbidden;                                            // a stream that may not be sent: its audio is dropped (:281-284)
+    s2.Push(aControl.CreateMsgDecodedStream(info));
+    for (int k = 0; k < 12; k++) s2.Push(audio());
+    TEST(s2.Driver().Frame() == 3 + 250 + 3);
+    s2.Driver().SetEnabled(false);                                                     // turning the sender off resets the frame counter (ResetLocked, :623-635)
+    TEST(s2.Driver().Frame() == 0);
 }
 
 static void SuiteSongcastSenderGpu(MsgFactory& aFactory)
