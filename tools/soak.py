@@ -27,8 +27,12 @@ def main():
     seed, counts = 1000, {"src_tilings": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
     real_rng = np.random.default_rng
     formats = [(48000, 24, 2), (44100, 16, 2), (96000, 32, 2), (44100, 24, 1), (48000, 24, 6), (48000, 32, 8), (44100, 16, 6), (48000, 8, 2), (192000, 24, 2)]
+    last = time.time()
     while time.time() < deadline:
         seed += 1
+        if time.time() - last > 30:                          # (a silent GPU job is taken to be hung)
+            print("soak:", counts, flush=True)
+            last = time.time()
         P.test_src_block_kernel_irregular_message_tilings(ctx, seed)
         counts["src_tilings"] += 1
         rng = np.random.default_rng(seed)
