@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the GPU paths against the oracle with seeds the test suite does not use (run on the GPU box; not part
-of the suite because of its length).  Usage: python tools/soak.py [--minutes 3]"""
+of the suite because of its length).  Usage: python tools/soak.py [--minutes 3] [--first-seed 1001]"""
 import argparse
 import os
 import sys
@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=3.0)
+    ap.add_argument("--first-seed", type=int, default=1001)
     a = ap.parse_args()
     import test_gpu_flywheel as F
     import test_gpu_fmt as M
@@ -24,7 +25,7 @@ def main():
     from ohpipeline_amd import capi
     ctx = capi.Context(0)
     deadline = time.time() + a.minutes * 60
-    seed, counts = 1000, {"src_tilings": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
+    seed, counts = a.first_seed - 1, {"src_tilings": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
     real_rng = np.random.default_rng
     formats = [(48000, 24, 2), (44100, 16, 2), (96000, 32, 2), (44100, 24, 1), (48000, 24, 6), (48000, 32, 8), (44100, 16, 6), (48000, 8, 2), (192000, 24, 2)]
     last = time.time()
@@ -60,7 +61,7 @@ def main():
                 np.random.default_rng = real_rng
             counts["flywheel"] += 1
             counts["fmt_mixed"] += 1
-    print("soak ok:", counts, "seeds", 1001, "..", seed)
+    print("soak ok:", counts, "seeds", a.first_seed, "..", seed)
     ctx.close()
 
 
