@@ -120,7 +120,18 @@ def cpu_baseline(work, n_streams, in_frames):
             times.append(time.perf_counter() - t0)
             assert all(r == 0 for r in rcs)
     dt = sorted(times)[1]
+    # SURVEY.md 8(d) also asks for one thread alone: the first streams of the same step, about a second of work
+    n_one = max(1, min(n_streams, 8))
+    part = np.ascontiguousarray(descs[:n_one * n_msgs])
+    one = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = lib.ohp_src_msg_process_batch(ref.h, part.ctypes.data_as(C.c_void_p), part.size,
+                                           src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+        one.append(time.perf_counter() - t0)
+        assert rc == 0
     return dict(value=round(n_streams * in_frames / dt / 1e6, 3), unit="Msamples/s", cores=threads, kind="port",
+                single_thread=round(n_one * in_frames / sorted(one)[1] / 1e6, 3),
                 sample=f"the whole step, median of 3 passes: {n_streams} streams x {in_frames} frames, {threads} threads "
                        f"(gcc -O2 oracle, {dt:.2f} s per pass, {sum(times) * threads:.0f} core-seconds in all)"), dst
 
