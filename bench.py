@@ -255,6 +255,27 @@ def main():
                     result["roofline"]["traffic_source"] = p.get("source")
             except Exception:
                 pass
+        if world == 1:
+            # the same step with the buffers on the host side of the boundary (pinned): H2D of the input,
+            # the launch, D2H of the output, wall clock.  Reported beside `value`, never as it.
+            h_src = ctx.malloc_host(work["src"].nbytes)
+            h_dst = ctx.malloc_host(work["dst_bytes"])
+            h_src[:] = work["src"].view(np.uint8).reshape(-1)
+            e2e = []
+            for _ in range(3):
+                ctx.sync()
+                t1 = time.perf_counter()
+                ctx.copy_h2d(d_src, h_src)
+                ctx.src_run(batch, d_src, d_dst)
+                ctx.copy_d2h(h_dst, d_dst)
+                ctx.sync()
+                e2e.append(time.perf_counter() - t1)
+            dt = sorted(e2e)[1]
+            result["end_to_end"] = {"value": round(frames_per_step / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+                                    "pcie_gbps": round((work["src"].nbytes + work["dst_bytes"]) / dt / 1e9, 2),
+                                    "what": "pinned host input -> H2D -> launch -> D2H -> pinned host output, median of 3"}
+            ctx.free_host(h_src)
+            ctx.free_host(h_dst)
         if world == 1 and not args.no_cpu:
             base, cpu_out = cpu_baseline(work, n_streams, in_frames)
             result["cpu_baseline"] = base

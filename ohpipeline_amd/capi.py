@@ -203,6 +203,22 @@ class Context:
     def free(self, dptr):
         check(lib().ohgpu_free(self._h, dptr))
 
+    def malloc_host(self, nbytes):
+        """Pinned host memory as a uint8 array (free with free_host(array))."""
+        p = C.c_void_p()
+        check(lib().ohgpu_malloc_host(self._h, max(nbytes, 1), C.byref(p)))
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))[:nbytes]
+        return a
+
+    def free_host(self, array):
+        check(lib().ohgpu_free_host(self._h, C.c_void_p(array.ctypes.data)))
+
+    def copy_h2d(self, dptr, array, stream=None):
+        check(lib().ohgpu_memcpy_h2d(self._h, dptr, array.ctypes.data_as(C.c_void_p), array.nbytes, stream))
+
+    def copy_d2h(self, array, dptr, stream=None):
+        check(lib().ohgpu_memcpy_d2h(self._h, array.ctypes.data_as(C.c_void_p), dptr, array.nbytes, stream))
+
     def upload(self, array, stream=None):
         a = np.ascontiguousarray(array)
         p = self.malloc(max(a.nbytes, 1))
