@@ -137,6 +137,7 @@ int ohgpu_stream_sync(ohgpu_ctx* ctx, void* stream);                /* NULL = th
 int ohgpu_event_create(ohgpu_ctx* ctx, void** event);
 int ohgpu_event_destroy(ohgpu_ctx* ctx, void* event);
 int ohgpu_event_record(ohgpu_ctx* ctx, void* event, void* stream);
+int ohgpu_stream_wait_event(ohgpu_ctx* ctx, void* stream, void* event);          /* work queued on stream after this waits for event */
 int ohgpu_event_elapsed_ms(ohgpu_ctx* ctx, void* start, void* stop, float* ms);  /* synchronises on stop */
 
 /* ---- RampArray.h:7-74: the 512 Q15 multipliers the device uses (generated) ---- */

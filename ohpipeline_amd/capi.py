@@ -79,6 +79,7 @@ SYMBOLS = {
     "ohgpu_event_create": (C.c_int, [_vp, _vpp]),
     "ohgpu_event_destroy": (C.c_int, [_vp, _vp]),
     "ohgpu_event_record": (C.c_int, [_vp, _vp, _vp]),
+    "ohgpu_stream_wait_event": (C.c_int, [_vp, _vp, _vp]),
     "ohgpu_event_elapsed_ms": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
     "ohgpu_ramp_table": (C.c_int, [C.POINTER(C.c_uint16)]),
     "ohgpu_pcm_batch_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
@@ -203,6 +204,14 @@ class Context:
     def free(self, dptr):
         check(lib().ohgpu_free(self._h, dptr))
 
+    def stream_create(self):
+        p = C.c_void_p()
+        check(lib().ohgpu_stream_create(self._h, C.byref(p)))
+        return p
+
+    def stream_destroy(self, stream):
+        check(lib().ohgpu_stream_destroy(self._h, stream))
+
     def malloc_host(self, nbytes):
         """Pinned host memory as a uint8 array (free with free_host(array))."""
         p = C.c_void_p()
@@ -249,6 +258,9 @@ class Context:
 
     def record(self, event, stream=None):
         check(lib().ohgpu_event_record(self._h, event, stream))
+
+    def wait_event(self, stream, event):
+        check(lib().ohgpu_stream_wait_event(self._h, stream, event))
 
     def elapsed_ms(self, start, stop):
         ms = C.c_float(0)

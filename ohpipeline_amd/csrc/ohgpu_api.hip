@@ -216,6 +216,14 @@ int ohgpu_event_record(ohgpu_ctx* ctx, void* event, void* stream)
     return OHGPU_OK;
 }
 
+int ohgpu_stream_wait_event(ohgpu_ctx* ctx, void* stream, void* event)
+{
+    CTX_GUARD("ohgpu_stream_wait_event");
+    if (!event) return set_error(OHGPU_ERR_INVALID, "ohgpu_stream_wait_event: null event");
+    OHGPU_HIP_TRY(hipStreamWaitEvent(pick_stream(ctx, stream), (hipEvent_t)event, 0));
+    return OHGPU_OK;
+}
+
 int ohgpu_event_elapsed_ms(ohgpu_ctx* ctx, void* start, void* stop, float* ms)
 {
     CTX_GUARD("ohgpu_event_elapsed_ms");
