@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=SECONDS, help="audio per stream (default 10 s = the throughput set)")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 baseline v1)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and end_to_end legs (profiling runs: only the timed launches)")
     ap.add_argument("--check", action="store_true", help="compare the GPU output of the last step with the oracle")
     ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per stream (the headline is stereo; 6 and 8 also run the block kernel)")
     ap.add_argument("--rate-in", type=int, default=RATE_IN, help="input rate (the headline is 44100; 96000 with --taps 64 is config 4's other rate)")
@@ -256,7 +256,7 @@ def main():
             except Exception:
                 pass
         overlapped_out = None
-        if world == 1:
+        if world == 1 and not args.no_cpu:
             # the same step with the buffers on the host side of the boundary (pinned): H2D of the input,
             # the launch, D2H of the output, wall clock.  Reported beside `value`, never as it.
             h_src = ctx.malloc_host(work["src"].nbytes)

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 TARGET=${OHGPU_PROFILE_TARGET:-$R/bench.py}                      # e.g. tools/bench_pcm.py (then pass its own arguments)
-if [ "$TARGET" = "$R/bench.py" ]; then BENCH_ARGS="--steps 5 --warmup 2 --no-cpu $*"; else BENCH_ARGS="$*"; fi
+if [ "$TARGET" = "$R/bench.py" ]; then BENCH_ARGS="--steps 10 --warmup 3 --no-cpu $*"; else BENCH_ARGS="$*"; fi
 echo "== kernel trace" | tee "$OUT/log.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$TARGET" $BENCH_ARGS >> "$OUT/log.txt" 2>&1 || echo "trace run failed" | tee -a "$OUT/log.txt"
 i=0

@@ -22,7 +22,7 @@ def short(name):
 
 def main():
     tag = sys.argv[1]
-    what = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 5 --warmup 2 --no-cpu"   # the profiled command
+    what = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 10 --warmup 3 --no-cpu"   # the profiled command
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = {"tag": tag, "kernels": {}, "counters": {}}
     for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
