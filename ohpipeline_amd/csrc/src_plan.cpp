@@ -70,7 +70,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     uint32_t rows = 0, ring = 0, coef_lds = 0, wave_lds = 0, max_waves = 0;
     if (!src_block_geometry(L, T, ch, sb, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
-    uint32_t L_blk = L * ((128 + L - 1) / L);
+    uint32_t min_blk = 128;
+    if (const char* e = getenv("OHGPU_EXP_MIN_BLOCK")) min_blk = (uint32_t)atoi(e);     // (experiments: longer blocks per lane)
+    uint32_t L_blk = L * ((min_blk + L - 1) / L);
     {
         uint32_t k = 1;
         while (k <= 64 && ((uint64_t)L_blk * k * fb_dst) % 64 != 0) k++;
