@@ -597,3 +597,51 @@ def test_src_config3_shape_256_streams(ctx):
     want = oracle_src(ref, descs, src, dbytes)
     assert np.array_equal(got, want)
     ctx.src_destroy(h)
+
+
+def test_src_groups_overlapped_on_two_streams(ctx):
+    """The bulk caller's pattern (bench.py's end_to_end.overlapped): pinned buffers, one batch per group
+    of streams, uploads on one HIP stream, launch + download on a second one that waits for each group's upload
+    (ohgpu_stream_wait_event).  The bytes that come back are the oracle's."""
+    import ctypes as C
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    n_streams, in_frames, groups = 32, 22050, 4
+    src = np.concatenate([W.noise_pcm(s, in_frames, 2, 24, LE) for s in range(n_streams)])
+    out_total = ref.out_frames(in_frames)
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 50 * O.JIFFIES_PER_MS, 200 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, sched)
+    assert sbytes == src.size and len(descs) == n_streams * n_msgs
+    per, sb, db = n_streams // groups, in_frames * 6, out_total * 6
+    h_src, h_dst = ctx.malloc_host(sbytes), ctx.malloc_host(dbytes)
+    h_src[:] = src
+    h_dst[:] = 0xA5
+    d_src, d_dst = ctx.malloc(sbytes), ctx.malloc(dbytes)
+    ctx.memset(d_dst, 0xA5, dbytes)
+    ctx.sync()
+    parts = [ctx.src_batch(h, descs[g * per * n_msgs:(g + 1) * per * n_msgs], sbytes, dbytes) for g in range(groups)]
+    up, down = ctx.stream_create(), ctx.stream_create()
+    arrived = [ctx.event() for _ in range(groups)]
+    for g in range(groups):
+        s0, s1, o0, o1 = g * per * sb, (g + 1) * per * sb, g * per * db, (g + 1) * per * db
+        ctx.copy_h2d(C.c_void_p(d_src.value + s0), h_src[s0:s1], up)
+        ctx.record(arrived[g], up)
+        ctx.wait_event(down, arrived[g])
+        ctx.src_run(parts[g], d_src, d_dst, down)
+        ctx.copy_d2h(h_dst[o0:o1], C.c_void_p(d_dst.value + o0), down)
+    ctx.sync(up)
+    ctx.sync(down)
+    got = np.array(h_dst)
+    want = oracle_src(ref, descs, src, dbytes)
+    assert np.array_equal(got, want)
+    with pytest.raises(capi.OhGpuError):
+        ctx.wait_event(down, None)
+    for b in parts:
+        ctx.batch_destroy(b)
+    ctx.stream_destroy(up)
+    ctx.stream_destroy(down)
+    ctx.free_host(h_src)
+    ctx.free_host(h_dst)
+    ctx.free(d_src)
+    ctx.free(d_dst)
+    ctx.src_destroy(h)
