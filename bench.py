@@ -257,63 +257,67 @@ def main():
                 pass
         overlapped_out = None
         if world == 1 and not args.no_cpu:
-            # the same step with the buffers on the host side of the boundary (pinned): H2D of the input,
-            # the launch, D2H of the output, wall clock.  Reported beside `value`, never as it.
-            h_src = ctx.malloc_host(work["src"].nbytes)
-            h_dst = ctx.malloc_host(work["dst_bytes"])
-            h_src[:] = work["src"].view(np.uint8).reshape(-1)
-            e2e = []
-            for _ in range(3):
-                ctx.sync()
-                t1 = time.perf_counter()
-                ctx.copy_h2d(d_src, h_src)
-                ctx.src_run(batch, d_src, d_dst)
-                ctx.copy_d2h(h_dst, d_dst)
-                ctx.sync()
-                e2e.append(time.perf_counter() - t1)
-            dt = sorted(e2e)[1]
-            result["end_to_end"] = {"value": round(frames_per_step / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
-                                    "pcie_gbps": round((work["src"].nbytes + work["dst_bytes"]) / dt / 1e9, 2),
-                                    "what": "pinned host input -> H2D -> launch -> D2H -> pinned host output, median of 3"}
-            # the same with the streams in groups: one HIP stream uploads, a second waits for each group's upload (event),
-            # launches it and downloads its output, so the link carries both directions while the kernel runs
-            groups = 8 if n_streams % 8 == 0 else 1
-            if groups > 1:
-                import ctypes as C
-                per, fb = n_streams // groups, CHANNELS * BITS // 8
-                n_msgs, sb, db = work["n_msgs"], in_frames * fb, work["out_total"] * fb
-                parts = [ctx.src_batch(h, work["descs"][g * per * n_msgs:(g + 1) * per * n_msgs], work["src"].size, work["dst_bytes"])
-                         for g in range(groups)]
-                lanes = [ctx.stream_create(), ctx.stream_create()]
-                up, down = lanes
-                arrived = [ctx.event() for _ in range(groups)]
-                h_dst[:] = 0
-                ctx.memset(d_dst, 0, work["dst_bytes"])
-                ov = []
+            try:                                             # (a reported extra: never let it cost the headline line)
+                # the same step with the buffers on the host side of the boundary (pinned): H2D of the input,
+                # the launch, D2H of the output, wall clock.  Reported beside `value`, never as it.
+                h_src = ctx.malloc_host(work["src"].nbytes)
+                h_dst = ctx.malloc_host(work["dst_bytes"])
+                h_src[:] = work["src"].view(np.uint8).reshape(-1)
+                e2e = []
                 for _ in range(3):
                     ctx.sync()
                     t1 = time.perf_counter()
-                    for g in range(groups):
-                        s0, s1, o0, o1 = g * per * sb, (g + 1) * per * sb, g * per * db, (g + 1) * per * db
-                        ctx.copy_h2d(C.c_void_p(d_src.value + s0), h_src[s0:s1], up)
-                        ctx.record(arrived[g], up)
-                        ctx.wait_event(down, arrived[g])
-                        ctx.src_run(parts[g], d_src, d_dst, down)
-                        ctx.copy_d2h(h_dst[o0:o1], C.c_void_p(d_dst.value + o0), down)
+                    ctx.copy_h2d(d_src, h_src)
+                    ctx.src_run(batch, d_src, d_dst)
+                    ctx.copy_d2h(h_dst, d_dst)
+                    ctx.sync()
+                    e2e.append(time.perf_counter() - t1)
+                dt = sorted(e2e)[1]
+                result["end_to_end"] = {"value": round(frames_per_step / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+                                        "pcie_gbps": round((work["src"].nbytes + work["dst_bytes"]) / dt / 1e9, 2),
+                                        "what": "pinned host input -> H2D -> launch -> D2H -> pinned host output, median of 3"}
+                # the same with the streams in groups: one HIP stream uploads, a second waits for each group's upload (event),
+                # launches it and downloads its output, so the link carries both directions while the kernel runs
+                groups = 8 if n_streams % 8 == 0 else 1
+                if groups > 1:
+                    import ctypes as C
+                    per, fb = n_streams // groups, CHANNELS * BITS // 8
+                    n_msgs, sb, db = work["n_msgs"], in_frames * fb, work["out_total"] * fb
+                    parts = [ctx.src_batch(h, work["descs"][g * per * n_msgs:(g + 1) * per * n_msgs], work["src"].size, work["dst_bytes"])
+                             for g in range(groups)]
+                    lanes = [ctx.stream_create(), ctx.stream_create()]
+                    up, down = lanes
+                    arrived = [ctx.event() for _ in range(groups)]
+                    h_dst[:] = 0
+                    ctx.memset(d_dst, 0, work["dst_bytes"])
+                    ov = []
+                    for _ in range(3):
+                        ctx.sync()
+                        t1 = time.perf_counter()
+                        for g in range(groups):
+                            s0, s1, o0, o1 = g * per * sb, (g + 1) * per * sb, g * per * db, (g + 1) * per * db
+                            ctx.copy_h2d(C.c_void_p(d_src.value + s0), h_src[s0:s1], up)
+                            ctx.record(arrived[g], up)
+                            ctx.wait_event(down, arrived[g])
+                            ctx.src_run(parts[g], d_src, d_dst, down)
+                            ctx.copy_d2h(h_dst[o0:o1], C.c_void_p(d_dst.value + o0), down)
+                        for st in lanes:
+                            ctx.sync(st)
+                        ov.append(time.perf_counter() - t1)
+                    dt = sorted(ov)[1]
+                    result["end_to_end"]["overlapped"] = {"value": round(frames_per_step / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 3),
+                                                          "pcie_gbps": round((work["src"].nbytes + work["dst_bytes"]) / dt / 1e9, 2),
+                                                          "what": f"{groups} groups of {per} streams, upload stream + launch/download stream"}
+                    overlapped_out = np.array(h_dst)
                     for st in lanes:
-                        ctx.sync(st)
-                    ov.append(time.perf_counter() - t1)
-                dt = sorted(ov)[1]
-                result["end_to_end"]["overlapped"] = {"value": round(frames_per_step / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 3),
-                                                      "pcie_gbps": round((work["src"].nbytes + work["dst_bytes"]) / dt / 1e9, 2),
-                                                      "what": f"{groups} groups of {per} streams, upload stream + launch/download stream"}
-                overlapped_out = np.array(h_dst)
-                for st in lanes:
-                    ctx.stream_destroy(st)
-                for b in parts:
-                    ctx.batch_destroy(b)
-            ctx.free_host(h_src)
-            ctx.free_host(h_dst)
+                        ctx.stream_destroy(st)
+                    for b in parts:
+                        ctx.batch_destroy(b)
+                ctx.free_host(h_src)
+                ctx.free_host(h_dst)
+            except Exception as e:
+                result["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+                overlapped_out = None
         if world == 1 and not args.no_cpu:
             base, cpu_out = cpu_baseline(work, n_streams, in_frames)
             result["cpu_baseline"] = base
