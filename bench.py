@@ -278,7 +278,9 @@ def main():
                                         "what": "pinned host input -> H2D -> launch -> D2H -> pinned host output, median of 3"}
                 # the same with the streams in groups: one HIP stream uploads, a second waits for each group's upload (event),
                 # launches it and downloads its output, so the link carries both directions while the kernel runs
-                groups = 8 if n_streams % 8 == 0 else 1
+                groups = int(os.environ.get("OHGPU_BENCH_GROUPS", "8"))
+                if n_streams % groups != 0:
+                    groups = 1
                 if groups > 1:
                     import ctypes as C
                     per, fb = n_streams // groups, CHANNELS * BITS // 8
