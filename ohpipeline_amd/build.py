@@ -10,10 +10,11 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libohgpu.so")
 
-HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "ohm_frame_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip"]
+HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "ohm_frame_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip", "src_lean_kernel.hip"]
+PARTED = ("src_block_kernel.hip", "src_lean_kernel.hip")     # compiled once per part of the instantiation list (csrc/src_block_common.h)
 HEADERS = ["ohgpu_internal.h", "pcm_device.h", os.path.join(ROOT, "include", "ohgpu.h")]
 ARCH = "gfx950"
-BLOCK_PARTS = 3                     # OHGPU_BLOCK_PARTS in csrc/src_block_kernel.hip
+BLOCK_PARTS = 3                     # OHGPU_BLOCK_PARTS in csrc/src_block_common.h
 
 
 def hipcc():
@@ -51,7 +52,7 @@ def build(force=False, verbose=False, save_temps=False):
     os.makedirs(obj_dir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              *os.environ.get("OHGPU_EXTRA_FLAGS", "").split(),
-             "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
+             "-Wall", "-Wno-inline-asm", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
     if save_temps:
         flags += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     headers = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
@@ -73,7 +74,7 @@ def build(force=False, verbose=False, save_temps=False):
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         # the block kernel's instantiations are compiled in BLOCK_PARTS parts (see the end of src_block_kernel.hip)
         jobs = [(src, part) for src in _sources()
-                for part in (range(1, BLOCK_PARTS + 1) if os.path.basename(src) == "src_block_kernel.hip" else (0,))]
+                for part in (range(1, BLOCK_PARTS + 1) if os.path.basename(src) in PARTED else (0,))]
         jobs.sort(key=lambda j: 0 if j[1] else 1)                # the long ones first
         objs = list(ex.map(compile_one, jobs))
     link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs

@@ -104,7 +104,7 @@ int ohgpu_device_name(ohgpu_ctx* ctx, char* buf, size_t buf_bytes)
 
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 1) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
+    if (!ctx || variant < 0 || variant > 2) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
     ctx->variant = variant;
     return OHGPU_OK;
 }
@@ -327,7 +327,7 @@ int ohgpu_pcm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!batch || batch->kind != kBatchPcm) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_run: not a pcm batch");
     if (batch->n == 0) return OHGPU_OK;
     if (!dst_base || (!src_base && batch->src_bytes_touched)) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_run: null arena pointer");
-    if (ctx->variant == 0 && batch->line.enabled)
+    if (ctx->variant != 1 && batch->line.enabled)
         OHGPU_HIP_TRY(launch_pcm_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
     else
         OHGPU_HIP_TRY(launch_pcm_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
@@ -447,9 +447,9 @@ int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!batch || batch->kind != kBatchFmt) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: not a fmt batch");
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: null arena pointer");
-    if (ctx->variant == 0 && batch->line.enabled)                       // stereo Songcast packs planned onto the PCM line kernel
+    if (ctx->variant != 1 && batch->line.enabled)                       // stereo Songcast packs planned onto the PCM line kernel
         OHGPU_HIP_TRY(launch_pcm_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
-    else if (ctx->variant == 0 && batch->fmtline.enabled)
+    else if (ctx->variant != 1 && batch->fmtline.enabled)
         OHGPU_HIP_TRY(launch_fmt_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
     else
         OHGPU_HIP_TRY(launch_fmt_v1(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
@@ -560,6 +560,7 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
         return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: bad geometry L=%u M=%u T=%u", L, M, T);
     const size_t n = (size_t)L * T;
     std::vector<double> cd(n);
+    int64_t max_sum_abs = 0;
     for (uint32_t p = 0; p < L; p++) {
         int64_t sabs = 0;
         for (uint32_t k = 0; k < T; k++) {
@@ -567,12 +568,14 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
             sabs += q < 0 ? -(int64_t)q : (int64_t)q;
             cd[(size_t)p * T + k] = (double)q;
         }
+        if (sabs > max_sum_abs) max_sum_abs = sabs;
         if (sabs >= ((int64_t)1 << 30))
             return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: phase %u has sum|c| = %lld >= 2^30 (exact fp64 accumulation bound)", p, (long long)sabs);
     }
     ohgpu_src* s = new (std::nothrow) ohgpu_src();
     if (!s) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_create: out of host memory");
     s->L = L; s->M = M; s->T = T;
+    s->max_sum_abs = max_sum_abs;
     hipError_t e = hipMalloc((void**)&s->d_coef, n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_coef_q28, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(s->d_coef, cd.data(), n * sizeof(double), hipMemcpyHostToDevice);
@@ -713,9 +716,12 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
     hipStream_t s = pick_stream(ctx, stream);
     const bool aligned = ((uintptr_t)src_base & 15u) == 0;          // the staging loads move aligned 16-byte pieces of the arena
-    if (ctx->variant == 0 && batch->fast.enabled && aligned) {
-        // whole phase-aligned blocks on the block kernel, block-unaligned heads/tails on the generic one
-        OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+    if (ctx->variant != 1 && batch->fast.enabled && aligned) {
+        // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
+        if (batch->fast.lean && ctx->variant == 0)
+            OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+        else
+            OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
     } else {
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->d_descs, batch->n, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));

@@ -61,7 +61,7 @@ struct SrcWork {              // one workgroup's share: up to `rows` consecutive
     uint32_t seg;
     uint32_t n_blocks;
     uint32_t msg_first;       // index (in the SegMsg array) of the message that holds the unit's first output frame
-    uint32_t pad;
+    uint32_t flags;           // kWorkRamped | kWorkChecked (src_block_common.h)
 };
 static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 24 && sizeof(SrcSeg) == 24, "plan layouts");
 
@@ -89,6 +89,8 @@ struct SrcFastPlan {
     uint32_t wave_lds_bytes = 0;  // per wave: input stages, message table, output ring
     uint32_t max_waves = 0;       // waves per workgroup the LDS allows (<= 12)
     uint32_t ring_bytes = 0;      // bytes of packed output a block row's LDS ring holds
+    bool     lean = false;        // the batch runs on src_lean_kernel (round 2) rather than src_block_kernel
+    uint32_t lean_wave_lds_bytes = 0, lean_max_waves = 0;
     void*    d_segs = nullptr;
     void*    d_msgs = nullptr;
     void*    d_work = nullptr;
@@ -205,6 +207,7 @@ struct ohgpu_ctx {
 
 struct ohgpu_src {
     uint32_t L, M, T;
+    int64_t  max_sum_abs;         // largest sum|c| over the phases, Q28 (the lean kernel's rounding bias needs < 2^29)
     double*  d_coef;              // [L][T] exact integer-valued doubles (Q28)
     int32_t* d_coef_q28;          // [L][T] int32
 };
@@ -252,6 +255,9 @@ hipError_t launch_flywheel(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
 hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* src_filter,
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
+                       uint32_t* rows, uint32_t* in_blocks, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                         uint32_t* rows, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);

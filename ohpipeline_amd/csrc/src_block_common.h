@@ -1,0 +1,93 @@
+// src_block_common.h -- what the two block resampler kernels (src_lean_kernel.hip, src_block_kernel.hip) and their host
+// glue share: address-space typedefs, the compile-time loop, the output ring's geometry, the instantiation list.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+namespace ohgpu {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* global_ptr_t;
+typedef __attribute__((address_space(3))) uint8_t* lds_u8_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// calls f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a compile-time unrolled loop
+template <typename F, int... S>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S...>)
+{
+    (f(std::integral_constant<int, S>{}), ...);
+}
+
+// Output ring: every block row owns `ring_bytes` of LDS that hold its packed output byte stream modulo ring_bytes.
+// ring_bytes is a multiple of the frame size (a frame never wraps) and of 16 (a 16-byte piece of a line never
+// wraps).  After a drain fewer than 64 bytes (a multiple of g = gcd(64, fb_dst)) are pending, and `out_per_drain`
+// more frames arrive before the next drain.  Rows are 4 bytes further apart so that they start in different banks.
+static constexpr uint32_t gcd_c(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
+static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain, bool pair)
+{
+    // pair mode (24-bit stereo): frames enter the ring two at a time, so one more frame can be waiting and the
+    // pending bytes are a multiple of gcd(64, 2 * fb_dst)
+    const uint32_t step = pair ? 2 * fb_dst : fb_dst;
+    const uint32_t unit = step * 16 / gcd_c(step, 16);
+    const uint32_t need = (64 - gcd_c(64, step)) + (out_per_drain + (pair ? 1 : 0)) * fb_dst;
+    return unit * ((need + unit - 1) / unit);
+}
+static constexpr bool ring_pair_mode(uint32_t ch, uint32_t db) { return ch == 2 && db == 3; }
+static constexpr uint32_t kRampLdsBytes = 1024;         // RampArray.h's 512 Q15 multipliers, kept after the coefficient table
+
+// lean kernel: 16-byte pieces per staged row.  The eight frames of a stage start anywhere in their first piece, so
+// the bytes that are USED span at most 15 + 8 * fb_src bytes.  Stereo rows drift against the banks by themselves (the
+// rows of a unit are M_blk frames apart, never a whole number of pieces for the stereo layouts); wider frames get an
+// odd count so that the rows start in different banks.
+static constexpr int lean_in_blocks(int ch, int sb)
+{
+    const int n = (8 * ch * sb + 14) / 16 + 1;
+#ifdef OHGPU_DIAG_IN_ODD
+    return n | 1;
+#else
+    return ch == 2 ? n : (n | 1);
+#endif
+}
+
+// SrcWork::flags
+enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output range
+       kWorkChecked = 2u };   // some staging piece of the unit lies outside the source arena (ends of the arena)
+
+}  // namespace ohgpu
+
+// ---- instantiations: (T, channels, source bytes, source LE, destination bytes, destination LE) ----
+// The list is compiled in parts so that the build can run them side by side (ohpipeline_amd/build.py compiles each kernel
+// file once per part with -DOHGPU_BLOCK_PART=k): part 1 also holds the host code and only DECLARES the other parts' kernels;
+// parts 2.. hold nothing but their kernels.  Without the macro (tools, tests) a file is one translation unit.
+#ifdef OHGPU_DIAG_ONE_KERNEL
+#define OHGPU_BLOCK_KERNELS_1(X) X(32, 2, 3, true, 3, false)
+#define OHGPU_BLOCK_KERNELS_2(X)
+#define OHGPU_BLOCK_KERNELS_3(X)
+#else
+#define OHGPU_BLOCK_KERNELS_1(X)    \
+    X(32, 2, 3, true, 3, false)     \
+    X(32, 2, 3, true, 3, true)      \
+    X(32, 2, 3, false, 3, false)    \
+    X(32, 2, 3, true, 4, false)     \
+    X(32, 2, 3, true, 2, false)     \
+    X(32, 2, 2, true, 3, false)     \
+    X(32, 2, 2, true, 2, true)      \
+    X(32, 2, 2, true, 2, false)
+#define OHGPU_BLOCK_KERNELS_2(X)    \
+    X(32, 6, 3, true, 3, false)     \
+    X(32, 6, 3, false, 3, false)    \
+    X(32, 8, 3, true, 3, false)     \
+    X(32, 8, 3, false, 3, false)
+#define OHGPU_BLOCK_KERNELS_3(X)    \
+    X(64, 2, 3, true, 3, false)     \
+    X(64, 6, 3, true, 3, false)     \
+    X(64, 8, 3, true, 3, false)     \
+    X(32, 2, 2, false, 3, false)    \
+    X(32, 2, 2, false, 2, false)
+#endif
+#define OHGPU_BLOCK_KERNELS(X) OHGPU_BLOCK_KERNELS_1(X) OHGPU_BLOCK_KERNELS_2(X) OHGPU_BLOCK_KERNELS_3(X)
+#define OHGPU_BLOCK_PARTS 3

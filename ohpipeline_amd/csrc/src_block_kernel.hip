@@ -30,21 +30,9 @@
 
 #include "ohgpu_internal.h"
 #include "pcm_device.h"
+#include "src_block_common.h"
 
 namespace ohgpu {
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* global_ptr_t;
-typedef __attribute__((address_space(3))) uint8_t* lds_u8_t;
-
-// calls f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a compile-time unrolled loop
-template <typename F, int... S>
-__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S...>)
-{
-    (f(std::integral_constant<int, S>{}), ...);
-}
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- hand-issued LDS traffic of the per-output loop, with counted waits ----
 // hipcc waits for LDS data with `s_waitcnt lgkmcnt(0)`, which also waits for whatever was issued last -- here the
@@ -152,23 +140,6 @@ struct BlockGeom {
     static constexpr int MAX_WAVES = T <= 32 ? 12 : 8;  // waves per workgroup: 3 per SIMD (168 VGPRs each), 2 when the window is 64 deep
     static constexpr int MSG_SLOTS = 32;                // messages of a wave's output range kept in LDS
 };
-
-// Output ring: every block row owns `ring_bytes` of LDS that hold its packed output byte stream modulo ring_bytes.
-// ring_bytes is a multiple of the frame size (a frame never wraps) and of 16 (a 16-byte piece of a line never
-// wraps).  After a drain fewer than 64 bytes (a multiple of g = gcd(64, fb_dst)) are pending, and `out_per_drain`
-// more frames arrive before the next drain.  Rows are 4 bytes further apart so that they start in different banks.
-static constexpr uint32_t gcd_c(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
-static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain, bool pair)
-{
-    // pair mode (24-bit stereo): frames enter the ring two at a time, so one more frame can be waiting and the
-    // pending bytes are a multiple of gcd(64, 2 * fb_dst)
-    const uint32_t step = pair ? 2 * fb_dst : fb_dst;
-    const uint32_t unit = step * 16 / gcd_c(step, 16);
-    const uint32_t need = (64 - gcd_c(64, step)) + (out_per_drain + (pair ? 1 : 0)) * fb_dst;
-    return unit * ((need + unit - 1) / unit);
-}
-static constexpr bool ring_pair_mode(uint32_t ch, uint32_t db) { return ch == 2 && db == 3; }
-static constexpr uint32_t kRampLdsBytes = 1024;         // RampArray.h's 512 Q15 multipliers, kept after the coefficient table
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
 __global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
@@ -650,35 +621,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 // The list is compiled in parts so that the build can run them side by side (ohpipeline_amd/build.py compiles this file
 // once per part with -DOHGPU_BLOCK_PART=k): part 1 also holds the host code and only DECLARES the other parts' kernels;
 // parts 2.. hold nothing but their kernels.  Without the macro (tools, tests) the file is one translation unit.
-#ifdef OHGPU_EXP_ONE_KERNEL
-#define OHGPU_BLOCK_KERNELS_1(X) X(32, 2, 3, true, 3, false)
-#define OHGPU_BLOCK_KERNELS_2(X)
-#define OHGPU_BLOCK_KERNELS_3(X)
-#else
-#define OHGPU_BLOCK_KERNELS_1(X)    \
-    X(32, 2, 3, true, 3, false)     \
-    X(32, 2, 3, true, 3, true)      \
-    X(32, 2, 3, false, 3, false)    \
-    X(32, 2, 3, true, 4, false)     \
-    X(32, 2, 3, true, 2, false)     \
-    X(32, 2, 2, true, 3, false)     \
-    X(32, 2, 2, true, 2, true)      \
-    X(32, 2, 2, true, 2, false)
-#define OHGPU_BLOCK_KERNELS_2(X)    \
-    X(32, 6, 3, true, 3, false)     \
-    X(32, 6, 3, false, 3, false)    \
-    X(32, 8, 3, true, 3, false)     \
-    X(32, 8, 3, false, 3, false)
-#define OHGPU_BLOCK_KERNELS_3(X)    \
-    X(64, 2, 3, true, 3, false)     \
-    X(64, 6, 3, true, 3, false)     \
-    X(64, 8, 3, true, 3, false)     \
-    X(32, 2, 2, false, 3, false)    \
-    X(32, 2, 2, false, 2, false)
-#endif
-#define OHGPU_BLOCK_KERNELS(X) OHGPU_BLOCK_KERNELS_1(X) OHGPU_BLOCK_KERNELS_2(X) OHGPU_BLOCK_KERNELS_3(X)
-#define OHGPU_BLOCK_PARTS 3
-
 #define OHGPU_KERNEL_ARGS const SrcSeg*, const SegMsg*, const SrcWork*, uint32_t, const double*, const uint16_t*, const uint8_t*, \
                           uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
 #define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_block_kernel<t, c, s_, sl, d, dl, false>(OHGPU_KERNEL_ARGS);

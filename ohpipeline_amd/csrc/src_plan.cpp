@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ohgpu_internal.h"
+#include "src_block_common.h"
 
 namespace ohgpu {
 
@@ -69,9 +70,16 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint32_t out_per_drain = (4 * L + M - 1) / M;
     uint32_t rows = 0, ring = 0, coef_lds = 0, wave_lds = 0, max_waves = 0;
     if (!src_block_geometry(L, T, ch, sb, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
+    // the lean kernel (round 2): same blocks, rows and ring; its rounding bias needs sum|c| < 2^29 in every phase
+    uint32_t lean_rows = 0, lean_inb = 0, lean_ring = 0, lean_coef = 0, lean_wave_lds = 0, lean_max_waves = 0;
+    const bool lean = flt->max_sum_abs < ((int64_t)1 << 29) &&
+                      src_lean_geometry(L, T, ch, sb, db, out_per_drain, &lean_rows, &lean_inb, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
+                      lean_rows == rows && lean_ring == ring && lean_coef == coef_lds;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
     uint32_t min_blk = 128;
-    if (const char* e = getenv("OHGPU_EXP_MIN_BLOCK")) min_blk = (uint32_t)atoi(e);     // (experiments: longer blocks per lane)
+#ifdef OHGPU_DIAG
+    if (const char* e = getenv("OHGPU_DIAG_MIN_BLOCK")) min_blk = (uint32_t)atoi(e);     // (diagnostic builds: longer blocks per lane)
+#endif
     uint32_t L_blk = L * ((min_blk + L - 1) / L);
     {
         uint32_t k = 1;
@@ -153,7 +161,17 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 bool ramped = false;
                 for (uint32_t m = mi; m < sg.msg_end && msgs[m].out0 < u_hi && !ramped; m++)
                     ramped = (msgs[m].flags & OHGPU_FLAG_RAMP) && msgs[m].out0 + msgs[m].n > u_lo;
-                w.pad = ramped ? 1u : 0u;
+                w.flags = ramped ? kWorkRamped : 0u;
+                // the lean kernel's staging moves, per stage q, the aligned 16-byte pieces that hold each row's eight frames:
+                // does every one of them lie inside the arena?  (Only a unit at an end of the arena can fail.)
+                {
+                    const int64_t total = (int64_t)M_blk + T, n_stages = (total + 7) >> 3;
+                    const int64_t g_first = sbase + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
+                    const int64_t g_last = g_first + (int64_t)(w.n_blocks - 1) * M_blk * fb_src;
+                    const int64_t lo = g_first - (g_first & 15);
+                    const int64_t hi = g_last - (g_last & 15) + 16 * (((g_last & 15) + 8 * fb_src + 15) >> 4) + (n_stages - 1) * 8 * fb_src;
+                    if (g_first < 0 || lo < 0 || (uint64_t)hi > b->src_arena_bytes) w.flags |= kWorkChecked;
+                }
                 work.push_back(w);
             }
             fast_frames += (blk_hi - blk_lo) * L_blk;
@@ -175,10 +193,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // Longest first: the waves claim units in this order, and the kernel ends when the last unit does.  With the ramped
     // units where the streams put them (each stream's fade-out is its last units) the launch ended on a few long units
     // with most of the chip idle.
-    if (!getenv("OHGPU_EXP_PLAN_ORDER"))                   // (experiments: keep the stream order)
-        std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {     // ramped first, partly filled units last
-            return (x.pad ? 3u : 1u) * x.n_blocks > (y.pad ? 3u : 1u) * y.n_blocks;
-        });
+    std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {     // ramped first, partly filled units last
+        return ((x.flags & kWorkRamped) ? 3u : 1u) * x.n_blocks > ((y.flags & kWorkRamped) ? 3u : 1u) * y.n_blocks;
+    });
 
     int err = upload_vec(segs, &f.d_segs);
     if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
@@ -194,6 +211,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.wave_lds_bytes = wave_lds;
     f.max_waves = max_waves;
     f.ring_bytes = ring;
+    f.lean = lean;
+    f.lean_wave_lds_bytes = lean_wave_lds;
+    f.lean_max_waves = lean_max_waves;
     f.fast_out_frames = fast_frames;
     SrcFastParams& p = f.params;
     memset(&p, 0, sizeof(p));

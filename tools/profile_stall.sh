@@ -27,7 +27,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if not any(k in row["Kernel_Name"] for k in ("src_block_kernel", "pcm_line_kernel", "pcm_msg_kernel")): continue
+        if not any(k in row["Kernel_Name"] for k in ("src_lean_kernel", "src_block_kernel", "pcm_line_kernel", "pcm_msg_kernel")): continue
         tot[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
 with open(out + "/summary.txt", "w") as o:
     for k in sorted(tot):
