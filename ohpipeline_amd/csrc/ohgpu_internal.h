@@ -62,8 +62,10 @@ struct SrcWork {              // one workgroup's share: up to `rows` consecutive
     uint32_t n_blocks;
     uint32_t msg_first;       // index (in the SegMsg array) of the message that holds the unit's first output frame
     uint32_t flags;           // kWorkRamped | kWorkChecked (src_block_common.h)
+    uint32_t plane;           // a ramped unit's multiplier plane (lean kernel): its index in SrcFastPlan::d_planes
+    uint32_t pad;
 };
-static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 24 && sizeof(SrcSeg) == 24, "plan layouts");
+static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24, "plan layouts");
 
 struct SrcFastParams {        // kernel argument block
     const SrcSeg*  segs;
@@ -90,7 +92,9 @@ struct SrcFastPlan {
     uint32_t max_waves = 0;       // waves per workgroup the LDS allows (<= 12)
     uint32_t ring_bytes = 0;      // bytes of packed output a block row's LDS ring holds
     bool     lean = false;        // the batch runs on src_lean_kernel (round 2) rather than src_block_kernel
-    uint32_t lean_wave_lds_bytes = 0, lean_max_waves = 0;
+    uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
+    void*    d_planes = nullptr;  // uint16 [n_planes][plane_stride / 2]: RampApplicator's multiplier per output frame of every ramped unit
+    uint32_t plane_stride = 0;    // bytes per plane: rows * L_blk entries and one load group of slack
     void*    d_segs = nullptr;
     void*    d_msgs = nullptr;
     void*    d_work = nullptr;
@@ -257,7 +261,8 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
-                       uint32_t* rows, uint32_t* in_blocks, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);
+                       uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
+                       uint32_t* wave_lds_bytes, uint32_t* max_waves);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                         uint32_t* rows, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);

@@ -39,18 +39,21 @@ static constexpr uint32_t ring_bytes_for(uint32_t fb_dst, uint32_t out_per_drain
 static constexpr bool ring_pair_mode(uint32_t ch, uint32_t db) { return ch == 2 && db == 3; }
 static constexpr uint32_t kRampLdsBytes = 1024;         // RampArray.h's 512 Q15 multipliers, kept after the coefficient table
 
-// lean kernel: 16-byte pieces per staged row.  The eight frames of a stage start anywhere in their first piece, so
-// the bytes that are USED span at most 15 + 8 * fb_src bytes.  Stereo rows drift against the banks by themselves (the
+// lean kernel: 16-byte pieces per staged row.  The frames of a stage start anywhere in their first piece, so
+// the bytes that are USED span at most 15 + frames * fb_src bytes.  Stereo rows drift against the banks by themselves (the
 // rows of a unit are M_blk frames apart, never a whole number of pieces for the stereo layouts); wider frames get an
 // odd count so that the rows start in different banks.
+#ifndef OHGPU_LEAN_STAGE_FRAMES
+#define OHGPU_LEAN_STAGE_FRAMES 16
+#endif
+// frames per stage: stereo rows take OHGPU_LEAN_STAGE_FRAMES at a time (each row's request then covers most of a 128-byte
+// line: with 8 frames -- 48 bytes of a 6-byte-frame row -- every line was requested by three or four stages and fetched
+// from memory 1.8 times), wider frames 8
+static constexpr int lean_stage_frames(int ch) { return ch == 2 ? OHGPU_LEAN_STAGE_FRAMES : 8; }
 static constexpr int lean_in_blocks(int ch, int sb)
 {
-    const int n = (8 * ch * sb + 14) / 16 + 1;
-#ifdef OHGPU_DIAG_IN_ODD
-    return n | 1;
-#else
+    const int n = (lean_stage_frames(ch) * ch * sb + 14) / 16 + 1;
     return ch == 2 ? n : (n | 1);
-#endif
 }
 
 // SrcWork::flags

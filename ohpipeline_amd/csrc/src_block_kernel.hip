@@ -1,4 +1,6 @@
-// src_block_kernel.hip -- the tuned resample -> ramp -> pack kernel ("block kernel").
+// src_block_kernel.hip -- round 1's resample -> ramp -> pack kernel ("block kernel").  Since round 2 the batches run on
+// src_lean_kernel.hip; this one stays for filters whose phase sums break the lean kernel's rounding bias (sum|c| >= 2^29) and as
+// the same-box A/B reference (ohgpu_set_kernel_variant(ctx, 2)).
 //
 // Mapping (DESIGN.md "Resampler kernel"):
 //   * A stream's output is cut into BLOCKS of L_blk frames that start where the polyphase phase is 0
@@ -66,11 +68,7 @@ __device__ __forceinline__ void lds_issue_store_u16(uint32_t addr, uint32_t v)
 {
     asm volatile("ds_write_b16 %0, %1" : : "v"(addr), "v"(v) : "memory");
 }
-#ifdef OHGPU_EXP_NOWAIT
-#define OHGPU_WAIT_INSN "s_nop 0 ; %"
-#else
 #define OHGPU_WAIT_INSN "s_waitcnt lgkmcnt(%"
-#endif
 __device__ __forceinline__ void lds_issue_store_3xu8(uint32_t addr, uint32_t v)   // bytes 0, 1, 2 of v at addr, addr + 1, addr + 2
 {
     asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8_d16_hi %0, %1 offset:2"
@@ -126,13 +124,6 @@ __device__ __forceinline__ int32_t unpack_subsample(const RawSubsample& r)      
     }
 }
 
-__device__ __forceinline__ uint64_t stamp_now()                               // diagnostic builds only
-{
-    uint64_t t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-
 template <int T, int CH>
 struct BlockGeom {
     static constexpr int BPW = 64 / CH;                 // blocks per wave
@@ -141,13 +132,13 @@ struct BlockGeom {
     static constexpr int MSG_SLOTS = 32;                // messages of a wave's output range kept in LDS
 };
 
-template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool STAMP = false>
+template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
 __global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
 void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
                       const uint32_t n_work, const double* __restrict__ coef, const uint16_t* __restrict__ ramp_table,
                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                       const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
-                      const uint32_t ring_bytes, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
+                      const uint32_t ring_bytes, uint32_t* __restrict__ unit_counter)
 {
     static_assert(T % 16 == 0 && T >= 32 && T <= 64, "T / 16 coefficient registers per lane: register r holds taps 16 r + (lane & 15)");
     constexpr int NCR = T / 16;
@@ -187,7 +178,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     const lds_u8_t lds = (lds_u8_t)wsmem;                            // write-back are private to the wave
     const int Mr = M % L;
 
-    uint64_t st_wait = 0, st_issue = 0, st_drain = 0, st_compute = 0, st_mark = 0, st_setup = 0, st_warm = 0;
 
     // Work units: every wave starts on its own unit, then claims further ones from a counter, so that the waves of
     // the whole grid finish together (waves sharing a SIMD run at very different speeds; a fixed share per wave
@@ -197,7 +187,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     while (unit < n_work) {
     uint32_t claim = 0;
     if (lane == 0) claim = atomicAdd(unit_counter, 1u);
-    if constexpr (STAMP) { st_wait = st_issue = st_drain = st_compute = st_setup = st_warm = 0; st_mark = stamp_now(); }
     const SrcWork wk = work[unit];
     const SrcSeg seg = segs[wk.seg];
     const uint32_t n_blocks = wk.n_blocks;
@@ -262,12 +251,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         // first message that holds this block's output 0: the last table entry that starts at or before it.  Counted
         // over the whole table at once (32 pipelined broadcast reads, one wait): walking there entry by entry cost the
         // last block of a unit some twenty dependent LDS round trips (a quarter of the unit's set-up time).
-#ifndef OHGPU_EXP_MSG_WALK
         uint32_t cnt = 0;
 #pragma unroll
         for (int idx = 0; idx < MSG_SLOTS; idx++) cnt += ((int32_t)msg_tab[idx].x <= lane_off) ? 1u : 0u;
         mi = cnt ? cnt - 1 : 0;
-#endif
         load_msg(mi);
         while ((uint32_t)(0 - msg_rel0) >= msg_n) load_msg(++mi);   // (beyond the table: the range has more than MSG_SLOTS messages)
     }
@@ -289,14 +276,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
         const uint32_t r = idx / IN_BLOCKS;
         const int64_t g = seg.src_base + ((int64_t)((wk.first_block + r) * M_blk) - T) * (int64_t)FB_SRC;   // row's frame at a_lin = 0
         piece_a[it] = (g & ~(int64_t)15) + 16 * (int64_t)(idx - r * IN_BLOCKS);
-#ifdef OHGPU_EXP_NODMA
-        piece_on[it] = false; (void)n_blocks;
-#else
         // a row whose first frame sits early in its piece does not reach into the last piece of the window
         // (8 frames + the 7 bytes the aligned two-word reads may touch beyond the last subsample)
         const uint32_t pieces_needed = (((uint32_t)g & 15u) + 8 * FB_SRC + 7 + 15) >> 4;
         piece_on[it] = r < n_blocks && r < (uint32_t)ROWS && (idx - r * IN_BLOCKS) < pieces_needed;
-#endif
         const int64_t last = piece_a[it] + (int64_t)(n_stages - 1) * (8 * FB_SRC);
         if (piece_on[it] && (piece_a[it] < 0 || (uint64_t)last + 16 > src_arena_bytes)) unit_safe = false;
     }
@@ -357,11 +340,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             for (int it = 0; it < (BPW * 4 + 63) / 64; it++) {
                 const uint32_t piece = it * 64 + lane;
                 const uint32_t r = piece >> 2, part = piece & 3;
-#ifdef OHGPU_EXP_NODRAIN
-                if (r < wave_rows && drained == 0x7fffffffu) {
-#else
                 if (r < wave_rows) {
-#endif
                     uint32_t pos = line_pos + part * 16;
                     if (pos >= ring_bytes) pos -= ring_bytes;
                     const __attribute__((address_space(3))) uint32_t* q =
@@ -371,11 +350,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                     u32x4* const o = (u32x4*)(dst + wave_dst + (int64_t)((uint64_t)r * L_blk) * FB_DST + drained * 64 + part * 16);
                     // written once, never read here: a non-temporal store keeps the output from pushing the input lines, which
                     // two or three stages re-read, out of the XCD's L2 (tools/exp_traffic.sh: 2.17 -> 1.80 GB per launch, -3.6 % time)
-#if defined(OHGPU_EXP_STORE_PLAIN)
-                    *o = v4;
-#else
                     __builtin_nontemporal_store(v4, o);
-#endif
                 }
             }
             drained++;
@@ -426,7 +401,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // Every later wait awaits c[r] (and the last one R as well): followed by the rest of last output's reloads, this
     // output's NS stores and the reloads already issued in this output                -> lgkmcnt(NCR - 1 + NS)
     // The newest sample is tap 0, used last, so its read has the first 16 taps to land.
-    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_setup = n - st_mark; st_mark = n; }     // unit set-up: descriptors, message table, first stages issued
     // ---- warm-up: the T advances before the block's first output only fill the window.  Nothing overlaps the staging
     // loads here, so their latency is what this pass costs: it runs TWO stages ahead (stages 0 and 1 were issued together,
     // stage q + 2 goes into the buffer stage q has just been read from), which halves the number of exposed waits; the
@@ -442,13 +416,8 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             RawSubsample r4[4];
             static_for([&](auto k4) __attribute__((always_inline)) {
                 constexpr int sp = 4 * h + decltype(k4)::value, ph = sp % PH;
-#ifdef OHGPU_EXP_NOSAMPLE
-                r4[sp & 3].words = lane + sp;
-                r4[sp & 3].shift = 0;
-#else
                 lds_issue_2xu32<FB_SRC * (sp - ph) / 4>(r4[sp & 3].words, in_addr[ph]);
                 r4[sp & 3].shift = in_shift[ph];
-#endif
             }, std::make_integer_sequence<int, 4>{});
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r4[0].words), "+v"(r4[1].words), "+v"(r4[2].words), "+v"(r4[3].words) : : "memory");
 #pragma unroll
@@ -462,7 +431,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 #pragma unroll
         for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
     }
-    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_warm = n - st_mark; st_mark = n; }
     for (int g = 1; g * T < total; g++) {
         static_for([&](auto slot) __attribute__((always_inline)) {
             constexpr int s = decltype(slot)::value;
@@ -470,13 +438,10 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
             if (a_lin >= total) return;
             const int a = a_lin - T;
             if constexpr ((s & 3) == 0) {
-                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_compute += n - st_mark; st_mark = n; }
                 if constexpr ((s & 7) == 0) {
                     const int q = a_lin >> 3;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage q has landed (this wave issued all of it)
-                    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_wait += n - st_mark; st_mark = n; }
                     if ((q + 1) * 8 < total) issue_stage(q + 1);
-                    if constexpr (STAMP) { const uint64_t n = stamp_now(); st_issue += n - st_mark; st_mark = n; }
 #pragma unroll
                     for (int ph = 0; ph < PH; ph++)     // (a stage shifts the row by whole 16-byte pieces: same misalignment)
                         in_addr[ph] = ((in_base + ph * FB_SRC) & ~3u) + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
@@ -484,18 +449,13 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                 issue_store();                                          // the last output's bytes must be in the ring
                 st_addr = idle_lane;
                 drain(j);
-                if constexpr (STAMP) { const uint64_t n = stamp_now(); st_drain += n - st_mark; st_mark = n; }
             }
             // ---- advance: this channel's sample of frame (n_start + a) enters slot s ----
-#ifdef OHGPU_EXP_NOSAMPLE
-            raw.words = lane + s; raw.shift = 0;
-#else
             {
                 constexpr int sp = s & 7, ph = sp % PH;                 // frame sp of the stage = frame ph + PH * k
                 lds_issue_2xu32<FB_SRC * (sp - ph) / 4>(raw.words, in_addr[ph]);
                 raw.shift = in_shift[ph];
             }
-#endif
             if (!(t < L * (a + 1))) {                                   // no output needs it yet (warm-up, or M > L)
                 lds_wait<0>(raw.words);
                 win[s] = (double)unpack_subsample<SB, SRC_LE>(raw);
@@ -510,56 +470,30 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
                     constexpr int r = NCR - 1 - decltype(rc)::value;          // highest taps (oldest samples) first, the newest sample last
                     if constexpr (r == NCR - 1) {
                         lds_wait<NCR - 1>(cf[r]);
-#ifndef OHGPU_EXP_NORING
                         issue_store();
-#endif
                     } else if constexpr (r == 0) {
-#ifdef OHGPU_EXP_NORING
-                        lds_wait<NCR - 1>(cf[0], raw.words);
-#else
                         lds_wait<NCR - 1 + NS>(cf[0], raw.words);
-#endif
                         win[s] = (double)unpack_subsample<SB, SRC_LE>(raw);
                     } else {
-#ifdef OHGPU_EXP_NORING
-                        lds_wait<NCR - 1>(cf[r]);
-#else
                         lds_wait<NCR - 1 + NS>(cf[r]);
-#endif
                     }
-#ifdef OHGPU_EXP_NOFMA
-                    acc0 += cf[r] + (r == 0 ? win[s] : 0.0);
-#else
                     static_for([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = 14 - 2 * decltype(kc)::value;       // taps 16 r + 15 .. 16 r
                         fmac_bcast<k + 1, k == 14>(acc1, cf[r], win[(s - (16 * r + k + 1) + 2 * T) % T]);
                         fmac_bcast<k, false>(acc0, cf[r], win[(s - (16 * r + k) + 2 * T) % T]);
                     }, std::make_integer_sequence<int, 8>{});
-#endif
-#ifdef OHGPU_EXP_NOCOEF
-                    lds_issue_f64<r * 128>(cf[r], coef_lane);
-#else
                     lds_issue_f64<r * 128>(cf[r], cp);
-#endif
                 }, std::make_integer_sequence<int, NCR>{});
                 int32_t y = (int32_t)floor(acc0 + acc1);
                 y = y > 8388607 ? 8388607 : (y < -8388608 ? -8388608 : y);
                 // pair mode packs straight from the S24 value; the other layouts (and the ramp) use the left-justified word (a11)
                 uint32_t w = PAIR ? (uint32_t)y : (uint32_t)y << 8;
-#ifdef OHGPU_EXP_NOEVT
-                if (j < 0) {
-#else
                 if (__builtin_expect(__any(j >= evt_j) != 0, 0)) {              // message boundary or ramping somewhere in the wave (rare: out of line)
-#endif
                     if (lane_valid && j >= evt_j) {
                         while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);   // next message of the segment
                         if (msg_flags & OHGPU_FLAG_RAMP) {
                             const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
-#ifdef OHGPU_EXP_RAMP_GLOBAL
-                            const uint32_t mult = ramp_table[ramp_index(rs, (int32_t)(rs - re), j - msg_rel0, (int32_t)msg_n)];
-#else
                             const uint32_t mult = ramp_lds[ramp_index_magic(rs, (int32_t)(rs - re), (uint32_t)(j - msg_rel0), msg_n, msg_m, (msg_flags >> 8) & 31u)];
-#endif
                             w = PAIR ? ramp_word(w << 8, mult, 3, CH, c) >> 8 : ramp_word(w, mult, 3, CH, c);
                             evt_j = j + 1;
                         } else {
@@ -597,13 +531,6 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
     // the last output's store, then the lines it completes (LDS operations of a wave execute in order)
     issue_store();
     drain(j);
-    if constexpr (STAMP) {
-        const uint64_t n = stamp_now(); st_drain += n - st_mark;
-        if (dbg != nullptr && lane == 0) {
-            uint64_t* o = dbg + (size_t)unit * 6;
-            o[0] = st_wait; o[1] = st_issue; o[2] = st_drain; o[3] = st_compute; o[4] = st_setup; o[5] = st_warm;
-        }
-    }
     unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     }   // units
     // The counters reset themselves: a wave reports in after its last claim, and the last wave of the grid to do so
@@ -622,9 +549,9 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 // once per part with -DOHGPU_BLOCK_PART=k): part 1 also holds the host code and only DECLARES the other parts' kernels;
 // parts 2.. hold nothing but their kernels.  Without the macro (tools, tests) the file is one translation unit.
 #define OHGPU_KERNEL_ARGS const SrcSeg*, const SegMsg*, const SrcWork*, uint32_t, const double*, const uint16_t*, const uint8_t*, \
-                          uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
-#define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_block_kernel<t, c, s_, sl, d, dl, false>(OHGPU_KERNEL_ARGS);
-#define X_DECLARE(t, c, s_, sl, d, dl) extern template __global__ void src_block_kernel<t, c, s_, sl, d, dl, false>(OHGPU_KERNEL_ARGS);
+                          uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*
+#define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_block_kernel<t, c, s_, sl, d, dl>(OHGPU_KERNEL_ARGS);
+#define X_DECLARE(t, c, s_, sl, d, dl) extern template __global__ void src_block_kernel<t, c, s_, sl, d, dl>(OHGPU_KERNEL_ARGS);
 #if defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 2
 OHGPU_BLOCK_KERNELS_2(X_DEFINE)
 #elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 3
@@ -660,7 +587,7 @@ static hipError_t launch_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const S
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
                        p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
                        p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_bytes,
-                       (uint32_t*)b->fast.d_counter, (uint64_t*)nullptr);
+                       (uint32_t*)b->fast.d_counter);
     return hipGetLastError();
 }
 
@@ -690,52 +617,9 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
     if (w > (T <= 32 ? 12u : 8u)) w = T <= 32 ? 12u : 8u;
-    if (const char* e = getenv("OHGPU_EXP_MAX_WAVES")) { const uint32_t x = (uint32_t)atoi(e); if (x >= 4 && x < w) w = x; }   // occupancy experiments
     if (w < 4) return false;            // too few waves per CU to be worth it: the generic kernel takes the batch
     *max_waves = w;
     return true;
-}
-
-// Diagnostic only (OHGPU_STAMP_FILE=<path>): runs the stamped build of the S24LE->S24BE stereo kernel once, waits,
-// and writes per-unit {wait, issue, drain, compute} cycle sums as text.  Never used by the product path.
-static hipError_t launch_stamped(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s, const char* path)
-{
-    auto kernel = src_block_kernel<32, 2, 3, true, 3, false, true>;
-    uint32_t grid, waves, lds;
-    launch_shape(ctx, b, &grid, &waves, &lds);
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    const size_t n = (size_t)b->fast.n_work * 6;
-    uint64_t* d = nullptr;
-    e = hipMalloc((void**)&d, n * sizeof(uint64_t));
-    if (e != hipSuccess) return e;
-    hipMemsetAsync(d, 0, n * sizeof(uint64_t), s);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, s,
-                       p.segs, p.msgs, p.work, b->fast.n_work, p.coef, p.ramp_table, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, b->fast.ring_bytes,
-                       (uint32_t*)b->fast.d_counter, d);
-    e = hipStreamSynchronize(s);
-    if (e == hipSuccess) {
-        std::vector<uint64_t> h(n);
-        e = hipMemcpy(h.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost);
-        if (FILE* f = fopen(path, "w")) {
-            double sum[6] = {0, 0, 0, 0, 0, 0};
-            for (size_t i = 0; i < n; i += 6)
-                for (int k = 0; k < 6; k++) sum[k] += (double)h[i + k];
-            const double units = (double)n / 6;
-            fprintf(f, "units %.0f mean ticks per unit: set-up %.0f warm-up pass %.0f | then wait %.0f issue %.0f drain %.0f compute %.0f | grid %u x %u waves, lds %u B\n",
-                    units, sum[4] / units, sum[5] / units, sum[0] / units, sum[1] / units, sum[2] / units, sum[3] / units, grid, waves, lds);
-            double mn = 1e30, mx = 0;
-            for (size_t u = 0; u < n / 6; u++) {
-                const double c = (double)(h[6 * u] + h[6 * u + 1] + h[6 * u + 2] + h[6 * u + 3] + h[6 * u + 4] + h[6 * u + 5]);
-                mn = c < mn ? c : mn; mx = c > mx ? c : mx;
-            }
-            fprintf(f, "cycles per unit: min %.0f max %.0f\n", mn, mx);
-            fclose(f);
-        }
-    }
-    hipFree(d);
-    return e;
 }
 
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
@@ -745,10 +629,6 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
     prm.src = src;
     prm.dst = dst;
     prm.ramp_table = ctx->d_ramp_table;
-    if (const char* path = getenv("OHGPU_STAMP_FILE")) {
-        if (b->fast.T == 32 && prm.channels == 2 && prm.sb == 3 && prm.src_le && prm.db == 3 && !prm.dst_le)
-            return launch_stamped(ctx, b, prm, s, path);
-    }
     const uint32_t T = b->fast.T;
 #define X(t, c, s_, sl, d, dl)                                                                                            \
     if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "ohgpu_internal.h"
 #include "pcm_device.h"
@@ -35,6 +36,10 @@
 namespace ohgpu {
 
 // ---- hand-issued instructions of the per-output loop ----
+// (A load's destination is a "+v" operand: the register is written when the data arrives, not when the statement is issued,
+// so the variable must LIVE in that register from the issue to the wait -- a read-write operand ties the two, where a pure
+// output may be given a scratch register that the compiler then copies from at once.  tests/test_block_kernel_asm.py checks
+// the generated code for such copies.)
 // The loop's LDS traffic is issued from inline asm so that the compiler's wait insertion does not see it (it would
 // wait with lgkmcnt(0), i.e. for the prefetches just issued as well); the waits are counted by hand.  A wave's LDS
 // operations complete in issue order, so lgkmcnt(N) retires all but the N youngest.  Every statement is volatile
@@ -42,12 +47,12 @@ namespace ohgpu {
 template <int BYTES>
 __device__ __forceinline__ void lean_issue_f64(double& dst, uint32_t addr)
 {
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(BYTES) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "i"(BYTES) : "memory");
 }
 template <int DW>
 __device__ __forceinline__ void lean_issue_2xu32(uint64_t& dst, uint32_t addr)
 {
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "i"(DW), "i"(DW + 1) : "memory");
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "+v"(dst) : "v"(addr), "i"(DW), "i"(DW + 1) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lean_wait(double& x)
@@ -64,21 +69,24 @@ __device__ __forceinline__ void lean_wait0(uint64_t& y)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y) : : "memory");
 }
 
-// sixteen taps of one coefficient register: taps 16 r + 15 .. 16 r, alternating between the two chains.  `w` are the
-// sixteen window slots in tap order 15 .. 0.  (cv is only ever written by an LDS load: no VALU-write -> DPP-read hazard.)
-#define OHGPU_FM(acc, k, x) "v_fmac_f64_dpp " acc ", %[cv], " x " row_newbcast:" #k " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void lean_taps16(double& acc0, double& acc1, const double cv,
+// sixteen taps of one coefficient register: taps 16 r + 15 .. 16 r, ONE accumulation chain.  `w` are the sixteen window slots
+// in tap order 15 .. 0.  (A second chain would need its own zero and a final add -- three more vector instructions per output;
+// with three or four waves on the SIMD the dependent v_fmac_f64 of one wave are issued between those of the others, and the
+// loop runs at the pipe's rate either way: tools/exp_lean.sh, same time.  cv is only ever written by an LDS load: no
+// VALU-write -> DPP-read hazard.)
+#define OHGPU_FM(k, x) "v_fmac_f64_dpp %[a0], %[cv], " x " row_newbcast:" #k " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void lean_taps16(double& acc0, const double cv,
                                             const double w15, const double w14, const double w13, const double w12,
                                             const double w11, const double w10, const double w9, const double w8,
                                             const double w7, const double w6, const double w5, const double w4,
                                             const double w3, const double w2, const double w1, const double w0)
 {
     asm volatile(
-        OHGPU_FM("%[a1]", 15, "%[w15]") OHGPU_FM("%[a0]", 14, "%[w14]") OHGPU_FM("%[a1]", 13, "%[w13]") OHGPU_FM("%[a0]", 12, "%[w12]")
-        OHGPU_FM("%[a1]", 11, "%[w11]") OHGPU_FM("%[a0]", 10, "%[w10]") OHGPU_FM("%[a1]", 9, "%[w9]") OHGPU_FM("%[a0]", 8, "%[w8]")
-        OHGPU_FM("%[a1]", 7, "%[w7]") OHGPU_FM("%[a0]", 6, "%[w6]") OHGPU_FM("%[a1]", 5, "%[w5]") OHGPU_FM("%[a0]", 4, "%[w4]")
-        OHGPU_FM("%[a1]", 3, "%[w3]") OHGPU_FM("%[a0]", 2, "%[w2]") OHGPU_FM("%[a1]", 1, "%[w1]") OHGPU_FM("%[a0]", 0, "%[w0]")
-        : [a0] "+v"(acc0), [a1] "+v"(acc1)
+        OHGPU_FM(15, "%[w15]") OHGPU_FM(14, "%[w14]") OHGPU_FM(13, "%[w13]") OHGPU_FM(12, "%[w12]")
+        OHGPU_FM(11, "%[w11]") OHGPU_FM(10, "%[w10]") OHGPU_FM(9, "%[w9]") OHGPU_FM(8, "%[w8]")
+        OHGPU_FM(7, "%[w7]") OHGPU_FM(6, "%[w6]") OHGPU_FM(5, "%[w5]") OHGPU_FM(4, "%[w4]")
+        OHGPU_FM(3, "%[w3]") OHGPU_FM(2, "%[w2]") OHGPU_FM(1, "%[w1]") OHGPU_FM(0, "%[w0]")
+        : [a0] "+v"(acc0)
         : [cv] "v"(cv), [w15] "v"(w15), [w14] "v"(w14), [w13] "v"(w13), [w12] "v"(w12), [w11] "v"(w11), [w10] "v"(w10), [w9] "v"(w9),
           [w8] "v"(w8), [w7] "v"(w7), [w6] "v"(w6), [w5] "v"(w5), [w4] "v"(w4), [w3] "v"(w3), [w2] "v"(w2), [w1] "v"(w1), [w0] "v"(w0));
 }
@@ -114,33 +122,42 @@ template <int T, int CH, int SB, int DB>
 struct LeanGeom {
     static constexpr int BPW = 64 / CH;
     static constexpr int ROWS = BPW;
-    static constexpr int MAX_WAVES = T <= 32 ? 12 : 8;
-    static constexpr int MSG_SLOTS = 32;
+    static constexpr int MAX_WAVES = T <= 32 ? 12 : 8;   // three per SIMD (what the LDS left by the coefficient table allows with 16-frame stages), two when the window alone is 128 registers
     static constexpr int FB_SRC = CH * SB, FB_DST = CH * DB;
-    // 16-byte pieces per staged row: the eight frames of a stage at any alignment ((15 + 8 FB_SRC) bytes), odd for the bank spread
+    static constexpr int SF = lean_stage_frames(CH);      // frames per stage
     static constexpr int IN_BLOCKS = lean_in_blocks(CH, SB);
     static constexpr int IN_STRIDE = IN_BLOCKS * 16;
     static constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
+    static constexpr int DUMMY = (64 % CH) ? 64 : 0;      // where the lanes beyond the last whole block store
 };
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
 __global__ __launch_bounds__((LeanGeom<T, CH, SB, DB>::MAX_WAVES * 64))
-void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
-                     const uint32_t n_work, const double* __restrict__ coef, const uint16_t* __restrict__ ramp_table,
+void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict__ work, const uint32_t n_work,
+                     const double* __restrict__ coef, const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                      const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
-                     const uint32_t ring_bytes, uint32_t* __restrict__ unit_counter)
+                     const uint32_t ring_bytes, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
 {
     static_assert(T % 16 == 0 && T >= 32 && T <= 64, "T / 16 coefficient registers per lane");
     using G = LeanGeom<T, CH, SB, DB>;
+#ifdef OHGPU_DIAG_STAMP
+    // diagnostic build: shader-clock stamps per phase, summed per wave, written to dbg[wave][8] at the end (never read by the kernel)
+    uint64_t st_setup = 0, st_warm = 0, st_stage = 0, st_drain = 0, st_out = 0, st_units = 0, st_mark = 0;
+    const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+#define STAMP(acc) { const uint64_t n_ = __builtin_amdgcn_s_memtime(); acc += n_ - st_mark; st_mark = n_; }
+#else
+#define STAMP(acc)
+#endif
     constexpr int NCR = T / 16;
-    constexpr int BPW = G::BPW, ROWS = G::ROWS, MSG_SLOTS = G::MSG_SLOTS;
+    constexpr int BPW = G::BPW, ROWS = G::ROWS;
     constexpr int FB_SRC = G::FB_SRC, FB_DST = G::FB_DST;
-    constexpr int IN_BLOCKS = G::IN_BLOCKS, IN_STRIDE = G::IN_STRIDE, IN_ITERS = G::IN_ITERS;
-    constexpr uint32_t OFF_IN = 0, OFF_MSG = OFF_IN + 2 * ROWS * IN_STRIDE, OFF_MSGM = OFF_MSG + MSG_SLOTS * 16, OFF_RING = OFF_MSGM + MSG_SLOTS * 4;
+    constexpr int IN_BLOCKS = G::IN_BLOCKS, IN_STRIDE = G::IN_STRIDE, IN_ITERS = G::IN_ITERS, SF = G::SF;
+    static_assert(T % (2 * SF) == 0, "a trip of T advances is a whole number of stage pairs: the buffer of a slot is static");
+    constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE;
     constexpr bool PAIR = ring_pair_mode(CH, DB);
     static_assert(DB >= 2 && DB <= 4, "destination depths 16 / 24 / 32 bit");
-    static_assert((8 * FB_SRC) % 16 == 0, "a stage advances every piece by a whole number of 16-byte pieces");
+    static_assert((SF * FB_SRC) % 16 == 0, "a stage advances every piece by a whole number of 16-byte pieces");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -148,22 +165,18 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t table_bytes = (uint32_t)L * T * 8;
-    const uint32_t coef_bytes = table_bytes + kRampLdsBytes;
-    const uint32_t row_stride = ring_bytes + 4;
+    const uint32_t row_stride = ring_bytes + 4;                       // rows start in different banks
     const uint32_t ring_area = (ROWS * row_stride + 15) & ~15u;
-    const uint32_t wave_lds = OFF_RING + ring_area + 64;               // + a slot for the stores of lanes beyond the last whole block
+    const uint32_t wave_lds = OFF_RING + ring_area + G::DUMMY;
 
     // ---- coefficient table -> LDS once per workgroup, scaled by 2^-36 (exact): the window holds samples x 256, so the
     // accumulator is in sample units with 28 fraction bits.
     for (uint32_t i = tid; i < (uint32_t)L * T; i += blockDim.x)
         ((__attribute__((address_space(3))) double*)(lds_u8_t)smem)[i] = coef[i] * (1.0 / 68719476736.0);
-    const __attribute__((address_space(3))) uint16_t* const ramp_lds =
-        (const __attribute__((address_space(3))) uint16_t*)((lds_u8_t)smem + table_bytes);
-    for (uint32_t i = tid; i < kRampLdsBytes / 4; i += blockDim.x)
-        ((__attribute__((address_space(3))) uint32_t*)((lds_u8_t)smem + table_bytes))[i] = ((const uint32_t*)ramp_table)[i];
     __syncthreads();
     const uint32_t coef_lane = (uint32_t)(uintptr_t)((lds_u8_t)smem + (lane & 15) * 8);
-    uint8_t* const wsmem = smem + coef_bytes + wave * wave_lds;
+    const uint32_t coef_lane_L = coef_lane + (uint32_t)L * (T * 8);     // + (phase - L) * T * 8, modulo 2^32
+    uint8_t* const wsmem = smem + table_bytes + wave * wave_lds;
     const lds_u8_t lds = (lds_u8_t)wsmem;
     const uint32_t wave_lds_addr = (uint32_t)(uintptr_t)lds;
     const int Mr = M % L;
@@ -177,9 +190,8 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
     constexpr uint32_t B0 = DST_LE ? 0 : 2, B1 = 1, B2 = DST_LE ? 2 : 0;      // byte of the S24 value that is memory byte 0, 1, 2
     const uint32_t sel_lo = c == 0 ? (B0 | B1 << 8 | B2 << 16 | (4 + B0) << 24) : (B1 | B2 << 8 | (4 + B0) << 16 | (4 + B1) << 24);
     const uint32_t sel_hi = c == 0 ? ((4 + B1) | (4 + B2) << 8 | B0 << 16 | B1 << 24) : ((4 + B2) | B0 << 8 | B1 << 16 | B2 << 24);
-    const uint32_t dummy_lane = wave_lds_addr + OFF_RING + ring_area + (lane & 3) * 16;
-    const uint32_t ring_lane0 = wave_lds_addr + OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB);
-    const uint32_t ring_lane = lane_block ? ring_lane0 : dummy_lane;
+    const uint32_t ring_lane = lane_block ? wave_lds_addr + OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB)
+                                          : wave_lds_addr + OFF_RING + ring_area + (lane & 3) * 16;
     const double bias = 16777216.5;                     // 2^24 + 0.5
     const uint32_t clamp_lo = 0x00800000u, clamp_hi = 0x017fffffu;   // 2^24 - 2^23 .. 2^24 + 2^23 - 1
 
@@ -188,6 +200,9 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
     while (unit < n_work) {
     uint32_t claim = 0;
     if (lane == 0) claim = atomicAdd(unit_counter, 1u);
+#ifdef OHGPU_DIAG_STAMP
+    st_mark = __builtin_amdgcn_s_memtime(); st_units++;
+#endif
     const SrcWork wk = work[unit];
     const SrcSeg seg = segs[wk.seg];
     const uint32_t n_blocks = wk.n_blocks;
@@ -199,65 +214,20 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
     const int64_t row_g = seg.src_base + (n_start - T) * (int64_t)FB_SRC;   // byte offset of the row's frame at a_lin = 0
     const bool first_block = n_start == 0;
 
-    // ---- messages: only a ramped unit looks at them (the table, the cursor and the arithmetic are round 1's) ----
-    const __attribute__((address_space(3))) u32x4* msg_tab = (const __attribute__((address_space(3))) u32x4*)(lds + OFF_MSG);
-    const uint64_t wave_m0 = wk.first_block * (uint64_t)L_blk;
-    const uint32_t tab_lo = wk.msg_first;
-    const int32_t lane_off = (int32_t)(bw * L_blk);
-    uint32_t mi = 0;
-    int32_t msg_rel0 = 0;
-    uint32_t msg_n = 0x7fffffffu, msg_ramp = 0, msg_flags = 0, msg_m = 0;
-    int32_t evt_j = 0x7fffffff;
-    auto load_msg = [&](uint32_t idx) __attribute__((always_inline)) {
-        if (idx < (uint32_t)MSG_SLOTS) {
-            const u32x4 e = msg_tab[idx];
-            msg_rel0 = (int32_t)e.x - lane_off; msg_n = e.y; msg_ramp = e.z; msg_flags = e.w;
-            if (msg_flags & OHGPU_FLAG_RAMP) msg_m = ((const __attribute__((address_space(3))) uint32_t*)(lds + OFF_MSGM))[idx];
-        } else {
-            const SegMsg m = msgs[tab_lo + idx];
-            msg_rel0 = (int32_t)(int64_t)(m.out0 - wave_m0) - lane_off;
-            msg_n = m.n; msg_ramp = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16); msg_flags = (uint32_t)m.flags | ((uint32_t)m.s_n1 << 8);
-            msg_m = m.m_n1;
-        }
-    };
-    if (ramped) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < (uint32_t)MSG_SLOTS) {
-            uint32_t em = 0;
-            u32x4 e = {0x7fffffffu, 0u, 0u, 0u};
-            if (tab_lo + lane < seg.msg_end) {
-                const SegMsg m = msgs[tab_lo + lane];
-                e.x = (uint32_t)(int32_t)(int64_t)(m.out0 - wave_m0);
-                e.y = m.n;
-                e.z = (uint32_t)m.ramp_start | ((uint32_t)m.ramp_end << 16);
-                e.w = (uint32_t)m.flags | ((uint32_t)m.s_n1 << 8);
-                em = m.m_n1;
-            }
-            ((__attribute__((address_space(3))) u32x4*)(lds + OFF_MSG))[lane] = e;
-            ((__attribute__((address_space(3))) uint32_t*)(lds + OFF_MSGM))[lane] = em;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane_valid) {
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int idx = 0; idx < MSG_SLOTS; idx++) cnt += ((int32_t)msg_tab[idx].x <= lane_off) ? 1u : 0u;
-            mi = cnt ? cnt - 1 : 0;
-            load_msg(mi);
-            while ((uint32_t)(0 - msg_rel0) >= msg_n) load_msg(++mi);
-        }
-        evt_j = (msg_flags & OHGPU_FLAG_RAMP) ? 0 : msg_rel0 + (int32_t)msg_n;
-    }
+    // ---- a ramped unit reads RampApplicator's multiplier of every output frame from its plane (src_plan.cpp): one uint16 per
+    // frame, rows side by side, 0xffff = the frame's message carries no ramp.  Eight frames per load.
+    const uint8_t* const mbase = (const uint8_t*)planes + (uint64_t)wk.plane * plane_stride;      // (wave-uniform)
+    const uint32_t mrow = lane_valid ? row * L_blk * 2u : 0u;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;              // the next multipliers of this lane's row, 16 bits each, next one lowest in m0
+    uint32_t moff = mrow;                                 // where this lane's next eight are, from mbase
+    const uint32_t ramped_u = ramped ? 1u : 0u;
 
-    // ---- input staging.  Stage q holds advances [8q - T, 8q + 8 - T) of every row as raw packed bytes: the aligned
+    // ---- input staging.  Stage q holds advances [SF q - T, SF q + SF - T) of every row as raw packed bytes: the aligned
     // 16-byte pieces that cover them, IN_BLOCKS per row, rows side by side.  Piece idx = it*64 + lane (row idx /
     // IN_BLOCKS) is moved by lane `lane` of DMA instruction `it`: its source is stage_base (wave-uniform, in SGPRs,
-    // + 8 frames per stage) + piece_off[it] (per lane, fixed for the unit).  A row whose first frame sits early in its
+    // + SF frames per stage) + piece_off[it] (per lane, fixed for the unit).  A row whose first frame sits early in its
     // first piece does not need its last piece: that lane re-reads the row's first piece instead (same line, no traffic).
     const int total = (int)M_blk + T;         // advances a = a_lin - T for a_lin in [0, total)
-    const int n_stages = (total + 7) >> 3;
     const int64_t g0 = seg.src_base + ((int64_t)(wk.first_block * M_blk) - T) * (int64_t)FB_SRC;    // row 0's frame at a_lin = 0
     const uint32_t a0 = (uint32_t)g0 & 15u;
     int64_t stage_off = g0 - (int64_t)a0;     // arena offset of row 0's first piece of the NEXT stage to issue (wave-uniform)
@@ -270,11 +240,14 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
         if (r >= n_blocks || r >= (uint32_t)ROWS) { r = 0; part = 0; }
         const uint32_t d_r = r * M_blk * FB_SRC;
         const uint32_t al = (a0 + d_r) & 15u;
-        const uint32_t pieces_needed = (al + 8 * FB_SRC + 15) >> 4;      // bytes al .. al + 8 FB_SRC - 1 of the row's first piece onwards
+        const uint32_t pieces_needed = (al + SF * FB_SRC + 15) >> 4;     // bytes al .. al + SF FB_SRC - 1 of the row's first piece onwards
         if (part >= pieces_needed) part = 0;
         piece_off[it] = d_r - al + a0 + 16 * part;
     }
     auto issue_stage = [&](int q) __attribute__((always_inline)) {
+#ifdef OHGPU_DIAG_NO_DMA
+        if (q >= 0) { stage_off += SF * FB_SRC; return; }
+#endif
         const uint32_t buf = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; it++) {
@@ -309,41 +282,42 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
                 }
             }
         }
-        stage_off += 8 * FB_SRC;
+        stage_off += SF * FB_SRC;
     };
 
     // ---- write-back: the block's output is a byte stream of L_blk*FB_DST bytes.  A finished subsample is packed and stored at
     // its place in the row's byte ring; whenever a 64-byte line of the stream is complete the wave writes that line of all its
-    // blocks, lane l of pass `it` copying 16-byte piece (l & 3) of block (it*16 + l/4): every HBM write is a whole line.
+    // blocks, lane l of pass `it` copying 16-byte piece (l & 3) of block (it*16 + l/4): every HBM write is a whole line.  The
+    // destination is a wave-uniform base (the unit's current line, pass `it`'s first row) plus the lane's fixed offset.
     const int64_t wave_dst = seg.dst_base + (int64_t)(wk.first_block * L_blk) * FB_DST;
     const uint32_t wave_rows = n_blocks < (uint32_t)BPW ? n_blocks : (uint32_t)BPW;
     constexpr int DRAIN_ITERS = (BPW * 4 + 63) / 64;
-    uint32_t drain_off[DRAIN_ITERS];          // per lane: its piece's offset from the unit's current line
-    uint32_t drain_lds[DRAIN_ITERS];          // per lane: its row's ring
-    bool drain_on[DRAIN_ITERS];
-#pragma unroll
-    for (int it = 0; it < DRAIN_ITERS; it++) {
-        const uint32_t piece = it * 64 + lane;
-        const uint32_t r = piece >> 2, part = piece & 3;
-        drain_on[it] = r < wave_rows;
-        drain_off[it] = (drain_on[it] ? r : 0u) * L_blk * FB_DST + part * 16;
-        drain_lds[it] = OFF_RING + (drain_on[it] ? r : 0u) * row_stride;
-    }
+    const uint32_t drain_off = (lane >> 2) * L_blk * FB_DST + (lane & 3) * 16;
+    const uint32_t drain_lds = OFF_RING + (lane >> 2) * row_stride;
     uint32_t drained = 0;                                 // lines written so far (wave-uniform)
     uint32_t line_pos = 0;                                // ring position of line `drained`
     auto drain = [&](int frames_stored) __attribute__((always_inline)) {
+#ifdef OHGPU_DIAG_NO_DRAIN
+        if (frames_stored >= 0) return;
+#endif
         while (drained < (((uint32_t)frames_stored * FB_DST) >> 6)) {
-            uint8_t* const line = dst + wave_dst + (uint64_t)drained * 64;        // wave-uniform
+            uint32_t pos = line_pos + (lane & 3) * 16;
+            if (pos >= ring_bytes) pos -= ring_bytes;
 #pragma unroll
             for (int it = 0; it < DRAIN_ITERS; it++) {
-                if (drain_on[it]) {
-                    uint32_t pos = line_pos + ((it * 64 + lane) & 3) * 16;
-                    if (pos >= ring_bytes) pos -= ring_bytes;
+                if ((uint32_t)(it * 16) + (lane >> 2) < wave_rows) {
+                    uint8_t* const line = dst + wave_dst + (uint64_t)drained * 64 + (uint64_t)(it * 16) * L_blk * FB_DST;    // wave-uniform
                     const __attribute__((address_space(3))) uint32_t* q =
-                        (const __attribute__((address_space(3))) uint32_t*)(lds + drain_lds[it] + pos);
+                        (const __attribute__((address_space(3))) uint32_t*)(lds + drain_lds + (uint32_t)(it * 16) * row_stride + pos);
                     u32x4 v4;
                     v4.x = q[0]; v4.y = q[1]; v4.z = q[2]; v4.w = q[3];
-                    __builtin_nontemporal_store(v4, (u32x4*)(line + drain_off[it]));
+#if defined(OHGPU_DIAG_STORE_PLAIN)
+                    *(u32x4*)(line + drain_off) = v4;
+#elif !defined(OHGPU_DIAG_NO_STORE)
+                    __builtin_nontemporal_store(v4, (u32x4*)(line + drain_off));
+#else
+                    if (v4.x == 0x12345678u && v4.y == 0x9abcdef0u) *(u32x4*)(line + drain_off) = v4;
+#endif
                 }
             }
             drained++;
@@ -352,16 +326,19 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
         }
     };
 
-    double win[T];
-#pragma unroll
-    for (int s = 0; s < T; s++) win[s] = 0.0;
+    double win[T];                            // (every slot is written by the warm-up before it is read)
 
-    int j = 0;                                // outputs emitted so far (wave-uniform)
+    // (wave-uniform scalars; the loop's control flow is kept to single compares -- the scalar unit serves the CU's four SIMDs
+    // one instruction per cycle between them, and round 2's first cut of this loop, with compound conditions, issued as many
+    // scalar instructions as vector ones and ran no faster for having fewer of the latter)
+    int j = 0;                                // outputs emitted so far
     int t = 0;                                // j * M
-    int p = 0;                                // phase of output j
+    int tl = 0;                               // L * (advances done): output j is due once t < tl ...
+    const int t_end = (int)L_blk * M;         // ... and the block's last output has been emitted once t == t_end
+    uint32_t pu = 0u - (uint32_t)L;           // phase of the NEXT coefficient reload, minus L, as an unsigned word (so that the wrap is a carry)
     uint32_t ring_pos = 0;                    // ring position of frame j (pair mode: of the pair)
     constexpr int PH = (FB_SRC % 4 == 0) ? 1 : ((FB_SRC % 2 == 0) ? 2 : 4);   // frames s' and s' + PH share their place in a dword
-    static_assert((FB_SRC * PH) % 4 == 0 && (8 % PH) == 0 && FB_SRC * 7 / 4 + 1 < 256, "immediate dword offsets of ds_read2_b32");
+    static_assert((FB_SRC * PH) % 4 == 0 && (SF % PH) == 0 && FB_SRC * (SF - 1) / 4 + 1 < 256, "immediate dword offsets of ds_read2_b32");
     const uint32_t in_base = wave_lds_addr + OFF_IN + row * IN_STRIDE + ((uint32_t)row_g & 15u) + c * SB;   // frame 0 of buffer 0
     uint32_t in_sel[PH];                      // byte selector of frame ph's subsample (the same in every stage)
     uint32_t in_addr[2][PH];                  // aligned LDS address of frame ph's dword, by buffer
@@ -373,12 +350,15 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
     }
     const bool any_first = __any(first_block) != 0;
 
-    // the pending store: the bytes of the last finished output (pair), stored by the NEXT output after its first wait
-    uint32_t st_addr = dummy_lane, st_lo = 0, st_hi = 0;
-    uint32_t y_even = 0;
-    bool pend = false;                        // (wave-uniform)
-    int stored = 0;                           // frames whose bytes are in the ring or pending
+    // The store of the last finished output (pair) is issued by the NEXT output, after its first wait, so that no wait ever
+    // covers a store just issued.  It is issued by EVERY output: when nothing new is pending the same bytes go to the same
+    // place once more (no branch, and the count of LDS operations per output stays fixed).
+    uint32_t st_addr = ring_lane, st_lo = 0, st_hi = 0;
+    uint32_t y_even = 0, y_odd = 0;                           // frames whose bytes are in the ring or in the pending store
     auto issue_store = [&]() __attribute__((always_inline)) {
+#ifdef OHGPU_DIAG_NO_RING
+        return;
+#endif
         if constexpr (PAIR) asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(st_addr), "v"(st_lo), "v"(st_hi) : "memory");
         else if constexpr (DB == 4) asm volatile("ds_write_b32 %0, %1" : : "v"(st_addr), "v"(st_lo) : "memory");
         else if constexpr (DB == 3) asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8_d16_hi %0, %1 offset:2"
@@ -388,155 +368,246 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
 
     // coefficients of output j: register r = taps 16 r .. 16 r + 15, tap k in lane (k & 15) of every 16-lane row
     double cf[NCR];
+#pragma unroll
+    for (int r = 0; r < NCR; r++) cf[r] = 0.0;
     static_for([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = NCR - 1 - decltype(rc)::value;
         lean_issue_f64<r * 128>(cf[r], coef_lane);
     }, std::make_integer_sequence<int, NCR>{});
     uint64_t raw = 0;
 
+    // ---- warm-up: the T advances before the block's first output only fill the window.  Stages 0 and 1 are issued together;
+    // from then on stage q + 1 is issued when stage q begins (into the buffer stage q - 1 was read from), here and in the loop.
     issue_stage(0);
     issue_stage(1);
-
-    // ---- warm-up: the T advances before the block's first output only fill the window; two stages ahead ----
+    STAMP(st_setup)
     static_for([&](auto stage) __attribute__((always_inline)) {
         constexpr int q = decltype(stage)::value;
-        if constexpr ((q & 1) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        static_for([&](auto half) __attribute__((always_inline)) {
-            constexpr int h = decltype(half)::value;
-            uint64_t r4[4];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // stage q has landed
+        if constexpr (q >= 1) {
+            if ((q + 1) * SF < total) issue_stage(q + 1);
+        }
+        static_for([&](auto quad) __attribute__((always_inline)) {
+            constexpr int h = decltype(quad)::value;                           // four sample reads per LDS round trip
+            uint64_t r4[4] = {0, 0, 0, 0};
             static_for([&](auto k4) __attribute__((always_inline)) {
                 constexpr int sp = 4 * h + decltype(k4)::value, ph = sp % PH;
                 lean_issue_2xu32<FB_SRC * (sp - ph) / 4>(r4[sp & 3], in_addr[q & 1][ph]);
             }, std::make_integer_sequence<int, 4>{});
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]) : : "memory");
 #pragma unroll
-            for (int k = 0; k < 4; k++) win[8 * q + 4 * h + k] = lean_unpack(r4[k], in_sel[(4 * h + k) % PH]);
-        }, std::make_integer_sequence<int, 2>{});
-        if constexpr (q + 2 <= T / 8) {
-            if ((q + 2) * 8 < total) issue_stage(q + 2);
-        }
-    }, std::make_integer_sequence<int, T / 8>{});
+            for (int k = 0; k < 4; k++) win[SF * q + 4 * h + k] = lean_unpack(r4[k], in_sel[(4 * h + k) % PH]);
+        }, std::make_integer_sequence<int, SF / 4>{});
+    }, std::make_integer_sequence<int, T / SF>{});
     if (any_first) {
 #pragma unroll
         for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
     }
+    STAMP(st_warm)
     // The coefficient reads above were issued before the warm-up's waits: they have landed.  From here on, in issue order:
-    //   per advance:  R (raw sample)
-    //   per output:   W  [S: the previous output's pending store]  16 taps(c[NCR-1])  C'[NCR-1]
-    //                 W  16 taps(c[NCR-2])  C'[NCR-2] ... W  unpack  16 taps(c[0])  C'[0]   round, clamp, (ramp,) pack
-    // Every W awaits a reload C'[r] issued one output earlier (the last one the raw sample R as well).  After C'[r] come at
-    // least the other NCR - 1 reloads (the rest of that output's, then this output's earlier ones) whatever else -- R, S --
-    // was issued in between, and R, when there is one, is followed by the same: lgkmcnt(NCR - 1) is enough for every W on
-    // every path.  Where more has been issued the wait also covers operations issued long before it (never the youngest).
+    //   per advance:  X (raw sample)
+    //   per output:   W  S  16 taps(c[NCR-1])  C'[NCR-1]   W  16 taps(c[NCR-2])  C'[NCR-2] ...
+    //                 W  unpack  16 taps(c[0])  C'[0]   round, clamp, (ramp,) pack
+    // Every W awaits a reload C'[r] issued one output earlier (the last one the raw sample X as well).  After C'[r] come at
+    // least the other NCR - 1 reloads (the rest of that output's, then this output's earlier ones) whatever else -- X, S --
+    // was issued in between, and X, when there is one, is followed by S and NCR - 1 reloads: lgkmcnt(NCR - 1) is enough for
+    // every W on every path.  Where more has been issued the wait also covers operations issued long before it, never the
+    // youngest ones.  The block ends after L_blk outputs; the advances left in the trip then only move samples.
     for (int g = 1; g * T < total; g++) {
         static_for([&](auto slot) __attribute__((always_inline)) {
             constexpr int s = decltype(slot)::value;
-            const int a_lin = g * T + s;
-            if (a_lin >= total) return;
-            const int a = a_lin - T;
             if constexpr ((s & 3) == 0) {
-                if constexpr ((s & 7) == 0) {
-                    const int q = a_lin >> 3;
+                STAMP(st_out)
+                if constexpr ((s % SF) == 0) {
+                    const int q = (g * T + s) / SF;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage q has landed (this wave issued all of it)
-                    if ((q + 1) * 8 < total) issue_stage(q + 1);
+                    if ((q + 1) * SF < total) issue_stage(q + 1);
+                    STAMP(st_stage)
                 }
-                if (pend) { issue_store(); pend = false; }
-                drain(stored);
+                issue_store();
+                drain(PAIR ? (j & ~1) : j);
+                STAMP(st_drain)
             }
-            // ---- advance: this channel's sample of frame (n_start + a) enters slot s ----
-            {
-                constexpr int sp = s & 7, ph = sp % PH;
-                lean_issue_2xu32<FB_SRC * (sp - ph) / 4>(raw, in_addr[(s >> 3) & 1][ph]);
-            }
-            if (!(t < L * (a + 1))) {                                   // no output needs it yet (M > L)
-                lean_wait0(raw);
-                win[s] = lean_unpack(raw, in_sel[(s & 7) % PH]);
-            }
-            // ---- emit the outputs whose newest input frame is this one: floor(t / L) == a ----
-            while (t < L * (a + 1)) {
-                double acc0, acc1;
-                asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, 0" : "=&v"(acc0), "=&v"(acc1) : "s"(bias));
-                p += Mr;                                                       // the next output's phase
-                if (p >= L) p -= L;
-                const uint32_t cp = coef_lane + (uint32_t)p * (T * 8);
+            // ---- advance: this channel's sample of the next input frame enters slot s ----
+            tl += L;
+            const int tle = tl < t_end ? tl : t_end;
+            if (!(t < tle)) {
+                // no output needs it yet (M > L), or the block is done: read, wait and convert in ONE statement (a register must
+                // not be touched between a load's issue and its wait, and across statements the compiler may copy it)
+                constexpr int sp = s % SF, ph = sp % PH;
+                uint32_t lo, hi;
+                asm volatile("ds_read_b32 %[lo], %[addr] offset:%[o0]\n\t"
+                             "ds_read_b32 %[hi], %[addr] offset:%[o1]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_perm_b32 %[lo], %[hi], %[lo], %[sel]\n\t"
+                             "v_cvt_f64_i32 %[d], %[lo]"
+                             : [lo] "=&v"(lo), [hi] "=&v"(hi), [d] "=v"(win[s])
+                             : [addr] "v"(in_addr[(s / SF) & 1][ph]), [o0] "i"(FB_SRC * (sp - ph)), [o1] "i"(FB_SRC * (sp - ph) + 4),
+                               [sel] "v"(in_sel[(s % SF) % PH]) : "memory");
+            } else {
+#ifndef OHGPU_DIAG_NO_X
+                {
+                    constexpr int sp = s % SF, ph = sp % PH;
+                    lean_issue_2xu32<FB_SRC * (sp - ph) / 4>(raw, in_addr[(s / SF) & 1][ph]);
+                }
+#endif
+                do {
+                // ---- emit the outputs whose newest input frame is this one ----
+                double acc0;
+                uint32_t cp;
+                // the next output's phase: pu += M mod L, and -L again on a carry; its coefficient row
+                asm volatile("v_mov_b64 %[acc], %[bias]\n\t"
+                             "s_add_u32 %[pu], %[pu], %[mr]\n\t"
+                             "s_cselect_b32 vcc_lo, %[nl], 0\n\t"
+                             "s_add_u32 %[pu], %[pu], vcc_lo\n\t"
+                             "v_lshl_add_u32 %[cp], %[pu], %[sh], %[cl]"
+                             : [acc] "=v"(acc0), [pu] "+s"(pu), [cp] "=v"(cp)
+                             : [bias] "s"(bias), [mr] "s"((uint32_t)Mr), [nl] "s"(0u - (uint32_t)L), [sh] "i"(T == 32 ? 8 : 9), [cl] "v"(coef_lane_L)
+                             : "vcc", "scc");
                 static_for([&](auto rc) __attribute__((always_inline)) {
                     constexpr int r = NCR - 1 - decltype(rc)::value;          // highest taps (oldest samples) first, the newest sample last
                     if constexpr (r == 0) {
                         lean_wait<NCR - 1>(cf[0], raw);
-                        win[s] = lean_unpack(raw, in_sel[(s & 7) % PH]);
+                        win[s] = lean_unpack(raw, in_sel[(s % SF) % PH]);
                     } else {
                         lean_wait<NCR - 1>(cf[r]);
                     }
-                    if constexpr (r == NCR - 1) {
-                        if (pend) { issue_store(); pend = false; }
-                    }
+                    if constexpr (r == NCR - 1) issue_store();
 #define W_(k) win[(s - (16 * r + (k)) + 2 * T) % T]
-                    lean_taps16(acc0, acc1, cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
+#ifndef OHGPU_DIAG_NO_TAPS
+                    lean_taps16(acc0, cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                 W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1), W_(0));
+#endif
 #undef W_
+#ifndef OHGPU_DIAG_NO_COEF
                     lean_issue_f64<r * 128>(cf[r], cp);
+#endif
                 }, std::make_integer_sequence<int, NCR>{});
-                uint32_t y;
-                {
-                    double sum;
-                    asm volatile("v_add_f64 %0, %2, %3\n\tv_cvt_u32_f64 %1, %0\n\tv_med3_u32 %1, %1, %4, %5"
-                                 : "=&v"(sum), "=&v"(y) : "v"(acc0), "v"(acc1), "s"(clamp_lo), "v"(clamp_hi));
-                }
-                // y = 2^24 + the clamped S24 value: its low 24 bits are the value in two's complement
-                if (ramped) {
-                    if (__any(j >= evt_j) != 0) {                               // message boundary or ramping somewhere in the wave
-                        if (lane_valid && j >= evt_j) {
-                            while ((uint32_t)(j - msg_rel0) >= msg_n) load_msg(++mi);
-                            if (msg_flags & OHGPU_FLAG_RAMP) {
-                                const uint32_t rs = msg_ramp & 0xffffu, re = msg_ramp >> 16;
-                                const uint32_t mult = ramp_lds[ramp_index_magic(rs, (int32_t)(rs - re), (uint32_t)(j - msg_rel0), msg_n, msg_m, (msg_flags >> 8) & 31u)];
-                                y = ramp_word(y << 8, mult, 3, CH, c) >> 8;
-                                evt_j = j + 1;
-                            } else {
-                                evt_j = msg_rel0 + (int32_t)msg_n;
-                            }
-                        }
-                    }
-                }
+                // ---- round, clamp, (ramp,) pack: ONE hand-written statement.  u = trunc(2^24 + 0.5 + sum) clamped to
+                // 2^24 + [-2^23, 2^23 - 1]; its low 24 bits are the S24 value.  Everything that survives the output is an in-place
+                // operand, and the branches (ramped unit?  multipliers to fetch?  second frame of a pair?) are inside the statement:
+                // a value written in one arm of a C++ branch comes back as register copies at the join, on every output of every unit.
+                // A ramped unit applies RampApplicator::GetNextSample (Msg.cpp:840-895) to the 24-bit value -- top 16 bits * Q15 >> 15,
+                // low byte zero -- with the multiplier in the low 16 bits of {m1, m0}, which then move on by one frame; eight frames'
+                // multipliers per fetch, waited for in place (once per eight outputs of a ramped unit; the other waves cover it).
+#define OHGPU_RAMP_ASM(Y, L0, L1)                                 \
+                    "s_and_b32 vcc_lo, %[j], 3\n\t"                \
+                    "s_cmp_lg_u32 vcc_lo, 0\n\t"                   \
+                    "s_cbranch_scc1 " #L1 "f\n\t"                  \
+                    "s_bitcmp1_b32 %[j], 2\n\t"                    \
+                    "s_cbranch_scc1 " #L0 "f\n\t"                  \
+                    "global_load_dword %[m0], %[moff], %[mb]\n\t"  \
+                    "global_load_dword %[m1], %[moff], %[mb] offset:4\n\t"  \
+                    "global_load_dword %[m2], %[moff], %[mb] offset:8\n\t"  \
+                    "global_load_dword %[m3], %[moff], %[mb] offset:12\n\t" \
+                    "v_add_u32 %[moff], 16, %[moff]\n\t"           \
+                    "s_waitcnt vmcnt(0)\n\t"                       \
+                    "s_branch " #L1 "f\n"                          \
+                    #L0 ":\n\t"                                    \
+                    "v_mov_b32 %[m0], %[m2]\n\t"                   \
+                    "v_mov_b32 %[m1], %[m3]\n"                     \
+                    #L1 ":\n\t"                                    \
+                    "v_bfe_i32 %[t], " Y ", 8, 16\n\t"             \
+                    "v_and_b32 %[mu], 0xffff, %[m0]\n\t"           \
+                    "v_mul_i32_i24 %[t], %[t], %[mu]\n\t"          \
+                    "v_alignbit_b32 %[m0], %[m1], %[m0], 16\n\t"   \
+                    "v_ashrrev_i32 %[t], 15, %[t]\n\t"             \
+                    "v_lshrrev_b32 %[m1], 16, %[m1]\n\t"           \
+                    "v_cmp_ne_u32 vcc, 0xffff, %[mu]\n\t"          \
+                    "v_lshlrev_b32 %[t], 8, %[t]\n\t"              \
+                    "v_cndmask_b32 " Y ", " Y ", %[t], vcc\n\t"
+                uint32_t t16, mu;
                 if constexpr (PAIR) {
-                    if (j & 1) {
-                        // lane A (channel 0) needs B's even value, lane B needs A's odd one: every lane offers what its partner
-                        // wants, one quad-permuted move fetches it (two wait states between the offer's write and its DPP read)
-                        uint32_t give, got;
-                        asm volatile("v_cndmask_b32_e64 %[give], %[ye], %[y], %[m]\n\t"
-                                     "v_add_u32 %[sta], %[rp], %[rl]\n\t"
-                                     "s_nop 0\n\t"
-                                     "v_mov_b32_dpp %[got], %[give] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_perm_b32 %[lo], %[got], %[ye], %[sl]\n\t"
-                                     "v_perm_b32 %[hi], %[got], %[y], %[sh]"
-                                     : [give] "=&v"(give), [got] "=&v"(got), [sta] "=&v"(st_addr), [lo] "=&v"(st_lo), [hi] "=&v"(st_hi)
-                                     : [ye] "v"(y_even), [y] "v"(y), [m] "s"(0x5555555555555555ull), [rp] "s"(ring_pos), [rl] "v"(ring_lane),
-                                       [sl] "v"(sel_lo), [sh] "v"(sel_hi));
-                        ring_pos += 2 * FB_DST;
-                        if (ring_pos == ring_bytes) ring_pos = 0;
-                        pend = true;
-                        stored = j + 1;
-                    } else {
-                        y_even = y;
-                    }
+                    // (laid out so that an output of a plain unit takes exactly one taken branch)
+                    uint32_t give, got;
+                    asm volatile(
+                        "s_bitcmp1_b32 %[j], 0\n\t"
+                        "s_cbranch_scc1 40f\n\t"
+                        // first frame of a pair: its value waits in ye
+                        "v_cvt_u32_f64 %[ye], %[acc]\n\t"
+                        "s_cmp_lg_u32 %[rf], 0\n\t"
+                        "v_med3_u32 %[ye], %[ye], %[clo], %[chi]\n\t"
+                        "s_cbranch_scc1 70f\n\t"
+                        "s_branch 99f\n"
+                        "70:\n\t"
+                        OHGPU_RAMP_ASM("%[ye]", 71, 72)
+                        "s_branch 99f\n"
+                        "80:\n\t"
+                        OHGPU_RAMP_ASM("%[yo]", 81, 82)
+                        "s_branch 41f\n"
+                        "40:\n\t"
+                        // second frame: lane A (channel 0) needs B's first value, lane B needs A's second one; every lane offers what
+                        // its partner wants and one quad-permuted move fetches it (two instructions between the offer's write and its
+                        // DPP read); two byte permutes make the lane's two words of the pair's three
+                        "v_cvt_u32_f64 %[yo], %[acc]\n\t"
+                        "s_cmp_lg_u32 %[rf], 0\n\t"
+                        "v_med3_u32 %[yo], %[yo], %[clo], %[chi]\n\t"
+                        "s_cbranch_scc1 80b\n"
+                        "41:\n\t"
+                        "v_cndmask_b32_e64 %[give], %[ye], %[yo], %[m55]\n\t"
+                        "v_add_u32 %[sta], %[rp], %[rl]\n\t"
+                        "s_add_u32 %[rp], %[rp], %[step]\n\t"
+                        "v_mov_b32_dpp %[got], %[give] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "s_cmp_eq_u32 %[rp], %[ring]\n\t"
+                        "v_perm_b32 %[lo], %[got], %[ye], %[sl]\n\t"
+                        "s_cselect_b32 %[rp], 0, %[rp]\n\t"
+                        "v_perm_b32 %[hi], %[got], %[yo], %[sh]\n"
+                        "99:"
+                        : [ye] "+v"(y_even), [yo] "+v"(y_odd), [sta] "+v"(st_addr), [lo] "+v"(st_lo), [hi] "+v"(st_hi), [rp] "+s"(ring_pos),
+                          [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [moff] "+v"(moff),
+                          [give] "=&v"(give), [got] "=&v"(got), [t] "=&v"(t16), [mu] "=&v"(mu)
+                        : [acc] "v"(acc0), [clo] "s"(clamp_lo), [chi] "v"(clamp_hi), [j] "s"(j), [rf] "s"(ramped_u), [mb] "s"(mbase),
+                          [m55] "s"(0x5555555555555555ull), [rl] "v"(ring_lane), [ring] "s"(ring_bytes), [sl] "v"(sel_lo), [sh] "v"(sel_hi),
+                          [step] "i"(2 * FB_DST)
+                        : "vcc", "scc", "memory");
                 } else {
-                    const uint32_t w = y << 8;                                  // left-justified (a11)
-                    st_lo = DST_LE ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);
-                    st_addr = ring_lane + ring_pos;
-                    ring_pos += FB_DST;
-                    if (ring_pos == ring_bytes) ring_pos = 0;
-                    pend = true;
-                    stored = j + 1;
+                    asm volatile(
+                        "v_cvt_u32_f64 %[yo], %[acc]\n\t"
+                        "s_cmp_lg_u32 %[rf], 0\n\t"
+                        "v_med3_u32 %[yo], %[yo], %[clo], %[chi]\n\t"
+                        "s_cbranch_scc0 41f\n\t"
+                        OHGPU_RAMP_ASM("%[yo]", 81, 82)
+                        "41:\n\t"
+                        // the DB bytes in memory order, first byte lowest: little endian = the top DB bytes of the value left-justified
+                        // to 32 bits (32-bit: value << 8; 24: the value; 16: value >> 8), big endian = bytes 2, 1, 0 of the value, then zero
+                        "v_add_u32 %[sta], %[rp], %[rl]\n\t"
+                        "s_add_u32 %[rp], %[rp], %[step]\n\t"
+                        ".if %[le] == 2\n\t"
+                        "v_lshlrev_b32 %[lo], 8, %[yo]\n\t"
+                        ".elseif %[le] == 1\n\t"
+                        "v_lshrrev_b32 %[lo], %[shr], %[yo]\n\t"
+                        ".else\n\t"
+                        "v_perm_b32 %[lo], %[yo], %[yo], %[bsw]\n\t"
+                        ".endif\n\t"
+                        "s_cmp_eq_u32 %[rp], %[ring]\n\t"
+                        "s_cselect_b32 %[rp], 0, %[rp]"
+                        : [yo] "+v"(y_odd), [sta] "+v"(st_addr), [lo] "+v"(st_lo), [rp] "+s"(ring_pos),
+                          [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [moff] "+v"(moff), [t] "=&v"(t16), [mu] "=&v"(mu)
+                        : [acc] "v"(acc0), [clo] "s"(clamp_lo), [chi] "v"(clamp_hi), [j] "s"(j), [rf] "s"(ramped_u), [mb] "s"(mbase),
+                          [rl] "v"(ring_lane), [ring] "s"(ring_bytes), [step] "i"(FB_DST), [le] "i"(DST_LE ? (DB == 4 ? 2 : 1) : 0),
+                          [shr] "i"(DB == 4 ? 0 : 24 - 8 * DB), [bsw] "s"(0x0c000102u)
+                        : "vcc", "scc", "memory");
                 }
+#undef OHGPU_RAMP_ASM
                 j++;
                 t += M;
+                } while (t < tle);
             }
         }, std::make_integer_sequence<int, T>{});
     }
-    if (pend) { issue_store(); pend = false; }
+    STAMP(st_out)
+    issue_store();
     drain(j);
+    STAMP(st_drain)
     unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     }   // units
+#ifdef OHGPU_DIAG_STAMP
+    if (dbg != nullptr && lane == 0) {
+        uint64_t* o = dbg + (size_t)(blockIdx.x * n_waves + wave) * 8;
+        o[0] = st_setup; o[1] = st_warm; o[2] = st_stage; o[3] = st_drain; o[4] = st_out; o[5] = st_units;
+        o[6] = st_begin; o[7] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     // The counters reset themselves: a wave reports in after its last claim, and the last wave of the grid zeroes both.
     if (lane == 0) {
         const uint32_t waves_total = gridDim.x * n_waves;
@@ -547,9 +618,8 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__
     }
 }
 
-
-#define OHGPU_LEAN_ARGS const SrcSeg*, const SegMsg*, const SrcWork*, uint32_t, const double*, const uint16_t*, const uint8_t*, \
-                        uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*
+#define OHGPU_LEAN_ARGS const SrcSeg*, const SrcWork*, uint32_t, const double*, const uint16_t*, uint32_t, const uint8_t*, \
+                        uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
 #define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
 #define X_DECLARE(t, c, s_, sl, d, dl) extern template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
 #if defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 2
@@ -564,17 +634,19 @@ OHGPU_BLOCK_KERNELS_3(X_DECLARE)
 #if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
 // Geometry the planner needs (must match the kernel's constexprs).  Returns false when the layout does not fit the CU's LDS.
 bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
-                       uint32_t* rows, uint32_t* in_blocks, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves)
+                       uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
+                       uint32_t* wave_lds_bytes, uint32_t* max_waves)
 {
     const uint32_t bpw = 64 / ch;
     const uint32_t fb_dst = ch * db;
     const uint32_t inb = (uint32_t)lean_in_blocks((int)ch, (int)sb);
+    *stage_frames = (uint32_t)lean_stage_frames((int)ch);
     const uint32_t rb = ring_bytes_for(fb_dst, out_per_drain, ring_pair_mode(ch, db));
     *rows = bpw;
     *in_blocks = inb;
     *ring_bytes = rb;
-    *coef_lds_bytes = L * T * 8 + kRampLdsBytes;
-    *wave_lds_bytes = 2 * bpw * inb * 16 + 32 * 16 + 32 * 4 + ((bpw * (rb + 4) + 15) & ~15u) + 64;
+    *coef_lds_bytes = L * T * 8;
+    *wave_lds_bytes = 2 * bpw * inb * 16 + ((bpw * (rb + 4) + 15) & ~15u) + ((64 % ch) ? 64u : 0u);
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
@@ -599,12 +671,42 @@ static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
     if (w > f.lean_max_waves) w = f.lean_max_waves;
     uint32_t g = (f.n_work + w - 1) / w;
     if (g > cus) g = cus;
-    const uint32_t lds = f.coef_lds_bytes + w * f.lean_wave_lds_bytes;
+    const uint32_t lds = f.lean_coef_lds_bytes + w * f.lean_wave_lds_bytes;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    uint64_t* dbg = nullptr;
+#ifdef OHGPU_DIAG_STAMP
+    const char* stamp_path = getenv("OHGPU_DIAG_STAMP_FILE");
+    const size_t n_dbg = (size_t)g * w * 8;
+    if (stamp_path && hipMalloc((void**)&dbg, n_dbg * 8) == hipSuccess) hipMemsetAsync(dbg, 0, n_dbg * 8, s);
+#endif
     hipLaunchKernelGGL(kernel, dim3(g), dim3(w * 64), lds, s,
-                       p.segs, p.msgs, p.work, f.n_work, p.coef, p.ramp_table, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, f.ring_bytes, (uint32_t*)f.d_counter);
+                       p.segs, p.work, f.n_work, p.coef, (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst,
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, f.ring_bytes, (uint32_t*)f.d_counter, dbg);
+#ifdef OHGPU_DIAG_STAMP
+    if (dbg) {      // diagnostic build only: wait, sum up, write a text report, never on the product path
+        hipStreamSynchronize(s);
+        std::vector<uint64_t> h(n_dbg);
+        hipMemcpy(h.data(), dbg, n_dbg * 8, hipMemcpyDeviceToHost);
+        hipFree(dbg);
+        if (FILE* fo = fopen(stamp_path, "w")) {
+            double sum[6] = {0, 0, 0, 0, 0, 0}, t0 = 1e300, t1 = 0, life = 0, last_min = 1e300;
+            for (size_t i = 0; i < n_dbg; i += 8) {
+                for (int k = 0; k < 6; k++) sum[k] += (double)h[i + k];
+                if ((double)h[i + 6] < t0) t0 = (double)h[i + 6];
+                if ((double)h[i + 7] > t1) t1 = (double)h[i + 7];
+                if ((double)h[i + 7] < last_min) last_min = (double)h[i + 7];
+                life += (double)(h[i + 7] - h[i + 6]);
+            }
+            const double nw = (double)(n_dbg / 8);
+            fprintf(fo, "waves %.0f (grid %u x %u), units %.0f; kernel span %.0f ticks, first wave done at %.0f; mean wave life %.0f\n", nw, g, w, sum[5], t1 - t0, last_min - t0, life / nw);
+            fprintf(fo, "mean ticks per wave: set-up %.0f warm-up %.0f stage wait+issue %.0f drain %.0f outputs %.0f | per unit: %.0f %.0f %.0f %.0f %.0f\n",
+                    sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw,
+                    sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / sum[5]);
+            fclose(fo);
+        }
+    }
+#endif
     return hipGetLastError();
 }
 

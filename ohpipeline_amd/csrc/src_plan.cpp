@@ -22,6 +22,7 @@ void free_src_fast(ohgpu_batch* b)
     if (f.d_work) hipFree(f.d_work);
     if (f.d_rem) hipFree(f.d_rem);
     if (f.d_counter) hipFree(f.d_counter);
+    if (f.d_planes) hipFree(f.d_planes);
     f = SrcFastPlan();
 }
 
@@ -35,6 +36,22 @@ static int upload_vec(const std::vector<V>& v, void** dptr)
     if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE,
                                           "block plan upload: %s", hipGetErrorString(e));
     return OHGPU_OK;
+}
+
+// RampApplicator's multiplier for frame i of a message of n frames (OpenHome/Media/Pipeline/Msg.cpp:826-837): the ramp value
+// moves from `start` towards `end` by C integer division (truncation toward zero, the numerator may be negative), is cast
+// to TUint16, and indexes RampArray.h's 512 entries through (kMax - ramp + 16) >> 5, limited to the last entry.
+static uint16_t ramp_multiplier(const uint16_t table[512], uint32_t start, uint32_t end, uint32_t i, uint32_t n)
+{
+    uint32_t ramp = start;
+    if (n != 1) {
+        const int32_t total = (int32_t)start - (int32_t)end;
+        const int32_t prod = (int32_t)i * total;                       // TInt arithmetic (validated: n <= 131071, |total| <= 16384)
+        ramp = start - (uint32_t)(prod / (int32_t)(n - 1));
+    }
+    ramp &= 0xffffu;
+    const uint32_t idx = (16384u - ramp + 16u) >> 5;
+    return table[idx < 511u ? idx : 511u];
 }
 
 // piece [m_lo, m_hi) of message d (device form dv) for the generic kernel
@@ -71,10 +88,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     uint32_t rows = 0, ring = 0, coef_lds = 0, wave_lds = 0, max_waves = 0;
     if (!src_block_geometry(L, T, ch, sb, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
     // the lean kernel (round 2): same blocks, rows and ring; its rounding bias needs sum|c| < 2^29 in every phase
-    uint32_t lean_rows = 0, lean_inb = 0, lean_ring = 0, lean_coef = 0, lean_wave_lds = 0, lean_max_waves = 0;
+    uint32_t lean_rows = 0, lean_inb = 0, lean_sf = 8, lean_ring = 0, lean_coef = 0, lean_wave_lds = 0, lean_max_waves = 0;
     const bool lean = flt->max_sum_abs < ((int64_t)1 << 29) &&
-                      src_lean_geometry(L, T, ch, sb, db, out_per_drain, &lean_rows, &lean_inb, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
-                      lean_rows == rows && lean_ring == ring && lean_coef == coef_lds;
+                      src_lean_geometry(L, T, ch, sb, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
+                      lean_rows == rows && lean_ring == ring;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
     uint32_t min_blk = 128;
 #ifdef OHGPU_DIAG
@@ -109,6 +126,11 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     std::vector<SrcWork> work;
     std::vector<DevSrcDesc> rem;
     uint64_t fast_frames = 0;
+    // lean kernel: one plane of multipliers per ramped unit -- rows * L_blk entries (uint16, 0xffff = no ramp on that frame)
+    // (the kernel loads eight entries at a time; a row is a whole number of loads when L_blk is a multiple of 8, else the slack covers the last one)
+    uint16_t ramp_table[512];
+    build_ramp_table(ramp_table);
+    std::vector<uint16_t> planes;
 
     size_t i = 0;
     while (i < n) {
@@ -162,14 +184,28 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 for (uint32_t m = mi; m < sg.msg_end && msgs[m].out0 < u_hi && !ramped; m++)
                     ramped = (msgs[m].flags & OHGPU_FLAG_RAMP) && msgs[m].out0 + msgs[m].n > u_lo;
                 w.flags = ramped ? kWorkRamped : 0u;
+                w.plane = 0; w.pad = 0;
+                if (ramped && lean) {
+                    const size_t per = (size_t)rows * L_blk + 8;
+                    w.plane = (uint32_t)(planes.size() / per);
+                    planes.resize(planes.size() + per, 0xffffu);
+                    uint16_t* pl = planes.data() + (size_t)w.plane * per;
+                    for (uint32_t m = mi; m < sg.msg_end && msgs[m].out0 < u_hi; m++) {
+                        const SegMsg& sm = msgs[m];
+                        if (!(sm.flags & OHGPU_FLAG_RAMP)) continue;
+                        const uint64_t lo = std::max<uint64_t>(sm.out0, u_lo), hi = std::min<uint64_t>(sm.out0 + sm.n, u_hi);
+                        for (uint64_t fr = lo; fr < hi; fr++)
+                            pl[fr - u_lo] = ramp_multiplier(ramp_table, sm.ramp_start, sm.ramp_end, (uint32_t)(fr - sm.out0), sm.n);
+                    }
+                }
                 // the lean kernel's staging moves, per stage q, the aligned 16-byte pieces that hold each row's eight frames:
                 // does every one of them lie inside the arena?  (Only a unit at an end of the arena can fail.)
                 {
-                    const int64_t total = (int64_t)M_blk + T, n_stages = (total + 7) >> 3;
+                    const int64_t total = (int64_t)M_blk + T, n_stages = (total + lean_sf - 1) / lean_sf;
                     const int64_t g_first = sbase + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
                     const int64_t g_last = g_first + (int64_t)(w.n_blocks - 1) * M_blk * fb_src;
                     const int64_t lo = g_first - (g_first & 15);
-                    const int64_t hi = g_last - (g_last & 15) + 16 * (((g_last & 15) + 8 * fb_src + 15) >> 4) + (n_stages - 1) * 8 * fb_src;
+                    const int64_t hi = g_last - (g_last & 15) + 16 * (((g_last & 15) + lean_sf * fb_src + 15) >> 4) + (n_stages - 1) * lean_sf * fb_src;
                     if (g_first < 0 || lo < 0 || (uint64_t)hi > b->src_arena_bytes) w.flags |= kWorkChecked;
                 }
                 work.push_back(w);
@@ -201,6 +237,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
     if (err == OHGPU_OK) err = upload_vec(work, &f.d_work);
     if (err == OHGPU_OK) err = upload_vec(rem, &f.d_rem);
+    if (err == OHGPU_OK) err = upload_vec(planes.empty() ? std::vector<uint16_t>(4, 0xffffu) : planes, &f.d_planes);
     if (err == OHGPU_OK) err = upload_vec(std::vector<uint32_t>(2, 0u), &f.d_counter);   // {units claimed, waves finished}: zero between launches
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
     f.enabled = true;
@@ -212,7 +249,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.max_waves = max_waves;
     f.ring_bytes = ring;
     f.lean = lean;
+    f.lean_coef_lds_bytes = lean_coef;
     f.lean_wave_lds_bytes = lean_wave_lds;
+    f.plane_stride = (uint32_t)(((size_t)rows * L_blk + 8) * sizeof(uint16_t));
     f.lean_max_waves = lean_max_waves;
     f.fast_out_frames = fast_frames;
     SrcFastParams& p = f.params;

@@ -1,9 +1,13 @@
-"""Static checks on the block kernel's gfx950 assembly (no GPU needed; hipcc cross-compiles).
+"""Static checks on the block resampler kernels' gfx950 assembly (no GPU needed; hipcc cross-compiles).
 
-The per-output loop of csrc/src_block_kernel.hip issues its LDS traffic from inline asm and waits for it with
-hand-counted `s_waitcnt lgkmcnt(N)`.  That is only sound while nothing else that shares the counter and completes out
-of order is in flight there, and the DPP taps need VALU-written EXEC/coefficients to be settled.  These are properties
-of the generated code, so they are checked on the generated code, for every instantiation.
+The per-output loops of csrc/src_lean_kernel.hip (round 2, the one the batches run on) and csrc/src_block_kernel.hip
+(round 1, kept as the A/B reference) issue their LDS traffic from inline asm and wait for it with hand-counted
+`s_waitcnt lgkmcnt(N)`.  That is only sound while
+  * nothing else that shares the counter and completes out of order is in flight there (scalar memory),
+  * the instructions keep the order the counts assume,
+  * and no instruction touches a load's destination register between the load's issue and the wait that covers it --
+    the compiler does not know the register is written late, and is free to copy a variable wherever it likes.
+These are properties of the generated code, so they are checked on the generated code, for every instantiation.
 """
 import os
 import re
@@ -12,24 +16,25 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "ohpipeline_amd", "csrc", "src_block_kernel.hip")
-OUT = os.path.join(ROOT, "ohpipeline_amd", "build", "src_block_kernel.test.s")
+CSRC = os.path.join(ROOT, "ohpipeline_amd", "csrc")
+OUTDIR = os.path.join(ROOT, "ohpipeline_amd", "build")
 
 SCALAR_MEM = re.compile(r"^\s*(s_load|s_buffer_load|s_memtime|s_memrealtime|s_scratch_load|s_store|s_atomic|s_dcache)")
+COUNTED_WAIT = re.compile(r"s_waitcnt lgkmcnt\(([1-9]\d*)\)")
 
 
-@pytest.fixture(scope="module")
-def kernels():
-    """Assembly of every product instantiation, compiled the way the build does: in parts, side by side."""
+def _compile(stem, prefix):
+    """Assembly of every product instantiation of csrc/<stem>.hip, compiled the way the build does: in parts, side by side."""
     from concurrent.futures import ThreadPoolExecutor
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    deps = [SRC] + [os.path.join(os.path.dirname(SRC), f) for f in ("ohgpu_internal.h", "pcm_device.h")]
+    os.makedirs(OUTDIR, exist_ok=True)
+    src = os.path.join(CSRC, stem + ".hip")
+    deps = [src] + [os.path.join(CSRC, f) for f in ("ohgpu_internal.h", "pcm_device.h", "src_block_common.h")]
 
     def compile_part(part):
-        out = OUT.replace(".test.s", f".test.{part}.s")
+        out = os.path.join(OUTDIR, f"{stem}.test.{part}.s")
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                   f"-DOHGPU_BLOCK_PART={part}", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", SRC, "-o", out]
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-inline-asm",
+                   f"-DOHGPU_BLOCK_PART={part}", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", src, "-o", out]
             subprocess.run(cmd, check=True, capture_output=True, timeout=1500)
         return open(out).read().split("\n")
 
@@ -39,66 +44,100 @@ def kernels():
     for text in texts:
         name, body = None, []
         for line in text:
-            m = re.match(r"^(_ZN5ohgpu16src_block_kernel\w+):", line)
+            m = re.match(r"^(_ZN5ohgpu\d+" + prefix + r"\w+):", line)
             if m:
                 name, body = m.group(1), []
             elif name is not None:
                 body.append(line)
                 if "s_endpgm" in line:
-                    # the diagnostic (stamped) instantiation reads the clock, each time with its own full wait: not a product path
-                    if "Lb1EEEv" not in name:
-                        found[name] = body
+                    found[name] = body
                     name = None
     assert len(found) >= 15, "expected every instantiation in the assembly"
     return found
 
 
-def test_no_scalar_memory_traffic_between_taps(kernels):
-    for name, body in kernels.items():
+@pytest.fixture(scope="module")
+def lean():
+    return _compile("src_lean_kernel", "src_lean_kernel")
+
+
+@pytest.fixture(scope="module")
+def block():
+    return _compile("src_block_kernel", "src_block_kernel")
+
+
+def _taps_of(name):
+    return int(re.search(r"kernelILi(\d+)E", name).group(1))
+
+
+@pytest.mark.parametrize("which", ["lean", "block"])
+def test_no_scalar_memory_traffic_between_taps(which, request):
+    for name, body in request.getfixturevalue(which).items():
         taps = [i for i, l in enumerate(body) if "v_fmac_f64_dpp" in l]
         assert taps, name
         bad = [l for l in body[taps[0]:taps[-1] + 1] if SCALAR_MEM.match(l)]
         assert not bad, (name, bad[:3])
 
 
-def test_no_scratch_and_no_valu_exec_writes(kernels):
-    for name, body in kernels.items():
+@pytest.mark.parametrize("which", ["lean", "block"])
+def test_no_scratch_and_no_valu_exec_writes(which, request):
+    for name, body in request.getfixturevalue(which).items():
         assert not any(re.match(r"^\s*scratch_", l) for l in body), name
-        # a VALU write of EXEC needs five wait states before a DPP instruction; the kernel relies on having none
+        # a VALU write of EXEC needs five wait states before a DPP instruction; the kernels rely on having none
         assert not any(re.match(r"^\s*v_cmpx", l) for l in body), name
+
+
+def test_lean_kernels_keep_three_waves_per_simd(lean):
+    """The 32-tap instantiations are launched with up to twelve waves per workgroup: at most 168 registers (and no spills:
+    test_no_scratch_and_no_valu_exec_writes)."""
+    for part in (1, 2, 3):
+        text = open(os.path.join(OUTDIR, f"src_lean_kernel.test.{part}.s")).read()
+        for m in re.finditer(r"\.name:\s+(_ZN5ohgpu15src_lean_kernelILi(\d+)E\w+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
+            if int(m.group(2)) <= 32:
+                assert int(m.group(3)) <= 168, (m.group(1), m.group(3))
 
 
 def main_loop(body):
     """From the first output's first counted wait (the last one before the first tap) to the end of the kernel."""
     first_tap = next(i for i, l in enumerate(body) if "v_fmac_f64_dpp" in l)
-    start = max(i for i in range(first_tap) if re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", body[i]))
+    start = max(i for i in range(first_tap) if COUNTED_WAIT.search(body[i]))
     return body[start:]
 
 
-def test_every_output_has_its_counted_waits(kernels):
-    for name, body in kernels.items():
-        T = int(re.search(r"src_block_kernelILi(\d+)E", name).group(1))
+@pytest.mark.parametrize("which", ["lean", "block"])
+def test_every_output_has_its_counted_waits(which, request):
+    for name, body in request.getfixturevalue(which).items():
+        T = _taps_of(name)
         taps = sum("v_fmac_f64_dpp" in l for l in body)
         assert taps % T == 0
         outputs = taps // T                                   # unrolled output bodies
         loop = main_loop(body)                                # (the unit's set-up has compiler-counted waits of its own)
-        counted = sum(1 for l in loop if re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l))
+        counted = [int(m.group(1)) for l in loop for m in [COUNTED_WAIT.search(l)] if m]
         # one wait per coefficient register (T / 16 of them) per output body, each leaving younger operations in flight
-        assert counted == outputs * (T // 16), (name, counted, outputs)
+        assert len(counted) == outputs * (T // 16), (name, len(counted), outputs)
+        if which == "lean":                                   # the lean kernel's waits are all lgkmcnt(NCR - 1)
+            assert set(counted) == {T // 16 - 1}, (name, set(counted))
 
 
-def test_lds_traffic_keeps_the_order_the_counts_assume(kernels):
+@pytest.mark.parametrize("which", ["lean", "block"])
+def test_lds_traffic_keeps_the_order_the_counts_assume(which, request):
     """After every counted wait: [the ring store(s), only after an output's first wait] 16 taps, then the reload of the
     coefficient register those taps used -- and no other LDS instruction in between (the counts in the waits are the
     number of LDS operations issued after the awaited one; a moved instruction would change it silently)."""
-    for name, body in kernels.items():
-        T = int(re.search(r"src_block_kernelILi(\d+)E", name).group(1))
+    for name, body in request.getfixturevalue(which).items():
+        T = _taps_of(name)
         ncr = T // 16
         body = main_loop(body)
-        waits = [i for i, l in enumerate(body) if re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l)]
+        waits = [i for i, l in enumerate(body) if COUNTED_WAIT.search(l)]
         assert waits
+        seen_in_output = 0
         for i in waits:
-            first = int(re.search(r"lgkmcnt\((\d+)\)", body[i]).group(1)) == ncr - 1      # an output's first wait
+            # an output's first wait: the old kernel tells it by its count, the lean kernel's waits all look the same
+            if which == "block":
+                first = int(COUNTED_WAIT.search(body[i]).group(1)) == ncr - 1
+            else:
+                first = seen_in_output == 0
+                seen_in_output = (seen_in_output + 1) % ncr
             taps, stores, k = 0, 0, i + 1
             while taps < 16:
                 line = body[k]
@@ -115,3 +154,41 @@ def test_lds_traffic_keeps_the_order_the_counts_assume(kernels):
             while not re.match(r"^\s*(ds_|s_waitcnt|s_cbranch|s_branch)", body[k]):
                 k += 1
             assert re.match(r"^\s*ds_read_b64", body[k]), (name, i, body[k])    # the reload follows its taps directly
+
+
+def _regs(tok):
+    """Vector registers a token names: 'v12' -> {12}, 'v[8:11]' -> {8..11}."""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+LOAD = re.compile(r"^\s*(ds_read\w*|global_load_(?:dword\w*|ushort|ubyte|sbyte|short\w*))\s+(v\[\d+:\d+\]|v\d+)\s*,")
+ANY_WAIT = {"ds": re.compile(r"s_waitcnt.*lgkmcnt"), "gl": re.compile(r"s_waitcnt.*vmcnt")}
+
+
+@pytest.mark.parametrize("which", ["lean", "block"])
+def test_no_instruction_touches_a_load_destination_before_its_wait(which, request):
+    """Between a load's issue and the next wait on its counter, no instruction of the straight-line code that follows may
+    name the destination registers (the scan stops at a branch or a label: there the next block opens with the wait)."""
+    for name, body in request.getfixturevalue(which).items():
+        for i, line in enumerate(body):
+            m = LOAD.match(line)
+            if not m or "lds" in m.group(1):
+                continue
+            dst = _regs(m.group(2))
+            wait = ANY_WAIT["ds" if m.group(1).startswith("ds_") else "gl"]
+            for follow in body[i + 1:i + 400]:
+                code = follow.split(";")[0].strip()
+                if not code or code.startswith("."):
+                    if re.match(r"^\.?LBB|^\d+:", code):
+                        break
+                    continue
+                if re.match(r"^(\d+|\.LBB\w+):", code) or re.match(r"^(s_cbranch|s_branch|s_endpgm|s_setpc)", code) or wait.search(code):
+                    break
+                used = set()
+                for tok in re.findall(r"v\[\d+:\d+\]|v\d+", code):
+                    used |= _regs(tok)
+                assert not (used & dst), (name, line.strip(), code)
