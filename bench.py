@@ -85,6 +85,8 @@ def build_workload(capi, first_stream, n_streams, in_frames):
     src = np.empty(n_streams * in_frames * fb, dtype=np.uint8)
     for s in range(n_streams):
         src[s * in_frames * fb:(s + 1) * in_frames * fb] = noise_s24le(first_stream + s, in_frames)
+    if os.environ.get("OHGPU_BENCH_ZERO_INPUT"):            # (diagnosis only: how much of the time is the clock the data costs)
+        src[:] = 0
     return dict(L=L_, M=M_, coef=coef, descs=descs, src=src, out_total=out_total, n_msgs=n_msgs,
                 dst_bytes=n_streams * out_total * fb)
 

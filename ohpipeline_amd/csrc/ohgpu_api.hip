@@ -382,6 +382,15 @@ int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n
 }
 
 /* ---------------------------------------------------------------- layout-changing processors (a11, a13, a14) */
+// end = off + a * b + c in 64 bits; false when any step wraps (a descriptor that wraps must fail validation as out of
+// bounds: a wrapped end can look smaller than the arena)
+static bool span_end(uint64_t off, uint64_t a, uint64_t b, uint64_t c, uint64_t* end)
+{
+    uint64_t p = 0, q = 0;
+    if (__builtin_mul_overflow(a, b, &p) || __builtin_add_overflow(off, p, &q) || __builtin_add_overflow(q, c, end)) return false;
+    return true;
+}
+
 int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n,
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
 {
@@ -404,12 +413,12 @@ int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n
         else if (d.kind == OHGPU_FMT_UNPACK_PLANAR || d.kind == OHGPU_FMT_SENDER_PACK) {
             if (!valid_bits(d.src_bits)) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: source depth %u", i, d.src_bits);   // ASSERTS(), StarvationRamper.cpp:178-180
             else {
-                src_hi = d.src_offset + nf * ch * sb;
+                if (!span_end(d.src_offset, nf, ch * sb, 0, &src_hi)) src_hi = UINT64_MAX;
                 if (d.kind == OHGPU_FMT_UNPACK_PLANAR) {
                     if (ch > 1 && d.dst_plane_stride < nf * 4) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: planes overlap (stride %llu < %llu)", i, (unsigned long long)d.dst_plane_stride, (unsigned long long)(nf * 4));
-                    dst_hi = d.dst_offset + (ch - 1) * d.dst_plane_stride + nf * 4;
+                    if (!span_end(d.dst_offset, ch - 1, d.dst_plane_stride, nf * 4, &dst_hi)) dst_hi = UINT64_MAX;
                 } else {
-                    dst_hi = d.dst_offset + nf * (ch < 2 ? ch : 2) * (sb < 3 ? sb : 3);
+                    if (!span_end(d.dst_offset, nf, (ch < 2 ? ch : 2) * (sb < 3 ? sb : 3), 0, &dst_hi)) dst_hi = UINT64_MAX;
                 }
             }
         } else if (d.kind == OHGPU_FMT_FLAC_PACK) {
@@ -418,8 +427,8 @@ int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n
             else if (d.src_bits != 32) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: FLAC planes are TInt32 (src_bits must be 32)", i);
             else if (d.src_offset % 4 != 0 || d.src_plane_stride % 4 != 0) err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: TInt32 planes must be 4-byte aligned", i);
             else {
-                src_hi = d.src_offset + (ch - 1) * d.src_plane_stride + nf * 4;
-                dst_hi = d.dst_offset + nf * ch * (d.dst_bits / 8);
+                if (!span_end(d.src_offset, ch - 1, d.src_plane_stride, nf * 4, &src_hi)) src_hi = UINT64_MAX;
+                if (!span_end(d.dst_offset, nf, ch * (d.dst_bits / 8), 0, &dst_hi)) dst_hi = UINT64_MAX;
             }
         } else {
             err = set_error(OHGPU_ERR_INVALID, "fmt desc %zu: unknown kind %u", i, d.kind);
@@ -481,7 +490,7 @@ int ohgpu_flywheel_batch_create(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs
         else if (d.in_samples / dec < 4) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: %u training samples after decimation by %u (need 4)", i, d.in_samples, dec);
         else if (d.in_samples > 65536) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: %u training samples (limit 65536)", i, d.in_samples);
         else if (d.block_frames == 0 && d.out_frames != 0) err = set_error(OHGPU_ERR_INVALID, "flywheel desc %zu: block_frames is 0", i);
-        else if (d.src_offset > src_arena_bytes || plane * d.channels > src_arena_bytes - d.src_offset)
+        else if (d.src_offset > src_arena_bytes || plane > src_arena_bytes || plane * d.channels > src_arena_bytes - d.src_offset)   // (plane <= arena: the product cannot wrap)
             err = set_error(OHGPU_ERR_BOUNDS, "flywheel desc %zu: training audio beyond the %llu-byte source arena", i, (unsigned long long)src_arena_bytes);
         else if (d.dst_offset > dst_arena_bytes || out_bytes > dst_arena_bytes - d.dst_offset)
             err = set_error(OHGPU_ERR_BOUNDS, "flywheel desc %zu: writes up to %llu beyond the %llu-byte destination arena", i,
@@ -556,7 +565,8 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
     CTX_GUARD("ohgpu_src_create");
     if (!out || !coef_q28) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: null argument");
     *out = nullptr;
-    if (L == 0 || M == 0 || T == 0 || (uint64_t)L * T > (1u << 22))
+    // (M < 2^15: a descriptor's out_frame0 may be 2^48, and out_frame0 * M is computed in 64 bits)
+    if (L == 0 || M == 0 || M >= (1u << 15) || T == 0 || (uint64_t)L * T > (1u << 22))
         return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: bad geometry L=%u M=%u T=%u", L, M, T);
     const size_t n = (size_t)L * T;
     std::vector<double> cd(n);

@@ -69,24 +69,39 @@ __device__ __forceinline__ void lean_wait0(uint64_t& y)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y) : : "memory");
 }
 
-// sixteen taps of one coefficient register: taps 16 r + 15 .. 16 r, ONE accumulation chain.  `w` are the sixteen window slots
-// in tap order 15 .. 0.  (A second chain would need its own zero and a final add -- three more vector instructions per output;
-// with three or four waves on the SIMD the dependent v_fmac_f64 of one wave are issued between those of the others, and the
-// loop runs at the pipe's rate either way: tools/exp_lean.sh, same time.  cv is only ever written by an LDS load: no
-// VALU-write -> DPP-read hazard.)
-#define OHGPU_FM(k, x) "v_fmac_f64_dpp %[a0], %[cv], " x " row_newbcast:" #k " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void lean_taps16(double& acc0, const double cv,
+// sixteen taps of one coefficient register: taps 16 r + 15 .. 16 r, dealt round-robin to OHGPU_LEAN_CHAINS accumulation chains.
+// `w` are the sixteen window slots in tap order 15 .. 0.  (cv is only ever written by an LDS load: no VALU-write -> DPP-read
+// hazard.)  A lone wave issues dependent v_fmac_f64_dpp 8.8 cycles apart, two chains 6.7, four 5.8 (tools/micro/fma_latency.hip):
+// with three waves on a SIMD the pipe is only kept full while EVERY wave is in its taps, so a wave's own speed matters whenever
+// another one is between units, waiting for its staging loads or writing lines back.
+#ifndef OHGPU_LEAN_CHAINS
+#define OHGPU_LEAN_CHAINS 1
+#endif
+#define OHGPU_FM(a, k, x) "v_fmac_f64_dpp %[a" #a "], %[cv], " x " row_newbcast:" #k " row_mask:0xf bank_mask:0xf\n\t"
+#if OHGPU_LEAN_CHAINS == 1
+#define OHGPU_FM4(k3, k2, k1, k0, x3, x2, x1, x0) OHGPU_FM(0, k3, x3) OHGPU_FM(0, k2, x2) OHGPU_FM(0, k1, x1) OHGPU_FM(0, k0, x0)
+#elif OHGPU_LEAN_CHAINS == 2
+#define OHGPU_FM4(k3, k2, k1, k0, x3, x2, x1, x0) OHGPU_FM(1, k3, x3) OHGPU_FM(0, k2, x2) OHGPU_FM(1, k1, x1) OHGPU_FM(0, k0, x0)
+#else
+#define OHGPU_FM4(k3, k2, k1, k0, x3, x2, x1, x0) OHGPU_FM(3, k3, x3) OHGPU_FM(2, k2, x2) OHGPU_FM(1, k1, x1) OHGPU_FM(0, k0, x0)
+#endif
+struct LeanAcc { double a0, a1, a2, a3; };
+__device__ __forceinline__ void lean_taps16(LeanAcc& acc, const double cv,
                                             const double w15, const double w14, const double w13, const double w12,
                                             const double w11, const double w10, const double w9, const double w8,
                                             const double w7, const double w6, const double w5, const double w4,
                                             const double w3, const double w2, const double w1, const double w0)
 {
     asm volatile(
-        OHGPU_FM(15, "%[w15]") OHGPU_FM(14, "%[w14]") OHGPU_FM(13, "%[w13]") OHGPU_FM(12, "%[w12]")
-        OHGPU_FM(11, "%[w11]") OHGPU_FM(10, "%[w10]") OHGPU_FM(9, "%[w9]") OHGPU_FM(8, "%[w8]")
-        OHGPU_FM(7, "%[w7]") OHGPU_FM(6, "%[w6]") OHGPU_FM(5, "%[w5]") OHGPU_FM(4, "%[w4]")
-        OHGPU_FM(3, "%[w3]") OHGPU_FM(2, "%[w2]") OHGPU_FM(1, "%[w1]") OHGPU_FM(0, "%[w0]")
-        : [a0] "+v"(acc0)
+        OHGPU_FM4(15, 14, 13, 12, "%[w15]", "%[w14]", "%[w13]", "%[w12]") OHGPU_FM4(11, 10, 9, 8, "%[w11]", "%[w10]", "%[w9]", "%[w8]")
+        OHGPU_FM4(7, 6, 5, 4, "%[w7]", "%[w6]", "%[w5]", "%[w4]") OHGPU_FM4(3, 2, 1, 0, "%[w3]", "%[w2]", "%[w1]", "%[w0]")
+        : [a0] "+v"(acc.a0)
+#if OHGPU_LEAN_CHAINS >= 2
+          , [a1] "+v"(acc.a1)
+#endif
+#if OHGPU_LEAN_CHAINS >= 4
+          , [a2] "+v"(acc.a2), [a3] "+v"(acc.a3)
+#endif
         : [cv] "v"(cv), [w15] "v"(w15), [w14] "v"(w14), [w13] "v"(w13), [w12] "v"(w12), [w11] "v"(w11), [w10] "v"(w10), [w9] "v"(w9),
           [w8] "v"(w8), [w7] "v"(w7), [w6] "v"(w6), [w5] "v"(w5), [w4] "v"(w4), [w3] "v"(w3), [w2] "v"(w2), [w1] "v"(w1), [w0] "v"(w0));
 }
@@ -165,7 +180,10 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t table_bytes = (uint32_t)L * T * 8;
-    const uint32_t row_stride = ring_bytes + 4;                       // rows start in different banks
+#ifndef OHGPU_LEAN_RING_PAD
+#define OHGPU_LEAN_RING_PAD 4
+#endif
+    const uint32_t row_stride = ring_bytes + OHGPU_LEAN_RING_PAD;     // rows start in different banks
     const uint32_t ring_area = (ROWS * row_stride + 15) & ~15u;
     const uint32_t wave_lds = OFF_RING + ring_area + G::DUMMY;
 
@@ -303,20 +321,27 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
         while (drained < (((uint32_t)frames_stored * FB_DST) >> 6)) {
             uint32_t pos = line_pos + (lane & 3) * 16;
             if (pos >= ring_bytes) pos -= ring_bytes;
+            // every pass's pieces are read before any is stored: one LDS round trip per line, not one per pass
+            u32x4 v4[DRAIN_ITERS];
 #pragma unroll
             for (int it = 0; it < DRAIN_ITERS; it++) {
+                const __attribute__((address_space(3))) uint32_t* q =
+                    (const __attribute__((address_space(3))) uint32_t*)(lds + drain_lds + (uint32_t)(it * 16) * row_stride + pos);
+                v4[it].x = q[0]; v4[it].y = q[1]; v4[it].z = q[2]; v4[it].w = q[3];
+            }
+#pragma unroll
+            for (int it = 0; it < DRAIN_ITERS; it++) {
+#ifdef OHGPU_DIAG_DRAIN_SEQ
+                asm volatile("" : "+v"(v4[it]) : : "memory");      // (diagnostic: one round trip per pass, as before)
+#endif
                 if ((uint32_t)(it * 16) + (lane >> 2) < wave_rows) {
                     uint8_t* const line = dst + wave_dst + (uint64_t)drained * 64 + (uint64_t)(it * 16) * L_blk * FB_DST;    // wave-uniform
-                    const __attribute__((address_space(3))) uint32_t* q =
-                        (const __attribute__((address_space(3))) uint32_t*)(lds + drain_lds + (uint32_t)(it * 16) * row_stride + pos);
-                    u32x4 v4;
-                    v4.x = q[0]; v4.y = q[1]; v4.z = q[2]; v4.w = q[3];
 #if defined(OHGPU_DIAG_STORE_PLAIN)
-                    *(u32x4*)(line + drain_off) = v4;
+                    *(u32x4*)(line + drain_off) = v4[it];
 #elif !defined(OHGPU_DIAG_NO_STORE)
-                    __builtin_nontemporal_store(v4, (u32x4*)(line + drain_off));
+                    __builtin_nontemporal_store(v4[it], (u32x4*)(line + drain_off));
 #else
-                    if (v4.x == 0x12345678u && v4.y == 0x9abcdef0u) *(u32x4*)(line + drain_off) = v4;
+                    if (v4[it].x == 0x12345678u && v4[it].y == 0x9abcdef0u) *(u32x4*)(line + drain_off) = v4[it];
 #endif
                 }
             }
@@ -453,15 +478,23 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
 #endif
                 do {
                 // ---- emit the outputs whose newest input frame is this one ----
+                LeanAcc acc;
                 double acc0;
                 uint32_t cp;
-                // the next output's phase: pu += M mod L, and -L again on a carry; its coefficient row
+                // the accumulators: the first starts at the rounding bias; the next output's phase: pu += M mod L, and -L again on
+                // a carry; its coefficient row
+#if OHGPU_LEAN_CHAINS >= 2
+                asm volatile("v_mov_b64 %0, 0" : "=v"(acc.a1));
+#endif
+#if OHGPU_LEAN_CHAINS >= 4
+                asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0" : "=v"(acc.a2), "=v"(acc.a3));
+#endif
                 asm volatile("v_mov_b64 %[acc], %[bias]\n\t"
                              "s_add_u32 %[pu], %[pu], %[mr]\n\t"
                              "s_cselect_b32 vcc_lo, %[nl], 0\n\t"
                              "s_add_u32 %[pu], %[pu], vcc_lo\n\t"
                              "v_lshl_add_u32 %[cp], %[pu], %[sh], %[cl]"
-                             : [acc] "=v"(acc0), [pu] "+s"(pu), [cp] "=v"(cp)
+                             : [acc] "=v"(acc.a0), [pu] "+s"(pu), [cp] "=v"(cp)
                              : [bias] "s"(bias), [mr] "s"((uint32_t)Mr), [nl] "s"(0u - (uint32_t)L), [sh] "i"(T == 32 ? 8 : 9), [cl] "v"(coef_lane_L)
                              : "vcc", "scc");
                 static_for([&](auto rc) __attribute__((always_inline)) {
@@ -475,7 +508,7 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
                     if constexpr (r == NCR - 1) issue_store();
 #define W_(k) win[(s - (16 * r + (k)) + 2 * T) % T]
 #ifndef OHGPU_DIAG_NO_TAPS
-                    lean_taps16(acc0, cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
+                    lean_taps16(acc, cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                 W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1), W_(0));
 #endif
 #undef W_
@@ -516,6 +549,14 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
                     "v_cmp_ne_u32 vcc, 0xffff, %[mu]\n\t"          \
                     "v_lshlrev_b32 %[t], 8, %[t]\n\t"              \
                     "v_cndmask_b32 " Y ", " Y ", %[t], vcc\n\t"
+#if OHGPU_LEAN_CHAINS == 1
+                acc0 = acc.a0;
+#elif OHGPU_LEAN_CHAINS == 2
+                asm volatile("v_add_f64 %0, %1, %2" : "=v"(acc0) : "v"(acc.a0), "v"(acc.a1));
+#else
+                asm volatile("v_add_f64 %1, %1, %3\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %0, %1, %2"
+                             : "=&v"(acc0), "+v"(acc.a0), "+v"(acc.a2) : "v"(acc.a1), "v"(acc.a3));
+#endif
                 uint32_t t16, mu;
                 if constexpr (PAIR) {
                     // (laid out so that an output of a plain unit takes exactly one taken branch)
@@ -646,7 +687,7 @@ bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_
     *in_blocks = inb;
     *ring_bytes = rb;
     *coef_lds_bytes = L * T * 8;
-    *wave_lds_bytes = 2 * bpw * inb * 16 + ((bpw * (rb + 4) + 15) & ~15u) + ((64 % ch) ? 64u : 0u);
+    *wave_lds_bytes = 2 * bpw * inb * 16 + ((bpw * (rb + OHGPU_LEAN_RING_PAD) + 15) & ~15u) + ((64 % ch) ? 64u : 0u);
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;

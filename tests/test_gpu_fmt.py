@@ -187,3 +187,27 @@ def test_config5_data_path_flac_planes_to_resampled_ramped_s24(ctx):
     ctx.batch_destroy(fb); ctx.batch_destroy(sbatch); ctx.src_destroy(h)
     for p in (d_planes, d_packed, d_out):
         ctx.free(p)
+
+
+def test_plane_strides_that_wrap_64_bits_are_out_of_bounds(ctx):
+    """A plane stride chosen so that (channels - 1) * stride wraps to something small must fail validation (OHGPU_ERR_BOUNDS),
+    not reach a kernel: unpack-to-planes destination, FLAC source planes, flywheel training planes."""
+    ERR_BOUNDS = -5
+    for stride in (1 << 63, (1 << 64) // 2, ((1 << 64) // 3) & ~3, (1 << 64) - 4):
+        d = np.zeros(1, capi.FMT_DESC)
+        d["kind"], d["channels"], d["src_bits"], d["n_frames"] = capi.FMT_UNPACK_PLANAR, 3, 16, 8
+        d["dst_plane_stride"] = stride
+        with pytest.raises(capi.OhGpuError) as e:
+            ctx.fmt_batch(d, 4096, 4096)
+        assert e.value.code == ERR_BOUNDS, (stride, str(e.value))
+        d = np.zeros(1, capi.FMT_DESC)
+        d["kind"], d["channels"], d["src_bits"], d["dst_bits"], d["n_frames"] = capi.FMT_FLAC_PACK, 3, 32, 16, 8
+        d["src_plane_stride"] = stride
+        with pytest.raises(capi.OhGpuError) as e:
+            ctx.fmt_batch(d, 4096, 4096)
+        assert e.value.code == ERR_BOUNDS, (stride, str(e.value))
+    f = np.zeros(1, capi.FLYWHEEL_DESC)
+    f["channel_bytes"], f["channels"], f["in_samples"], f["out_frames"], f["block_frames"], f["sample_rate"] = (1 << 63), 2, 48, 48, 48, 48000
+    with pytest.raises(capi.OhGpuError) as e:
+        ctx.flywheel_batch(f, 4096, 4096)
+    assert e.value.code in (ERR_BOUNDS, -1), str(e.value)
