@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: PCM Msamples/s on 256 independent stereo S24 44.1->48 kHz streams,
-resample + ramp + format, per GPU (BASELINE.json configs[2]).
+"""bench.py -- PCM Msamples/s of the resample + ramp + format hot path on MI355X (BASELINE.json).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 5 --warmup 2                  # configs[2], the headline (default)
+    python bench.py --config 4                                      # configs[3]: 2048 mixed streams (44.1/96 -> 48 kHz, 2/6/8 channels)
+    python bench.py --config 5                                      # configs[4]: FLAC frames -> pack -> resample -> ramp -> S24
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (one fused resample->ramp->pack launch) over the whole batch:
-256 streams x 10 s of audio per GPU, inputs and descriptors already resident in HBM.  Streams shard
-across ranks with no collective (weak scaling: every rank owns 256 streams of its own).
-Rank 0 prints ONE JSON line.  The CPU oracle is used only for the `cpu_baseline` leg.
+A "step" is one pass of the hot path over the whole batch a rank owns: every launch the batch needs (one fused
+resample->ramp->pack launch per filter/layout group; config 5 also the FLAC pack), inputs and descriptors already resident in
+HBM.  Streams shard across ranks with no collective.  Rank 0 prints ONE JSON line with `roofline` (HIP events around every
+launch of the step, on the launch stream), `cpu_baseline` (the CPU oracle timed on this host's cores, and the full-size
+bit-exact check of the GPU's output against it) and `cadence` (one 5 ms message per stream per call, the live regime).
+The CPU oracle (oracle/, tests/oracle_lib.py) is used only for the `cpu_baseline` leg, never on the measured path.
 """
 import argparse
 import json
@@ -22,11 +25,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-STREAMS_PER_GPU = 256
-SECONDS = 10
-RATE_IN, RATE_OUT = 44100, 48000
-CHANNELS, BITS = 2, 24
-TAPS, BETA, F_PASS = 32, 9.0, 20000.0
+RATE_OUT = 48000
+BITS = 24
+BETA, F_PASS = 9.0, 20000.0
 OUT_FRAMES_PER_MSG = 240            # 5 ms at 48 kHz (CodecController.cpp:792-793 chunking, at the output rate)
 JIFFIES_PER_MS = 56448
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
@@ -46,9 +47,9 @@ def lcg_block(seed, n):
     return out
 
 
-def noise_s24le(stream_id, n_frames):
+def noise_s24le(stream_id, n_subsamples):
     """Seeded LCG full-scale noise: subsample = top 24 bits of each LCG word, packed little endian."""
-    x = lcg_block((0x9E3779B9 * (stream_id + 1)) & MASK, n_frames * CHANNELS)
+    x = lcg_block((0x9E3779B9 * (stream_id + 1)) & MASK, n_subsamples)
     b = np.empty((x.size, 3), dtype=np.uint8)
     b[:, 0] = (x >> 8) & 0xFF
     b[:, 1] = (x >> 16) & 0xFF
@@ -56,105 +57,319 @@ def noise_s24le(stream_id, n_frames):
     return b.reshape(-1)
 
 
-def build_workload(capi, first_stream, n_streams, in_frames):
-    """Input arena + one descriptor per 5 ms output message, ramp endpoints from the host ramp algebra."""
-    from ohpipeline_amd import hostmodel
-    L_, M_, coef = capi.src_design(RATE_IN, RATE_OUT, TAPS, BETA, F_PASS)
-    out_total = (in_frames * L_ + M_ - 1) // M_
-    n_msgs = (out_total + OUT_FRAMES_PER_MSG - 1) // OUT_FRAMES_PER_MSG
-    jps_out = 56448000 // RATE_OUT
-    first = np.arange(n_msgs, dtype=np.int64) * OUT_FRAMES_PER_MSG
-    count = np.minimum(OUT_FRAMES_PER_MSG, out_total - first)
-    sched = hostmodel.stream_ramp_schedule([int(c) * jps_out for c in count], 50 * JIFFIES_PER_MS, 500 * JIFFIES_PER_MS)
-    sched = np.array(sched, dtype=np.int64)
-    fb = CHANNELS * BITS // 8
-    descs = np.zeros(n_streams * n_msgs, dtype=capi.SRC_MSG_DESC)
-    for s in range(n_streams):
-        sl = slice(s * n_msgs, (s + 1) * n_msgs)
-        descs["src_offset"][sl] = s * in_frames * fb
-        descs["src_frames"][sl] = in_frames
-        descs["out_frame0"][sl] = first
-        descs["dst_offset"][sl] = s * out_total * fb + first * fb
-        descs["n_frames"][sl] = count
-        descs["flags"][sl] = sched[:, 0]
-        descs["ramp_start"][sl] = sched[:, 1]
-        descs["ramp_end"][sl] = sched[:, 2]
-    descs["attenuation"] = 256
-    descs["channels"], descs["src_bits"], descs["src_endian"] = CHANNELS, BITS, capi.ENDIAN_LITTLE
-    descs["dst_bits"], descs["dst_endian"] = BITS, capi.ENDIAN_BIG
-    src = np.empty(n_streams * in_frames * fb, dtype=np.uint8)
-    for s in range(n_streams):
-        src[s * in_frames * fb:(s + 1) * in_frames * fb] = noise_s24le(first_stream + s, in_frames)
-    if os.environ.get("OHGPU_BENCH_ZERO_INPUT"):            # (diagnosis only: how much of the time is the clock the data costs)
-        src[:] = 0
-    return dict(L=L_, M=M_, coef=coef, descs=descs, src=src, out_total=out_total, n_msgs=n_msgs,
-                dst_bytes=n_streams * out_total * fb)
+def taps_for(rate_in):
+    return 64 if rate_in >= 2 * RATE_OUT else 32        # 96 -> 48 kHz: twice the prototype length per phase
 
 
-def cpu_baseline(work, n_streams, in_frames):
-    """Times the CPU oracle (the restatement of the reference path + the resampler model, gcc -O2) on the GPU box's
-    host cores: the same descriptors and input, streams statically partitioned over one thread per core."""
+class Group:
+    """Streams that share a filter and a layout: one source arena, one destination arena, one batch, one launch per step."""
+
+    def __init__(self, capi, rate_in, channels, stream_ids, in_frames, src_bits=BITS, src_endian=None):
+        self.rate_in, self.channels, self.stream_ids, self.in_frames = rate_in, channels, list(stream_ids), in_frames
+        self.taps = taps_for(rate_in)
+        self.L, self.M, self.coef = capi.src_design(rate_in, RATE_OUT, self.taps, BETA, F_PASS)
+        self.out_total = (in_frames * self.L + self.M - 1) // self.M
+        self.n_msgs = (self.out_total + OUT_FRAMES_PER_MSG - 1) // OUT_FRAMES_PER_MSG
+        self.src_bits = src_bits
+        self.src_endian = capi.ENDIAN_LITTLE if src_endian is None else src_endian
+        self.fb_src, self.fb_dst = channels * src_bits // 8, channels * BITS // 8
+        n = len(self.stream_ids)
+        self.src_bytes, self.dst_bytes = n * in_frames * self.fb_src, n * self.out_total * self.fb_dst
+        self.descs = self._descs(capi)
+        self.src = None                                       # filled by the caller (noise, or config 5's packed FLAC audio)
+        self.d_src_external = None                            # config 5: the FLAC pack's destination arena IS this group's source
+        # algorithmic bytes of a step (SURVEY.md 8d): every input frame read once, every output frame written once
+        self.algorithmic_bytes = n * in_frames * self.fb_src + n * self.out_total * self.fb_dst
+        self.flops = 2.0 * self.taps * channels * n * self.out_total
+
+    def _descs(self, capi):
+        from ohpipeline_amd import hostmodel
+        jps_out = 56448000 // RATE_OUT
+        first = np.arange(self.n_msgs, dtype=np.int64) * OUT_FRAMES_PER_MSG
+        count = np.minimum(OUT_FRAMES_PER_MSG, self.out_total - first)
+        # Ramper's schedule (Ramper.cpp:114-134 through the host ramp algebra): up over the first 50 ms, down over the last 500 ms
+        sched = np.array(hostmodel.stream_ramp_schedule([int(c) * jps_out for c in count], 50 * JIFFIES_PER_MS, 500 * JIFFIES_PER_MS), dtype=np.int64)
+        n = len(self.stream_ids)
+        d = np.zeros(n * self.n_msgs, dtype=capi.SRC_MSG_DESC)
+        for s in range(n):
+            sl = slice(s * self.n_msgs, (s + 1) * self.n_msgs)
+            d["src_offset"][sl] = s * self.in_frames * self.fb_src
+            d["src_frames"][sl] = self.in_frames
+            d["out_frame0"][sl] = first
+            d["dst_offset"][sl] = s * self.out_total * self.fb_dst + first * self.fb_dst
+            d["n_frames"][sl] = count
+            d["flags"][sl] = sched[:, 0]
+            d["ramp_start"][sl] = sched[:, 1]
+            d["ramp_end"][sl] = sched[:, 2]
+        d["attenuation"] = 256
+        d["channels"], d["src_bits"], d["src_endian"] = self.channels, self.src_bits, self.src_endian
+        d["dst_bits"], d["dst_endian"] = BITS, capi.ENDIAN_BIG
+        return d
+
+    def fill_noise(self):
+        self.src = np.empty(self.src_bytes, dtype=np.uint8)
+        per = self.in_frames * self.fb_src
+        for k, sid in enumerate(self.stream_ids):
+            self.src[k * per:(k + 1) * per] = noise_s24le(sid, self.in_frames * self.channels)
+
+    def attach(self, ctx):
+        self.h = ctx.src_create(self.L, self.M, self.taps, self.coef)
+        self.d_src = self.d_src_external if self.d_src_external is not None else ctx.upload(self.src)
+        self.d_dst = ctx.malloc(self.dst_bytes)
+        ctx.memset(self.d_dst, 0, self.dst_bytes)
+        self.batch = ctx.src_batch(self.h, self.descs, self.src_bytes, self.dst_bytes)
+        self.info, self.plan = ctx.batch_info(self.batch), ctx.src_plan(self.batch)
+
+    def detach(self, ctx):
+        ctx.batch_destroy(self.batch)
+        ctx.src_destroy(self.h)
+        if self.d_src_external is None:
+            ctx.free(self.d_src)
+        ctx.free(self.d_dst)
+
+
+def partition_by_bytes(weights, world):
+    """Contiguous blocks of streams, balanced by bytes: rank r owns streams [cut[r], cut[r+1])."""
+    w = np.asarray(weights, dtype=np.float64)
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(c, c[-1] * r / world, side="left")))
+    cuts.append(len(w))
+    for r in range(1, world + 1):                  # every rank at least one stream when there are enough
+        cuts[r] = max(cuts[r], cuts[r - 1] + (1 if len(w) >= world else 0))
+    cuts[-1] = len(w)
+    return cuts
+
+
+def config4_stream(sid):
+    """BASELINE configs[3]: the mix is a function of the stream id -- rate 44.1 / 96 kHz alternating, channels 2 / 6 / 8 in turn
+    (the reference admits more than two channels for raw PCM only, Codec/CodecController.cpp:727-730)."""
+    return (44100 if sid % 2 == 0 else 96000), (2, 6, 8)[sid % 3]
+
+
+def stream_weight(rate_in, channels, seconds):
+    fin = int(round(seconds * rate_in))
+    return fin * channels * 3 + int(round(seconds * RATE_OUT)) * channels * 3
+
+
+def config4_share(total_streams, seconds, rank, world):
+    """The streams of `rank`: a contiguous block, the blocks balanced by the bytes a stream moves."""
+    w = [stream_weight(*config4_stream(s), seconds) for s in range(total_streams)]
+    cuts = partition_by_bytes(w, world)
+    return range(cuts[rank], cuts[rank + 1]), w
+
+
+def build_groups(capi, args, rank, world):
+    """The rank's share of the workload as a list of Groups."""
+    if args.config == 3:
+        ids = range(rank * args.streams, (rank + 1) * args.streams)          # weak scaling: every rank owns `streams` of its own
+        g = Group(capi, args.rate_in, args.channels, ids, int(round(args.seconds * args.rate_in)))
+        g.fill_noise()
+        return [g], "weak"
+    mine, _ = config4_share(args.streams, args.seconds, rank, world)         # strong scaling: 2048 streams over the ranks, by bytes
+    groups = []
+    for rate in (44100, 96000):
+        for ch in (2, 6, 8):
+            ids = [s for s in mine if config4_stream(s) == (rate, ch)]
+            if ids:
+                g = Group(capi, rate, ch, ids, int(round(args.seconds * rate)))
+                g.fill_noise()
+                groups.append(g)
+    return groups, "strong"
+
+
+def pin_and_call(cpu, fn, *a):
+    try:
+        os.sched_setaffinity(0, {cpu})             # (the calling thread only)
+    except OSError:
+        pass
+    return fn(*a)
+
+
+def cpu_baseline(groups, got_by_group):
+    """Times the CPU oracle (restatement of the reference path + the resampler's integer model, gcc -O2) on this host: the same
+    descriptors and input, streams statically partitioned over pinned threads, scratch buffers allocated once per job
+    (ohp_src_msg_process_batch_steady); median of three passes.  Its output is the bit-exact check of the GPU's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle_lib as O
-    ref = O.Src(RATE_IN, RATE_OUT, TAPS, BETA, F_PASS)
-    assert np.array_equal(ref.coef_q28, work["coef"])
-    cores = len(os.sched_getaffinity(0))
-    threads = max(1, min(cores, n_streams, int(os.environ.get("OHGPU_BENCH_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share
-    descs, src = work["descs"], work["src"]
-    dst = np.zeros(work["dst_bytes"], dtype=np.uint8)
-    n_msgs = work["n_msgs"]
-    bounds = np.linspace(0, n_streams, threads + 1).astype(int)
+    cpus = sorted(os.sched_getaffinity(0))
+    threads = max(1, min(len(cpus), int(os.environ.get("OHGPU_BENCH_CPU_THREADS", "16"))))
     lib = O.lib()
+    jobs, outs, frames = [], [], 0
+    for g in groups:
+        ref = O.Src(g.rate_in, RATE_OUT, g.taps, BETA, F_PASS)
+        assert np.array_equal(ref.coef_q28, g.coef)
+        dst = np.zeros(g.dst_bytes, dtype=np.uint8)
+        outs.append(dst)
+        n = len(g.stream_ids)
+        frames += n * g.in_frames
+        bounds = np.linspace(0, n, min(2 * threads, n) + 1).astype(int)
+        for t in range(len(bounds) - 1):
+            if bounds[t + 1] > bounds[t]:
+                part = np.ascontiguousarray(g.descs[bounds[t] * g.n_msgs:bounds[t + 1] * g.n_msgs])
+                jobs.append((ref, part, g.src, dst, (bounds[t + 1] - bounds[t]) * g.in_frames * g.channels))
+    jobs.sort(key=lambda j: -j[4])                                       # longest first over the pinned threads
 
-    def job(t):
-        part = np.ascontiguousarray(descs[bounds[t] * n_msgs:bounds[t + 1] * n_msgs])
-        return lib.ohp_src_msg_process_batch(ref.h, part.ctypes.data_as(C.c_void_p), part.size,
-                                             src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+    def run(kj):
+        k, (ref, part, src, dst, _) = kj
+        return pin_and_call(cpus[k % threads], lib.ohp_src_msg_process_batch_steady, ref.h, part.ctypes.data_as(C.c_void_p), part.size,
+                            src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
 
     times = []
     with ThreadPoolExecutor(threads) as ex:
-        for _ in range(3):                                        # median of three passes: about 20 core-seconds in all
+        for _ in range(3):
             t0 = time.perf_counter()
-            rcs = list(ex.map(job, range(threads)))
+            rcs = list(ex.map(run, enumerate(jobs)))
             times.append(time.perf_counter() - t0)
             assert all(r == 0 for r in rcs)
     dt = sorted(times)[1]
-    # SURVEY.md 8(d) also asks for one thread alone: the first streams of the same step, about a second of work
-    n_one = max(1, min(n_streams, 8))
-    part = np.ascontiguousarray(descs[:n_one * n_msgs])
+    # one thread alone (SURVEY.md 8d): the first streams of the first group, about a second of work
+    g0 = groups[0]
+    ref0 = jobs[0][0] if False else O.Src(g0.rate_in, RATE_OUT, g0.taps, BETA, F_PASS)
+    n_one = max(1, min(len(g0.stream_ids), 8))
+    one_part = np.ascontiguousarray(g0.descs[:n_one * g0.n_msgs])
     one = []
     for _ in range(3):
         t0 = time.perf_counter()
-        rc = lib.ohp_src_msg_process_batch(ref.h, part.ctypes.data_as(C.c_void_p), part.size,
-                                           src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+        rc = lib.ohp_src_msg_process_batch_steady(ref0.h, one_part.ctypes.data_as(C.c_void_p), one_part.size,
+                                                  g0.src.ctypes.data_as(C.c_void_p), outs[0].ctypes.data_as(C.c_void_p))
         one.append(time.perf_counter() - t0)
         assert rc == 0
-    return dict(value=round(n_streams * in_frames / dt / 1e6, 3), unit="Msamples/s", cores=threads, kind="port",
-                single_thread=round(n_one * in_frames / sorted(one)[1] / 1e6, 3),
-                sample=f"the whole step, median of 3 passes: {n_streams} streams x {in_frames} frames, {threads} threads "
-                       f"(gcc -O2 oracle, {dt:.2f} s per pass, {sum(times) * threads:.0f} core-seconds in all)"), dst
+    ok = all(np.array_equal(a, b) for a, b in zip(got_by_group, outs))
+    base = dict(value=round(frames / dt / 1e6, 3), unit="Msamples/s", cores=threads, kind="port",
+                host_cores_online=os.cpu_count(), host_cores_allowed=len(cpus),
+                single_thread=round(n_one * g0.in_frames / sorted(one)[1] / 1e6, 3),
+                sample=f"the whole step, median of 3 passes: {frames} input frames in {len(jobs)} jobs on {threads} pinned threads "
+                       f"(gcc -O2 oracle, scratch allocated once per job; {dt:.2f} s per pass, {sum(times) * threads:.0f} core-seconds in all)")
+    return base, ("bit-exact vs oracle" if ok else "MISMATCH")
+
+
+def cadence(ctx, capi, g, calls=200):
+    """The live regime (AnimatorBasic.h:30: one pull per 5 ms): ONE 5 ms message per stream per call, for the group's streams.
+    `host_buffers` = ohgpu_src_process_host: descriptors validated, input uploaded, launch, output downloaded, synchronised --
+    what a driver thread pays per period with host buffers; `resident_launch` = a batch created once, launched and
+    synchronised per call."""
+    n = len(g.stream_ids)
+    k = g.n_msgs // 2                                                       # a message in the middle of the stream (no ramp)
+    d = np.ascontiguousarray(g.descs[k::g.n_msgs][:n]).copy()
+    m0, nf = int(d["out_frame0"][0]), int(d["n_frames"][0])
+    n_lo = max(0, (m0 * g.M) // g.L - (g.taps - 1))                         # the message's window of input, per stream
+    n_hi = ((m0 + nf - 1) * g.M) // g.L
+    frames = n_hi - n_lo + 1
+    src = np.empty(n * frames * g.fb_src, dtype=np.uint8)
+    for s in range(n):
+        a = s * g.in_frames * g.fb_src + n_lo * g.fb_src
+        src[s * frames * g.fb_src:(s + 1) * frames * g.fb_src] = g.src[a:a + frames * g.fb_src]
+    d["src_offset"] = np.arange(n, dtype=np.uint64) * (frames * g.fb_src)
+    d["src_frame0"], d["src_frames"] = n_lo, frames
+    d["dst_offset"] = np.arange(n, dtype=np.uint64) * (nf * g.fb_dst)
+    dst_bytes = n * nf * g.fb_dst
+    dst = np.zeros(dst_bytes, dtype=np.uint8)
+    host = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        ctx.src_process_host(g.h, d, src, dst)
+        host.append((time.perf_counter() - t0) * 1e6)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dst_bytes)
+    b = ctx.src_batch(g.h, d, src.size, dst_bytes)
+    ctx.sync()
+    res = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        ctx.src_run(b, d_src, d_dst)
+        ctx.sync()
+        res.append((time.perf_counter() - t0) * 1e6)
+    ctx.batch_destroy(b)
+    ctx.free(d_src)
+    ctx.free(d_dst)
+
+    def q(v, p):
+        return round(float(np.percentile(v, p)), 1)
+    return {"what": f"{n} streams x one 5 ms message per call ({nf} output frames each), {calls} calls, wall clock per call",
+            "period_us": 5000, "host_buffers_us": {"median": q(host, 50), "p99": q(host, 99)},
+            "resident_launch_us": {"median": q(res, 50), "p99": q(res, 99)}}
+
+
+def end_to_end(ctx, capi, g):
+    """the same step with the buffers on the host side of the boundary (pinned): H2D of the input, the launch,
+    D2H of the output, wall clock -- and the same with the streams in groups on two HIP streams, so that the link carries both
+    directions while the kernel runs.  Reported beside `value`, never as it."""
+    import ctypes as C
+    n_streams = len(g.stream_ids)
+    h_src = ctx.malloc_host(g.src.nbytes)
+    h_dst = ctx.malloc_host(g.dst_bytes)
+    h_src[:] = g.src.view(np.uint8).reshape(-1)
+    e2e = []
+    for _ in range(3):
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.copy_h2d(g.d_src, h_src)
+        ctx.src_run(g.batch, g.d_src, g.d_dst)
+        ctx.copy_d2h(h_dst, g.d_dst)
+        ctx.sync()
+        e2e.append(time.perf_counter() - t1)
+    dt = sorted(e2e)[1]
+    frames = n_streams * g.in_frames
+    out = {"value": round(frames / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
+           "pcie_gbps": round((g.src.nbytes + g.dst_bytes) / dt / 1e9, 2),
+           "what": "pinned host input -> H2D -> launch -> D2H -> pinned host output, median of 3"}
+    groups = int(os.environ.get("OHGPU_BENCH_GROUPS", "8"))
+    if n_streams % groups == 0 and groups > 1:
+        per = n_streams // groups
+        sb, db = g.in_frames * g.fb_src, g.out_total * g.fb_dst
+        parts = [ctx.src_batch(g.h, g.descs[k * per * g.n_msgs:(k + 1) * per * g.n_msgs], g.src_bytes, g.dst_bytes) for k in range(groups)]
+        up, down = ctx.stream_create(), ctx.stream_create()
+        arrived = [ctx.event() for _ in range(groups)]
+        ov = []
+        for _ in range(3):
+            ctx.sync()
+            t1 = time.perf_counter()
+            for k in range(groups):
+                s0, s1, o0, o1 = k * per * sb, (k + 1) * per * sb, k * per * db, (k + 1) * per * db
+                ctx.copy_h2d(C.c_void_p(g.d_src.value + s0), h_src[s0:s1], up)
+                ctx.record(arrived[k], up)
+                ctx.wait_event(down, arrived[k])
+                ctx.src_run(parts[k], g.d_src, g.d_dst, down)
+                ctx.copy_d2h(h_dst[o0:o1], C.c_void_p(g.d_dst.value + o0), down)
+            ctx.sync(up)
+            ctx.sync(down)
+            ov.append(time.perf_counter() - t1)
+        dt = sorted(ov)[1]
+        out["overlapped"] = {"value": round(frames / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 3),
+                             "pcie_gbps": round((g.src.nbytes + g.dst_bytes) / dt / 1e9, 2),
+                             "what": f"{groups} groups of {per} streams, upload stream + launch/download stream",
+                             "check": "bit-exact vs the resident run" if np.array_equal(np.array(h_dst), ctx.download(g.d_dst, g.dst_bytes)) else "MISMATCH"}
+        for st in (up, down):
+            ctx.stream_destroy(st)
+        for b in parts:
+            ctx.batch_destroy(b)
+    ctx.free_host(h_src)
+    ctx.free_host(h_dst)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seconds", type=float, default=SECONDS, help="audio per stream (default 10 s = the throughput set)")
-    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 baseline v1)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and end_to_end legs (profiling runs: only the timed launches)")
-    ap.add_argument("--check", action="store_true", help="compare the GPU output of the last step with the oracle")
-    ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per stream (the headline is stereo; 6 and 8 also run the block kernel)")
-    ap.add_argument("--rate-in", type=int, default=RATE_IN, help="input rate (the headline is 44100; 96000 with --taps 64 is config 4's other rate)")
-    ap.add_argument("--taps", type=int, default=TAPS, help="taps per phase")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json configs[config-1]: 3 = the headline")
+    ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: 10 s for config 3, 4 s for configs 4 and 5)")
+    ap.add_argument("--streams", type=int, default=None, help="config 3/5: streams per GPU (256); config 4: streams in all (2048)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 2 round 1's block kernel)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / check, end_to_end and cadence legs (profiling runs)")
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the warm-up and the timed steps, so that they see the clock the chip holds under this load")
+    ap.add_argument("--channels", type=int, default=2, help="config 3: channels per stream (the headline is stereo)")
+    ap.add_argument("--rate-in", type=int, default=44100, help="config 3: input rate (the headline is 44100)")
     args = ap.parse_args()
-    globals()["CHANNELS"] = args.channels
-    globals()["RATE_IN"] = args.rate_in
-    globals()["TAPS"] = args.taps
+    if args.seconds is None:
+        args.seconds = {3: 10.0, 4: 4.0, 5: 4.0}[args.config]
+    if args.streams is None:
+        args.streams = 2048 if args.config == 4 else 256
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -166,176 +381,149 @@ def main():
         dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
 
     from ohpipeline_amd import capi
-    n_streams = args.streams
-    in_frames = int(round(args.seconds * RATE_IN))
-    work = build_workload(capi, rank * n_streams, n_streams, in_frames)
-
-    # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal) the ranks share what there is
-    ctx = capi.Context(local_rank % max(capi.device_count(), 1) if world > 1 else 0)
+    ctx = capi.Context(local_rank % max(capi.device_count(), 1) if world > 1 else 0)   # fewer GPUs than ranks (a rehearsal): shared
     ctx.set_kernel_variant(args.variant)
-    h = ctx.src_create(work["L"], work["M"], TAPS, work["coef"])
-    d_src = ctx.upload(work["src"])
-    d_dst = ctx.malloc(work["dst_bytes"])
-    ctx.memset(d_dst, 0, work["dst_bytes"])
-    batch = ctx.src_batch(h, work["descs"], work["src"].size, work["dst_bytes"])
-    info = ctx.batch_info(batch)
-    plan = ctx.src_plan(batch)
+    flac = None
+    if args.config == 5:
+        import bench_flac
+        groups, scaling, flac = bench_flac.build(capi, ctx, args, rank, world, Group)
+    else:
+        groups, scaling = build_groups(capi, args, rank, world)
+    for g in groups:
+        g.attach(ctx)
     ctx.sync()
+
+    def step(events=None):
+        if flac is not None:
+            flac.run(ctx, events[-1] if events is not None else None)
+        for i, g in enumerate(groups):
+            if events is not None:
+                ctx.record(events[i][0])
+            ctx.src_run(g.batch, g.d_src, g.d_dst)
+            if events is not None:
+                ctx.record(events[i][1])
 
     def barrier():
         ctx.sync()
         if dist is not None:
             dist.barrier()
 
+    # steady state first: about `sustain` seconds of launches (untimed), so that the timed steps see the clock the chip holds
+    t0 = time.perf_counter()
+    step()
+    ctx.sync()
+    one = max(time.perf_counter() - t0, 1e-4)
+    for _ in range(int(min(args.sustain / one, 20000))):
+        step()
     for _ in range(args.warmup):
-        ctx.src_run(batch, d_src, d_dst)
+        step()
     barrier()
-    ev = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+    n_ev = len(groups) + (1 if flac is not None else 0)
+    ev = [[(ctx.event(), ctx.event()) for _ in range(n_ev)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ctx.record(ev[k][0])
-        ctx.src_run(batch, d_src, d_dst)
-        ctx.record(ev[k][1])
+        step(ev[k])
     ctx.sync()
     elapsed = time.perf_counter() - t0
     barrier()
+    frames_all = float(sum(len(g.stream_ids) * g.in_frames for g in groups))
+    subs_all = float(sum(len(g.stream_ids) * g.in_frames * g.channels for g in groups))
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        tot = torch.tensor([frames_all, subs_all], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        frames_all, subs_all = float(tot[0]), float(tot[1])
 
-    kernel_ms = [ctx.elapsed_ms(a, b) for a, b in ev]
-    kernel_avg_ms = float(np.mean(kernel_ms))
-    frames_per_step = n_streams * in_frames                       # input frames per rank per step
-    bytes_per_in_frame = CHANNELS * BITS / 8 * (1.0 + work["L"] / work["M"])   # 6 + 6*160/147 = 12.531 B
-    algorithmic_bytes = frames_per_step * bytes_per_in_frame
-    achieved_gbps = algorithmic_bytes / (kernel_avg_ms * 1e-3) / 1e9
+    # per-launch kernel time (HIP events on the launch stream), this rank
+    grp_ms = [float(np.mean([ctx.elapsed_ms(ev[k][i][0], ev[k][i][1]) for k in range(args.steps)])) for i in range(n_ev)]
+    kernel_ms = float(sum(grp_ms[:len(groups)]))
+    alg_bytes = float(sum(g.algorithmic_bytes for g in groups))
+    flops = float(sum(g.flops for g in groups))
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     result = None
     if rank == 0:
-        total_frames = frames_per_step * world * args.steps
+        names = {3: "configs[2]", 4: "configs[3]", 5: "configs[4]"}
+        head = groups[int(np.argmax([g.algorithmic_bytes for g in groups]))]
+        if args.config == 3:
+            what = (f"{args.streams} independent {'stereo' if args.channels == 2 else str(args.channels) + '-channel'} S24LE streams per GPU, "
+                    f"{args.rate_in / 1000:g}->48 kHz")
+        elif args.config == 4:
+            what = (f"{args.streams} S24LE streams in all, by stream id 44.1 / 96 kHz x 2 / 6 / 8 channels, ->48 kHz, "
+                    f"contiguous blocks of streams per rank balanced by bytes")
+        else:
+            what = (f"{args.streams} stereo FLAC streams per GPU (16- and 24-bit, level 5), frames decoded on the host by the reference's libFLAC, "
+                    f"planar TInt32 -> packed (Flac.cpp:379-417) -> 44.1->48 kHz")
         result = {
-            "metric": "PCM Msamples/s, 256-stream 44.1->48k S24 resample+ramp+fmt",
-            "value": round(total_frames / elapsed / 1e6, 3),
+            "metric": "PCM Msamples/s, 256-stream 44.1->48k S24 resample+ramp+fmt" if args.config == 3 else
+                      ("PCM Msamples/s, 2048-stream mixed 44.1/96->48k 2/6/8-channel S24 resample+ramp+fmt" if args.config == 4 else
+                       "PCM Msamples/s, 256-stream FLAC frames -> pack -> 44.1->48k resample+ramp+fmt"),
+            "value": round(frames_all * args.steps / elapsed / 1e6, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "msubsamples_per_s": round(total_frames * CHANNELS / elapsed / 1e6, 3),   # frames x channels
+            "msubsamples_per_s": round(subs_all * args.steps / elapsed / 1e6, 3),   # frames x channels
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: {n_streams} independent {'stereo' if CHANNELS == 2 else str(CHANNELS) + '-channel'} S24LE streams per GPU, {RATE_IN / 1000:g}->48 kHz, "
-                                   f"{args.seconds:g} s each ({in_frames} frames), 5 ms output messages, "
-                                   f"ramp up 50 ms / down 500 ms, S24 BE out",
-                       "streams_per_gpu": n_streams, "channels": CHANNELS, "frames_per_stream": in_frames, "taps_per_phase": TAPS,
-                       "msgs_per_step": int(info["n_msgs"]), "kernel_variant": args.variant,
-                       "block_kernel_out_frames": plan["block_kernel_out_frames"], "generic_pieces": plan["generic_pieces"],
-                       "sharding": f"streams x{world} ranks, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved_gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "fused resample+ramp+pack", "kernel_avg_ms": round(kernel_avg_ms, 4),
-                         "algorithmic_bytes_per_launch": int(algorithmic_bytes),
-                         "bytes_per_input_frame": round(bytes_per_in_frame, 4),
-                         # the pipe that actually bounds this kernel: 2*T*channels*L/M fp64 flop per input frame
-                         # on the vector (= matrix) fp64 pipe, 78.6 TFLOP/s dense on MI355X
-                         "fp64_tflops": round(frames_per_step * 2.0 * TAPS * CHANNELS * work["L"] / work["M"] / (kernel_avg_ms * 1e-3) / 1e12, 2),
-                         "fp64_peak_tflops": 78.6,
-                         "fp64_frac": round(frames_per_step * 2.0 * TAPS * CHANNELS * work["L"] / work["M"] / (kernel_avg_ms * 1e-3) / 1e12 / 78.6, 4)},
+            "config": {"workload": f"{names[args.config]}: {what}, {args.seconds:g} s each, 5 ms output messages, ramp up 50 ms / down 500 ms, S24 BE out",
+                       "kernel_variant": args.variant, "sustain_s": args.sustain,
+                       "streams_per_gpu": len(set(s for g in groups for s in g.stream_ids)),
+                       "groups": [{"rate_in": g.rate_in, "channels": g.channels, "src_bits": g.src_bits, "streams": len(g.stream_ids),
+                                   "taps_per_phase": g.taps, "frames_per_stream": g.in_frames, "msgs": int(g.info["n_msgs"]),
+                                   "kernel_ms": round(grp_ms[i], 4), "gbps": round(g.algorithmic_bytes / (grp_ms[i] * 1e-3) / 1e9, 1),
+                                   "block_kernel_out_frames": g.plan["block_kernel_out_frames"], "generic_pieces": g.plan["generic_pieces"]}
+                                  for i, g in enumerate(groups)],
+                       "sharding": f"streams over {world} rank(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": ("fused resample+ramp+pack (src_lean_kernel), every launch of the step" if args.variant == 0 else f"variant {args.variant}"),
+                         "kernel_avg_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "bytes_per_input_frame": round(head.fb_src + head.fb_dst * head.L / head.M, 4),
+                         # the pipe the taps run on: 2*T*channels fp64 flop per output frame on the vector fp64
+                         # pipe, 78.6 TFLOP/s dense on MI355X
+                         "fp64_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 2), "fp64_peak_tflops": 78.6,
+                         "fp64_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / 78.6, 4)},
         }
+        if flac is not None:
+            result["config"]["flac"] = flac.report(grp_ms[-1])
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.config == 3:
             try:
                 p = json.load(open(pmc))
-                if p.get("streams_per_gpu") == n_streams and p.get("frames_per_stream") == in_frames \
+                if p.get("streams_per_gpu") == args.streams and p.get("frames_per_stream") == groups[0].in_frames \
                         and p.get("kernel_variant") == args.variant:
                     result["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
                     result["roofline"]["traffic_source"] = p.get("source")
             except Exception:
                 pass
-        overlapped_out = None
         if world == 1 and not args.no_cpu:
-            try:                                             # (a reported extra: never let it cost the headline line)
-                # the same step with the buffers on the host side of the boundary (pinned): H2D of the input,
-                # the launch, D2H of the output, wall clock.  Reported beside `value`, never as it.
-                h_src = ctx.malloc_host(work["src"].nbytes)
-                h_dst = ctx.malloc_host(work["dst_bytes"])
-                h_src[:] = work["src"].view(np.uint8).reshape(-1)
-                e2e = []
-                for _ in range(3):
-                    ctx.sync()
-                    t1 = time.perf_counter()
-                    ctx.copy_h2d(d_src, h_src)
-                    ctx.src_run(batch, d_src, d_dst)
-                    ctx.copy_d2h(h_dst, d_dst)
-                    ctx.sync()
-                    e2e.append(time.perf_counter() - t1)
-                dt = sorted(e2e)[1]
-                result["end_to_end"] = {"value": round(frames_per_step / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3),
-                                        "pcie_gbps": round((work["src"].nbytes + work["dst_bytes"]) / dt / 1e9, 2),
-                                        "what": "pinned host input -> H2D -> launch -> D2H -> pinned host output, median of 3"}
-                # the same with the streams in groups: one HIP stream uploads, a second waits for each group's upload (event),
-                # launches it and downloads its output, so the link carries both directions while the kernel runs
-                groups = int(os.environ.get("OHGPU_BENCH_GROUPS", "8"))
-                if n_streams % groups != 0:
-                    groups = 1
-                if groups > 1:
-                    import ctypes as C
-                    per, fb = n_streams // groups, CHANNELS * BITS // 8
-                    n_msgs, sb, db = work["n_msgs"], in_frames * fb, work["out_total"] * fb
-                    parts = [ctx.src_batch(h, work["descs"][g * per * n_msgs:(g + 1) * per * n_msgs], work["src"].size, work["dst_bytes"])
-                             for g in range(groups)]
-                    lanes = [ctx.stream_create(), ctx.stream_create()]
-                    up, down = lanes
-                    arrived = [ctx.event() for _ in range(groups)]
-                    h_dst[:] = 0
-                    ctx.memset(d_dst, 0, work["dst_bytes"])
-                    ov = []
-                    for _ in range(3):
-                        ctx.sync()
-                        t1 = time.perf_counter()
-                        for g in range(groups):
-                            s0, s1, o0, o1 = g * per * sb, (g + 1) * per * sb, g * per * db, (g + 1) * per * db
-                            ctx.copy_h2d(C.c_void_p(d_src.value + s0), h_src[s0:s1], up)
-                            ctx.record(arrived[g], up)
-                            ctx.wait_event(down, arrived[g])
-                            ctx.src_run(parts[g], d_src, d_dst, down)
-                            ctx.copy_d2h(h_dst[o0:o1], C.c_void_p(d_dst.value + o0), down)
-                        for st in lanes:
-                            ctx.sync(st)
-                        ov.append(time.perf_counter() - t1)
-                    dt = sorted(ov)[1]
-                    result["end_to_end"]["overlapped"] = {"value": round(frames_per_step / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 3),
-                                                          "pcie_gbps": round((work["src"].nbytes + work["dst_bytes"]) / dt / 1e9, 2),
-                                                          "what": f"{groups} groups of {per} streams, upload stream + launch/download stream"}
-                    overlapped_out = np.array(h_dst)
-                    for st in lanes:
-                        ctx.stream_destroy(st)
-                    for b in parts:
-                        ctx.batch_destroy(b)
-                ctx.free_host(h_src)
-                ctx.free_host(h_dst)
+            got = [ctx.download(g.d_dst, g.dst_bytes) for g in groups]
+            try:                                             # (reported extras: never let them cost the headline line)
+                if args.config == 3:
+                    result["end_to_end"] = end_to_end(ctx, capi, groups[0])
+                result["cadence"] = cadence(ctx, capi, head)
             except Exception as e:
-                result["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
-                overlapped_out = None
-        if world == 1 and not args.no_cpu:
-            base, cpu_out = cpu_baseline(work, n_streams, in_frames)
+                result["extras_error"] = f"{type(e).__name__}: {e}"
+            base, check = cpu_baseline(groups, got)
             result["cpu_baseline"] = base
-            if args.check:
-                got = ctx.download(d_dst, work["dst_bytes"])
-                result["check"] = "bit-exact vs oracle" if np.array_equal(got, cpu_out) else "MISMATCH"
-                if overlapped_out is not None:
-                    result["check_overlapped"] = "bit-exact vs oracle" if np.array_equal(overlapped_out, cpu_out) else "MISMATCH"
+            result["check"] = check
+            if flac is not None:
+                result["check_flac_pack"] = flac.check(ctx)
         else:
             result["cpu_baseline"] = None
-    ctx.batch_destroy(batch)
-    ctx.src_destroy(h)
-    ctx.free(d_src)
-    ctx.free(d_dst)
+    for g in groups:
+        g.detach(ctx)
+    if flac is not None:
+        flac.close(ctx)
     ctx.close()
     if dist is not None:
         dist.barrier()

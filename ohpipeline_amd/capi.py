@@ -346,6 +346,15 @@ class Context:
                                            dst_arena_bytes, C.byref(b)))
         return b
 
+    def src_process_host(self, src, descs, src_bytes, dst_bytes_array):
+        """ohgpu_src_process_host: host buffers in, host buffers out (validation, upload, launch, download, sync in one call)."""
+        d = np.ascontiguousarray(descs)
+        assert d.dtype == SRC_MSG_DESC
+        check(lib().ohgpu_src_process_host(self._h, src, d.ctypes.data_as(C.c_void_p), d.size,
+                                           src_bytes.ctypes.data_as(C.c_void_p), src_bytes.nbytes,
+                                           dst_bytes_array.ctypes.data_as(C.c_void_p), dst_bytes_array.nbytes))
+        return dst_bytes_array
+
     def src_plan(self, batch):
         a, b = C.c_uint64(0), C.c_uint64(0)
         check(lib().ohgpu_src_batch_plan(batch, C.byref(a), C.byref(b)))

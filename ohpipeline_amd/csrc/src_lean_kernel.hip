@@ -143,7 +143,7 @@ struct LeanGeom {
     static constexpr int IN_BLOCKS = lean_in_blocks(CH, SB);
     static constexpr int IN_STRIDE = IN_BLOCKS * 16;
     static constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
-    static constexpr int DUMMY = (64 % CH) ? 64 : 0;      // where the lanes beyond the last whole block store
+    static constexpr bool DUMMY = (64 % CH) != 0;         // the lanes beyond the last whole block store into a ring of their own
 };
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
@@ -169,7 +169,10 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
     constexpr int FB_SRC = G::FB_SRC, FB_DST = G::FB_DST;
     constexpr int IN_BLOCKS = G::IN_BLOCKS, IN_STRIDE = G::IN_STRIDE, IN_ITERS = G::IN_ITERS, SF = G::SF;
     static_assert(T % (2 * SF) == 0, "a trip of T advances is a whole number of stage pairs: the buffer of a slot is static");
-    constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * ROWS * IN_STRIDE;
+    // (every region a DMA instruction is aimed at starts on a 128-byte boundary -- more than the 16 bytes it needs, so that a
+    // wave's staging buffers sit the same way against the LDS banks whatever its number in the workgroup)
+    constexpr uint32_t BUF_BYTES = (ROWS * IN_STRIDE + 127) & ~127;
+    constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * BUF_BYTES;
     constexpr bool PAIR = ring_pair_mode(CH, DB);
     static_assert(DB >= 2 && DB <= 4, "destination depths 16 / 24 / 32 bit");
     static_assert((SF * FB_SRC) % 16 == 0, "a stage advances every piece by a whole number of 16-byte pieces");
@@ -185,7 +188,8 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
 #endif
     const uint32_t row_stride = ring_bytes + OHGPU_LEAN_RING_PAD;     // rows start in different banks
     const uint32_t ring_area = (ROWS * row_stride + 15) & ~15u;
-    const uint32_t wave_lds = OFF_RING + ring_area + G::DUMMY;
+    const uint32_t dummy_bytes = G::DUMMY ? ring_bytes + 64u : 0u;    // (their store address moves with ring_pos like everyone's)
+    const uint32_t wave_lds = (OFF_RING + ring_area + dummy_bytes + 127u) & ~127u;
 
     // ---- coefficient table -> LDS once per workgroup, scaled by 2^-36 (exact): the window holds samples x 256, so the
     // accumulator is in sample units with 28 fraction bits.
@@ -266,7 +270,7 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
 #ifdef OHGPU_DIAG_NO_DMA
         if (q >= 0) { stage_off += SF * FB_SRC; return; }
 #endif
-        const uint32_t buf = OFF_IN + (uint32_t)(q & 1) * ROWS * IN_STRIDE;
+        const uint32_t buf = OFF_IN + (uint32_t)(q & 1) * BUF_BYTES;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; it++) {
             constexpr int kTail = ROWS * IN_BLOCKS - (IN_ITERS - 1) * 64;     // lanes of the last instruction that own a piece
@@ -371,7 +375,7 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
     for (int ph = 0; ph < PH; ph++) {
         in_sel[ph] = lean_unpack_sel<SB, SRC_LE>((in_base + ph * FB_SRC) & 3u);
         in_addr[0][ph] = (lane_block ? ((in_base + ph * FB_SRC) & ~3u) : (wave_lds_addr + OFF_IN));
-        in_addr[1][ph] = in_addr[0][ph] + ROWS * IN_STRIDE;
+        in_addr[1][ph] = in_addr[0][ph] + BUF_BYTES;
     }
     const bool any_first = __any(first_block) != 0;
 
@@ -687,7 +691,7 @@ bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_
     *in_blocks = inb;
     *ring_bytes = rb;
     *coef_lds_bytes = L * T * 8;
-    *wave_lds_bytes = 2 * bpw * inb * 16 + ((bpw * (rb + OHGPU_LEAN_RING_PAD) + 15) & ~15u) + ((64 % ch) ? 64u : 0u);
+    *wave_lds_bytes = (2 * ((bpw * inb * 16 + 127u) & ~127u) + ((bpw * (rb + OHGPU_LEAN_RING_PAD) + 15) & ~15u) + ((64 % ch) ? rb + 64u : 0u) + 127u) & ~127u;
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;

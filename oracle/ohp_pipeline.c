@@ -116,6 +116,88 @@ int ohp_src_msg_process_batch(const ohp_src* s, const ohp_src_msg_desc* d, size_
     return OHP_OK;
 }
 
+/* ---- steady-state variant for timing (bench.py's cpu_baseline leg): the same arithmetic as ohp_src_msg_process, with the
+ * scratch buffers allocated once per batch instead of four times per message and the resampler's bounds checks made once
+ * per message instead of twice per tap.  tests/test_oracle_baseline.py holds it equal, byte for byte, to the plain one. */
+typedef struct { int32_t* x; int32_t* y; uint8_t* be24; uint8_t* ramped; size_t x_cap, y_cap; } src_ws;
+
+static int src_process_i64_checked_once(const ohp_src* s, const int32_t* x, int64_t x_first, uint64_t x_frames, uint32_t channels,
+                                        uint64_t m0, uint32_t n_out, int32_t* y)
+{
+    const uint32_t L = s->L, M = s->M, T = s->T;
+    const uint64_t t_first = m0 * (uint64_t)M, t_last = (m0 + n_out - 1) * (uint64_t)M;
+    const int64_t n_first = (int64_t)(t_first / L), n_last = (int64_t)(t_last / L);
+    /* a message whose every window lies inside [x_first, x_first + x_frames) and after the stream start needs no checks */
+    if (n_first - (int64_t)(T - 1) < 0 || n_first - (int64_t)(T - 1) < x_first || (uint64_t)(n_last - x_first) >= x_frames)
+        return ohp_src_process_i64(s, x, x_first, x_frames, channels, m0, n_out, y);
+    uint64_t t = t_first;
+    for (uint32_t o = 0; o < n_out; o++, t += M) {
+        const int64_t n0 = (int64_t)(t / L);
+        const int32_t* c = s->coef_q28 + (size_t)(t % L) * T;
+        const int32_t* xp = x + (size_t)(n0 - x_first) * channels;
+        for (uint32_t ch = 0; ch < channels; ch++) {
+            int64_t acc = 0;
+            const int32_t* q = xp + ch;
+            for (uint32_t k = 0; k < T; k++, q -= channels) acc += (int64_t)c[k] * (int64_t)*q;
+            int64_t v = (acc + ((int64_t)1 << 27)) >> 28;
+            if (v > 8388607) v = 8388607;
+            if (v < -8388608) v = -8388608;
+            y[(size_t)o * channels + ch] = (int32_t)v;
+        }
+    }
+    return OHP_OK;
+}
+
+static int src_msg_process_ws(const ohp_src* s, const ohp_src_msg_desc* d, const uint8_t* src_base, uint8_t* dst_base, src_ws* w)
+{
+    const uint32_t sb = d->src_bits / 8, db = d->dst_bits / 8, ch = d->channels;
+    if (sb < 1 || sb > 4 || db < 1 || db > 4 || ch == 0) return OHP_ERR_ASSERT;
+    if (d->attenuation != OHP_UNITY_ATTENUATION) return OHP_ERR_ASSERT;
+    if (d->n_frames == 0) return OHP_OK;
+    const uint64_t m_first = d->out_frame0, m_last = d->out_frame0 + d->n_frames - 1;
+    const int64_t n_hi = (int64_t)((m_last * s->M) / s->L);
+    int64_t n_lo = (int64_t)((m_first * s->M) / s->L) - (int64_t)(s->T - 1);
+    if (n_lo < 0) n_lo = 0;
+    if (n_lo < (int64_t)d->src_frame0) return OHP_ERR_ASSERT;
+    if (n_hi >= (int64_t)(d->src_frame0 + d->src_frames)) return OHP_ERR_ASSERT;
+    const uint64_t frames = (uint64_t)(n_hi - n_lo + 1);
+    if (frames * ch > w->x_cap || (size_t)d->n_frames * ch > w->y_cap) return OHP_ERR_ASSERT;
+    const uint8_t* p = src_base + d->src_offset + (uint64_t)(n_lo - (int64_t)d->src_frame0) * ch * sb;
+    int err = ohp_unpack_s24(p, (uint32_t)(frames * ch), d->src_bits, d->src_endian, w->x);
+    if (err == OHP_OK) err = src_process_i64_checked_once(s, w->x, n_lo, frames, ch, d->out_frame0, d->n_frames, w->y);
+    if (err == OHP_OK) err = ohp_pack_from_s24(w->y, d->n_frames * ch, 24, OHP_ENDIAN_BIG, w->be24);
+    const uint8_t* stage = w->be24;
+    if (err == OHP_OK && (d->flags & OHP_FLAG_RAMP)) {
+        err = ohp_ramp_apply(w->be24, d->n_frames * ch * 3, 24, ch, d->ramp_start, d->ramp_end, w->ramped);
+        stage = w->ramped;
+    }
+    if (err == OHP_OK)
+        err = ohp_convert_format(stage, d->n_frames * ch, 24, OHP_ENDIAN_BIG, d->dst_bits, d->dst_endian,
+                                 (d->flags & OHP_FLAG_ZERO_LSB32) ? 1 : 0, dst_base + d->dst_offset);
+    return err;
+}
+
+int ohp_src_msg_process_batch_steady(const ohp_src* s, const ohp_src_msg_desc* d, size_t n, const uint8_t* src_base, uint8_t* dst_base)
+{
+    size_t max_out = 0, max_in = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t o = (size_t)d[i].n_frames * d[i].channels;
+        const size_t in = ((size_t)d[i].n_frames * s->M / s->L + s->T + 2) * d[i].channels;
+        if (o > max_out) max_out = o;
+        if (in > max_in) max_in = in;
+    }
+    src_ws w;
+    w.x = (int32_t*)malloc((max_in + 1) * sizeof(int32_t));
+    w.y = (int32_t*)malloc((max_out + 1) * sizeof(int32_t));
+    w.be24 = (uint8_t*)malloc(max_out * 3 + 1);
+    w.ramped = (uint8_t*)malloc(max_out * 3 + 1);
+    w.x_cap = max_in; w.y_cap = max_out;
+    int err = (w.x && w.y && w.be24 && w.ramped) ? OHP_OK : OHP_ERR_ASSERT;
+    for (size_t i = 0; i < n && err == OHP_OK; i++) err = src_msg_process_ws(s, &d[i], src_base, dst_base, &w);
+    free(w.x); free(w.y); free(w.be24); free(w.ramped);
+    return err;
+}
+
 /* fp64 yardstick for the resampler: unquantised coefficients, result before rounding, one message */
 int ohp_src_msg_process_f64(const ohp_src* s, const ohp_src_msg_desc* d, const uint8_t* src_base, double* y)
 {

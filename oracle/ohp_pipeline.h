@@ -55,6 +55,8 @@ int ohp_msg_process_batch(const ohp_msg_desc* d, size_t n, const uint8_t* src_ba
 
 int ohp_src_msg_process(const ohp_src* s, const ohp_src_msg_desc* d, const uint8_t* src_base, uint8_t* dst_base);
 int ohp_src_msg_process_batch(const ohp_src* s, const ohp_src_msg_desc* d, size_t n, const uint8_t* src_base, uint8_t* dst_base);
+/* the same bytes, for timing: scratch buffers allocated once per batch, window bounds checked once per message */
+int ohp_src_msg_process_batch_steady(const ohp_src* s, const ohp_src_msg_desc* d, size_t n, const uint8_t* src_base, uint8_t* dst_base);
 int ohp_src_msg_process_f64(const ohp_src* s, const ohp_src_msg_desc* d, const uint8_t* src_base, double* y);
 
 ohp_src*       ohp_src_new(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, double f_pass);

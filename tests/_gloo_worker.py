@@ -1,6 +1,8 @@
 """Worker for tests/test_multirank_gloo.py (launched by torch.distributed.run, gloo backend, CPU only).
-Each rank builds its shard of the bench workload exactly as bench.py does, runs it through the CPU oracle, and the
-ranks check together that shards are disjoint, complete, and equal to what one process computes for all streams."""
+Each rank builds its shard of the bench workloads exactly as bench.py does -- config 3: rank r owns streams [r*S, (r+1)*S);
+config 4: a contiguous block of the mixed streams, the blocks balanced by bytes -- runs it through the CPU oracle, and the
+ranks check together that the shards are disjoint, complete, and equal to what one process computes for all streams."""
+import argparse
 import hashlib
 import json
 import os
@@ -19,30 +21,60 @@ import oracle_lib as O  # noqa: E402
 from ohpipeline_amd import capi  # noqa: E402
 
 
-def run_shard(first_stream, n_streams, in_frames):
-    work = bench.build_workload(capi, first_stream, n_streams, in_frames)
-    ref = O.Src(bench.RATE_IN, bench.RATE_OUT, bench.TAPS, bench.BETA, bench.F_PASS)
-    dst = np.zeros(work["dst_bytes"], dtype=np.uint8)
-    assert ref.process_batch(work["descs"].view(O.SRC_MSG_DESC), work["src"], dst) == 0
-    per_stream = work["dst_bytes"] // n_streams
-    return [hashlib.sha256(dst[s * per_stream:(s + 1) * per_stream].tobytes()).hexdigest() for s in range(n_streams)]
+def digests(groups):
+    """{stream id: sha256 of its output bytes}, computed by the CPU oracle."""
+    out = {}
+    for g in groups:
+        ref = O.Src(g.rate_in, bench.RATE_OUT, g.taps, bench.BETA, bench.F_PASS)
+        dst = np.zeros(g.dst_bytes, dtype=np.uint8)
+        assert ref.process_batch(g.descs.view(O.SRC_MSG_DESC), g.src, dst) == 0
+        per = g.dst_bytes // len(g.stream_ids)
+        for k, sid in enumerate(g.stream_ids):
+            out[sid] = hashlib.sha256(dst[k * per:(k + 1) * per].tobytes()).hexdigest()
+    return out
+
+
+def shard(config, streams, seconds, rank, world):
+    args = argparse.Namespace(config=config, streams=streams, seconds=seconds, rate_in=44100, channels=2)
+    groups, scaling = bench.build_groups(capi, args, rank, world)
+    return digests(groups), scaling, sum(g.algorithmic_bytes for g in groups)
 
 
 def main():
     dist.init_process_group(backend="gloo", init_method="env://")
     rank, world = dist.get_rank(), dist.get_world_size()
-    n_streams, in_frames = 3, 4410
-    mine = run_shard(rank * n_streams, n_streams, in_frames)
+    res = {}
+    # config 3: weak scaling, 3 streams per rank
+    mine, scaling3, _ = shard(3, 3, 0.1, rank, world)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)       # bench.py's max-over-ranks of the timed region
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        union = {}
+        for part in gathered:
+            assert not (set(part) & set(union))
+            union.update(part)
+        whole, _, _ = shard(3, 3 * world, 0.1, 0, 1)
+        res["config3"] = bool(union == whole and len(union) == 3 * world and scaling3 == "weak" and t.item() == float(world))
+    # config 4: strong scaling, 12 mixed streams in all, contiguous blocks balanced by bytes
+    mine, scaling4, my_bytes = shard(4, 12, 0.05, rank, world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, my_bytes))
     dist.barrier()
     if rank == 0:
-        flat = [h for part in gathered for h in part]
-        whole = run_shard(0, n_streams * world, in_frames)
-        ok = flat == whole and len(set(flat)) == len(flat) and t.item() == float(world)
-        print(json.dumps({"ok": bool(ok), "streams": len(flat), "max": t.item()}))
+        union, sizes = {}, []
+        for part, nbytes in gathered:
+            assert not (set(part) & set(union))
+            ids = sorted(part)
+            assert ids == list(range(ids[0], ids[-1] + 1))          # a contiguous block
+            union.update(part)
+            sizes.append(nbytes)
+        whole, _, all_bytes = shard(4, 12, 0.05, 0, 1)
+        biggest = max(bench.stream_weight(*bench.config4_stream(s), 0.05) for s in range(12))
+        balanced = max(sizes) - min(sizes) <= 2 * biggest            # as even as whole streams allow
+        res["config4"] = bool(union == whole and len(union) == 12 and scaling4 == "strong" and balanced)
+        print(json.dumps({"ok": bool(res["config3"] and res["config4"]), "streams": len(union), "max": t.item(), **res}))
     dist.destroy_process_group()
 
 

@@ -142,6 +142,7 @@ def lib():
         "ohp_msg_process_batch": (C.c_int, [vp, C.c_size_t, vp, vp]),
         "ohp_src_msg_process": (C.c_int, [vp, vp, vp, vp]),
         "ohp_src_msg_process_batch": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+        "ohp_src_msg_process_batch_steady": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
         "ohp_src_msg_process_f64": (C.c_int, [vp, vp, vp, vp]),
         "ohp_src_new": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
         "ohp_src_delete": (None, [vp]),

@@ -435,6 +435,30 @@ def test_src_config4_mix_runs_on_the_block_kernel(ctx):
         ctx.src_destroy(h)
 
 
+@pytest.mark.parametrize("rate,taps,ch", [(44100, 32, 6), (96000, 64, 6), (44100, 32, 8), (44100, 32, 2)])
+def test_src_workgroups_of_several_waves(ctx, rate, taps, ch):
+    """Enough units that every workgroup runs several waves side by side (bench.py's config 4 at full size found what the small
+    cases could not: six-channel waves have four lanes that own no block, and their stores walked out of their corner of the
+    wave's LDS into the next wave's staging rows)."""
+    h, ref = make_src(ctx, rate, 48000, taps)
+    n_streams, out_frames = 12, 48000
+    in_frames = out_frames * ref.M // ref.L
+    src = np.concatenate([W.noise_pcm(700 + s, in_frames, ch, 24, LE) for s in range(n_streams)])
+    out_total = ref.out_frames(in_frames)
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 50 * O.JIFFIES_PER_MS, 100 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, ch, 24, LE, 24, BE, sched)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+    ctx.memset(d_dst, 0xA5, dbytes)
+    b = ctx.src_batch(h, descs, src.size, dbytes)
+    assert ctx.src_plan(b)["generic_pieces"] == 0
+    ctx.src_run(b, d_src, d_dst)
+    got = ctx.download(d_dst, dbytes)
+    assert np.array_equal(got, oracle_src(ref, descs, src, dbytes))
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
 def test_src_batch_can_be_run_repeatedly(ctx):
     """A batch is planned once and launched every period: the block kernel's work counters must be back at zero after
     each launch (they reset themselves), so the second and third run write the same bytes as the first."""

@@ -1,5 +1,6 @@
-"""N > 1 path on the CPU: two ranks over gloo build their stream shards as bench.py does (rank r owns streams
-[r*S, (r+1)*S), no data-path collective), and the union equals the single-process result."""
+"""N > 1 path on the CPU: two ranks over gloo build their stream shards as bench.py does -- config 3: rank r owns streams
+[r*S, (r+1)*S); config 4: contiguous blocks of the mixed streams balanced by bytes -- with no data-path collective, and the
+union equals the single-process result."""
 import json
 import os
 import socket
@@ -28,4 +29,17 @@ def test_two_ranks_shard_streams_without_collectives():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
-    assert res == {"ok": True, "streams": 6, "max": 2.0}
+    assert res == {"ok": True, "streams": 12, "max": 2.0, "config3": True, "config4": True}
+
+
+def test_partition_by_bytes_is_contiguous_complete_and_even():
+    sys.path.insert(0, ROOT)
+    import bench
+    for total, world in ((2048, 1), (2048, 2), (2048, 4), (2048, 8), (13, 4), (3, 8)):
+        w = [bench.stream_weight(*bench.config4_stream(s), 2.0) for s in range(total)]
+        cuts = bench.partition_by_bytes(w, world)
+        assert cuts[0] == 0 and cuts[-1] == total and len(cuts) == world + 1
+        assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+        if total >= 4 * world:
+            shares = [sum(w[a:b]) for a, b in zip(cuts, cuts[1:])]
+            assert max(shares) - min(shares) <= 2 * max(w), (total, world, shares)
