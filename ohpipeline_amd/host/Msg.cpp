@@ -558,5 +558,29 @@ OH_PASS_THROUGH(MsgSilence, eSilence)
 OH_PASS_THROUGH(MsgPlayable, ePlayable)
 OH_PASS_THROUGH(MsgQuit, eQuit)
 
+// ---- MsgKind
+namespace {
+class KindVisitor : public IMsgProcessor {
+public:
+    MsgKind iKind = MsgKind::Quit;
+private:
+#define OH_KIND(Type, Value) Msg* ProcessMsg(Type* aMsg) override { iKind = MsgKind::Value; return aMsg; }
+    OH_KIND(MsgMode, Mode) OH_KIND(MsgTrack, Track) OH_KIND(MsgDrain, Drain) OH_KIND(MsgDelay, Delay)
+    OH_KIND(MsgEncodedStream, EncodedStream) OH_KIND(MsgStreamSegment, StreamSegment) OH_KIND(MsgAudioEncoded, AudioEncoded)
+    OH_KIND(MsgMetaText, MetaText) OH_KIND(MsgStreamInterrupted, StreamInterrupted) OH_KIND(MsgHalt, Halt) OH_KIND(MsgFlush, Flush)
+    OH_KIND(MsgWait, Wait) OH_KIND(MsgDecodedStream, DecodedStream) OH_KIND(MsgAudioPcm, AudioPcm) OH_KIND(MsgAudioDsd, AudioDsd)
+    OH_KIND(MsgSilence, Silence) OH_KIND(MsgPlayable, Playable) OH_KIND(MsgQuit, Quit)
+#undef OH_KIND
+};
+
+} // namespace
+
+MsgKind KindOf(Msg* aMsg)
+{
+    KindVisitor v;
+    (void)aMsg->Process(v);
+    return v.iKind;
+}
+
 } // namespace Media
 } // namespace OpenHome

@@ -386,6 +386,11 @@ public:
     virtual Msg* Pull() = 0;
 };
 
+/** The dynamic type of a message, found by one visit (elements that treat most kinds alike switch on it instead of overriding eighteen hooks). */
+enum class MsgKind { Mode, Track, Drain, Delay, EncodedStream, StreamSegment, AudioEncoded, MetaText, StreamInterrupted, Halt,
+                     Flush, Wait, DecodedStream, AudioPcm, AudioDsd, Silence, Playable, Quit };
+MsgKind KindOf(Msg* aMsg);
+
 class IPipelineElementDownstream {
 public:
     virtual ~IPipelineElementDownstream() {}

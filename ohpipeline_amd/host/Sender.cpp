@@ -162,7 +162,6 @@ OhmSenderDriver::OhmSenderDriver(OhmFrameBatch& aBatch, IOhmDatagramSink& aSink)
     , iSampleStart(0)
     , iLatencyMs(0)
     , iLatencyOhm(0)
-    , iFirstFrame(true)
 {
 }
 
@@ -198,9 +197,6 @@ void OhmSenderDriver::SendAudio(std::vector<MsgPlayable*>& aPlayables, TUint aSa
         release();                                                    // nothing to usefully communicate to receivers
         return;
     }
-    if (iFirstFrame) {
-        iFirstFrame = false;
-    }
     OhmFrameWork w;
     w.playables.swap(aPlayables);
     w.halt = aHalt;
@@ -222,33 +218,20 @@ void OhmSenderDriver::SendAudio(std::vector<MsgPlayable*>& aPlayables, TUint aSa
 
 void OhmSenderDriver::StreamInterrupted()
 {
-    iFrame += 250;
+    iFrame += 250;                                       // a gap in the frame numbers is what makes receivers resync, OhmSender.cpp:482-488
 }
 
-void OhmSenderDriver::SetEnabled(TBool aValue)
+// Frames go out while the sender is both enabled (configuration) and active (somebody listens).  Leaving that state
+// restarts the frame numbering (OhmSender.cpp:490-525, 623-635).
+void OhmSenderDriver::Gate(TBool aEnabled, TBool aActive)
 {
-    iEnabled = aValue;
-    if (iSend) {
-        if (!aValue) {
-            ResetLocked();
-        }
+    iEnabled = aEnabled;
+    iActive = aActive;
+    const TBool send = aEnabled && aActive;
+    if (iSend && !send) {
+        iFrame = 0;
     }
-    else if (aValue && iActive) {
-        iSend = true;
-    }
-}
-
-void OhmSenderDriver::SetActive(TBool aValue)
-{
-    iActive = aValue;
-    if (iSend) {
-        if (!aValue) {
-            ResetLocked();
-        }
-    }
-    else if (aValue && iEnabled) {
-        iSend = true;
-    }
+    iSend = send;
 }
 
 void OhmSenderDriver::SetLatency(TUint aValue)
@@ -263,54 +246,21 @@ void OhmSenderDriver::SetTrackPosition(TUint64 aSamplesTotal, TUint64 aSampleSta
     iSampleStart = aSampleStart;
 }
 
-void OhmSenderDriver::ResetLocked()
-{
-    iSend = false;
-    iFrame = 0;
-    iFirstFrame = true;
-}
-
 // ---------------------------------------------------------------------------------------------- Sender
-namespace {
-
-class PlayableCreator : private IMsgProcessor {          // Sender::PlayableCreator, Sender.cpp:401-522
-public:
-    MsgPlayable* Process(MsgAudio* aMsg) { iPlayable = nullptr; (void)aMsg->Process(*this); return iPlayable; }
-private:
-    Msg* ProcessMsg(MsgMode*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgTrack*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgDrain*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgDelay*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgEncodedStream*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgStreamSegment*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgAudioEncoded*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgMetaText*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgStreamInterrupted*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgHalt*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgFlush*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgWait*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgDecodedStream*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgAudioPcm* aMsg) override { iPlayable = aMsg->CreatePlayable(); return nullptr; }
-    Msg* ProcessMsg(MsgAudioDsd*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgSilence* aMsg) override { iPlayable = aMsg->CreatePlayable(); return nullptr; }
-    Msg* ProcessMsg(MsgPlayable*) override { ASSERTS(); return nullptr; }
-    Msg* ProcessMsg(MsgQuit*) override { ASSERTS(); return nullptr; }
-private:
-    MsgPlayable* iPlayable = nullptr;
-};
-
-} // namespace
-
+// A packetiser: audio queues up until 5 ms are there, every full 5 ms leave as one frame; anything that marks a
+// discontinuity (new track or stream, halt, wait, interruption, quit) sends what is queued first.  The reference reaches the
+// same packets through a visitor with one hook per message type (Sender.cpp:125-321); here the message's kind selects a row
+// of a small table and the queue keeps a running length.
 Sender::Sender(MsgFactory& aFactory, IOhmDatagramSink& aSink, TUint aMinLatencyMs, OhmFrameBatch* aSharedBatch)
     : iOwnBatch(aSharedBatch == nullptr ? new OhmFrameBatch(aFactory) : nullptr)
     , iBatch(aSharedBatch == nullptr ? *iOwnBatch : *aSharedBatch)
     , iDriver(iBatch, aSink)
+    , iQueuedJiffies(0)
     , iSampleRate(0)
     , iNumChannels(0)
     , iBitDepth(0)
     , iMinLatencyMs(aMinLatencyMs)
     , iStreamForbidden(false)
-    , iFirstChannelIndex(0)
     , iBatchFrames(1)
 {
     // what the OhmSender constructor, the "enabled" configuration value and the first listener do to the driver
@@ -318,12 +268,11 @@ Sender::Sender(MsgFactory& aFactory, IOhmDatagramSink& aSink, TUint aMinLatencyM
     iDriver.SetLatency(aMinLatencyMs);
     iDriver.SetEnabled(true);
     iDriver.SetActive(true);
-    iPendingAudio.reserve(100);
 }
 
 Sender::~Sender()
 {
-    for (auto* m : iPendingAudio) {
+    for (MsgAudio* m : iQueued) {
         m->RemoveRef();
     }
     delete iOwnBatch;
@@ -336,182 +285,101 @@ void Sender::Transmit()
 
 void Sender::Push(Msg* aMsg)
 {
-    Msg* msg = aMsg->Process(*this);
-    if (msg != nullptr) {
-        msg->RemoveRef();
+    enum : TUint { Cut = 1, CutWithHalt = 2, Consume = 4, Never = 8 };     // what a kind does to the queue and to the message
+    TUint what = 0;
+    const MsgKind kind = KindOf(aMsg);
+    switch (kind) {
+    case MsgKind::Mode:              what = Consume; break;        // (:125-144 compares with the receiver's own mode; no receiver here)
+    case MsgKind::Track:             what = Cut; break;            // :146-152
+    case MsgKind::Drain:             what = Consume; break;
+    case MsgKind::Delay:             what = Cut | Consume; break;  // :160-170
+    case MsgKind::StreamInterrupted: what = CutWithHalt | Consume; break;   // :187-193
+    case MsgKind::Halt:              what = CutWithHalt; break;    // :196-201
+    case MsgKind::Wait:              what = CutWithHalt; break;
+    case MsgKind::Quit:              what = CutWithHalt; break;
+    case MsgKind::DecodedStream:     what = Cut; break;            // a new stream may be a discontinuity within the track
+    case MsgKind::MetaText:
+    case MsgKind::Flush:             break;
+    case MsgKind::AudioPcm:
+    case MsgKind::Silence:
+        ASSERT(iSampleRate != 0);                                  // :246, :258
+        Queue(static_cast<MsgAudio*>(aMsg));
+        return;
+    case MsgKind::AudioDsd:
+        ASSERT(iStreamForbidden);                                  // :252
+        what = Consume;
+        break;
+    default:                         what = Never; break;          // encoded audio and playables never get this far (:172-176, :264-268)
     }
-}
-
-Msg* Sender::ProcessMsg(MsgMode* aMsg)
-{
-    // the reference compares the mode's name with its own Songcast receiver mode (Sender.cpp:125-144); this mirror has no
-    // receiver, so every mode may be sent
-    aMsg->RemoveRef();
-    return nullptr;
-}
-
-Msg* Sender::ProcessMsg(MsgTrack* aMsg)
-{
-    SendPendingAudio();
-    return aMsg;
-}
-
-Msg* Sender::ProcessMsg(MsgDrain* aMsg)
-{
-    aMsg->RemoveRef();
-    return nullptr;
-}
-
-Msg* Sender::ProcessMsg(MsgDelay* aMsg)
-{
-    SendPendingAudio();
-    iDriver.SetLatency(iMinLatencyMs);                   // std::max(latencyMs, iMinLatencyMs), Sender.cpp:163-164; the mirror's MsgDelay carries no delay
-    aMsg->RemoveRef();
-    return nullptr;
-}
-
-Msg* Sender::ProcessMsg(MsgEncodedStream* aMsg) { ASSERTS(); return aMsg; }
-Msg* Sender::ProcessMsg(MsgStreamSegment* aMsg) { ASSERTS(); return aMsg; }
-Msg* Sender::ProcessMsg(MsgAudioEncoded* aMsg) { ASSERTS(); return aMsg; }
-
-Msg* Sender::ProcessMsg(MsgMetaText* aMsg)
-{
-    return aMsg;
-}
-
-Msg* Sender::ProcessMsg(MsgStreamInterrupted* aMsg)
-{
-    SendPendingAudio(true);
-    iDriver.StreamInterrupted();
-    aMsg->RemoveRef();
-    return nullptr;
-}
-
-Msg* Sender::ProcessMsg(MsgHalt* aMsg)
-{
-    SendPendingAudio(true);
-    return aMsg;
-}
-
-Msg* Sender::ProcessMsg(MsgFlush* aMsg)
-{
-    return aMsg;
-}
-
-Msg* Sender::ProcessMsg(MsgWait* aMsg)
-{
-    SendPendingAudio(true);
-    return aMsg;
-}
-
-Msg* Sender::ProcessMsg(MsgDecodedStream* aMsg)
-{
-    // send any pending audio in case the stream msg indicates a discontinuity in the track
-    SendPendingAudio();
-
-    const DecodedStreamInfo& streamInfo = aMsg->StreamInfo();
-    iSampleRate = streamInfo.SampleRate();
-    iStreamForbidden = (streamInfo.Multiroom() == Multiroom::Forbidden);
-
-    const TUint bitDepth = std::min(streamInfo.BitDepth(), (TUint)24);
-    const TUint numChannels = streamInfo.NumChannels();
-    const TUint64 samplesTotal = streamInfo.TrackLength() / Jiffies::PerSample(iSampleRate);
-    iFirstChannelIndex = FirstChannelToSend(numChannels);
-    iNumChannels = numChannels;
-    iBitDepth = streamInfo.BitDepth();
-
-    iDriver.SetTrackPosition(samplesTotal, streamInfo.SampleStart());
-    if (!iStreamForbidden) {
-        iDriver.SetAudioFormat(iSampleRate, streamInfo.BitRate(), std::min(numChannels, (TUint)2), bitDepth,
-                               streamInfo.Lossless(), streamInfo.CodecName(), streamInfo.SampleStart());
+    ASSERT(!(what & Never));
+    if (what & (Cut | CutWithHalt)) {
+        SendQueued((what & CutWithHalt) != 0);
     }
-    return aMsg;
-}
-
-Msg* Sender::ProcessMsg(MsgAudioPcm* aMsg)
-{
-    ASSERT(iSampleRate != 0);
-    ProcessAudio(aMsg);
-    return nullptr;
-}
-
-Msg* Sender::ProcessMsg(MsgAudioDsd* aMsg)
-{
-    ASSERT(iStreamForbidden);
-    aMsg->RemoveRef();
-    return nullptr;
-}
-
-Msg* Sender::ProcessMsg(MsgSilence* aMsg)
-{
-    ASSERT(iSampleRate != 0);
-    ProcessAudio(aMsg);
-    return nullptr;
-}
-
-Msg* Sender::ProcessMsg(MsgPlayable* aMsg)
-{
-    ASSERTS(); // don't expect this msg at this stage of the pipeline
-    return aMsg;
-}
-
-Msg* Sender::ProcessMsg(MsgQuit* aMsg)
-{
-    SendPendingAudio(true);
-    if (iOwnBatch != nullptr) {
+    if (kind == MsgKind::Delay) {
+        iDriver.SetLatency(iMinLatencyMs);               // std::max(latencyMs, iMinLatencyMs), :163-164; this MsgDelay carries no delay
+    }
+    else if (kind == MsgKind::StreamInterrupted) {
+        iDriver.StreamInterrupted();
+    }
+    else if (kind == MsgKind::DecodedStream) {
+        NewStream(static_cast<MsgDecodedStream*>(aMsg)->StreamInfo());
+    }
+    else if (kind == MsgKind::Quit && iOwnBatch != nullptr) {
         iBatch.Run();                                    // nothing may stay queued behind the last message
     }
-    return aMsg;
+    aMsg->RemoveRef();                                   // the end of the line: nothing is passed on
 }
 
-void Sender::ProcessAudio(MsgAudio* aMsg)
-{
+void Sender::NewStream(const DecodedStreamInfo& aInfo)
+{   // :203-230: the wire carries at most stereo, at most 24 bits
+    iSampleRate = aInfo.SampleRate();
+    iNumChannels = aInfo.NumChannels();
+    iBitDepth = aInfo.BitDepth();
+    iStreamForbidden = aInfo.Multiroom() == Multiroom::Forbidden;
+    iDriver.SetTrackPosition(aInfo.TrackLength() / Jiffies::PerSample(iSampleRate), aInfo.SampleStart());
+    if (!iStreamForbidden) {
+        iDriver.SetAudioFormat(iSampleRate, aInfo.BitRate(), std::min(iNumChannels, (TUint)2), std::min(iBitDepth, (TUint)24),
+                               aInfo.Lossless(), aInfo.CodecName(), aInfo.SampleStart());
+    }
+}
+
+void Sender::Queue(MsgAudio* aAudio)
+{   // :277-305: packets are cut at exactly 5 ms of queued audio, wherever the messages' own boundaries fall
     if (iStreamForbidden) {
-        aMsg->RemoveRef();
+        aAudio->RemoveRef();
         return;
     }
-    TUint jiffies = 0;
-    for (TUint i = 0; i < iPendingAudio.size(); i++) {
-        jiffies += iPendingAudio[i]->Jiffies();
-    }
-    TUint newJiffies = jiffies + aMsg->Jiffies();
-    if (newJiffies < kSongcastPacketJiffies) {
-        iPendingAudio.push_back(aMsg);
-        return;
-    }
-    MsgAudio* msg = aMsg;
-    MsgAudio* remaining;
-    do {
-        remaining = (newJiffies == kSongcastPacketJiffies ? nullptr : msg->Split(kSongcastPacketJiffies - jiffies));
-        iPendingAudio.push_back(msg);
-        SendPendingAudio();
-        msg = remaining;
-        jiffies = 0;
-        newJiffies = (remaining == nullptr ? 0 : remaining->Jiffies());
-    } while (remaining != nullptr && newJiffies >= kSongcastPacketJiffies);
-    if (remaining != nullptr) {
-        iPendingAudio.push_back(remaining);
+    while (aAudio != nullptr) {
+        const TUint room = kSongcastPacketJiffies - iQueuedJiffies;
+        const TUint length = aAudio->Jiffies();
+        MsgAudio* rest = nullptr;
+        if (length > room) {
+            rest = aAudio->Split(room);
+        }
+        iQueued.push_back(aAudio);
+        iQueuedJiffies += aAudio->Jiffies();
+        if (length >= room) {
+            SendQueued(false);
+        }
+        aAudio = rest;
     }
 }
 
-void Sender::SendPendingAudio(TBool aHalt)
-{
-    PlayableCreator pc;
+void Sender::SendQueued(TBool aHalt)
+{   // :307-321 with PlayableCreator (:401-522) folded in: the queue only ever holds decoded audio or silence
     std::vector<MsgPlayable*> playables;
     TUint samples = 0;
-    for (TUint i = 0; i < iPendingAudio.size(); i++) {
-        MsgPlayable* playable = pc.Process(iPendingAudio[i]);    // consumes the pending message's reference
+    for (MsgAudio* m : iQueued) {
+        MsgPlayable* playable = KindOf(m) == MsgKind::AudioPcm ? static_cast<MsgAudioPcm*>(m)->CreatePlayable()
+                                                               : static_cast<MsgSilence*>(m)->CreatePlayable();
         samples += playable->Work().frames;
-        playables.push_back(playable);                            // read on the device, by OhmFrameBatch::Run
+        playables.push_back(playable);                   // read on the device, by OhmFrameBatch::Run
     }
-    iPendingAudio.clear();
+    iQueued.clear();
+    iQueuedJiffies = 0;
     iDriver.SendAudio(playables, samples, iNumChannels, iBitDepth, aHalt);
     if (iOwnBatch != nullptr && iBatchFrames != 0 && iBatch.Count() >= iBatchFrames) {
         iBatch.Run();
     }
 }
 
-TUint Sender::FirstChannelToSend(TUint aNumChannels)
-{
-    return (aNumChannels < 10) ? 0 : 8;
-}

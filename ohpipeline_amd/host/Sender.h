@@ -59,15 +59,15 @@ public:
      *  aNumChannels / aBitDepth describe the playables (SetAudioFormat was told the wire's). */
     void SendAudio(std::vector<Media::MsgPlayable*>& aPlayables, TUint aSamples, TUint aNumChannels, TUint aBitDepth, TBool aHalt);
     void StreamInterrupted();                                                             // :482-488
-    void SetEnabled(TBool aValue);                                                        // :490-505
-    void SetActive(TBool aValue);                                                         // :507-525
+    void SetEnabled(TBool aValue) { Gate(aValue, iActive); }                              // :490-505
+    void SetActive(TBool aValue) { Gate(iEnabled, aValue); }                              // :507-525
     void SetLatency(TUint aValue);                                                        // :544-549
     void SetTrackPosition(TUint64 aSamplesTotal, TUint64 aSampleStart);                   // :551-556
     TUint Frame() const { return iFrame; }
     TUint64 SampleStart() const { return iSampleStart; }
 private:
     void UpdateLatencyOhm() { iLatencyOhm = iLatencyMs * iTimestampMultiplier / 1000; } // :320-323
-    void ResetLocked();                                                                   // :623-635
+    void Gate(TBool aEnabled, TBool aActive);
 private:
     OhmFrameBatch& iBatch;
     IOhmDatagramSink& iSink;
@@ -77,10 +77,9 @@ private:
     TUint64 iSamplesTotal, iSampleStart;
     TUint iLatencyMs, iLatencyOhm;
     std::string iCodecName;
-    TBool iFirstFrame;
 };
 
-class Sender : public Media::IPipelineElementDownstream, private Media::IMsgProcessor {
+class Sender : public Media::IPipelineElementDownstream {
 public:
     static const TUint kSongcastPacketMs = 5;                                             // Sender.h:35-37
     static const TUint kSongcastPacketJiffies = Media::Jiffies::kPerMs * kSongcastPacketMs;
@@ -94,39 +93,20 @@ public:
     void Transmit();                                     // run what has been collected now
     OhmSenderDriver& Driver() { return iDriver; }
 public: // from Media::IPipelineElementDownstream
-    void Push(Media::Msg* aMsg) override;                                                 // Sender.cpp:117-123
-private: // from Media::IMsgProcessor
-    Media::Msg* ProcessMsg(Media::MsgMode* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgTrack* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgDrain* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgDelay* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgEncodedStream* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgStreamSegment* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgAudioEncoded* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgMetaText* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgStreamInterrupted* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgHalt* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgFlush* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgWait* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgDecodedStream* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgAudioPcm* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgAudioDsd* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgSilence* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgPlayable* aMsg) override;
-    Media::Msg* ProcessMsg(Media::MsgQuit* aMsg) override;
+    void Push(Media::Msg* aMsg) override;                // consumes the message (Sender.cpp:117-123)
 private:
-    void ProcessAudio(Media::MsgAudio* aMsg);                                             // Sender.cpp:277-305
-    void SendPendingAudio(TBool aHalt = false);                                           // Sender.cpp:307-321
-    static TUint FirstChannelToSend(TUint aNumChannels);                                  // Sender.cpp:346-349
+    void NewStream(const Media::DecodedStreamInfo& aInfo);
+    void Queue(Media::MsgAudio* aAudio);                 // cuts a packet every kSongcastPacketJiffies
+    void SendQueued(TBool aHalt);
 private:
     OhmFrameBatch* iOwnBatch;
     OhmFrameBatch& iBatch;
     OhmSenderDriver iDriver;
-    std::vector<Media::MsgAudio*> iPendingAudio;
+    std::vector<Media::MsgAudio*> iQueued;
+    TUint iQueuedJiffies;
     TUint iSampleRate, iNumChannels, iBitDepth;
     const TUint iMinLatencyMs;
     TBool iStreamForbidden;
-    TUint iFirstChannelIndex;
     TUint iBatchFrames;
 };
 

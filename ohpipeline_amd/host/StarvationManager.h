@@ -1,0 +1,116 @@
+// StarvationManager.h -- what happens to MANY streams when their audio runs out, designed for the device.
+//
+// The reference gives every pipeline one StarvationRamper (OpenHome/Media/Pipeline/StarvationRamper.cpp): a reservoir fed
+// by a puller thread; when the driver finds it empty the last millisecond of audio is extrapolated by FlywheelRamper
+// (:491-537 -> FlywheelRamper.cpp:45-66), handed out as 20 ms of down-ramped audio and followed by a MsgHalt; the next audio
+// ramps up over aRampUpSize (:791-832); Flush(id) ramps down and discards to the flush, DrainAllAudio() forces the ramp and
+// discards to the next MsgDrain (:622-673).  One stream at a time that is a few thousand integer operations on its own thread.
+//
+// On a GPU the unit of work is the DRIVER TICK: every period each stream ("lane") owes the driver one message, and every lane
+// that ran dry in that tick is rescued in the SAME device passes -- one read of the lanes' last milliseconds (row a7), one
+// unpack to planes (a11), one flywheel launch (N1), one pack (a12).  So the manager is a table of lanes advanced per tick:
+//     Tick():  1. look at every lane: gate on occupancy, notice an empty inbox or a pending drain, collect who must be rescued
+//              2. ONE RescueBatch for all of them
+//              3. every lane hands over its next message (rescue audio first, then the halt, then whatever the inbox holds)
+// A lane's behaviour towards ITS driver is the reference's, message for message (the reference's own suite, restated in
+// tests/cpp/test_host.cpp, runs against the one-lane facade StarvationRamper).  No PCM byte is touched on the host.
+// Left out: DSD (MsgAudioDsd passes through unramped), the observer thread (observers are called synchronously, as the
+// reference's tests do with ElementObserverSync), thread priorities.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "Msg.h"
+
+namespace OpenHome {
+namespace Media {
+
+class IStarvationRamperObserver {                        // StarvationRamper.h:22-27
+public:
+    virtual ~IStarvationRamperObserver() {}
+    virtual void NotifyStarvationRamperBuffering(TBool aBuffering) = 0;
+};
+
+enum class LaneState { Starting, Running, Halted, RampingUp, FlywheelRamping, RampingDown, Flushing };
+
+/** One stream's last millisecond, as the rescue wants it: the messages that hold it (references owned), oldest first. */
+struct RescueRequest {
+    std::deque<MsgAudio*> audio;
+    TUint jiffies = 0, sampleRate = 0, bitDepth = 0, channels = 0;
+    TUint rampValue = 0;                                 // where the stream's ramp stood
+    std::deque<Msg*>* out = nullptr;                     // receives the 1 ms messages of extrapolated, down-ramped audio
+};
+
+/** Extrapolates every request's audio in one chain of device passes (a7 read, a11, N1, a12) and queues the messages. */
+class RescueBatch {
+public:
+    static const TUint kTrainingJiffies = Jiffies::kPerMs * 1;       // StarvationRamper.cpp:374-376
+    static const TUint kRampDownJiffies = Jiffies::kPerMs * 20;
+public:
+    explicit RescueBatch(MsgFactory& aFactory) : iFactory(aFactory) {}
+    void Add(RescueRequest&& aRequest) { iRequests.push_back(std::move(aRequest)); }
+    TUint Count() const { return (TUint)iRequests.size(); }
+    void Run();
+    /** Extrapolation launches (ohgpu_flywheel_batch_run calls) by every batch of this process so far. */
+    static TUint64 FlywheelLaunches();
+private:
+    MsgFactory& iFactory;
+    std::vector<RescueRequest> iRequests;
+};
+
+class StarvationManager {
+public:
+    static const TUint kTrainingJiffies = RescueBatch::kTrainingJiffies;
+    static const TUint kRampDownJiffies = RescueBatch::kRampDownJiffies;
+    static const TUint kMaxAudioOutJiffies = Jiffies::kPerMs * 5;
+    struct LaneConfig {
+        IPipelineElementUpstream* upstream = nullptr;    // pulled by the lane's feeder thread until the inbox holds sizeJiffies
+        IStarvationRamperObserver* observer = nullptr;
+        TUint sizeJiffies = 0, rampUpJiffies = 0, maxStreamCount = 0;
+    };
+public:
+    explicit StarvationManager(MsgFactory& aFactory);
+    /** A lane's feeder ends once it has passed a MsgQuit on, as the reference's puller does: send one before destroying. */
+    ~StarvationManager();
+    TUint AddLane(const LaneConfig& aConfig);
+    TUint LaneCount() const { return (TUint)iLanes.size(); }
+    /** One driver period for every lane: aOut[i] is lane i's next message (the call blocks until every lane has one);
+     *  nullptr for a lane whose MsgQuit has already gone out. */
+    void Tick(std::vector<Msg*>& aOut);
+    /** One driver period for one lane (what IPipelineElementUpstream::Pull is to the reference). */
+    Msg* Pull(TUint aLane);
+    void Flush(TUint aLane, TUint aId);                  // ramps down quickly, then discards everything up to the flush with this id
+    void DrainAllAudio(TUint aLane);                     // discards buffered audio, forcing a rescue, until the next MsgDrain
+    void WaitForOccupancy(TUint aLane, TUint aJiffies);  // the lane's next Pull blocks once until this level is reached
+public: // inspection (the reference's suite reads these as a friend)
+    LaneState State(TUint aLane) const;
+    TBool IsEmpty(TUint aLane) const;
+    TUint SizeInJiffies(TUint aLane) const;
+    TBool Draining(TUint aLane) const;
+    TBool DrainRequested(TUint aLane) const;             // DrainAllAudio() called, not yet seen by a tick
+    TUint64 RescueLaunches() const { return iRescueLaunches.load(); }   // device rescues so far (one per tick that needed any)
+private:
+    struct Lane;
+    void Prepare(Lane& aLane, RescueBatch& aBatch);      // tick step 1
+    Msg* Next(Lane& aLane);                              // tick step 3
+    Msg* Handle(Lane& aLane, Msg* aMsg);                 // one message leaving the inbox; nullptr = consumed
+    void QueueRescue(Lane& aLane, RescueBatch& aBatch);  // the lane's last millisecond -> a request
+    void RescueNow(Lane& aLane);                         // a rescue decided while dequeuing (drain, flush): a batch of one
+    void RememberAudio(Lane& aLane, MsgAudio* aMsg);
+    void SetBuffering(Lane& aLane, TBool aBuffering);
+    void NewStream(Lane& aLane);
+private:
+    MsgFactory& iFactory;
+    std::vector<std::unique_ptr<Lane>> iLanes;
+    std::atomic<TUint64> iRescueLaunches;
+};
+
+} // namespace Media
+} // namespace OpenHome

@@ -5,6 +5,7 @@
 // C ABI and compares the bytes with the CPU oracle.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -14,10 +15,8 @@
 #include <vector>
 
 #include "../../ohpipeline_amd/host/DecodedAudioAggregator.h"
-#include "../../ohpipeline_amd/host/Elements.h"
 #include "../../ohpipeline_amd/host/FlywheelRamper.h"
 #include "../../ohpipeline_amd/host/Msg.h"
-#include "../../ohpipeline_amd/host/RampGenerator.h"
 #include "../../ohpipeline_amd/host/SampleRateConverter.h"
 #include "../../ohpipeline_amd/host/Sender.h"
 #include "../../ohpipeline_amd/host/StarvationRamper.h"
@@ -30,6 +29,70 @@ using namespace OpenHome;
 using namespace OpenHome::Media;
 
 static int gFailures = 0, gChecks = 0;
+
+// ---- fixtures of these suites.  They stand where two of the reference's own elements stand in a pipeline -- Ramper
+// (Pipeline/Ramper.cpp: a stream that starts live or mid-track fades in) and PreDriver (Pipeline/PreDriver.cpp: audio becomes
+// playables for the driver) -- so that the chains under test have the neighbours they have in a product.  They are test code:
+// a drop-in keeps the reference's elements, the product ships neither.
+class FadeInAtStreamStart : public PipelineElement, public IPipelineElementUpstream {
+public:
+    FadeInAtStreamStart(IPipelineElementUpstream& aUpstream, TUint aLongJiffies, TUint aShortJiffies)
+        : PipelineElement(0xffffffffu), iUpstream(aUpstream), iLong(aLongJiffies), iShort(aShortJiffies), iFade(aLongJiffies) {}
+    Msg* Pull() override
+    {
+        Msg* next = nullptr;
+        if (iHeld.empty()) next = iUpstream.Pull();
+        else { next = iHeld.front(); iHeld.pop_front(); }
+        return next->Process(*this);
+    }
+    TBool Holding() const { return !iHeld.empty(); }
+private:
+    Msg* ProcessMsg(MsgMode* aMsg) override { iFade = aMsg->Info().RampPauseResumeLong() ? iLong : iShort; return aMsg; }
+    Msg* ProcessMsg(MsgDecodedStream* aMsg) override
+    {
+        const DecodedStreamInfo& info = aMsg->StreamInfo();
+        iLeft = (info.Live() || info.SampleStart() > 0) ? iFade : 0;
+        iLevel = Ramp::kMin;
+        return aMsg;
+    }
+    Msg* ProcessMsg(MsgAudioPcm* aMsg) override
+    {
+        if (iLeft == 0) return aMsg;
+        if (aMsg->Jiffies() > iLeft) iHeld.push_front(aMsg->Split(iLeft));
+        MsgAudio* rest = nullptr;
+        iLevel = aMsg->SetRamp(iLevel, iLeft, Ramp::EUp, rest);
+        if (rest != nullptr) iHeld.push_front(rest);
+        return aMsg;
+    }
+private:
+    IPipelineElementUpstream& iUpstream;
+    const TUint iLong, iShort;
+    TUint iFade, iLeft = 0, iLevel = Ramp::kMin;
+    std::deque<Msg*> iHeld;
+};
+
+class DriverEdge : public PipelineElement, public IPipelineElementUpstream {
+public:
+    explicit DriverEdge(IPipelineElementUpstream& aUpstream) : PipelineElement(0xffffffffu), iUpstream(aUpstream) {}
+    Msg* Pull() override { return iUpstream.Pull()->Process(*this); }
+private:
+    Msg* ProcessMsg(MsgAudioPcm* aMsg) override { return aMsg->CreatePlayable(); }
+    Msg* ProcessMsg(MsgSilence* aMsg) override { return aMsg->CreatePlayable(); }
+private:
+    IPipelineElementUpstream& iUpstream;
+};
+
+class Semaphore {                                        // the counting semaphore the reference's suites lean on
+public:
+    explicit Semaphore(TUint aCount = 0) : iCount(aCount) {}
+    void Wait() { std::unique_lock<std::mutex> lock(iLock); iCv.wait(lock, [this] { return iCount > 0; }); iCount--; }
+    void Signal() { { std::lock_guard<std::mutex> lock(iLock); iCount++; } iCv.notify_one(); }
+    TBool Clear() { std::lock_guard<std::mutex> lock(iLock); const TBool pending = iCount > 0; iCount = 0; return pending; }
+private:
+    std::mutex iLock;
+    std::condition_variable iCv;
+    TUint iCount;
+};
 #define TEST(x) do { gChecks++; if (!(x)) { gFailures++; printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #x); } } while (0)
 #define TEST_THROWS(expr, Ex) do { gChecks++; bool thrown_ = false; try { expr; } catch (Ex&) { thrown_ = true; } \
     if (!thrown_) { gFailures++; printf("FAILED %s:%d  %s did not throw %s\n", __FILE__, __LINE__, #expr, #Ex); } } while (0)
@@ -222,7 +285,7 @@ private:
     void Push(Msg* aMsg) { iPending.push_back(aMsg); }
     Msg* Pull() override { ASSERT(!iPending.empty()); Msg* m = iPending.front(); iPending.pop_front(); return m; }
     void PullNext() { Msg* m = iRamper.Pull(); m = m->Process(*this); m->RemoveRef(); }
-    void PullNextAll() { do { PullNext(); } while (!iPending.empty() || iMoreQueued); }
+    void PullNextAll() { do { PullNext(); } while (!iPending.empty() || iRamper.Holding()); }
     Msg* Stream(TBool aLive, TUint64 aSampleStart)
     {
         DecodedStreamInfo info;
@@ -288,7 +351,7 @@ private:
     Msg* ProcessMsg(MsgQuit* m) override { return m; }
 private:
     MsgFactory& iFactory;
-    Ramper iRamper;
+    FadeInAtStreamStart iRamper;
     std::deque<Msg*> iPending;
     TUint iNextStreamId = 1;
     TUint64 iTrackOffset = 0;
@@ -408,8 +471,8 @@ public:
 private:
     MsgFactory& iFactory;
     SampleRateConverter iSrc;
-    Ramper iRamper;
-    PreDriver iPreDriver;
+    FadeInAtStreamStart iRamper;
+    DriverEdge iPreDriver;
     std::deque<Msg*> iPending;
     std::vector<TByte> iInput;
 };
@@ -486,80 +549,215 @@ static void SuiteFlywheelGpu(MsgFactory& aFactory)
     TEST_THROWS(manager.Ramp(Brn(few, sizeof few), 44100, 11), AssertionFailed);
 }
 
-// ------------------------------------------------------------------------------------------- starvation ramp (a11 + N1 + a12 + a7)
-// What StarvationRamper does when its upstream runs dry (StarvationRamper.cpp:590-640): FlywheelInput::Prepare on the
-// recent audio, RampGenerator::Start, then the generated messages flow downstream and are read like any other audio.
-static void SuiteStarvationRampGpu(MsgFactory& aFactory)
-{
-    const TUint kTraining = Jiffies::kPerMs, kRampDown = 20 * Jiffies::kPerMs;         // :374-375
-    const struct { TUint rate, channels, bits; } cases[] = { {44100, 2, 24}, {48000, 2, 16}, {96000, 6, 32}, {44100, 1, 8} };
-    uint32_t x = 4242;
-    for (const auto& cs : cases) {
-        const TUint frameBytes = cs.channels * cs.bits / 8;
-        // 3 ms of recent audio as three messages (big-endian, as the pipeline holds it), a slow decaying tone plus noise
-        std::deque<MsgAudio*> recent;
-        std::vector<TByte> all;
-        const TUint framesPerMsg = Jiffies::ToSamples(Jiffies::kPerMs, cs.rate);
-        for (TUint m = 0; m < 3; m++) {
-            std::vector<TByte> data((size_t)framesPerMsg * frameBytes);
-            for (TUint f = 0; f < framesPerMsg; f++) {
-                for (TUint c = 0; c < cs.channels; c++) {
-                    x = x * 1664525u + 1013904223u;
-                    int32_t v = (int32_t)(0x30000000 - (int32_t)((m * framesPerMsg + f) * 0x00080000u)) + (int32_t)(x >> 10) - (1 << 21);
-                    for (TUint b = 0; b < cs.bits / 8; b++) data[(size_t)f * frameBytes + c * (cs.bits / 8) + b] = (TByte)((uint32_t)v >> (24 - 8 * b));
-                }
-            }
-            all.insert(all.end(), data.begin(), data.end());
-            recent.push_back(aFactory.CreateMsgAudioPcm(Brn(data.data(), (TUint)data.size()), cs.channels, cs.rate, cs.bits, AudioDataEndian::Big, 0));
-        }
-        FlywheelInput input(aFactory, kTraining);
-        const Brx& planar = input.Prepare(recent, kTraining, cs.rate, cs.bits, cs.channels);
-        const TUint inSamples = Jiffies::ToSamples(kTraining, cs.rate);
-        TEST(recent.empty() && planar.Bytes() == inSamples * 4 * cs.channels);
-        // oracle a11 on the newest millisecond
-        std::vector<TByte> wantPlanar(planar.Bytes());
-        std::vector<uint32_t> pos(cs.channels, 0);
-        const TByte* newest = all.data() + all.size() - (size_t)inSamples * frameBytes;
-        TEST(ohp_flywheel_unpack(newest, inSamples * frameBytes, cs.channels, cs.bits / 8, wantPlanar.data(), inSamples * 4, pos.data()) == 0);
-        TEST(memcmp(planar.Ptr(), wantPlanar.data(), wantPlanar.size()) == 0);
+// ------------------------------------------------------------------------------------------- starvation rescue (a7 + a11 + N1 + a12)
+struct RescueCase { TUint rate, channels, bits, startRamp; };
 
-        RampGenerator gen(aFactory, kTraining, kRampDown);
-        const TUint startRamp = Ramp::kMax;
-        gen.Start(planar, cs.rate, cs.channels, cs.bits, startRamp);
-        // oracle: flywheel -> a12 pack, then every 1 ms message read with the ramp the host algebra gave it
-        const TUint outFrames = Jiffies::ToSamples(kRampDown, cs.rate), block = Jiffies::ToSamples(Jiffies::kPerMs, cs.rate);
-        std::vector<TByte> ramp32((size_t)outFrames * cs.channels * 4), packed((size_t)outFrames * frameBytes);
-        TEST(ohp_flywheel_ramp(wantPlanar.data(), inSamples * 4, inSamples, cs.rate, cs.channels, outFrames, block, ramp32.data()) == 0);
-        uint32_t packedBytes = 0;
-        TEST(ohp_rampgen_pack(ramp32.data(), (uint32_t)ramp32.size(), cs.bits, packed.data(), &packedBytes) == 0 && packedBytes == packed.size());
-        PlayableBatch batch(aFactory);
-        std::vector<ProcessorPcmBufTest> sinks((outFrames + block - 1) / block);
-        std::vector<ohp_msg_desc> descs;
-        Msg* msg = nullptr;
-        TUint n = 0, frames = 0, lastEnd = startRamp;
-        while (gen.TryGetAudio(msg)) {
-            MsgAudioPcm* pcm = dynamic_cast<MsgAudioPcm*>(msg);
-            TEST(pcm != nullptr && n < sinks.size());
-            TEST(pcm->Ramp().IsEnabled() && pcm->Ramp().Direction() == Ramp::EDown && pcm->Ramp().Start() == lastEnd);
-            lastEnd = pcm->Ramp().End();
-            MsgPlayable* playable = pcm->CreatePlayable();
-            ohp_msg_desc d;
-            memset(&d, 0, sizeof(d));
-            d.src_offset = (uint64_t)frames * frameBytes; d.dst_offset = d.src_offset; d.n_frames = playable->Bytes() / frameBytes;
-            d.ramp_start = (uint16_t)playable->Ramp().Start(); d.ramp_end = (uint16_t)playable->Ramp().End(); d.attenuation = 256;
-            d.channels = (uint8_t)cs.channels; d.src_bits = d.dst_bits = (uint8_t)cs.bits; d.src_endian = d.dst_endian = OHP_ENDIAN_BIG;
-            d.flags = OHP_FLAG_RAMP;
-            descs.push_back(d);
-            frames += d.n_frames;
-            batch.Add(playable, sinks[n++]);
+// `count` frames of a slowly decaying tone plus noise, big-endian as the pipeline holds it; aFirst = index of the first frame
+static std::vector<TByte> RescueSignal(const RescueCase& cs, uint32_t& x, TUint aFirst, TUint aCount)
+{
+    const TUint sb = cs.bits / 8, frameBytes = cs.channels * sb;
+    std::vector<TByte> data((size_t)aCount * frameBytes);
+    for (TUint f = 0; f < aCount; f++) {
+        for (TUint c = 0; c < cs.channels; c++) {
+            x = x * 1664525u + 1013904223u;
+            const int32_t v = (int32_t)(0x30000000 - (int32_t)((aFirst + f) * 0x00080000u)) + (int32_t)(x >> 10) - (1 << 21);
+            for (TUint b = 0; b < sb; b++) data[(size_t)f * frameBytes + c * sb + b] = (TByte)((uint32_t)v >> (24 - 8 * b));
         }
-        TEST(frames == outFrames && lastEnd == Ramp::kMin);                      // the whole 20 ms, down to silence
-        batch.Run();
-        std::vector<TByte> got, want(packed.size());
-        for (TUint i = 0; i < n; i++) got.insert(got.end(), sinks[i].Ptr(), sinks[i].Ptr() + sinks[i].Buf().Bytes());
-        TEST(ohp_msg_process_batch(descs.data(), descs.size(), packed.data(), want.data()) == 0);
-        TEST(got.size() == want.size() && memcmp(got.data(), want.data(), want.size()) == 0);
-        TEST(!gen.TryGetAudio(msg));
+    }
+    return data;
+}
+
+// The oracle's view of one rescue: a11 on the newest millisecond (aNewest: packed big-endian frames), the flywheel, the a12
+// pack, then every message read with the ramp the host algebra gave it.  aMsgs: what the rescue queued (consumed here).
+static void CheckRescued(MsgFactory& aFactory, const RescueCase& cs, const TByte* aNewest, std::deque<Msg*>& aMsgs)
+{
+    const TUint kTraining = Jiffies::kPerMs, kRampDown = 20 * Jiffies::kPerMs;         // StarvationRamper.cpp:374-375
+    const TUint frameBytes = cs.channels * cs.bits / 8;
+    const TUint inSamples = Jiffies::ToSamples(kTraining, cs.rate);
+    std::vector<TByte> wantPlanar((size_t)inSamples * 4 * cs.channels);
+    std::vector<uint32_t> pos(cs.channels, 0);
+    TEST(ohp_flywheel_unpack(aNewest, inSamples * frameBytes, cs.channels, cs.bits / 8, wantPlanar.data(), inSamples * 4, pos.data()) == 0);
+    const TUint outFrames = Jiffies::ToSamples(kRampDown, cs.rate), block = Jiffies::ToSamples(Jiffies::kPerMs, cs.rate);
+    std::vector<TByte> ramp32((size_t)outFrames * cs.channels * 4), packed((size_t)outFrames * frameBytes);
+    TEST(ohp_flywheel_ramp(wantPlanar.data(), inSamples * 4, inSamples, cs.rate, cs.channels, outFrames, block, ramp32.data()) == 0);
+    uint32_t packedBytes = 0;
+    TEST(ohp_rampgen_pack(ramp32.data(), (uint32_t)ramp32.size(), cs.bits, packed.data(), &packedBytes) == 0 && packedBytes == packed.size());
+    PlayableBatch batch(aFactory);
+    std::vector<ProcessorPcmBufTest> sinks((outFrames + block - 1) / block);
+    std::vector<ohp_msg_desc> descs;
+    TUint k = 0, frames = 0, lastEnd = cs.startRamp;
+    TEST(aMsgs.size() == sinks.size());
+    while (!aMsgs.empty() && k < sinks.size()) {
+        Msg* msg = aMsgs.front();
+        aMsgs.pop_front();
+        MsgAudioPcm* pcm = dynamic_cast<MsgAudioPcm*>(msg);
+        TEST(pcm != nullptr);
+        if (pcm == nullptr) { msg->RemoveRef(); continue; }
+        TEST(pcm->Ramp().IsEnabled() && pcm->Ramp().Direction() == Ramp::EDown && pcm->Ramp().Start() == lastEnd);
+        lastEnd = pcm->Ramp().End();
+        MsgPlayable* playable = pcm->CreatePlayable();
+        ohp_msg_desc d;
+        memset(&d, 0, sizeof(d));
+        d.src_offset = (uint64_t)frames * frameBytes; d.dst_offset = d.src_offset; d.n_frames = playable->Bytes() / frameBytes;
+        d.ramp_start = (uint16_t)playable->Ramp().Start(); d.ramp_end = (uint16_t)playable->Ramp().End(); d.attenuation = 256;
+        d.channels = (uint8_t)cs.channels; d.src_bits = d.dst_bits = (uint8_t)cs.bits; d.src_endian = d.dst_endian = OHP_ENDIAN_BIG;
+        d.flags = OHP_FLAG_RAMP;
+        descs.push_back(d);
+        frames += d.n_frames;
+        batch.Add(playable, sinks[k++]);
+    }
+    TEST(frames == outFrames && lastEnd == Ramp::kMin);                          // the whole 20 ms, down to silence
+    batch.Run();
+    std::vector<TByte> got, want(packed.size());
+    for (TUint j = 0; j < k; j++) got.insert(got.end(), sinks[j].Ptr(), sinks[j].Ptr() + sinks[j].Buf().Bytes());
+    TEST(ohp_msg_process_batch(descs.data(), descs.size(), packed.data(), want.data()) == 0);
+    TEST(got.size() == want.size() && memcmp(got.data(), want.data(), want.size()) == 0);
+}
+
+// What happens when streams run dry (StarvationRamper.cpp:491-537 -> FlywheelRamper.cpp:45-131 -> :281-364), for SEVERAL streams of
+// different formats in ONE RescueBatch: the last millisecond of each is read, unpacked, extrapolated and packed in the same
+// device passes; the generated messages are then read like any other audio.
+static void SuiteStarvationRescueGpu(MsgFactory& aFactory)
+{
+    const RescueCase cases[] = {
+        {44100, 2, 24, Ramp::kMax}, {48000, 2, 16, Ramp::kMax}, {96000, 6, 32, Ramp::kMax}, {44100, 1, 8, Ramp::kMax}, {192000, 8, 24, 9000} };
+    const size_t n = sizeof cases / sizeof cases[0];
+    uint32_t x = 4242;
+    std::vector<std::vector<TByte>> newest(n);
+    std::vector<std::deque<Msg*>> out(n);
+    const TUint64 launches = RescueBatch::FlywheelLaunches();
+    RescueBatch rescue(aFactory);
+    for (size_t i = 0; i < n; i++) {
+        const RescueCase& cs = cases[i];
+        // the manager hands over one training window: here the window's one message, after 2 ms of earlier audio
+        const TUint perMs = Jiffies::ToSamples(Jiffies::kPerMs, cs.rate);
+        (void)RescueSignal(cs, x, 0, 2 * perMs);
+        newest[i] = RescueSignal(cs, x, 2 * perMs, perMs);
+        MsgAudioPcm* msg = aFactory.CreateMsgAudioPcm(Brn(newest[i].data(), (TUint)newest[i].size()), cs.channels, cs.rate, cs.bits, AudioDataEndian::Big, 0);
+        RescueRequest rq;
+        rq.audio.push_back(msg);
+        rq.jiffies = msg->Jiffies();
+        rq.sampleRate = cs.rate; rq.bitDepth = cs.bits; rq.channels = cs.channels; rq.rampValue = cs.startRamp;
+        rq.out = &out[i];
+        rescue.Add(std::move(rq));
+    }
+    TEST(rescue.Count() == n);
+    rescue.Run();
+    TEST(RescueBatch::FlywheelLaunches() == launches + 1);                         // five streams, one extrapolation launch
+    for (size_t i = 0; i < n; i++) {
+        CheckRescued(aFactory, cases[i], newest[i].data(), out[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- many lanes, one tick (N4)
+// 64 streams of mixed formats play through one StarvationManager and ALL run dry in the same driver period: the manager
+// must rescue them with one chain of device passes (one flywheel launch), every lane's 20 ms must be what the reference
+// would have produced for that lane alone, and every lane must then halt.
+class ScriptedSource : public IPipelineElementUpstream {
+public:
+    void Push(Msg* aMsg) { { std::lock_guard<std::mutex> lock(iLock); iQueue.push_back(aMsg); } iCv.notify_one(); }
+    Msg* Pull() override
+    {
+        std::unique_lock<std::mutex> lock(iLock);
+        iCv.wait(lock, [this] { return !iQueue.empty(); });
+        Msg* msg = iQueue.front();
+        iQueue.pop_front();
+        return msg;
+    }
+private:
+    std::mutex iLock;
+    std::condition_variable iCv;
+    std::deque<Msg*> iQueue;
+};
+
+class CountingObserver : public IStarvationRamperObserver {
+public:
+    void NotifyStarvationRamperBuffering(TBool aBuffering) override { aBuffering ? iStarted++ : iStopped++; }
+    std::atomic<TUint> iStarted{0}, iStopped{0};
+};
+
+static void SuiteManyLanesStarveTogetherGpu(MsgFactory& aFactory)
+{
+    const TUint kLanes = 64, kMsgs = 3;
+    const RescueCase formats[] = { {44100, 2, 16, Ramp::kMax}, {48000, 2, 24, Ramp::kMax}, {96000, 2, 24, Ramp::kMax}, {44100, 1, 24, Ramp::kMax},
+                                   {48000, 6, 16, Ramp::kMax}, {192000, 2, 32, Ramp::kMax}, {88200, 2, 8, Ramp::kMax} };
+    const size_t kFormats = sizeof formats / sizeof formats[0];
+    std::vector<std::unique_ptr<ScriptedSource>> sources;
+    CountingObserver observer;
+    std::vector<std::vector<TByte>> sent(kLanes);
+    uint32_t x = 77;
+    {
+        StarvationManager manager(aFactory);
+        TUint total[64];
+        for (TUint l = 0; l < kLanes; l++) {
+            sources.emplace_back(new ScriptedSource());
+            StarvationManager::LaneConfig cfg;
+            cfg.upstream = sources.back().get(); cfg.observer = &observer;
+            cfg.sizeJiffies = 100 * Jiffies::kPerMs; cfg.rampUpJiffies = 50 * Jiffies::kPerMs; cfg.maxStreamCount = 10;
+            TEST(manager.AddLane(cfg) == l);
+            const RescueCase& cs = formats[l % kFormats];
+            sources[l]->Push(aFactory.CreateMsgMode(ModeInfo()));
+            DecodedStreamInfo info;
+            info.iStreamId = 100 + l; info.iBitDepth = cs.bits; info.iSampleRate = cs.rate; info.iNumChannels = cs.channels;
+            sources[l]->Push(aFactory.CreateMsgDecodedStream(info));
+            const TUint perMsg = 2 * Jiffies::ToSamples(Jiffies::kPerMs, cs.rate) + l % 5;     // 2 ms and a few frames: ragged windows
+            total[l] = 0;
+            for (TUint m = 0; m < kMsgs; m++) {
+                const std::vector<TByte> data = RescueSignal(cs, x, m * perMsg, perMsg);
+                sent[l].insert(sent[l].end(), data.begin(), data.end());
+                MsgAudioPcm* audio = aFactory.CreateMsgAudioPcm(Brn(data.data(), (TUint)data.size()), cs.channels, cs.rate, cs.bits, AudioDataEndian::Big, 0);
+                total[l] += audio->Jiffies();
+                sources[l]->Push(audio);
+            }
+        }
+        for (TUint l = 0; l < kLanes; l++) {                 // every lane's feeder has taken what its source holds
+            while (manager.SizeInJiffies(l) != total[l]) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        std::vector<Msg*> out;
+        for (TUint t = 0; t < 2 + kMsgs; t++) {              // mode, stream, then the audio: nothing to rescue yet
+            manager.Tick(out);
+            TEST(out.size() == kLanes);
+            for (Msg* m : out) {
+                TEST(KindOf(m) == (t == 0 ? MsgKind::Mode : t == 1 ? MsgKind::DecodedStream : MsgKind::AudioPcm));
+                m->RemoveRef();
+            }
+        }
+        TEST(manager.RescueLaunches() == 0);
+        for (TUint l = 0; l < kLanes; l++) TEST(manager.State(l) == LaneState::Running && manager.IsEmpty(l));
+        const TUint64 launches = RescueBatch::FlywheelLaunches();
+        std::vector<std::deque<Msg*>> rescued(kLanes);
+        // the driver's next periods: 1 ms of extrapolated audio per lane and tick (20 of them, 21 where a millisecond is not a
+        // whole number of frames), then the lane's halt; a lane that has passed its quit on has nothing more to give
+        std::vector<TUint> halted(kLanes, 0), quit(kLanes, 0);
+        for (TUint t = 0; t < 23; t++) {
+            manager.Tick(out);
+            if (t == 0) {                                    // (the sources end only now: a lane whose quit is in sight is not rescued)
+                for (TUint l = 0; l < kLanes; l++) sources[l]->Push(aFactory.CreateMsgQuit());
+            }
+            TEST(out.size() == kLanes);
+            for (TUint l = 0; l < kLanes; l++) {
+                if (out[l] == nullptr) { TEST(quit[l] == 1); continue; }
+                const MsgKind kind = KindOf(out[l]);
+                if (kind == MsgKind::AudioPcm) {
+                    TEST(!halted[l] && manager.State(l) == LaneState::FlywheelRamping);
+                    rescued[l].push_back(out[l]);
+                    continue;
+                }
+                if (kind == MsgKind::Halt) { TEST(!halted[l] && !quit[l] && manager.State(l) == LaneState::RampingUp); halted[l]++; }
+                else if (kind == MsgKind::Quit) { TEST(halted[l] == 1); quit[l]++; }
+                else TEST(false);
+                out[l]->RemoveRef();
+            }
+        }
+        TEST(manager.RescueLaunches() == 1);                 // ONE rescue for 64 lanes...
+        TEST(RescueBatch::FlywheelLaunches() == launches + 1);                     // ...and one flywheel launch on the device
+        for (TUint l = 0; l < kLanes; l++) TEST(halted[l] == 1 && quit[l] == 1);
+        TEST(observer.iStarted.load() == 2 * kLanes && observer.iStopped.load() == kLanes);     // buffering at start, playing, buffering again
+        for (TUint l = 0; l < kLanes; l++) {
+            const RescueCase& cs = formats[l % kFormats];
+            const size_t window = (size_t)Jiffies::ToSamples(Jiffies::kPerMs, cs.rate) * cs.channels * cs.bits / 8;
+            CheckRescued(aFactory, cs, sent[l].data() + sent[l].size() - window, rescued[l]);
+        }
     }
 }
 
@@ -1358,11 +1556,11 @@ private:
         iJiffies = 0;
         iStarvationRamper->DrainAllAudio();
         TEST(!iStarvationRamper->Draining());
-        TEST(iStarvationRamper->StartDrainPending());
+        TEST(iStarvationRamper->DrainRequested());
         iRampingDown = true;
         do {
             PullNext(EMsgAudioPcm);
-            TEST(!iStarvationRamper->StartDrainPending());
+            TEST(!iStarvationRamper->DrainRequested());
             TEST(iStarvationRamper->Draining());
         } while (iJiffies < StarvationRamper::kRampDownJiffies);
         TEST(iJiffies == StarvationRamper::kRampDownJiffies);
@@ -1371,9 +1569,9 @@ private:
         TEST(iStarvationRamper->Draining());
         PullNext(EMsgDecodedStream);
         PullNext(EMsgHalt);
-        TEST(!iStarvationRamper->StartDrainPending() && iStarvationRamper->Draining());
+        TEST(!iStarvationRamper->DrainRequested() && iStarvationRamper->Draining());
         PullNext(EMsgDrain);
-        TEST(!iStarvationRamper->StartDrainPending() && !iStarvationRamper->Draining());
+        TEST(!iStarvationRamper->DrainRequested() && !iStarvationRamper->Draining());
         Quit(false);
     }
     void TestAllSampleRates()
@@ -1465,7 +1663,8 @@ int main(int argc, char** argv)
             SuiteSrcGpu src(f);
             src.Run();
             SuiteFlywheelGpu(f);
-            SuiteStarvationRampGpu(f);
+            SuiteStarvationRescueGpu(f);
+            SuiteManyLanesStarveTogetherGpu(f);
             SuiteSongcastSenderGpu(f);
             SuiteStarvationRamper starvation(f);
             starvation.RunControl();

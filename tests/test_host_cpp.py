@@ -1,5 +1,6 @@
-"""Builds and runs tests/cpp/test_host.cpp: the C++ host adapter (Msg model mirror, Ramper, PreDriver,
-SampleRateConverter) exercised the way the reference's TestMsg.cpp / TestRamper.cpp exercise the originals."""
+"""Builds and runs tests/cpp/test_host.cpp: the C++ host adapter (Msg model mirror, SampleRateConverter, Songcast sender,
+StarvationManager) exercised the way the reference's TestMsg.cpp / TestRamper.cpp / TestStarvationRamper.cpp exercise the
+originals; with a GPU every byte is checked against the oracle, including 64 lanes starving in one tick."""
 import os
 import subprocess
 
@@ -33,7 +34,9 @@ def build_test_binary():
 def run(mode):
     exe = build_test_binary()
     out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    if out.returncode != 0:
+        lines = out.stdout.splitlines()
+        raise AssertionError("\n".join(sorted(set(lines), key=lines.index)[:60]) + out.stderr[-2000:])
     return out.stdout
 
 
