@@ -13,6 +13,10 @@ LIB_PATH = os.path.join(LIB_DIR, "libohgpu.so")
 HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "ohm_frame_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip", "src_lean_kernel.hip"]
 PARTED = ("src_block_kernel.hip", "src_lean_kernel.hip")     # compiled once per part of the instantiation list (csrc/src_block_common.h)
 HEADERS = ["ohgpu_internal.h", "pcm_device.h", os.path.join(ROOT, "include", "ohgpu.h")]
+# Per-source flags.  The lean kernel's per-frame control flow is wave-uniform (scalar compares); LLVM's structurizer
+# rewrites uniform diamonds into flag-and-test chains unless told to leave uniform regions alone (3-4 scalar instructions
+# per input frame in a loop the scalar unit co-limits).
+SOURCE_FLAGS = {"src_lean_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions"]}
 ARCH = "gfx950"
 BLOCK_PARTS = 3                     # OHGPU_BLOCK_PARTS in csrc/src_block_common.h
 
@@ -62,10 +66,11 @@ def build(force=False, verbose=False, save_temps=False):
 
     def compile_one(job):
         src, part = job
-        obj = os.path.join(obj_dir, f"{os.path.basename(src)}.{tag}.{part}.o")
+        own = [] if os.environ.get("OHGPU_NO_SOURCE_FLAGS") else SOURCE_FLAGS.get(os.path.basename(src), [])
+        obj = os.path.join(obj_dir, f"{os.path.basename(src)}.{tag}{'.f' if own else ''}.{part}.o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
             return obj
-        cmd = [hipcc(), *flags, *([f"-DOHGPU_BLOCK_PART={part}"] if part else []), "-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc(), *flags, *own, *([f"-DOHGPU_BLOCK_PART={part}"] if part else []), "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd, cwd=PKG)

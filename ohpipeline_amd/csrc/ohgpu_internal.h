@@ -65,7 +65,16 @@ struct SrcWork {              // one workgroup's share: up to `rows` consecutive
     uint32_t plane;           // a ramped unit's multiplier plane (lean kernel): its index in SrcFastPlan::d_planes
     uint32_t pad;
 };
-static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24, "plan layouts");
+struct LeanUnit {             // the lean kernel's own view of a unit (same order as the SrcWork array): ONE 32-byte scalar load,
+                              // nothing to look up behind it -- a unit's set-up used to wait for work[], then for segs[work.seg]
+    int64_t  src_row0;        // source arena offset of row 0's input frame at advance -T: seg.src_base + (first_block * M_blk - T) * fb_src
+    int64_t  dst_row0;        // destination arena offset of row 0's first output byte: seg.dst_base + first_block * L_blk * fb_dst
+    uint32_t n_blocks;
+    uint32_t flags;           // kWorkRamped | kWorkChecked | kWorkFirst
+    uint32_t plane;
+    uint32_t pad;
+};
+static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24 && sizeof(LeanUnit) == 32, "plan layouts");
 
 struct SrcFastParams {        // kernel argument block
     const SrcSeg*  segs;
@@ -98,6 +107,7 @@ struct SrcFastPlan {
     void*    d_segs = nullptr;
     void*    d_msgs = nullptr;
     void*    d_work = nullptr;
+    void*    d_lean_units = nullptr;   // LeanUnit [n_work], when `lean`
     void*    d_counter = nullptr; // uint32[2]: units claimed / waves finished by the running launch; the kernel's last wave zeroes them
     void*    d_rem = nullptr;     // DevSrcDesc[] the generic kernel finishes (block-unaligned heads and tails)
     size_t   n_rem = 0;

@@ -58,7 +58,8 @@ static constexpr int lean_in_blocks(int ch, int sb)
 
 // SrcWork::flags
 enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output range
-       kWorkChecked = 2u };   // some staging piece of the unit lies outside the source arena (ends of the arena)
+       kWorkChecked = 2u,     // some staging piece of the unit lies outside the source arena (ends of the arena)
+       kWorkFirst = 4u };     // LeanUnit only: row 0 is its stream's block 0 (the frames before it read as zeros)
 
 }  // namespace ohgpu
 

@@ -148,7 +148,7 @@ struct LeanGeom {
 
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
 __global__ __launch_bounds__((LeanGeom<T, CH, SB, DB>::MAX_WAVES * 64))
-void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict__ work, const uint32_t n_work,
+void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                      const double* __restrict__ coef, const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                      const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
@@ -219,22 +219,19 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
 
     const uint32_t first_claimed = gridDim.x * n_waves;
     uint32_t unit = blockIdx.x * n_waves + wave;
+    LeanUnit wk = units[unit < n_work ? unit : 0u];
     while (unit < n_work) {
     uint32_t claim = 0;
     if (lane == 0) claim = atomicAdd(unit_counter, 1u);
 #ifdef OHGPU_DIAG_STAMP
     st_mark = __builtin_amdgcn_s_memtime(); st_units++;
 #endif
-    const SrcWork wk = work[unit];
-    const SrcSeg seg = segs[wk.seg];
     const uint32_t n_blocks = wk.n_blocks;
     const bool ramped = (wk.flags & kWorkRamped) != 0;                 // wave-uniform
     const bool checked = (wk.flags & kWorkChecked) != 0;               // some staging piece of the unit lies outside the arena
     const bool lane_valid = lane_block && row < n_blocks;
-    const uint64_t blk = wk.first_block + row;
-    const int64_t n_start = (int64_t)(blk * M_blk);
-    const int64_t row_g = seg.src_base + (n_start - T) * (int64_t)FB_SRC;   // byte offset of the row's frame at a_lin = 0
-    const bool first_block = n_start == 0;
+    const int64_t row_g = wk.src_row0 + (int64_t)(row * M_blk) * FB_SRC;   // byte offset of the row's frame at a_lin = 0
+    const bool first_block = (wk.flags & kWorkFirst) != 0 && row == 0;        // the stream's block 0: nothing before it
 
     // ---- a ramped unit reads RampApplicator's multiplier of every output frame from its plane (src_plan.cpp): one uint16 per
     // frame, rows side by side, 0xffff = the frame's message carries no ramp.  Eight frames per load.
@@ -250,7 +247,7 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
     // + SF frames per stage) + piece_off[it] (per lane, fixed for the unit).  A row whose first frame sits early in its
     // first piece does not need its last piece: that lane re-reads the row's first piece instead (same line, no traffic).
     const int total = (int)M_blk + T;         // advances a = a_lin - T for a_lin in [0, total)
-    const int64_t g0 = seg.src_base + ((int64_t)(wk.first_block * M_blk) - T) * (int64_t)FB_SRC;    // row 0's frame at a_lin = 0
+    const int64_t g0 = wk.src_row0;            // row 0's frame at a_lin = 0
     const uint32_t a0 = (uint32_t)g0 & 15u;
     int64_t stage_off = g0 - (int64_t)a0;     // arena offset of row 0's first piece of the NEXT stage to issue (wave-uniform)
     uint32_t piece_off[IN_ITERS];
@@ -311,7 +308,7 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
     // its place in the row's byte ring; whenever a 64-byte line of the stream is complete the wave writes that line of all its
     // blocks, lane l of pass `it` copying 16-byte piece (l & 3) of block (it*16 + l/4): every HBM write is a whole line.  The
     // destination is a wave-uniform base (the unit's current line, pass `it`'s first row) plus the lane's fixed offset.
-    const int64_t wave_dst = seg.dst_base + (int64_t)(wk.first_block * L_blk) * FB_DST;
+    const int64_t wave_dst = wk.dst_row0;
     const uint32_t wave_rows = n_blocks < (uint32_t)BPW ? n_blocks : (uint32_t)BPW;
     constexpr int DRAIN_ITERS = (BPW * 4 + 63) / 64;
     const uint32_t drain_off = (lane >> 2) * L_blk * FB_DST + (lane & 3) * 16;
@@ -641,10 +638,13 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
         }, std::make_integer_sequence<int, T>{});
     }
     STAMP(st_out)
+    // the next unit's descriptor is fetched while the last lines are written back
+    unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
+    const LeanUnit next_wk = units[unit < n_work ? unit : n_work - 1u];
     issue_store();
     drain(j);
+    wk = next_wk;
     STAMP(st_drain)
-    unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     }   // units
 #ifdef OHGPU_DIAG_STAMP
     if (dbg != nullptr && lane == 0) {
@@ -663,7 +663,7 @@ void src_lean_kernel(const SrcSeg* __restrict__ segs, const SrcWork* __restrict_
     }
 }
 
-#define OHGPU_LEAN_ARGS const SrcSeg*, const SrcWork*, uint32_t, const double*, const uint16_t*, uint32_t, const uint8_t*, \
+#define OHGPU_LEAN_ARGS const LeanUnit*, uint32_t, const double*, const uint16_t*, uint32_t, const uint8_t*, \
                         uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
 #define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
 #define X_DECLARE(t, c, s_, sl, d, dl) extern template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
@@ -726,7 +726,7 @@ static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
     if (stamp_path && hipMalloc((void**)&dbg, n_dbg * 8) == hipSuccess) hipMemsetAsync(dbg, 0, n_dbg * 8, s);
 #endif
     hipLaunchKernelGGL(kernel, dim3(g), dim3(w * 64), lds, s,
-                       p.segs, p.work, f.n_work, p.coef, (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst,
+                       (const LeanUnit*)f.d_lean_units, f.n_work, p.coef, (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst,
                        p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, f.ring_bytes, (uint32_t*)f.d_counter, dbg);
 #ifdef OHGPU_DIAG_STAMP
     if (dbg) {      // diagnostic build only: wait, sum up, write a text report, never on the product path

@@ -20,6 +20,7 @@ void free_src_fast(ohgpu_batch* b)
     if (f.d_segs) hipFree(f.d_segs);
     if (f.d_msgs) hipFree(f.d_msgs);
     if (f.d_work) hipFree(f.d_work);
+    if (f.d_lean_units) hipFree(f.d_lean_units);
     if (f.d_rem) hipFree(f.d_rem);
     if (f.d_counter) hipFree(f.d_counter);
     if (f.d_planes) hipFree(f.d_planes);
@@ -233,9 +234,25 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         return ((x.flags & kWorkRamped) ? 3u : 1u) * x.n_blocks > ((y.flags & kWorkRamped) ? 3u : 1u) * y.n_blocks;
     });
 
+    std::vector<LeanUnit> lean_units;
+    if (lean) {
+        lean_units.reserve(work.size());
+        for (const SrcWork& w : work) {
+            LeanUnit u;
+            u.src_row0 = segs[w.seg].src_base + ((int64_t)(w.first_block * M_blk) - (int64_t)T) * fb_src;
+            u.dst_row0 = segs[w.seg].dst_base + (int64_t)(w.first_block * L_blk) * fb_dst;
+            u.n_blocks = w.n_blocks;
+            u.flags = w.flags | (w.first_block == 0 ? (uint32_t)kWorkFirst : 0u);
+            u.plane = w.plane;
+            u.pad = 0;
+            lean_units.push_back(u);
+        }
+    }
+
     int err = upload_vec(segs, &f.d_segs);
     if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
     if (err == OHGPU_OK) err = upload_vec(work, &f.d_work);
+    if (err == OHGPU_OK && lean) err = upload_vec(lean_units, &f.d_lean_units);
     if (err == OHGPU_OK) err = upload_vec(rem, &f.d_rem);
     if (err == OHGPU_OK) err = upload_vec(planes.empty() ? std::vector<uint16_t>(4, 0xffffu) : planes, &f.d_planes);
     if (err == OHGPU_OK) err = upload_vec(std::vector<uint32_t>(2, 0u), &f.d_counter);   // {units claimed, waves finished}: zero between launches

@@ -30,10 +30,14 @@ def _compile(stem, prefix):
     src = os.path.join(CSRC, stem + ".hip")
     deps = [src] + [os.path.join(CSRC, f) for f in ("ohgpu_internal.h", "pcm_device.h", "src_block_common.h")]
 
+    from ohpipeline_amd import build as product_build
+    own = product_build.SOURCE_FLAGS.get(stem + ".hip", [])
+    deps.append(os.path.join(ROOT, "ohpipeline_amd", "build.py"))
+
     def compile_part(part):
         out = os.path.join(OUTDIR, f"{stem}.test.{part}.s")
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-inline-asm",
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-inline-asm", *own,
                    f"-DOHGPU_BLOCK_PART={part}", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", src, "-o", out]
             subprocess.run(cmd, check=True, capture_output=True, timeout=1500)
         return open(out).read().split("\n")
