@@ -69,24 +69,20 @@ __device__ __forceinline__ void lean_wait0(uint64_t& y)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y) : : "memory");
 }
 
-// sixteen taps of one coefficient register: taps 16 r + 15 .. 16 r, dealt round-robin to OHGPU_LEAN_CHAINS accumulation chains.
+// sixteen taps of one coefficient register: taps 16 r + 15 .. 16 r in one dependent chain (two or four chains were measured
+// slower: their extra moves and adds cost more than the latency they hide -- tools/micro/fma_latency.hip, exp10).
 // `w` are the sixteen window slots in tap order 15 .. 0.  (cv is only ever written by an LDS load: no VALU-write -> DPP-read
-// hazard.)  A lone wave issues dependent v_fmac_f64_dpp 8.8 cycles apart, two chains 6.7, four 5.8 (tools/micro/fma_latency.hip):
-// with three waves on a SIMD the pipe is only kept full while EVERY wave is in its taps, so a wave's own speed matters whenever
-// another one is between units, waiting for its staging loads or writing lines back.
-#ifndef OHGPU_LEAN_CHAINS
-#define OHGPU_LEAN_CHAINS 1
-#endif
-#define OHGPU_FM(a, k, x) "v_fmac_f64_dpp %[a" #a "], %[cv], " x " row_newbcast:" #k " row_mask:0xf bank_mask:0xf\n\t"
-#if OHGPU_LEAN_CHAINS == 1
-#define OHGPU_FM4(k3, k2, k1, k0, x3, x2, x1, x0) OHGPU_FM(0, k3, x3) OHGPU_FM(0, k2, x2) OHGPU_FM(0, k1, x1) OHGPU_FM(0, k0, x0)
-#elif OHGPU_LEAN_CHAINS == 2
-#define OHGPU_FM4(k3, k2, k1, k0, x3, x2, x1, x0) OHGPU_FM(1, k3, x3) OHGPU_FM(0, k2, x2) OHGPU_FM(1, k1, x1) OHGPU_FM(0, k0, x0)
-#else
-#define OHGPU_FM4(k3, k2, k1, k0, x3, x2, x1, x0) OHGPU_FM(3, k3, x3) OHGPU_FM(2, k2, x2) OHGPU_FM(1, k1, x1) OHGPU_FM(0, k0, x0)
-#endif
-struct LeanAcc { double a0, a1, a2, a3; };
-__device__ __forceinline__ void lean_taps16(LeanAcc& acc, const double cv,
+// hazard.)
+// THE ACCUMULATOR IS v[0:1], BY NAME.  An output's body is several statements (an asm statement takes 30 operands at most,
+// a tap group alone has 18), and LLVM pads a statement that READS a vector register operand which the statement before it
+// WROTE with an s_nop -- it cannot see that no sub-dword write is involved (the gfx940 "dst_sel forwarding" hazard) -- which
+// cost three s_nop per output.  A register the statements only name in their text and list as clobbered is no operand:
+// nothing to pad.  It lives from an output's v_mov_b64 to its v_cvt_u32_f64 and nowhere else.
+#define OHGPU_ACC "v[0:1]"
+#define OHGPU_ACC_CLOBBER "v0", "v1"
+#define OHGPU_FM(k, x) "v_fmac_f64_dpp " OHGPU_ACC ", %[cv], " x " row_newbcast:" #k " row_mask:0xf bank_mask:0xf\n\t"
+#define OHGPU_FM4(k3, k2, k1, k0, x3, x2, x1, x0) OHGPU_FM(k3, x3) OHGPU_FM(k2, x2) OHGPU_FM(k1, x1) OHGPU_FM(k0, x0)
+__device__ __forceinline__ void lean_taps16(const double cv,
                                             const double w15, const double w14, const double w13, const double w12,
                                             const double w11, const double w10, const double w9, const double w8,
                                             const double w7, const double w6, const double w5, const double w4,
@@ -95,15 +91,28 @@ __device__ __forceinline__ void lean_taps16(LeanAcc& acc, const double cv,
     asm volatile(
         OHGPU_FM4(15, 14, 13, 12, "%[w15]", "%[w14]", "%[w13]", "%[w12]") OHGPU_FM4(11, 10, 9, 8, "%[w11]", "%[w10]", "%[w9]", "%[w8]")
         OHGPU_FM4(7, 6, 5, 4, "%[w7]", "%[w6]", "%[w5]", "%[w4]") OHGPU_FM4(3, 2, 1, 0, "%[w3]", "%[w2]", "%[w1]", "%[w0]")
-        : [a0] "+v"(acc.a0)
-#if OHGPU_LEAN_CHAINS >= 2
-          , [a1] "+v"(acc.a1)
-#endif
-#if OHGPU_LEAN_CHAINS >= 4
-          , [a2] "+v"(acc.a2), [a3] "+v"(acc.a3)
-#endif
+        :
         : [cv] "v"(cv), [w15] "v"(w15), [w14] "v"(w14), [w13] "v"(w13), [w12] "v"(w12), [w11] "v"(w11), [w10] "v"(w10), [w9] "v"(w9),
-          [w8] "v"(w8), [w7] "v"(w7), [w6] "v"(w6), [w5] "v"(w5), [w4] "v"(w4), [w3] "v"(w3), [w2] "v"(w2), [w1] "v"(w1), [w0] "v"(w0));
+          [w8] "v"(w8), [w7] "v"(w7), [w6] "v"(w6), [w5] "v"(w5), [w4] "v"(w4), [w3] "v"(w3), [w2] "v"(w2), [w1] "v"(w1), [w0] "v"(w0)
+        : OHGPU_ACC_CLOBBER);
+}
+// The last tap group of an output, with the unpack of the advance's new sample (lean_unpack below) in the same statement.
+__device__ __forceinline__ void lean_taps16_unpack(const double cv, const uint64_t words, const uint32_t sel, double& w0,
+                                                   const double w15, const double w14, const double w13, const double w12,
+                                                   const double w11, const double w10, const double w9, const double w8,
+                                                   const double w7, const double w6, const double w5, const double w4,
+                                                   const double w3, const double w2, const double w1)
+{
+    uint32_t w;
+    asm volatile(
+        "v_perm_b32 %[w], %[hi], %[lo], %[sel]\n\tv_cvt_f64_i32 %[w0], %[w]\n\t"
+        OHGPU_FM4(15, 14, 13, 12, "%[w15]", "%[w14]", "%[w13]", "%[w12]") OHGPU_FM4(11, 10, 9, 8, "%[w11]", "%[w10]", "%[w9]", "%[w8]")
+        OHGPU_FM4(7, 6, 5, 4, "%[w7]", "%[w6]", "%[w5]", "%[w4]") OHGPU_FM4(3, 2, 1, 0, "%[w3]", "%[w2]", "%[w1]", "%[w0]")
+        : [w0] "=&v"(w0), [w] "=&v"(w)
+        : [cv] "v"(cv), [hi] "v"((uint32_t)(words >> 32)), [lo] "v"((uint32_t)words), [sel] "v"(sel),
+          [w15] "v"(w15), [w14] "v"(w14), [w13] "v"(w13), [w12] "v"(w12), [w11] "v"(w11), [w10] "v"(w10), [w9] "v"(w9),
+          [w8] "v"(w8), [w7] "v"(w7), [w6] "v"(w6), [w5] "v"(w5), [w4] "v"(w4), [w3] "v"(w3), [w2] "v"(w2), [w1] "v"(w1)
+        : OHGPU_ACC_CLOBBER);
 }
 
 // One subsample -> sample x 256 as an exact double: the two aligned words that hold it (LDS accepts unaligned reads
@@ -330,11 +339,13 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                     (const __attribute__((address_space(3))) uint32_t*)(lds + drain_lds + (uint32_t)(it * 16) * row_stride + pos);
                 v4[it].x = q[0]; v4[it].y = q[1]; v4[it].z = q[2]; v4[it].w = q[3];
             }
+            // (the reads are awaited HERE, by every lane: left to the compiler the wait sits inside the stores' lane mask, a wave
+            // that skips a pass leaves its reads pending, and the compiler then opens the output loop that follows with lgkmcnt(0))
+            static_assert(DRAIN_ITERS <= 2, "one wait for every pass's reads");
+            if constexpr (DRAIN_ITERS == 1) asm volatile("" : "+v"(v4[0]));
+            else asm volatile("" : "+v"(v4[0]), "+v"(v4[DRAIN_ITERS - 1]));
 #pragma unroll
             for (int it = 0; it < DRAIN_ITERS; it++) {
-#ifdef OHGPU_DIAG_DRAIN_SEQ
-                asm volatile("" : "+v"(v4[it]) : : "memory");      // (diagnostic: one round trip per pass, as before)
-#endif
                 if ((uint32_t)(it * 16) + (lane >> 2) < wave_rows) {
                     uint8_t* const line = dst + wave_dst + (uint64_t)drained * 64 + (uint64_t)(it * 16) * L_blk * FB_DST;    // wave-uniform
 #if defined(OHGPU_DIAG_STORE_PLAIN)
@@ -479,38 +490,48 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 #endif
                 do {
                 // ---- emit the outputs whose newest input frame is this one ----
-                LeanAcc acc;
-                double acc0;
                 uint32_t cp;
-                // the accumulators: the first starts at the rounding bias; the next output's phase: pu += M mod L, and -L again on
-                // a carry; its coefficient row
-#if OHGPU_LEAN_CHAINS >= 2
-                asm volatile("v_mov_b64 %0, 0" : "=v"(acc.a1));
-#endif
-#if OHGPU_LEAN_CHAINS >= 4
-                asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0" : "=v"(acc.a2), "=v"(acc.a3));
-#endif
-                asm volatile("v_mov_b64 %[acc], %[bias]\n\t"
+                // the accumulator starts at the rounding bias; the next output's phase: pu += M mod L, and -L again on a carry; its
+                // coefficient row
+                asm volatile("v_mov_b64 " OHGPU_ACC ", %[bias]\n\t"
                              "s_add_u32 %[pu], %[pu], %[mr]\n\t"
                              "s_cselect_b32 vcc_lo, %[nl], 0\n\t"
                              "s_add_u32 %[pu], %[pu], vcc_lo\n\t"
                              "v_lshl_add_u32 %[cp], %[pu], %[sh], %[cl]"
-                             : [acc] "=v"(acc.a0), [pu] "+s"(pu), [cp] "=v"(cp)
+                             : [pu] "+s"(pu), [cp] "=v"(cp)
                              : [bias] "s"(bias), [mr] "s"((uint32_t)Mr), [nl] "s"(0u - (uint32_t)L), [sh] "i"(T == 32 ? 8 : 9), [cl] "v"(coef_lane_L)
-                             : "vcc", "scc");
+                             : "vcc", "scc", OHGPU_ACC_CLOBBER);
                 static_for([&](auto rc) __attribute__((always_inline)) {
                     constexpr int r = NCR - 1 - decltype(rc)::value;          // highest taps (oldest samples) first, the newest sample last
-                    if constexpr (r == 0) {
-                        lean_wait<NCR - 1>(cf[0], raw);
-                        win[s] = lean_unpack(raw, in_sel[(s % SF) % PH]);
-                    } else {
-                        lean_wait<NCR - 1>(cf[r]);
+                    // (no register operands: the statements keep their order among themselves, and an operand written right in front
+                    // of a statement that reads it gets that statement an s_nop)
+                    if constexpr (r == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw) : "i"(NCR - 1) : "memory");   // (the raw sample passes through its wait)
+                    else asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(NCR - 1) : "memory");
+                    // Consecutive statements that touch the accumulator are padded apart with an s_nop by the compiler (see OHGPU_ACC)
+                    // unless an instruction of its own lies between them: the output is counted in front of its first taps and t
+                    // moves on in front of its last ones, each pinned by scheduling barriers (the constant the pack needs happens to
+                    // be rebuilt in front of the third).  The round-clamp-pack statement therefore sees j already incremented.
+                    if constexpr (r == NCR - 1) {
+                        issue_store();
+                        __builtin_amdgcn_sched_barrier(0);
+                        j++;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (r == NCR - 1) issue_store();
+                    if constexpr (r == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        t += M;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #define W_(k) win[(s - (16 * r + (k)) + 2 * T) % T]
 #ifndef OHGPU_DIAG_NO_TAPS
-                    lean_taps16(acc, cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
-                                W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1), W_(0));
+                    if constexpr (r == 0)
+                        lean_taps16_unpack(cf[0], raw, in_sel[(s % SF) % PH], win[s], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
+                                           W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1));
+                    else
+                        lean_taps16(cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
+                                    W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1), W_(0));
+#else
+                    if constexpr (r == 0) win[s] = lean_unpack(raw, in_sel[(s % SF) % PH]);
 #endif
 #undef W_
 #ifndef OHGPU_DIAG_NO_COEF
@@ -526,7 +547,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 // multipliers per fetch, waited for in place (once per eight outputs of a ramped unit; the other waves cover it).
 #define OHGPU_RAMP_ASM(Y, L0, L1)                                 \
                     "s_and_b32 vcc_lo, %[j], 3\n\t"                \
-                    "s_cmp_lg_u32 vcc_lo, 0\n\t"                   \
+                    "s_cmp_lg_u32 vcc_lo, 1\n\t"                   \
                     "s_cbranch_scc1 " #L1 "f\n\t"                  \
                     "s_bitcmp1_b32 %[j], 2\n\t"                    \
                     "s_cbranch_scc1 " #L0 "f\n\t"                  \
@@ -550,23 +571,15 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                     "v_cmp_ne_u32 vcc, 0xffff, %[mu]\n\t"          \
                     "v_lshlrev_b32 %[t], 8, %[t]\n\t"              \
                     "v_cndmask_b32 " Y ", " Y ", %[t], vcc\n\t"
-#if OHGPU_LEAN_CHAINS == 1
-                acc0 = acc.a0;
-#elif OHGPU_LEAN_CHAINS == 2
-                asm volatile("v_add_f64 %0, %1, %2" : "=v"(acc0) : "v"(acc.a0), "v"(acc.a1));
-#else
-                asm volatile("v_add_f64 %1, %1, %3\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %0, %1, %2"
-                             : "=&v"(acc0), "+v"(acc.a0), "+v"(acc.a2) : "v"(acc.a1), "v"(acc.a3));
-#endif
                 uint32_t t16, mu;
                 if constexpr (PAIR) {
                     // (laid out so that an output of a plain unit takes exactly one taken branch)
                     uint32_t give, got;
                     asm volatile(
-                        "s_bitcmp1_b32 %[j], 0\n\t"
+                        "s_bitcmp0_b32 %[j], 0\n\t"
                         "s_cbranch_scc1 40f\n\t"
                         // first frame of a pair: its value waits in ye
-                        "v_cvt_u32_f64 %[ye], %[acc]\n\t"
+                        "v_cvt_u32_f64 %[ye], " OHGPU_ACC "\n\t"
                         "s_cmp_lg_u32 %[rf], 0\n\t"
                         "v_med3_u32 %[ye], %[ye], %[clo], %[chi]\n\t"
                         "s_cbranch_scc1 70f\n\t"
@@ -581,7 +594,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         // second frame: lane A (channel 0) needs B's first value, lane B needs A's second one; every lane offers what
                         // its partner wants and one quad-permuted move fetches it (two instructions between the offer's write and its
                         // DPP read); two byte permutes make the lane's two words of the pair's three
-                        "v_cvt_u32_f64 %[yo], %[acc]\n\t"
+                        "v_cvt_u32_f64 %[yo], " OHGPU_ACC "\n\t"
                         "s_cmp_lg_u32 %[rf], 0\n\t"
                         "v_med3_u32 %[yo], %[yo], %[clo], %[chi]\n\t"
                         "s_cbranch_scc1 80b\n"
@@ -598,13 +611,13 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         : [ye] "+v"(y_even), [yo] "+v"(y_odd), [sta] "+v"(st_addr), [lo] "+v"(st_lo), [hi] "+v"(st_hi), [rp] "+s"(ring_pos),
                           [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [moff] "+v"(moff),
                           [give] "=&v"(give), [got] "=&v"(got), [t] "=&v"(t16), [mu] "=&v"(mu)
-                        : [acc] "v"(acc0), [clo] "s"(clamp_lo), [chi] "v"(clamp_hi), [j] "s"(j), [rf] "s"(ramped_u), [mb] "s"(mbase),
+                        : [clo] "s"(clamp_lo), [chi] "v"(clamp_hi), [j] "s"(j), [rf] "s"(ramped_u), [mb] "s"(mbase),
                           [m55] "s"(0x5555555555555555ull), [rl] "v"(ring_lane), [ring] "s"(ring_bytes), [sl] "v"(sel_lo), [sh] "v"(sel_hi),
                           [step] "i"(2 * FB_DST)
-                        : "vcc", "scc", "memory");
+                        : "vcc", "scc", "memory", OHGPU_ACC_CLOBBER);
                 } else {
                     asm volatile(
-                        "v_cvt_u32_f64 %[yo], %[acc]\n\t"
+                        "v_cvt_u32_f64 %[yo], " OHGPU_ACC "\n\t"
                         "s_cmp_lg_u32 %[rf], 0\n\t"
                         "v_med3_u32 %[yo], %[yo], %[clo], %[chi]\n\t"
                         "s_cbranch_scc0 41f\n\t"
@@ -625,14 +638,12 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         "s_cselect_b32 %[rp], 0, %[rp]"
                         : [yo] "+v"(y_odd), [sta] "+v"(st_addr), [lo] "+v"(st_lo), [rp] "+s"(ring_pos),
                           [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [moff] "+v"(moff), [t] "=&v"(t16), [mu] "=&v"(mu)
-                        : [acc] "v"(acc0), [clo] "s"(clamp_lo), [chi] "v"(clamp_hi), [j] "s"(j), [rf] "s"(ramped_u), [mb] "s"(mbase),
+                        : [clo] "s"(clamp_lo), [chi] "v"(clamp_hi), [j] "s"(j), [rf] "s"(ramped_u), [mb] "s"(mbase),
                           [rl] "v"(ring_lane), [ring] "s"(ring_bytes), [step] "i"(FB_DST), [le] "i"(DST_LE ? (DB == 4 ? 2 : 1) : 0),
                           [shr] "i"(DB == 4 ? 0 : 24 - 8 * DB), [bsw] "s"(0x0c000102u)
-                        : "vcc", "scc", "memory");
+                        : "vcc", "scc", "memory", OHGPU_ACC_CLOBBER);
                 }
 #undef OHGPU_RAMP_ASM
-                j++;
-                t += M;
                 } while (t < tle);
             }
         }, std::make_integer_sequence<int, T>{});

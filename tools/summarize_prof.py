@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = name.split("(")[0]
+    if "src_lean_kernel" in name:                                      # keep the instantiation: <T, channels, src bytes, src LE, dst bytes, dst LE>
+        return "src_lean_kernel" + name[name.index("src_lean_kernel") + len("src_lean_kernel"):].replace(" ", "")
     for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_line_kernel", "pcm_msg_kernel_v1", "fmt_line_kernel", "fmt_kernel_v1", "flywheel_kernel", "ohm_header_kernel", "ohm_select_ramp_kernel",
               "unpack_stereo_kernel", "flac_stereo_kernel"):
         if k in name:
@@ -23,6 +25,7 @@ def short(name):
 def main():
     tag = sys.argv[1]
     what = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 10 --warmup 3 --no-cpu"   # the profiled command
+    latest = len(sys.argv) > 3 and sys.argv[3] == "--latest"           # this run is bench.py's default workload: feed roofline.traffic
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = {"tag": tag, "kernels": {}, "counters": {}}
     for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
@@ -67,7 +70,7 @@ def main():
                "write_size_kib": c["WRITE_SIZE"], "kernel_avg_us_trace": out["kernels"][dom]["avg_us"],
                "source": f"profiles/{tag}_summary.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes",
                "streams_per_gpu": 256, "frames_per_stream": 441000, "kernel_variant": 0}
-        if dom == "src_block_kernel":                                  # bench.py reads this one for roofline.traffic
+        if latest:                                                     # bench.py reads this one for roofline.traffic
             json.dump(pmc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
         out["hbm_traffic"] = pmc
     print(json.dumps(out, indent=1, sort_keys=True))
