@@ -97,6 +97,45 @@ private:
 #define TEST_THROWS(expr, Ex) do { gChecks++; bool thrown_ = false; try { expr; } catch (Ex&) { thrown_ = true; } \
     if (!thrown_) { gFailures++; printf("FAILED %s:%d  %s did not throw %s\n", __FILE__, __LINE__, #expr, #Ex); } } while (0)
 
+// RampValidator's continuity rule (Pipeline/RampValidator.cpp:73-124) as a checker the suites below hang behind the manager's
+// lanes: a ramp starts at an end of the scale, every message of a ramp starts where the last one ended (a drain may jump to an
+// end), a ramp that reached its end is over; Mode and DecodedStream start afresh.  The reference logs a warning; here it fails.
+class RampContinuity {
+public:
+    void NewStream() { iRamping = false; iLast = 0xffffffffu; iDraining = false; }
+    void Drain() { iDraining = true; }
+    void Audio(const Media::Ramp& aRamp)
+    {
+        if (iRamping) {
+            if (aRamp.Start() != iLast) {
+                TEST(iDraining && (aRamp.Start() == Ramp::kMin || aRamp.Start() == Ramp::kMax));
+            }
+            iLast = aRamp.End();
+            Complete(aRamp);
+        }
+        else if (aRamp.IsEnabled()) {
+            iRamping = true;
+            if (aRamp.Direction() == Ramp::EUp) TEST(aRamp.Start() == Ramp::kMin);
+            else if (aRamp.Direction() == Ramp::EDown) TEST(aRamp.Start() == Ramp::kMax);
+            iLast = aRamp.End();
+            Complete(aRamp);
+        }
+        iDraining = false;
+        iChecked++;
+    }
+    TUint Checked() const { return iChecked; }
+private:
+    void Complete(const Media::Ramp& aRamp)
+    {
+        if ((aRamp.Direction() == Ramp::EUp && iLast == Ramp::kMax) || (aRamp.Direction() == Ramp::EDown && iLast == Ramp::kMin)) {
+            iRamping = false;
+            iLast = 0xffffffffu;
+        }
+    }
+    TBool iRamping = false, iDraining = false;
+    TUint iLast = 0xffffffffu, iChecked = 0;
+};
+
 // ------------------------------------------------------------------------------------------- control plane
 static void SuiteRampControl()
 {   // TestMsg.cpp:1391-1443, 1593-1625
@@ -714,11 +753,14 @@ static void SuiteManyLanesStarveTogetherGpu(MsgFactory& aFactory)
             while (manager.SizeInJiffies(l) != total[l]) std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
         std::vector<Msg*> out;
+        std::vector<RampContinuity> continuity(kLanes);      // RampValidator's rule behind every lane
         for (TUint t = 0; t < 2 + kMsgs; t++) {              // mode, stream, then the audio: nothing to rescue yet
             manager.Tick(out);
             TEST(out.size() == kLanes);
-            for (Msg* m : out) {
+            for (TUint l = 0; l < kLanes; l++) {
+                Msg* m = out[l];
                 TEST(KindOf(m) == (t == 0 ? MsgKind::Mode : t == 1 ? MsgKind::DecodedStream : MsgKind::AudioPcm));
+                if (t >= 2) continuity[l].Audio(static_cast<MsgAudioPcm*>(m)->Ramp());
                 m->RemoveRef();
             }
         }
@@ -740,6 +782,7 @@ static void SuiteManyLanesStarveTogetherGpu(MsgFactory& aFactory)
                 const MsgKind kind = KindOf(out[l]);
                 if (kind == MsgKind::AudioPcm) {
                     TEST(!halted[l] && manager.State(l) == LaneState::FlywheelRamping);
+                    continuity[l].Audio(static_cast<MsgAudioPcm*>(out[l])->Ramp());
                     rescued[l].push_back(out[l]);
                     continue;
                 }
@@ -751,7 +794,7 @@ static void SuiteManyLanesStarveTogetherGpu(MsgFactory& aFactory)
         }
         TEST(manager.RescueLaunches() == 1);                 // ONE rescue for 64 lanes...
         TEST(RescueBatch::FlywheelLaunches() == launches + 1);                     // ...and one flywheel launch on the device
-        for (TUint l = 0; l < kLanes; l++) TEST(halted[l] == 1 && quit[l] == 1);
+        for (TUint l = 0; l < kLanes; l++) TEST(halted[l] == 1 && quit[l] == 1 && continuity[l].Checked() >= kMsgs + 20);
         TEST(observer.iStarted.load() == 2 * kLanes && observer.iStopped.load() == kLanes);     // buffering at start, playing, buffering again
         for (TUint l = 0; l < kLanes; l++) {
             const RescueCase& cs = formats[l % kFormats];
@@ -1262,9 +1305,9 @@ private: // from IStreamHandler / IStarvationRamperObserver
     }
     void NotifyStarvationRamperBuffering(TBool aBuffering) override { iBuffering = aBuffering; }
 private: // from IMsgProcessor
-    Msg* ProcessMsg(MsgMode* aMsg) override { iLastPulledMsg = EMsgMode; return aMsg; }
+    Msg* ProcessMsg(MsgMode* aMsg) override { iLastPulledMsg = EMsgMode; iContinuity.NewStream(); return aMsg; }
     Msg* ProcessMsg(MsgTrack* aMsg) override { iLastPulledMsg = EMsgTrack; return aMsg; }
-    Msg* ProcessMsg(MsgDrain* aMsg) override { iLastPulledMsg = EMsgDrain; return aMsg; }
+    Msg* ProcessMsg(MsgDrain* aMsg) override { iLastPulledMsg = EMsgDrain; iContinuity.Drain(); return aMsg; }
     Msg* ProcessMsg(MsgDelay* aMsg) override { iLastPulledMsg = EMsgDelay; return aMsg; }
     Msg* ProcessMsg(MsgEncodedStream* aMsg) override { iLastPulledMsg = EMsgEncodedStream; return aMsg; }
     Msg* ProcessMsg(MsgStreamSegment* aMsg) override { ASSERTS(); return aMsg; }
@@ -1274,12 +1317,13 @@ private: // from IMsgProcessor
     Msg* ProcessMsg(MsgHalt* aMsg) override { iLastPulledMsg = EMsgHalt; return aMsg; }
     Msg* ProcessMsg(MsgFlush* aMsg) override { iLastPulledMsg = EMsgFlush; return aMsg; }
     Msg* ProcessMsg(MsgWait* aMsg) override { iLastPulledMsg = EMsgWait; return aMsg; }
-    Msg* ProcessMsg(MsgDecodedStream* aMsg) override { iLastPulledMsg = EMsgDecodedStream; return aMsg; }
+    Msg* ProcessMsg(MsgDecodedStream* aMsg) override { iLastPulledMsg = EMsgDecodedStream; iContinuity.NewStream(); return aMsg; }
     Msg* ProcessMsg(MsgAudioPcm* aMsg) override
     {   // ProcessAudio, :323-346
         iLastPulledMsg = EMsgAudioPcm;
         iJiffies += aMsg->Jiffies();
         const Media::Ramp& ramp = aMsg->Ramp();
+        iContinuity.Audio(ramp);
         if (iRampingDown) {
             TEST(ramp.Direction() == Ramp::EDown);
             TEST(ramp.Start() == iLastRampPos);
@@ -1627,6 +1671,7 @@ private:
     EMsgType iLastPulledMsg = ENone;
     TBool iRampingUp = false, iRampingDown = false, iBuffering = false, iStarving = false;
     TUint iStreamId = 0, iLastRampPos = 0, iNextStreamId = 1, iStarvingStreamId = 0, iSampleRate = 0, iBitDepth = 0;
+    RampContinuity iContinuity;
     TUint64 iTrackOffset = 0, iJiffies = 0;
     std::vector<TByte> iPcmData;
 };

@@ -112,3 +112,35 @@ def test_product_never_touches_the_oracle():
                 assert "ohp_" not in code and "oracle_lib" not in code, f"{f} references the oracle"
     needed = subprocess.check_output(["readelf", "-d", capi.LIB_PATH]).decode()
     assert "ohp_oracle" not in needed
+
+
+def test_the_shipped_library_is_not_a_diagnostic_build():
+    """The ablation switches, phase stamps and environment hooks of the kernels exist only under -DOHGPU_DIAG, which
+    build.py adds only when OHGPU_EXTRA_FLAGS asks for it (tools/exp_*.sh).  The shipped object must carry none of it: no
+    hook names in its data, no getenv among its imports, and every mention of a hook in the sources inside an #ifdef."""
+    from ohpipeline_amd import build as product_build
+    lib_path = product_build.LIB_PATH
+    blob = open(lib_path, "rb").read()
+    for needle in (b"OHGPU_DIAG", b"OHGPU_EXP", b"STAMP_FILE"):
+        assert needle not in blob, needle
+    imports = subprocess.run(["nm", "-D", "--undefined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in imports
+    assert "OHGPU_DIAG" not in " ".join(sum(product_build.SOURCE_FLAGS.values(), []))
+    csrc = os.path.join(ROOT, "ohpipeline_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        depth_diag = []                                   # stack of "is this #if level a DIAG guard (or inside one)"
+        for no, line in enumerate(open(os.path.join(csrc, name), errors="replace"), 1):
+            code = line.split("//")[0]
+            s = code.strip()
+            if s.startswith(("#ifdef", "#ifndef", "#if ")):
+                inside = bool(depth_diag and depth_diag[-1])
+                depth_diag.append(inside or ("OHGPU_DIAG" in s and not s.startswith("#ifndef")) or
+                                  (s.startswith("#ifndef") and "OHGPU_DIAG" in s and False))
+            elif s.startswith("#endif"):
+                depth_diag.pop()
+            elif s.startswith(("#else", "#elif")):
+                pass                                      # (the other arm of a DIAG guard is product code, but it names no hook)
+            elif "getenv" in code or re.search(r"OHGPU_DIAG_\w+", code):
+                if s.startswith("#define STAMP") or "#ifndef OHGPU_DIAG" in s:
+                    continue
+                assert depth_diag and depth_diag[-1], f"{name}:{no}: a diagnostic hook outside #ifdef OHGPU_DIAG*: {s}"
