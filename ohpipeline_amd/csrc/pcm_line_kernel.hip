@@ -99,161 +99,9 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
         }
         return issued;
     };
-    uint32_t grp_sel[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};        // group path: selector of destination dword j over source dwords {2pr+1, 2pr}
-    uint32_t grp_for = 0xffffffffu;                                   // the per-subsample selector they were derived from
-    PcmChunk ck = chunks[chunk];
-    PcmChunk nx = ck;
-    bool has_nx = chunk + stride < n_chunks;
-    if (has_nx) nx = chunks[chunk + stride];
-    stage_in(ck, 0);
-    uint32_t buf = 0;
-    while (true) {
-        // fetch the record after next, start the next chunk's input, then wait for this chunk's input only
-        const bool has_nn = has_nx && chunk + 2 * stride < n_chunks;
-        PcmChunk nn = nx;
-        if (has_nn) nn = chunks[chunk + 2 * stride];
-        const uint32_t k_nx = has_nx ? stage_in(nx, buf ^ 1) : 0u;
-        if constexpr (SB != 0 && DB != 0) {
-            if (is_plain(ck)) {
-                // ---- plain chunk of a uniform batch: registers only.  Lane = GROUP of four subsamples: 4*SB source bytes
-                // (one unaligned 8/12/16-byte load: unaligned wide accesses run at full rate, tools/micro/unaligned_store.hip),
-                // a fixed byte shuffle (per destination dword: one v_perm_b32 per pair of source dwords, selectors derived
-                // from the record's per-subsample selector when the layout changes), 4*DB destination bytes (one store).
-                if (ck.plain_sel != grp_for) {
-                    grp_for = ck.plain_sel;
-#pragma unroll
-                    for (int j = 0; j < DB; j++)
-#pragma unroll
-                        for (int pr = 0; pr < 2; pr++) {
-                            uint32_t sel = 0;
-#pragma unroll
-                            for (int t = 0; t < 4; t++) {
-                                const int B = 4 * j + t, qi = B / DB, m = B % DB;
-                                const uint32_t sbyte = (ck.plain_sel >> (8 * m)) & 0xffu;
-                                const uint32_t sidx = (uint32_t)(qi * SB) + sbyte;              // source byte of the group
-                                uint32_t code = 0x0c;                                            // zero
-                                if (sbyte != 0x0c && (sidx >> 3) == (uint32_t)pr) code = sidx & 7u;   // byte of {I[2pr+1], I[2pr]}
-                                sel |= code << (8 * t);
-                            }
-                            grp_sel[j][pr] = sel;
-                        }
-                }
-                const uint32_t n_grp = ck.nq >> 2;
-                const uint8_t* const sp = src + ck.src_off;
-                uint8_t* const dp = dst + ck.dst_off;
-                for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {
-                    typename GroupVec<SB>::type in_a = {}, in_b = {};
-                    const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
-                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
-                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
-                    if (ga < n_grp) group_store<SB, DB>(dp + (size_t)ga * (4 * DB), in_a, grp_sel);
-                    if (gb < n_grp) group_store<SB, DB>(dp + (size_t)gb * (4 * DB), in_b, grp_sel);
-                }
-                // the chunk's last 1..3 subsamples: byte by byte
-                const uint32_t tail0 = n_grp * 4, tail_bytes = (ck.nq - tail0) * DB;
-                if (lane < tail_bytes) {
-                    const uint32_t q = tail0 + lane / DB, m = lane % DB;
-                    const uint32_t sbyte = (ck.plain_sel >> (8 * m)) & 0xffu;
-                    dp[(size_t)q * DB + m] = sbyte == 0x0c ? (uint8_t)0 : sp[(size_t)q * SB + sbyte];
-                }
-                if (!has_nx) break;
-                chunk += stride;
-                ck = nx; nx = nn; has_nx = has_nn;
-                buf ^= 1;
-                continue;
-            }
-            if (!(ck.flags & kChunkSilence)) {
-                // ---- attenuated and / or ramped chunk of a uniform batch: the same groups of four subsamples, each
-                // subsample taken out of the loaded registers (static positions), run through pcm_device.h's expressions and
-                // put back at its (static) place in the destination registers.
-                const bool src_le = (ck.flags & kChunkSrcLe) != 0, dst_le = (ck.flags & kChunkDstLe) != 0;
-                const bool ramp = (ck.flags & kChunkRamp) != 0, atten = ck.attenuation != OHGPU_UNITY_ATTENUATION;
-                const uint32_t keep = DB == 4 ? ((ck.flags & kChunkZeroLsb) ? 0xffffff00u : 0xffffffffu) : ~(0xffffffffu >> (8 * (DB & 3)));
-                const int32_t total = (int32_t)((uint32_t)ck.ramp_start - (uint32_t)ck.ramp_end);
-                auto transform = [&](uint32_t raw, uint32_t sub) __attribute__((always_inline)) -> uint32_t {
-                    uint32_t w = src_le ? (raw << (32 - 8 * SB)) : (__builtin_bswap32(raw) & ~(SB == 4 ? 0u : (0xffffffffu >> (8 * (SB & 3)))));
-                    if (atten) w = attenuate_word(w, ck.attenuation);
-                    if (ramp) {
-                        const uint32_t frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
-                        const uint32_t mult = s_ramp[ramp_index_magic(ck.ramp_start, total, frame, ck.n_frames, ck.m_n1, ck.s_n1)];
-                        w = ramp_word(w, mult, SB, ck.channels, sub - frame * ck.channels);
-                    }
-                    w &= keep;
-                    return dst_le ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);      // destination bytes in memory order, first byte low
-                };
-                const uint32_t n_grp = ck.nq >> 2;
-                const uint8_t* const sp = src + ck.src_off;
-                uint8_t* const dp = dst + ck.dst_off;
-                const bool stereo_even = ck.channels == 2 && (ck.q0 & 1) == 0;     // a group = two whole frames: two ramp look-ups, not four
-                auto ramp_mult = [&](uint32_t frame) __attribute__((always_inline)) -> uint32_t {
-                    return s_ramp[ramp_index_magic(ck.ramp_start, total, frame, ck.n_frames, ck.m_n1, ck.s_n1)];
-                };
-                auto do_group = [&](uint32_t g, const typename GroupVec<SB>::type& in) __attribute__((always_inline)) {
-                    uint32_t iw[5] = {in[0], in[1], SB > 2 ? in[2 < SB ? 2 : 0] : 0u, SB > 3 ? in[3 < SB ? 3 : 0] : 0u, 0u};
-                    uint32_t ow[5] = {0, 0, 0, 0, 0};
-                    uint32_t m_lo = 0, m_hi = 0;
-                    if (ramp && stereo_even) { const uint32_t f = (ck.q0 >> 1) + 2 * g; m_lo = ramp_mult(f); m_hi = ramp_mult(f + 1); }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int off = k * SB, o = k * DB;
-                        const uint32_t raw = (off & 3) ? __builtin_amdgcn_alignbyte(iw[(off >> 2) + 1], iw[off >> 2], off & 3) : iw[off >> 2];
-                        uint32_t w = src_le ? (raw << (32 - 8 * SB)) : (__builtin_bswap32(raw) & ~(SB == 4 ? 0u : (0xffffffffu >> (8 * (SB & 3)))));
-                        if (atten) w = attenuate_word(w, ck.attenuation);
-                        if (ramp) {
-                            if (stereo_even) {
-                                w = ramp_word(w, k < 2 ? m_lo : m_hi, SB, 2, (uint32_t)(k & 1));
-                            } else {
-                                const uint32_t sub = ck.q0 + 4 * g + k, frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
-                                w = ramp_word(w, ramp_mult(frame), SB, ck.channels, sub - frame * ck.channels);
-                            }
-                        }
-                        w &= keep;
-                        const uint32_t v = dst_le ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);   // destination bytes in memory order
-                        ow[o >> 2] |= v << (8 * (o & 3));
-                        if ((o & 3) + DB > 4) ow[(o >> 2) + 1] |= v >> (32 - 8 * (o & 3));
-                    }
-                    typename GroupVec<DB>::type out;
-#pragma unroll
-                    for (int j = 0; j < DB; j++) out[j] = ow[j];
-                    uint8_t* const op = dp + (size_t)g * (4 * DB);
-                    if constexpr (DB == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
-                    else if constexpr (DB == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
-                    else asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
-                };
-                for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {      // two groups per lane in flight
-                    const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
-                    typename GroupVec<SB>::type in_a = {}, in_b = {};
-                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
-                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
-                    if (ga < n_grp) do_group(ga, in_a);
-                    if (gb < n_grp) do_group(gb, in_b);
-                }
-                const uint32_t tail0 = n_grp * 4;                   // the chunk's last 1..3 subsamples, one lane each
-                if (lane < ck.nq - tail0) {
-                    const uint32_t q = tail0 + lane;
-                    uint32_t raw = 0;
-#pragma unroll
-                    for (int bq = 0; bq < SB; bq++) raw |= (uint32_t)sp[(size_t)q * SB + bq] << (8 * bq);
-                    const uint32_t v = transform(raw, ck.q0 + q);
-#pragma unroll
-                    for (int bq = 0; bq < DB; bq++) dp[(size_t)q * DB + bq] = (uint8_t)(v >> (8 * bq));
-                }
-                if (!has_nx) break;
-                chunk += stride;
-                ck = nx; nx = nn; has_nx = has_nn;
-                buf ^= 1;
-                continue;
-            }
-        }
-        if (k_nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (k_nx == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if (k_nx == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        const __attribute__((address_space(3))) uint8_t* in = (const __attribute__((address_space(3))) uint8_t*)&s_in[wave][buf][0];
+    // ---- one chunk through the general path: lane = aligned destination dword.  `in`: the chunk's staged source bytes (the
+    // aligned 16-byte pieces that cover them), not read for a silent chunk ----
+    auto generic_chunk = [&](const PcmChunk& ck, const __attribute__((address_space(3))) uint8_t* in) __attribute__((always_inline)) {
         const uint32_t ch = ck.channels, sb = SB ? SB : ck.sb, db = DB ? DB : ck.db;
         const bool src_le = (ck.flags & kChunkSrcLe) != 0;
         const bool dst_le = (ck.flags & kChunkDstLe) != 0;
@@ -328,11 +176,7 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
                         v = sub_fn(upos) | (sub_fn(upos + 1) << 8) | (sub_fn(upos + 2) << 16) | (sub_fn(upos + 3) << 24);
                     }
                     if (pos >= 0 && (uint32_t)pos + 4 <= len) {
-#ifdef OHGPU_EXP_STORE_PLAIN
-                        *(uint32_t*)(obase + (size_t)k * 4) = v;
-#else
                         __builtin_nontemporal_store(v, (uint32_t*)(obase + (size_t)k * 4));   // written once, never read here
-#endif
                     } else {                                                // first / last dword of the chunk: only its own bytes
                         const uint32_t skip = pos < 0 ? (uint32_t)(-pos) : 0u;   // v starts at stream byte upos = pos + skip
                         for (uint32_t b = skip; b < 4; b++) {
@@ -343,6 +187,197 @@ __global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChun
             }
         };
         if (!(ramp || silence || atten)) emit(subsample_plain); else emit(subsample);
+    };
+    if constexpr (SB != 0 && DB != 0) {
+        // ================= uniform batch: registers only, TWO chunks per trip =================
+        // Lane = GROUP of four subsamples: 4*SB source bytes (one unaligned 8/12/16-byte load: unaligned wide accesses run at
+        // full rate, tools/micro/unaligned_store.hip) -> 4*DB destination bytes (one store).  A chunk is a message (or a run of
+        // plain messages): at most a few hundred groups, so a wave that takes one chunk at a time has two loads per lane in
+        // flight and then waits out the whole HBM latency -- round 1's kernel moved 24 KB per CU per latency, 3 TB/s of reads.
+        // Every trip now loads the first 128 groups of BOTH its chunks before it touches either, and the records of the next
+        // trip's chunks are fetched before this trip's are processed.  (Measured and dropped, same box: pulling the next trip's
+        // lines into the L2 ahead of time through the LDS DMA path, -7 % on ramped stereo; computing every group's ramp
+        // multipliers -- two or three per group whatever the channel count -- before the wait, -14 %: both cost registers,
+        // and with them waves.)
+        typedef typename GroupVec<SB>::type Vec;
+        uint32_t grp_sel[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};    // plain path: selector of destination dword j over source dwords {2pr+1, 2pr}
+        uint32_t grp_for = 0xffffffffu;                               // the per-subsample selector they were derived from
+        auto is_silence = [](const PcmChunk& c) __attribute__((always_inline)) -> bool { return (c.flags & kChunkSilence) != 0; };
+        auto load_head = [&](const PcmChunk& c, bool on, Vec& a, Vec& b) __attribute__((always_inline)) {
+            if (!on || is_silence(c)) return;
+            const uint32_t n_grp = c.nq >> 2;
+            const uint8_t* const sp = src + c.src_off;
+            if (lane < n_grp) group_load<SB>(a, sp + (size_t)lane * (4 * SB));
+            if (64 + lane < n_grp) group_load<SB>(b, sp + (size_t)(64 + lane) * (4 * SB));
+        };
+        // ---- plain chunk: a fixed byte shuffle (per destination dword: one v_perm_b32 per pair of source dwords, selectors
+        // derived from the record's per-subsample selector when the layout changes) ----
+        auto plain_chunk = [&](const PcmChunk& ck, Vec& in_a, Vec& in_b) __attribute__((always_inline)) {
+            if (ck.plain_sel != grp_for) {
+                grp_for = ck.plain_sel;
+#pragma unroll
+                for (int j = 0; j < DB; j++)
+#pragma unroll
+                    for (int pr = 0; pr < 2; pr++) {
+                        uint32_t sel = 0;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int B = 4 * j + t, qi = B / DB, m = B % DB;
+                            const uint32_t sbyte = (ck.plain_sel >> (8 * m)) & 0xffu;
+                            const uint32_t sidx = (uint32_t)(qi * SB) + sbyte;              // source byte of the group
+                            uint32_t code = 0x0c;                                            // zero
+                            if (sbyte != 0x0c && (sidx >> 3) == (uint32_t)pr) code = sidx & 7u;   // byte of {I[2pr+1], I[2pr]}
+                            sel |= code << (8 * t);
+                        }
+                        grp_sel[j][pr] = sel;
+                    }
+            }
+            const uint32_t n_grp = ck.nq >> 2;
+            const uint8_t* const sp = src + ck.src_off;
+            uint8_t* const dp = dst + ck.dst_off;
+            for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {
+                const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
+                if (g0 != 0) {                                          // (the first 128 groups were loaded by the trip)
+                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
+                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
+                }
+                if (ga < n_grp) group_store<SB, DB>(dp + (size_t)ga * (4 * DB), in_a, grp_sel);
+                if (gb < n_grp) group_store<SB, DB>(dp + (size_t)gb * (4 * DB), in_b, grp_sel);
+            }
+            // the chunk's last 1..3 subsamples: byte by byte
+            const uint32_t tail0 = n_grp * 4, tail_bytes = (ck.nq - tail0) * DB;
+            if (lane < tail_bytes) {
+                const uint32_t q = tail0 + lane / DB, m = lane % DB;
+                const uint32_t sbyte = (ck.plain_sel >> (8 * m)) & 0xffu;
+                dp[(size_t)q * DB + m] = sbyte == 0x0c ? (uint8_t)0 : sp[(size_t)q * SB + sbyte];
+            }
+        };
+        // ---- attenuated and / or ramped chunk: the same groups of four subsamples, each subsample taken out of the loaded
+        // registers (static positions), run through pcm_device.h's expressions and put back at its (static) place in the
+        // destination registers ----
+        auto xform_chunk = [&](const PcmChunk& ck, Vec& in_a, Vec& in_b) __attribute__((always_inline)) {
+            const bool src_le = (ck.flags & kChunkSrcLe) != 0, dst_le = (ck.flags & kChunkDstLe) != 0;
+            const bool ramp = (ck.flags & kChunkRamp) != 0, atten = ck.attenuation != OHGPU_UNITY_ATTENUATION;
+            const uint32_t keep = DB == 4 ? ((ck.flags & kChunkZeroLsb) ? 0xffffff00u : 0xffffffffu) : ~(0xffffffffu >> (8 * (DB & 3)));
+            const int32_t total = (int32_t)((uint32_t)ck.ramp_start - (uint32_t)ck.ramp_end);
+            auto transform = [&](uint32_t raw, uint32_t sub) __attribute__((always_inline)) -> uint32_t {
+                uint32_t w = src_le ? (raw << (32 - 8 * SB)) : (__builtin_bswap32(raw) & ~(SB == 4 ? 0u : (0xffffffffu >> (8 * (SB & 3)))));
+                if (atten) w = attenuate_word(w, ck.attenuation);
+                if (ramp) {
+                    const uint32_t frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
+                    const uint32_t mult = s_ramp[ramp_index_magic(ck.ramp_start, total, frame, ck.n_frames, ck.m_n1, ck.s_n1)];
+                    w = ramp_word(w, mult, SB, ck.channels, sub - frame * ck.channels);
+                }
+                w &= keep;
+                return dst_le ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);      // destination bytes in memory order, first byte low
+            };
+            const uint32_t n_grp = ck.nq >> 2;
+            const uint8_t* const sp = src + ck.src_off;
+            uint8_t* const dp = dst + ck.dst_off;
+            const bool stereo_even = ck.channels == 2 && (ck.q0 & 1) == 0;     // a group = two whole frames: two ramp look-ups, not four
+            auto ramp_mult = [&](uint32_t frame) __attribute__((always_inline)) -> uint32_t {
+                return s_ramp[ramp_index_magic(ck.ramp_start, total, frame, ck.n_frames, ck.m_n1, ck.s_n1)];
+            };
+            auto do_group = [&](uint32_t g, const Vec& in) __attribute__((always_inline)) {
+                uint32_t iw[5] = {in[0], in[1], SB > 2 ? in[2 < SB ? 2 : 0] : 0u, SB > 3 ? in[3 < SB ? 3 : 0] : 0u, 0u};
+                uint32_t ow[5] = {0, 0, 0, 0, 0};
+                uint32_t m_lo = 0, m_hi = 0;
+                if (ramp && stereo_even) { const uint32_t f = (ck.q0 >> 1) + 2 * g; m_lo = ramp_mult(f); m_hi = ramp_mult(f + 1); }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int off = k * SB, o = k * DB;
+                    const uint32_t raw = (off & 3) ? __builtin_amdgcn_alignbyte(iw[(off >> 2) + 1], iw[off >> 2], off & 3) : iw[off >> 2];
+                    uint32_t w = src_le ? (raw << (32 - 8 * SB)) : (__builtin_bswap32(raw) & ~(SB == 4 ? 0u : (0xffffffffu >> (8 * (SB & 3)))));
+                    if (atten) w = attenuate_word(w, ck.attenuation);
+                    if (ramp) {
+                        if (stereo_even) {
+                            w = ramp_word(w, k < 2 ? m_lo : m_hi, SB, 2, (uint32_t)(k & 1));
+                        } else {
+                            const uint32_t sub = ck.q0 + 4 * g + k, frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
+                            w = ramp_word(w, ramp_mult(frame), SB, ck.channels, sub - frame * ck.channels);
+                        }
+                    }
+                    w &= keep;
+                    const uint32_t v = dst_le ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);   // destination bytes in memory order
+                    ow[o >> 2] |= v << (8 * (o & 3));
+                    if ((o & 3) + DB > 4) ow[(o >> 2) + 1] |= v >> (32 - 8 * (o & 3));
+                }
+                typename GroupVec<DB>::type out;
+#pragma unroll
+                for (int j = 0; j < DB; j++) out[j] = ow[j];
+                uint8_t* const op = dp + (size_t)g * (4 * DB);
+                if constexpr (DB == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
+                else if constexpr (DB == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
+            };
+            for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {
+                const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
+                if (g0 != 0) {                                          // (the first 128 groups were loaded by the trip)
+                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
+                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
+                }
+                if (ga < n_grp) do_group(ga, in_a);
+                if (gb < n_grp) do_group(gb, in_b);
+            }
+            const uint32_t tail0 = n_grp * 4;                   // the chunk's last 1..3 subsamples, one lane each
+            if (lane < ck.nq - tail0) {
+                const uint32_t q = tail0 + lane;
+                uint32_t raw = 0;
+#pragma unroll
+                for (int bq = 0; bq < SB; bq++) raw |= (uint32_t)sp[(size_t)q * SB + bq] << (8 * bq);
+                const uint32_t v = transform(raw, ck.q0 + q);
+#pragma unroll
+                for (int bq = 0; bq < DB; bq++) dp[(size_t)q * DB + bq] = (uint8_t)(v >> (8 * bq));
+            }
+        };
+        PcmChunk c0 = chunks[chunk];
+        bool has1 = chunk + stride < n_chunks;
+        PcmChunk c1 = chunks[has1 ? chunk + stride : chunk];
+        while (true) {
+            Vec a0 = {}, b0 = {}, a1 = {}, b1 = {};
+            load_head(c0, true, a0, b0);
+            load_head(c1, has1, a1, b1);
+            // the next trip's records, while this trip's audio is on its way
+            const uint32_t next = chunk + 2 * stride;
+            const bool more = next < n_chunks, more1 = next + stride < n_chunks;
+            const PcmChunk n0 = chunks[more ? next : chunk];
+            const PcmChunk n1 = chunks[more1 ? next + stride : chunk];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : : "memory");
+            if (is_silence(c0)) generic_chunk(c0, nullptr);
+            else if (is_plain(c0)) plain_chunk(c0, a0, b0);
+            else xform_chunk(c0, a0, b0);
+            if (has1) {
+                if (is_silence(c1)) generic_chunk(c1, nullptr);
+                else if (is_plain(c1)) plain_chunk(c1, a1, b1);
+                else xform_chunk(c1, a1, b1);
+            }
+            if (!more) break;
+            chunk = next;
+            c0 = n0; c1 = n1; has1 = more1;
+        }
+        return;
+    }
+    PcmChunk ck = chunks[chunk];
+    PcmChunk nx = ck;
+    bool has_nx = chunk + stride < n_chunks;
+    if (has_nx) nx = chunks[chunk + stride];
+    stage_in(ck, 0);
+    uint32_t buf = 0;
+    while (true) {
+        // fetch the record after next, start the next chunk's input, then wait for this chunk's input only
+        const bool has_nn = has_nx && chunk + 2 * stride < n_chunks;
+        PcmChunk nn = nx;
+        if (has_nn) nn = chunks[chunk + 2 * stride];
+        const uint32_t k_nx = has_nx ? stage_in(nx, buf ^ 1) : 0u;
+        if (k_nx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (k_nx == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (k_nx == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        generic_chunk(ck, (const __attribute__((address_space(3))) uint8_t*)&s_in[wave][buf][0]);
         if (!has_nx) break;
         chunk += stride;
         ck = nx; nx = nn; has_nx = has_nn;
