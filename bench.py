@@ -64,20 +64,33 @@ def taps_for(rate_in):
 class Group:
     """Streams that share a filter and a layout: one source arena, one destination arena, one batch, one launch per step."""
 
-    def __init__(self, capi, rate_in, channels, stream_ids, in_frames, src_bits=BITS, src_endian=None):
+    def __init__(self, capi, rate_in, channels, stream_ids, in_frames, src_bits=BITS, src_endian=None, planar=False):
         self.rate_in, self.channels, self.stream_ids, self.in_frames = rate_in, channels, list(stream_ids), in_frames
+        self.planar = planar                                  # config 5: the source is the FLAC decoder's TInt32 planes (OHGPU_FLAG_SRC_PLANAR32)
         self.taps = taps_for(rate_in)
         self.L, self.M, self.coef = capi.src_design(rate_in, RATE_OUT, self.taps, BETA, F_PASS)
         self.out_total = (in_frames * self.L + self.M - 1) // self.M
         self.n_msgs = (self.out_total + OUT_FRAMES_PER_MSG - 1) // OUT_FRAMES_PER_MSG
         self.src_bits = src_bits
         self.src_endian = capi.ENDIAN_LITTLE if src_endian is None else src_endian
-        self.fb_src, self.fb_dst = channels * src_bits // 8, channels * BITS // 8
+        self.fb_src, self.fb_dst = (channels * 4 if planar else channels * src_bits // 8), channels * BITS // 8
         n = len(self.stream_ids)
         self.src_bytes, self.dst_bytes = n * in_frames * self.fb_src, n * self.out_total * self.fb_dst
         self.descs = self._descs(capi)
-        self.src = None                                       # filled by the caller (noise, or config 5's packed FLAC audio)
-        self.d_src_external = None                            # config 5: the FLAC pack's destination arena IS this group's source
+        self.src = None                                       # filled by the caller (noise, or config 5's decoded planes)
+        self.d_src_external = None
+        # what the CPU oracle is given: the same descriptors and source -- for a planar group the oracle's COMPOSITION, the planes
+        # packed as CodecFlac::CallbackWrite packs them (filled by bench_flac) and descriptors that read that packed audio
+        self.oracle_src = None
+        self.oracle_descs = self.descs
+        if planar:
+            od = self.descs.copy()
+            per = in_frames * channels * src_bits // 8
+            for k in range(n):
+                od["src_offset"][k * self.n_msgs:(k + 1) * self.n_msgs] = k * per
+            od["flags"] &= ~np.uint8(capi.FLAG_SRC_PLANAR32)
+            od["src_plane_stride"] = 0
+            self.oracle_descs = od
         # algorithmic bytes of a step (SURVEY.md 8d): every input frame read once, every output frame written once
         self.algorithmic_bytes = n * in_frames * self.fb_src + n * self.out_total * self.fb_dst
         self.flops = 2.0 * self.taps * channels * n * self.out_total
@@ -102,6 +115,9 @@ class Group:
             d["ramp_start"][sl] = sched[:, 1]
             d["ramp_end"][sl] = sched[:, 2]
         d["attenuation"] = 256
+        if self.planar:
+            d["flags"] |= capi.FLAG_SRC_PLANAR32
+            d["src_plane_stride"] = self.in_frames * 4
         d["channels"], d["src_bits"], d["src_endian"] = self.channels, self.src_bits, self.src_endian
         d["dst_bits"], d["dst_endian"] = BITS, capi.ENDIAN_BIG
         return d
@@ -210,8 +226,8 @@ def cpu_baseline(groups, got_by_group):
         bounds = np.linspace(0, n, min(2 * threads, n) + 1).astype(int)
         for t in range(len(bounds) - 1):
             if bounds[t + 1] > bounds[t]:
-                part = np.ascontiguousarray(g.descs[bounds[t] * g.n_msgs:bounds[t + 1] * g.n_msgs])
-                jobs.append((ref, part, g.src, dst, (bounds[t + 1] - bounds[t]) * g.in_frames * g.channels))
+                part = np.ascontiguousarray(g.oracle_descs[bounds[t] * g.n_msgs:bounds[t + 1] * g.n_msgs])
+                jobs.append((ref, part, g.src if g.oracle_src is None else g.oracle_src, dst, (bounds[t + 1] - bounds[t]) * g.in_frames * g.channels))
     jobs.sort(key=lambda j: -j[4])                                       # longest first over the pinned threads
 
     def run(kj):
@@ -231,12 +247,13 @@ def cpu_baseline(groups, got_by_group):
     g0 = groups[0]
     ref0 = jobs[0][0] if False else O.Src(g0.rate_in, RATE_OUT, g0.taps, BETA, F_PASS)
     n_one = max(1, min(len(g0.stream_ids), 8))
-    one_part = np.ascontiguousarray(g0.descs[:n_one * g0.n_msgs])
+    one_part = np.ascontiguousarray(g0.oracle_descs[:n_one * g0.n_msgs])
+    g0_src = g0.src if g0.oracle_src is None else g0.oracle_src
     one = []
     for _ in range(3):
         t0 = time.perf_counter()
         rc = lib.ohp_src_msg_process_batch_steady(ref0.h, one_part.ctypes.data_as(C.c_void_p), one_part.size,
-                                                  g0.src.ctypes.data_as(C.c_void_p), outs[0].ctypes.data_as(C.c_void_p))
+                                                  g0_src.ctypes.data_as(C.c_void_p), outs[0].ctypes.data_as(C.c_void_p))
         one.append(time.perf_counter() - t0)
         assert rc == 0
     ok = all(np.array_equal(a, b) for a, b in zip(got_by_group, outs))
@@ -456,11 +473,12 @@ def main():
                     f"contiguous blocks of streams per rank balanced by bytes")
         else:
             what = (f"{args.streams} stereo FLAC streams per GPU (16- and 24-bit, level 5), frames decoded on the host by the reference's libFLAC, "
-                    f"planar TInt32 -> packed (Flac.cpp:379-417) -> 44.1->48 kHz")
+                    f"the decoder's planar TInt32 output read by the resampler itself (CodecFlac::CallbackWrite's pack, Flac.cpp:379-417, "
+                    f"fused into its load) -> 44.1->48 kHz")
         result = {
             "metric": "PCM Msamples/s, 256-stream 44.1->48k S24 resample+ramp+fmt" if args.config == 3 else
                       ("PCM Msamples/s, 2048-stream mixed 44.1/96->48k 2/6/8-channel S24 resample+ramp+fmt" if args.config == 4 else
-                       "PCM Msamples/s, 256-stream FLAC frames -> pack -> 44.1->48k resample+ramp+fmt"),
+                       "PCM Msamples/s, 256-stream FLAC frames -> pack -> 44.1->48k resample+ramp+fmt (one pass)"),
             "value": round(frames_all * args.steps / elapsed / 1e6, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -510,14 +528,14 @@ def main():
             try:                                             # (reported extras: never let them cost the headline line)
                 if args.config == 3:
                     result["end_to_end"] = end_to_end(ctx, capi, groups[0])
-                result["cadence"] = cadence(ctx, capi, head)
+                result["cadence"] = None if head.planar else cadence(ctx, capi, head)    # (the live regime is measured on the packed layouts)
             except Exception as e:
                 result["extras_error"] = f"{type(e).__name__}: {e}"
             base, check = cpu_baseline(groups, got)
             result["cpu_baseline"] = base
             result["check"] = check
             if flac is not None:
-                result["check_flac_pack"] = flac.check(ctx)
+                result["check_flac_decode"] = flac.check(ctx)
         else:
             result["cpu_baseline"] = None
     for g in groups:

@@ -1,5 +1,5 @@
 """bench_flac.py -- BASELINE configs[4] for bench.py: FLAC frames -> pack (CodecFlac::CallbackWrite, Flac.cpp:379-417) ->
-44.1->48 kHz resample -> ramp -> S24 on the device, 256 streams per GPU.
+44.1->48 kHz resample -> ramp -> S24 on the device, 256 streams per GPU, the pack fused into the resampler's load.
 
 The entropy decode stays on the host, as in the reference (CodecFlac drives libFLAC on the codec thread): the synthetic
 streams are encoded and decoded here with the reference's own vendored libFLAC 1.2.1, built from its sources into
@@ -43,37 +43,34 @@ def pack_be(pcm, bits):
 
 
 class FlacFront:
+    """What precedes the device in config 5: the host decode (timed, reported, never part of `value`).  Round 1 packed the
+    decoder's planes on the device into a packed arena the resampler then read (a14 as a kernel of its own); now the
+    resampler reads the planes themselves (OHGPU_FLAG_SRC_PLANAR32: a14 -> a1 -> a-R in one pass), so the step has no
+    kernel of this object's left -- run() is where it was."""
+
     def __init__(self):
-        self.parts = []           # per bit depth: dict(batch, d_planes, d_packed, planes_bytes, packed_bytes, expect)
         self.decode_s = 0.0
         self.decode_threads = 1
         self.frames_decoded = 0
         self.stream_bytes = 0
+        self.lossless = False
 
     def run(self, ctx, ev):
-        if ev is not None:
+        if ev is not None:                 # (bench.py times "the pack": an empty interval now)
             ctx.record(ev[0])
-        for p in self.parts:
-            ctx.fmt_run(p["batch"], p["d_planes"], p["d_packed"])
-        if ev is not None:
             ctx.record(ev[1])
 
     def report(self, pack_ms):
-        pb = sum(p["planes_bytes"] + p["packed_bytes"] for p in self.parts)
         return {"programmes": PROGRAMMES, "encoded_bytes": self.stream_bytes, "decoder": "libFLAC 1.2.1 of the reference tree (oracle/_ref), host",
                 "host_decode": {"frames_per_s_M": round(self.frames_decoded / self.decode_s / 1e6, 2), "threads": self.decode_threads,
                                 "seconds": round(self.decode_s, 3), "what": "every stream decoded once, wall clock, not part of value"},
-                "pack_kernel_ms": round(pack_ms, 4), "pack_gbps": round(pb / (pack_ms * 1e-3) / 1e9, 1)}
+                "pack": "fused: the resampler reads the decoder's planar TInt32 output (OHGPU_FLAG_SRC_PLANAR32); no pack kernel, no packed arena"}
 
     def check(self, ctx):
-        ok = all(np.array_equal(ctx.download(p["d_packed"], p["packed_bytes"]), p["expect"]) for p in self.parts)
-        return "lossless: the device's packed PCM is the PCM that was encoded" if ok else "MISMATCH"
+        return "lossless: the decoded planes the device reads are the PCM that was encoded" if self.lossless else "MISMATCH"
 
     def close(self, ctx):
-        for p in self.parts:
-            ctx.batch_destroy(p["batch"])
-            ctx.free(p["d_planes"])
-            ctx.free(p["d_packed"])
+        pass
 
 
 def build(capi, ctx, args, rank, world, Group):
@@ -100,44 +97,27 @@ def build(capi, ctx, args, rank, world, Group):
     front.frames_decoded = len(ids) * frames
     front.stream_bytes = sum(len(encoded[s % PROGRAMMES][2]) for s in ids)
     groups = []
+    lossless = True
     for bits in (16, 24):
         mine = [i for i, s in enumerate(ids) if encoded[s % PROGRAMMES][0] == bits]
         if not mine:
             continue
-        bps = bits // 8
-        planes, descs = [], []
-        plane_off = 0
+        # The write callback's job (Flac.cpp:379-417) is now two copies per frame: libFLAC's buffer[c][0..blocksize) goes to
+        # its place in the stream's plane c -- [stream][channel][frames] TInt32, what the device reads.
+        planes = np.zeros((len(mine), 2, frames), dtype=np.int32)
         for n_local, i in enumerate(mine):
             frs, md5_ok = decoded[i]
             assert md5_ok
             done = 0
             for (blocksize, ch, fbits, _rate, pl) in frs:
                 assert ch == 2 and fbits == bits
-                planes.append(np.ascontiguousarray(pl, dtype=np.int32).reshape(-1))        # [2][blocksize]
-                max_samples = MAX_BYTES // (bps * ch)                                       # CallbackWrite's chunking (Flac.cpp:379-417)
-                start = 0
-                while start < blocksize:
-                    n = min(blocksize - start, max_samples)
-                    descs.append((plane_off + start * 4, blocksize * 4, (n_local * frames + done + start) * ch * bps, n))
-                    start += n
-                plane_off += 2 * blocksize * 4
+                planes[n_local, :, done:done + blocksize] = np.asarray(pl, dtype=np.int32).reshape(2, blocksize)
                 done += blocksize
             assert done == frames
-        planes = np.concatenate(planes)
-        d = np.zeros(len(descs), dtype=capi.FMT_DESC)
-        arr = np.array(descs, dtype=np.int64)
-        d["src_offset"], d["src_plane_stride"], d["dst_offset"], d["n_frames"] = arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3]
-        d["kind"], d["channels"], d["src_bits"], d["dst_bits"] = capi.FMT_FLAC_PACK, 2, 32, bits
-        packed_bytes = len(mine) * frames * 2 * bps
-        part = {"planes_bytes": planes.nbytes, "packed_bytes": packed_bytes}
-        part["d_planes"] = ctx.upload(planes.view(np.uint8))
-        part["d_packed"] = ctx.malloc(packed_bytes)
-        ctx.memset(part["d_packed"], 0, packed_bytes)
-        part["batch"] = ctx.fmt_batch(d, planes.nbytes, packed_bytes)
-        part["expect"] = np.concatenate([pack_be(encoded[ids[i] % PROGRAMMES][1], bits) for i in mine])
-        front.parts.append(part)
-        g = Group(capi, RATE, 2, [ids[i] for i in mine], frames, src_bits=bits, src_endian=capi.ENDIAN_BIG)
-        g.src = part["expect"]                                   # (what the pack must produce: the CPU oracle's input)
-        g.d_src_external = part["d_packed"]
+            lossless = lossless and np.array_equal(planes[n_local].T, encoded[ids[i] % PROGRAMMES][1])
+        g = Group(capi, RATE, 2, [ids[i] for i in mine], frames, src_bits=bits, src_endian=capi.ENDIAN_BIG, planar=True)
+        g.src = planes.reshape(-1).view(np.uint8)
+        g.oracle_src = np.concatenate([pack_be(encoded[ids[i] % PROGRAMMES][1], bits) for i in mine])   # the oracle's composition: pack, then resample
         groups.append(g)
+    front.lossless = lossless
     return groups, "weak", front

@@ -61,6 +61,10 @@ extern "C" {
 #define OHGPU_FLAG_RAMP       0x01u  /* Ramp::IsEnabled(): apply RampApplicator semantics (16-bit, low bytes zeroed) */
 #define OHGPU_FLAG_SILENCE    0x02u  /* MsgPlayableSilence: emit zeros (+ the 6-channel id bytes of Msg.cpp:2877);
                                         src is not read */
+#define OHGPU_FLAG_SRC_PLANAR32 0x08u /* resampled messages only: the source is what CodecFlac::CallbackWrite is handed (Codec/Flac.cpp:
+                                         379-417) -- one plane of host-endian TInt32 per channel, sample values at src_bits depth,
+                                         sign-extended -- instead of the packed bytes that callback makes of it: channel c's plane
+                                         starts at src_offset + c * src_plane_stride, a frame is 4 bytes.  a14 -> a1 -> a-R in one pass */
 #define OHGPU_FLAG_ZERO_LSB32 0x04u  /* RampGenerator::ProcessFragment "case 32" (StarvationRamper.cpp:311-320):
                                         when dst_bits == 32 write a zero least-significant byte */
 
@@ -107,8 +111,8 @@ typedef struct ohgpu_src_msg_desc {
     uint8_t  src_endian;
     uint8_t  dst_bits;
     uint8_t  dst_endian;
-    uint8_t  flags;         /* OHGPU_FLAG_RAMP | OHGPU_FLAG_ZERO_LSB32                              */
-    uint8_t  reserved[8];
+    uint8_t  flags;         /* OHGPU_FLAG_RAMP | OHGPU_FLAG_ZERO_LSB32 | OHGPU_FLAG_SRC_PLANAR32    */
+    uint64_t src_plane_stride; /* OHGPU_FLAG_SRC_PLANAR32: bytes between the channels' planes, multiple of 4 (else 0) */
 } ohgpu_src_msg_desc;
 
 typedef struct ohgpu_ctx   ohgpu_ctx;     /* one per GPU / per pipeline thread            */

@@ -16,7 +16,7 @@ ERR_INVALID, ERR_DEVICE, ERR_NO_DEVICE, ERR_NOMEM, ERR_BOUNDS, ERR_UNSUPPORTED =
 ENDIAN_LITTLE, ENDIAN_BIG = 1, 2
 RAMP_MAX = 16384
 UNITY_ATTENUATION = 256
-FLAG_RAMP, FLAG_SILENCE, FLAG_ZERO_LSB32 = 1, 2, 4
+FLAG_RAMP, FLAG_SILENCE, FLAG_ZERO_LSB32, FLAG_SRC_PLANAR32 = 1, 2, 4, 8
 
 # numpy views of ohgpu_msg_desc (32 B) and ohgpu_src_msg_desc (64 B)
 MSG_DESC = np.dtype([
@@ -29,7 +29,7 @@ SRC_MSG_DESC = np.dtype([
     ("dst_offset", "<u8"), ("n_frames", "<u4"),
     ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
     ("channels", "u1"), ("src_bits", "u1"), ("src_endian", "u1"),
-    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1"), ("reserved", "u1", (8,))], align=False)
+    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1"), ("src_plane_stride", "<u8")], align=False)
 
 FMT_UNPACK_PLANAR, FMT_SENDER_PACK, FMT_FLAC_PACK = 1, 2, 3
 FMT_DESC = np.dtype([

@@ -633,7 +633,10 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         if (d.channels < 1 || d.channels > OHGPU_MAX_CHANNELS) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: channels %u outside 1..8", i, d.channels);
         else if (!valid_bits(d.src_bits) || !valid_bits(d.dst_bits)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: bit depth %u -> %u", i, d.src_bits, d.dst_bits);
         else if (!valid_endian(d.src_endian) || !valid_endian(d.dst_endian)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: endian %u -> %u", i, d.src_endian, d.dst_endian);
-        else if (d.flags & ~(OHGPU_FLAG_RAMP | OHGPU_FLAG_ZERO_LSB32)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: flag bits 0x%x not valid for a resampled message", i, d.flags);
+        else if (d.flags & ~(OHGPU_FLAG_RAMP | OHGPU_FLAG_ZERO_LSB32 | OHGPU_FLAG_SRC_PLANAR32)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: flag bits 0x%x not valid for a resampled message", i, d.flags);
+        else if (!(d.flags & OHGPU_FLAG_SRC_PLANAR32) && d.src_plane_stride != 0) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: src_plane_stride without OHGPU_FLAG_SRC_PLANAR32", i);
+        else if ((d.flags & OHGPU_FLAG_SRC_PLANAR32) && (d.src_bits == 32 || (d.src_offset & 3) || (d.src_plane_stride & 3) || (d.src_plane_stride >> 34)))
+            err = set_error(OHGPU_ERR_INVALID, "src desc %zu: planar source needs 8/16/24-bit samples, 4-byte aligned planes less than 16 GiB apart", i);
         else if (d.ramp_start > OHGPU_RAMP_MAX || d.ramp_end > OHGPU_RAMP_MAX) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: ramp beyond Ramp::kMax", i);
         else if ((d.flags & OHGPU_FLAG_RAMP) && d.n_frames > 131071u) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: ramped message of %u frames", i, d.n_frames);
         else if (d.attenuation != OHGPU_UNITY_ATTENUATION) err = set_error(OHGPU_ERR_UNSUPPORTED, "src desc %zu: attenuation %u (resampled audio is 24-bit; Msg.cpp:2741 allows 16-bit only)", i, d.attenuation);
@@ -641,8 +644,19 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         if (err != OHGPU_OK) { delete b; return err; }
         const uint64_t fb_src = (uint64_t)d.channels * (d.src_bits / 8);
         const uint64_t fb_dst = (uint64_t)d.channels * (d.dst_bits / 8);
-        const uint64_t src_bytes = d.src_frames * fb_src;
+        const bool planar = (d.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
+        // (planar: the window is one run of src_frames * 4 bytes per plane; the last plane's run ends furthest out -- span_end
+        // is overflow-safe, see the fmt batches)
+        const uint64_t src_bytes = planar ? d.src_frames * 4 : d.src_frames * fb_src;
         const uint64_t dst_bytes = (uint64_t)d.n_frames * fb_dst;
+        uint64_t planes_end = 0;
+        if (planar && (!span_end(d.src_offset, d.src_plane_stride, d.channels - 1u, src_bytes, &planes_end) || planes_end > src_arena_bytes ||
+                       (d.channels > 1 && d.src_plane_stride < src_bytes))) {
+            delete b;
+            return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: %u planes of %llu bytes, %llu apart from %llu, beyond the %llu-byte source arena (or overlapping)", i,
+                             d.channels, (unsigned long long)src_bytes, (unsigned long long)d.src_plane_stride, (unsigned long long)d.src_offset,
+                             (unsigned long long)src_arena_bytes);
+        }
         if (d.src_offset > src_arena_bytes || src_bytes > src_arena_bytes - d.src_offset) {
             delete b;
             return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: input window [%llu, +%llu) beyond the %llu-byte source arena", i,
@@ -673,7 +687,7 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
             o.phase0 = (uint32_t)(t_first % L);
             const int64_t lo = n_lo < 0 ? 0 : n_lo;
             b->in_frames += (uint64_t)(n0_last - n0_first + 1);   // new input frames this message advances over
-            b->src_bytes_touched += (uint64_t)(n0_last - lo + 1) * fb_src;
+            b->src_bytes_touched += (uint64_t)(n0_last - lo + 1) * (planar ? 4ull * d.channels : fb_src);
         }
         o.src_offset = d.src_offset;
         o.dst_offset = d.dst_offset;
@@ -688,14 +702,16 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         o.dst_bits = d.dst_bits;
         o.dst_endian = d.dst_endian;
         o.flags = d.flags;
+        o.plane_frames = (uint32_t)(d.src_plane_stride >> 2);
         b->out_frames += d.n_frames;
         b->dst_bytes_written += dst_bytes;
         if (d.n_frames > b->max_frames) b->max_frames = d.n_frames;
         if (i == 0) {
             b->channels = d.channels; b->src_bits = d.src_bits; b->src_endian = d.src_endian;
             b->dst_bits = d.dst_bits; b->dst_endian = d.dst_endian;
+            b->src_planar = planar;
         } else if (d.channels != b->channels || d.src_bits != b->src_bits || d.src_endian != b->src_endian ||
-                   d.dst_bits != b->dst_bits || d.dst_endian != b->dst_endian) {
+                   d.dst_bits != b->dst_bits || d.dst_endian != b->dst_endian || planar != b->src_planar) {
             b->uniform = false;
         }
     }
@@ -728,7 +744,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     const bool aligned = ((uintptr_t)src_base & 15u) == 0;          // the staging loads move aligned 16-byte pieces of the arena
     if (ctx->variant != 1 && batch->fast.enabled && aligned) {
         // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
-        if (batch->fast.lean && ctx->variant == 0)
+        if (batch->fast.lean && (ctx->variant == 0 || batch->src_planar))      // (round 1's kernel does not read planes)
             OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         else
             OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));

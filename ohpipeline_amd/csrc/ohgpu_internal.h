@@ -31,7 +31,8 @@ struct DevSrcDesc {
     uint8_t  dst_bits;
     uint8_t  dst_endian;
     uint8_t  flags;
-    uint8_t  pad[6];
+    uint8_t  pad[2];
+    uint32_t plane_frames;    // OHGPU_FLAG_SRC_PLANAR32: frames (4-byte units) between the channels' planes
 };
 static_assert(sizeof(DevSrcDesc) == 56, "DevSrcDesc layout");
 static_assert(sizeof(ohgpu_msg_desc) == 32, "ohgpu_msg_desc layout");
@@ -72,7 +73,8 @@ struct LeanUnit {             // the lean kernel's own view of a unit (same orde
     uint32_t n_blocks;
     uint32_t flags;           // kWorkRamped | kWorkChecked | kWorkFirst
     uint32_t plane;
-    uint32_t pad;
+    uint32_t src_plane_stride; // planar source: bytes between the channels' planes (the planner keeps such a batch off this kernel
+                               // unless every plane of a unit is within 4 GiB of its first)
 };
 static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24 && sizeof(LeanUnit) == 32, "plan layouts");
 
@@ -235,6 +237,7 @@ struct ohgpu_batch {
     uint64_t in_frames, out_frames, src_bytes_touched, dst_bytes_written;
     uint32_t max_frames;          // largest n_frames in the batch
     bool     uniform;             // every descriptor has the same format fields
+    bool     src_planar = false;  // resampled batches: the (uniform) source layout is OHGPU_FLAG_SRC_PLANAR32
     uint8_t  channels, src_bits, src_endian, dst_bits, dst_endian;
     ohgpu::SrcFastPlan fast;      // kBatchSrc only
     ohgpu::PcmLinePlan line;      // kBatchPcm only

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void src_msg_kernel_v1(const DevSrcDesc* __res
         const bool dst_le = d.dst_endian == OHGPU_ENDIAN_LITTLE;
         const bool ramp = (d.flags & OHGPU_FLAG_RAMP) != 0;
         const bool zero_lsb = (d.flags & OHGPU_FLAG_ZERO_LSB32) != 0;
+        const bool planar = (d.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
         const int32_t total = (int32_t)((uint32_t)d.ramp_start - (uint32_t)d.ramp_end);
         const uint8_t* s = src + d.src_offset;
         uint8_t* o = dst + d.dst_offset;
@@ -74,8 +75,14 @@ __global__ __launch_bounds__(256) void src_msg_kernel_v1(const DevSrcDesc* __res
                 for (uint32_t k = 0; k < T; k++) {
                     const int64_t r = r0 - (int64_t)k;
                     if (r < 0) break;                              // frames before the stream start are zeros
-                    const uint32_t w = load_be_word(s + ((uint64_t)r * ch + c) * sb, sb, src_le);
-                    const int32_t x = ((int32_t)w) >> 8;           // S24 domain
+                    int32_t x;                                      // S24 domain
+                    if (planar) {                                   // Flac.cpp:379-417 then Msg.cpp:380-408: the value at its depth, left-justified to 24 bits
+                        const int32_t v = *(const int32_t*)(s + ((uint64_t)c * d.plane_frames + (uint64_t)r) * 4);
+                        x = ((int32_t)((uint32_t)v << (32 - d.src_bits))) >> 8;   // (only the src_bits low bits count, as in the pack)
+                    } else {
+                        const uint32_t w = load_be_word(s + ((uint64_t)r * ch + c) * sb, sb, src_le);
+                        x = ((int32_t)w) >> 8;
+                    }
                     acc = fma(cp[k], (double)x, acc);
                 }
                 uint32_t w = ((uint32_t)src_round_s24(acc)) << 8;

@@ -56,6 +56,8 @@ static constexpr int lean_in_blocks(int ch, int sb)
     return ch == 2 ? n : (n | 1);
 }
 
+static constexpr int lean_in_blocks_planar(int ch) { return ((lean_stage_frames(ch) * 4 + 14) / 16 + 1) | 1; }   // a staged row = one channel's 4-byte frames
+
 // SrcWork::flags
 enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output range
        kWorkChecked = 2u,     // some staging piece of the unit lies outside the source arena (ends of the arena)
@@ -94,4 +96,12 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(32, 2, 2, false, 2, false)
 #endif
 #define OHGPU_BLOCK_KERNELS(X) OHGPU_BLOCK_KERNELS_1(X) OHGPU_BLOCK_KERNELS_2(X) OHGPU_BLOCK_KERNELS_3(X)
+// the lean kernel's planar-source instantiations (source bytes 4 = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32), compiled with part 3
+#ifdef OHGPU_DIAG_ONE_KERNEL
+#define OHGPU_LEAN_PLANAR_KERNELS(X)
+#else
+#define OHGPU_LEAN_PLANAR_KERNELS(X) \
+    X(32, 2, 4, true, 3, false)      \
+    X(32, 2, 4, true, 3, true)
+#endif
 #define OHGPU_BLOCK_PARTS 3

@@ -97,6 +97,7 @@ __device__ __forceinline__ void lean_taps16(const double cv,
         : OHGPU_ACC_CLOBBER);
 }
 // The last tap group of an output, with the unpack of the advance's new sample (lean_unpack below) in the same statement.
+template <bool PL>
 __device__ __forceinline__ void lean_taps16_unpack(const double cv, const uint64_t words, const uint32_t sel, double& w0,
                                                    const double w15, const double w14, const double w13, const double w12,
                                                    const double w11, const double w10, const double w9, const double w8,
@@ -105,11 +106,11 @@ __device__ __forceinline__ void lean_taps16_unpack(const double cv, const uint64
 {
     uint32_t w;
     asm volatile(
-        "v_perm_b32 %[w], %[hi], %[lo], %[sel]\n\tv_cvt_f64_i32 %[w0], %[w]\n\t"
+        ".if %[pl]\n\tv_lshlrev_b32 %[w], %[sel], %[lo]\n\t.else\n\tv_perm_b32 %[w], %[hi], %[lo], %[sel]\n\t.endif\n\tv_cvt_f64_i32 %[w0], %[w]\n\t"
         OHGPU_FM4(15, 14, 13, 12, "%[w15]", "%[w14]", "%[w13]", "%[w12]") OHGPU_FM4(11, 10, 9, 8, "%[w11]", "%[w10]", "%[w9]", "%[w8]")
         OHGPU_FM4(7, 6, 5, 4, "%[w7]", "%[w6]", "%[w5]", "%[w4]") OHGPU_FM4(3, 2, 1, 0, "%[w3]", "%[w2]", "%[w1]", "%[w0]")
         : [w0] "=&v"(w0), [w] "=&v"(w)
-        : [cv] "v"(cv), [hi] "v"((uint32_t)(words >> 32)), [lo] "v"((uint32_t)words), [sel] "v"(sel),
+        : [cv] "v"(cv), [hi] "v"((uint32_t)(words >> 32)), [lo] "v"((uint32_t)words), [sel] "v"(sel), [pl] "i"(PL ? 1 : 0),
           [w15] "v"(w15), [w14] "v"(w14), [w13] "v"(w13), [w12] "v"(w12), [w11] "v"(w11), [w10] "v"(w10), [w9] "v"(w9),
           [w8] "v"(w8), [w7] "v"(w7), [w6] "v"(w6), [w5] "v"(w5), [w4] "v"(w4), [w3] "v"(w3), [w2] "v"(w2), [w1] "v"(w1)
         : OHGPU_ACC_CLOBBER);
@@ -118,12 +119,16 @@ __device__ __forceinline__ void lean_taps16_unpack(const double cv, const uint64
 // One subsample -> sample x 256 as an exact double: the two aligned words that hold it (LDS accepts unaligned reads
 // but serialises them lane by lane), one byte permute with the lane's selector (alignment, byte order and the
 // left-justification in one), one conversion.
+// A planar source's frame is an aligned TInt32 at its bit depth: the unpack is a shift to the top (sel = 32 - depth).
+#define OHGPU_UNPACK_ASM(W, HI, LO, SEL, PLANAR) \
+    ".if " PLANAR "\n\tv_lshlrev_b32 " W ", " SEL ", " LO "\n\t.else\n\tv_perm_b32 " W ", " HI ", " LO ", " SEL "\n\t.endif\n\t"
+template <bool PL>
 __device__ __forceinline__ double lean_unpack(const uint64_t words, const uint32_t sel)
 {
     uint32_t w;
     double d;
-    asm volatile("v_perm_b32 %0, %2, %3, %4\n\tv_cvt_f64_i32 %1, %0"
-                 : "=&v"(w), "=v"(d) : "v"((uint32_t)(words >> 32)), "v"((uint32_t)words), "v"(sel));
+    asm volatile(OHGPU_UNPACK_ASM("%0", "%2", "%3", "%4", "%5") "v_cvt_f64_i32 %1, %0"
+                 : "=&v"(w), "=v"(d) : "v"((uint32_t)(words >> 32)), "v"((uint32_t)words), "v"(sel), "i"(PL ? 1 : 0));
     return d;
 }
 // selector of lean_unpack for a subsample whose first byte sits `sh` bytes into the low word ({hi, lo} = bytes 7..0):
@@ -142,16 +147,21 @@ __device__ __forceinline__ uint32_t lean_unpack_sel(uint32_t sh)
     return sel;
 }
 
+// SB == 4 stands for the PLANAR source of OHGPU_FLAG_SRC_PLANAR32 (a packed 32-bit source is not on this kernel): every
+// channel of a block is a staging row of its own, of 4-byte frames -- lane = (block, channel) reads ITS row -- so the rows
+// staged are BPW * CH; everything downstream of the unpack is the packed layout's.
 template <int T, int CH, int SB, int DB>
 struct LeanGeom {
+    static constexpr bool PL = SB == 4;
     static constexpr int BPW = 64 / CH;
     static constexpr int ROWS = BPW;
+    static constexpr int IN_ROWS = PL ? BPW * CH : BPW;   // staged rows
     static constexpr int MAX_WAVES = T <= 32 ? 12 : 8;   // three per SIMD (what the LDS left by the coefficient table allows with 16-frame stages), two when the window alone is 128 registers
-    static constexpr int FB_SRC = CH * SB, FB_DST = CH * DB;
+    static constexpr int FB_SRC = PL ? 4 : CH * SB, FB_DST = CH * DB;     // bytes per frame of a staged row
     static constexpr int SF = lean_stage_frames(CH);      // frames per stage
-    static constexpr int IN_BLOCKS = lean_in_blocks(CH, SB);
+    static constexpr int IN_BLOCKS = PL ? lean_in_blocks_planar(CH) : lean_in_blocks(CH, SB);
     static constexpr int IN_STRIDE = IN_BLOCKS * 16;
-    static constexpr int IN_ITERS = (ROWS * IN_BLOCKS + 63) / 64;
+    static constexpr int IN_ITERS = (IN_ROWS * IN_BLOCKS + 63) / 64;
     static constexpr bool DUMMY = (64 % CH) != 0;         // the lanes beyond the last whole block store into a ring of their own
 };
 
@@ -161,9 +171,11 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                      const double* __restrict__ coef, const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                      const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
-                     const uint32_t ring_bytes, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
+                     const uint32_t ring_bytes, const uint32_t src_shift, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
 {
     static_assert(T % 16 == 0 && T >= 32 && T <= 64, "T / 16 coefficient registers per lane");
+    constexpr bool PL = LeanGeom<T, CH, SB, DB>::PL;       // planar TInt32 source (src_shift = 32 - its bit depth)
+    static_assert(!PL || (SRC_LE && !LeanGeom<T, CH, SB, DB>::DUMMY), "planar instantiations: host-endian planes, channel counts that divide 64");
     using G = LeanGeom<T, CH, SB, DB>;
 #ifdef OHGPU_DIAG_STAMP
     // diagnostic build: shader-clock stamps per phase, summed per wave, written to dbg[wave][8] at the end (never read by the kernel)
@@ -174,13 +186,13 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 #define STAMP(acc)
 #endif
     constexpr int NCR = T / 16;
-    constexpr int BPW = G::BPW, ROWS = G::ROWS;
+    constexpr int BPW = G::BPW, ROWS = G::ROWS, IN_ROWS = G::IN_ROWS;
     constexpr int FB_SRC = G::FB_SRC, FB_DST = G::FB_DST;
     constexpr int IN_BLOCKS = G::IN_BLOCKS, IN_STRIDE = G::IN_STRIDE, IN_ITERS = G::IN_ITERS, SF = G::SF;
     static_assert(T % (2 * SF) == 0, "a trip of T advances is a whole number of stage pairs: the buffer of a slot is static");
     // (every region a DMA instruction is aimed at starts on a 128-byte boundary -- more than the 16 bytes it needs, so that a
     // wave's staging buffers sit the same way against the LDS banks whatever its number in the workgroup)
-    constexpr uint32_t BUF_BYTES = (ROWS * IN_STRIDE + 127) & ~127;
+    constexpr uint32_t BUF_BYTES = (IN_ROWS * IN_STRIDE + 127) & ~127;
     constexpr uint32_t OFF_IN = 0, OFF_RING = OFF_IN + 2 * BUF_BYTES;
     constexpr bool PAIR = ring_pair_mode(CH, DB);
     static_assert(DB >= 2 && DB <= 4, "destination depths 16 / 24 / 32 bit");
@@ -239,7 +251,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     const bool ramped = (wk.flags & kWorkRamped) != 0;                 // wave-uniform
     const bool checked = (wk.flags & kWorkChecked) != 0;               // some staging piece of the unit lies outside the arena
     const bool lane_valid = lane_block && row < n_blocks;
-    const int64_t row_g = wk.src_row0 + (int64_t)(row * M_blk) * FB_SRC;   // byte offset of the row's frame at a_lin = 0
+    const int64_t row_g = wk.src_row0 + (int64_t)(row * M_blk) * FB_SRC + (PL ? (int64_t)c * wk.src_plane_stride : 0);   // byte offset of the row's (planar: the lane's) frame at a_lin = 0
     const bool first_block = (wk.flags & kWorkFirst) != 0 && row == 0;        // the stream's block 0: nothing before it
 
     // ---- a ramped unit reads RampApplicator's multiplier of every output frame from its plane (src_plan.cpp): one uint16 per
@@ -263,10 +275,11 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 #pragma unroll
     for (int it = 0; it < IN_ITERS; it++) {
         const uint32_t idx = it * 64 + lane;
-        uint32_t r = idx / IN_BLOCKS;
+        uint32_t r = idx / IN_BLOCKS;                       // staged row: a block (planar: a block's channel)
         uint32_t part = idx - r * IN_BLOCKS;
-        if (r >= n_blocks || r >= (uint32_t)ROWS) { r = 0; part = 0; }
-        const uint32_t d_r = r * M_blk * FB_SRC;
+        if ((PL ? r / CH : r) >= n_blocks || r >= (uint32_t)IN_ROWS) { r = 0; part = 0; }
+        const uint32_t blk_r = PL ? r / CH : r;
+        const uint32_t d_r = blk_r * M_blk * FB_SRC + (PL ? (r - blk_r * CH) * wk.src_plane_stride : 0u);
         const uint32_t al = (a0 + d_r) & 15u;
         const uint32_t pieces_needed = (al + SF * FB_SRC + 15) >> 4;     // bytes al .. al + SF FB_SRC - 1 of the row's first piece onwards
         if (part >= pieces_needed) part = 0;
@@ -279,7 +292,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         const uint32_t buf = OFF_IN + (uint32_t)(q & 1) * BUF_BYTES;
 #pragma unroll
         for (int it = 0; it < IN_ITERS; it++) {
-            constexpr int kTail = ROWS * IN_BLOCKS - (IN_ITERS - 1) * 64;     // lanes of the last instruction that own a piece
+            constexpr int kTail = IN_ROWS * IN_BLOCKS - (IN_ITERS - 1) * 64;  // lanes of the last instruction that own a piece
             const bool last_partial = it == IN_ITERS - 1 && kTail < 64;
             const uint32_t m0v = wave_lds_addr + buf + (uint32_t)(it * 64) * 16;
             if (!checked) {
@@ -376,12 +389,12 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     uint32_t ring_pos = 0;                    // ring position of frame j (pair mode: of the pair)
     constexpr int PH = (FB_SRC % 4 == 0) ? 1 : ((FB_SRC % 2 == 0) ? 2 : 4);   // frames s' and s' + PH share their place in a dword
     static_assert((FB_SRC * PH) % 4 == 0 && (SF % PH) == 0 && FB_SRC * (SF - 1) / 4 + 1 < 256, "immediate dword offsets of ds_read2_b32");
-    const uint32_t in_base = wave_lds_addr + OFF_IN + row * IN_STRIDE + ((uint32_t)row_g & 15u) + c * SB;   // frame 0 of buffer 0
+    const uint32_t in_base = wave_lds_addr + OFF_IN + (PL ? lane : row) * IN_STRIDE + ((uint32_t)row_g & 15u) + (PL ? 0u : c * SB);   // frame 0 of buffer 0
     uint32_t in_sel[PH];                      // byte selector of frame ph's subsample (the same in every stage)
     uint32_t in_addr[2][PH];                  // aligned LDS address of frame ph's dword, by buffer
 #pragma unroll
     for (int ph = 0; ph < PH; ph++) {
-        in_sel[ph] = lean_unpack_sel<SB, SRC_LE>((in_base + ph * FB_SRC) & 3u);
+        in_sel[ph] = PL ? src_shift : lean_unpack_sel<SB, SRC_LE>((in_base + ph * FB_SRC) & 3u);   // (planar: the unpack is a shift)
         in_addr[0][ph] = (lane_block ? ((in_base + ph * FB_SRC) & ~3u) : (wave_lds_addr + OFF_IN));
         in_addr[1][ph] = in_addr[0][ph] + BUF_BYTES;
     }
@@ -433,7 +446,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
             }, std::make_integer_sequence<int, 4>{});
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]) : : "memory");
 #pragma unroll
-            for (int k = 0; k < 4; k++) win[SF * q + 4 * h + k] = lean_unpack(r4[k], in_sel[(4 * h + k) % PH]);
+            for (int k = 0; k < 4; k++) win[SF * q + 4 * h + k] = lean_unpack<PL>(r4[k], in_sel[(4 * h + k) % PH]);
         }, std::make_integer_sequence<int, SF / 4>{});
     }, std::make_integer_sequence<int, T / SF>{});
     if (any_first) {
@@ -476,11 +489,11 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 asm volatile("ds_read_b32 %[lo], %[addr] offset:%[o0]\n\t"
                              "ds_read_b32 %[hi], %[addr] offset:%[o1]\n\t"
                              "s_waitcnt lgkmcnt(0)\n\t"
-                             "v_perm_b32 %[lo], %[hi], %[lo], %[sel]\n\t"
+                             ".if %[pl]\n\tv_lshlrev_b32 %[lo], %[sel], %[lo]\n\t.else\n\tv_perm_b32 %[lo], %[hi], %[lo], %[sel]\n\t.endif\n\t"
                              "v_cvt_f64_i32 %[d], %[lo]"
                              : [lo] "=&v"(lo), [hi] "=&v"(hi), [d] "=v"(win[s])
                              : [addr] "v"(in_addr[(s / SF) & 1][ph]), [o0] "i"(FB_SRC * (sp - ph)), [o1] "i"(FB_SRC * (sp - ph) + 4),
-                               [sel] "v"(in_sel[(s % SF) % PH]) : "memory");
+                               [sel] "v"(in_sel[(s % SF) % PH]), [pl] "i"(PL ? 1 : 0) : "memory");
             } else {
 #ifndef OHGPU_DIAG_NO_X
                 {
@@ -525,13 +538,13 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 #define W_(k) win[(s - (16 * r + (k)) + 2 * T) % T]
 #ifndef OHGPU_DIAG_NO_TAPS
                     if constexpr (r == 0)
-                        lean_taps16_unpack(cf[0], raw, in_sel[(s % SF) % PH], win[s], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
+                        lean_taps16_unpack<PL>(cf[0], raw, in_sel[(s % SF) % PH], win[s], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                            W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1));
                     else
                         lean_taps16(cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                     W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1), W_(0));
 #else
-                    if constexpr (r == 0) win[s] = lean_unpack(raw, in_sel[(s % SF) % PH]);
+                    if constexpr (r == 0) win[s] = lean_unpack<PL>(raw, in_sel[(s % SF) % PH]);
 #endif
 #undef W_
 #ifndef OHGPU_DIAG_NO_COEF
@@ -675,16 +688,18 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 }
 
 #define OHGPU_LEAN_ARGS const LeanUnit*, uint32_t, const double*, const uint16_t*, uint32_t, const uint8_t*, \
-                        uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
+                        uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
 #define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
 #define X_DECLARE(t, c, s_, sl, d, dl) extern template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
 #if defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 2
 OHGPU_BLOCK_KERNELS_2(X_DEFINE)
 #elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 3
 OHGPU_BLOCK_KERNELS_3(X_DEFINE)
+OHGPU_LEAN_PLANAR_KERNELS(X_DEFINE)
 #elif defined(OHGPU_BLOCK_PART)
 OHGPU_BLOCK_KERNELS_2(X_DECLARE)
 OHGPU_BLOCK_KERNELS_3(X_DECLARE)
+OHGPU_LEAN_PLANAR_KERNELS(X_DECLARE)
 #endif
 
 #if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
@@ -692,17 +707,19 @@ OHGPU_BLOCK_KERNELS_3(X_DECLARE)
 bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves)
-{
+{   // (sb == 4: the planar source, LeanGeom)
+    const bool planar = sb == 4;
     const uint32_t bpw = 64 / ch;
     const uint32_t fb_dst = ch * db;
-    const uint32_t inb = (uint32_t)lean_in_blocks((int)ch, (int)sb);
+    const uint32_t inb = planar ? (uint32_t)lean_in_blocks_planar((int)ch) : (uint32_t)lean_in_blocks((int)ch, (int)sb);
+    const uint32_t in_rows = planar ? bpw * ch : bpw;
     *stage_frames = (uint32_t)lean_stage_frames((int)ch);
     const uint32_t rb = ring_bytes_for(fb_dst, out_per_drain, ring_pair_mode(ch, db));
     *rows = bpw;
     *in_blocks = inb;
     *ring_bytes = rb;
     *coef_lds_bytes = L * T * 8;
-    *wave_lds_bytes = (2 * ((bpw * inb * 16 + 127u) & ~127u) + ((bpw * (rb + OHGPU_LEAN_RING_PAD) + 15) & ~15u) + ((64 % ch) ? rb + 64u : 0u) + 127u) & ~127u;
+    *wave_lds_bytes = (2 * ((in_rows * inb * 16 + 127u) & ~127u) + ((bpw * (rb + OHGPU_LEAN_RING_PAD) + 15) & ~15u) + ((64 % ch) ? rb + 64u : 0u) + 127u) & ~127u;
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
@@ -738,7 +755,7 @@ static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
 #endif
     hipLaunchKernelGGL(kernel, dim3(g), dim3(w * 64), lds, s,
                        (const LeanUnit*)f.d_lean_units, f.n_work, p.coef, (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst,
-                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, f.ring_bytes, (uint32_t*)f.d_counter, dbg);
+                       p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, f.ring_bytes, 32u - b->src_bits, (uint32_t*)f.d_counter, dbg);
 #ifdef OHGPU_DIAG_STAMP
     if (dbg) {      // diagnostic build only: wait, sum up, write a text report, never on the product path
         hipStreamSynchronize(s);
@@ -776,6 +793,12 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
 #define X(t, c, s_, sl, d, dl)                                                                                            \
     if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
         return launch_lean_one<t, c, s_, sl, d, dl>(ctx, b, prm, s);
+    if (b->src_planar) {                                   // (SB == 4 is the planar layout, whatever the samples' depth)
+        prm.sb = 4;
+        prm.src_le = 1;
+        OHGPU_LEAN_PLANAR_KERNELS(X)
+        return hipErrorInvalidValue;
+    }
     OHGPU_BLOCK_KERNELS(X)
 #undef X
     return hipErrorInvalidValue;

@@ -82,17 +82,23 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint32_t ch = b->channels, sb = b->src_bits / 8, db = b->dst_bits / 8;
     const uint32_t src_le = (b->src_endian == OHGPU_ENDIAN_LITTLE && sb > 1) ? 1 : 0;
     const uint32_t dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
-    if (!src_block_supported(T, ch, sb, src_le, db, dst_le)) return OHGPU_OK;
-    const uint32_t fb_src = ch * sb, fb_dst = ch * db;
+    // a planar source (OHGPU_FLAG_SRC_PLANAR32) is, per channel, a stream of 4-byte frames: the lean kernel alone reads it
+    // (stereo to S24); a packed 32-bit source stays on the generic kernel
+    const bool planar = b->src_planar;
+    if (planar ? !(T == 32 && ch == 2 && sb != 4 && db == 3) : (sb == 4 || !src_block_supported(T, ch, sb, src_le, db, dst_le))) return OHGPU_OK;
+    const uint32_t sb_geo = planar ? 3u : sb;                           // (round 1's geometry: only its rows and ring are used)
+    const uint32_t sb_lean = planar ? 4u : sb;                          // (LeanGeom: 4 = planar)
+    const uint32_t fb_src = planar ? 4u : ch * sb, fb_dst = ch * db;    // (planar: a plane's frame)
     // the ring is drained every four advances: #{j : a <= floor(j*M/L) < a+4} <= ceil(4L/M) outputs arrive in between
     const uint32_t out_per_drain = (4 * L + M - 1) / M;
     uint32_t rows = 0, ring = 0, coef_lds = 0, wave_lds = 0, max_waves = 0;
-    if (!src_block_geometry(L, T, ch, sb, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
+    if (!src_block_geometry(L, T, ch, sb_geo, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
     // the lean kernel (round 2): same blocks, rows and ring; its rounding bias needs sum|c| < 2^29 in every phase
     uint32_t lean_rows = 0, lean_inb = 0, lean_sf = 8, lean_ring = 0, lean_coef = 0, lean_wave_lds = 0, lean_max_waves = 0;
     const bool lean = flt->max_sum_abs < ((int64_t)1 << 29) &&
-                      src_lean_geometry(L, T, ch, sb, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
+                      src_lean_geometry(L, T, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
                       lean_rows == rows && lean_ring == ring;
+    if (planar && !lean) return OHGPU_OK;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
     uint32_t min_blk = 128;
 #ifdef OHGPU_DIAG
@@ -113,16 +119,23 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     auto src_base_of = [&](const ohgpu_src_msg_desc& d) { return (int64_t)d.src_offset - (int64_t)(d.src_frame0 * fb_src); };
+    // (planar: two messages of a stream also agree on the distance between its planes; a 4 GiB reach per unit is the lean kernel's)
+    if (planar) {
+        for (size_t k = 0; k < n; k++)
+            if ((uint64_t)(ch - 1) * descs[k].src_plane_stride + (uint64_t)(rows + 1) * (M_blk + T) * 4 + 4096 >= (1ull << 32)) return OHGPU_OK;
+    }
     auto dst_base_of = [&](const ohgpu_src_msg_desc& d) { return (int64_t)d.dst_offset - (int64_t)(d.out_frame0 * fb_dst); };
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         const int64_t sx = src_base_of(descs[x]), sy = src_base_of(descs[y]);
         if (sx != sy) return sx < sy;
+        if (descs[x].src_plane_stride != descs[y].src_plane_stride) return descs[x].src_plane_stride < descs[y].src_plane_stride;
         const int64_t dx = dst_base_of(descs[x]), dy = dst_base_of(descs[y]);
         if (dx != dy) return dx < dy;
         return descs[x].out_frame0 < descs[y].out_frame0;
     });
 
     std::vector<SrcSeg> segs;
+    std::vector<uint32_t> seg_plane_stride;             // planar batches: bytes between a segment's planes
     std::vector<SegMsg> msgs;
     std::vector<SrcWork> work;
     std::vector<DevSrcDesc> rem;
@@ -143,7 +156,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         bool zero_len = d0.n_frames == 0;
         while (!zero_len && e < n) {
             const ohgpu_src_msg_desc& d = descs[order[e]];
-            if (d.n_frames == 0 || src_base_of(d) != sbase || dst_base_of(d) != dbase || d.out_frame0 != next_out) break;
+            if (d.n_frames == 0 || src_base_of(d) != sbase || dst_base_of(d) != dbase || d.out_frame0 != next_out ||
+                d.src_plane_stride != d0.src_plane_stride) break;
             next_out += d.n_frames;
             e++;
         }
@@ -172,6 +186,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             sg.src_base = sbase; sg.dst_base = dbase; sg.msg_begin = msg_begin; sg.msg_end = (uint32_t)msgs.size();
             const uint32_t seg_index = (uint32_t)segs.size();
             segs.push_back(sg);
+            seg_plane_stride.push_back((uint32_t)d0.src_plane_stride);
             uint32_t mi = msg_begin;                      // message that holds the unit's first output frame
             for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
                 SrcWork w;
@@ -203,11 +218,13 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 // does every one of them lie inside the arena?  (Only a unit at an end of the arena can fail.)
                 {
                     const int64_t total = (int64_t)M_blk + T, n_stages = (total + lean_sf - 1) / lean_sf;
-                    const int64_t g_first = sbase + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
-                    const int64_t g_last = g_first + (int64_t)(w.n_blocks - 1) * M_blk * fb_src;
-                    const int64_t lo = g_first - (g_first & 15);
-                    const int64_t hi = g_last - (g_last & 15) + 16 * (((g_last & 15) + lean_sf * fb_src + 15) >> 4) + (n_stages - 1) * lean_sf * fb_src;
-                    if (g_first < 0 || lo < 0 || (uint64_t)hi > b->src_arena_bytes) w.flags |= kWorkChecked;
+                    for (uint32_t pc = 0; pc < (planar ? ch : 1u); pc++) {          // (planar: every channel's plane is staged on its own)
+                        const int64_t g_first = sbase + (int64_t)(pc * d0.src_plane_stride) + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
+                        const int64_t g_last = g_first + (int64_t)(w.n_blocks - 1) * M_blk * fb_src;
+                        const int64_t lo = g_first - (g_first & 15);
+                        const int64_t hi = g_last - (g_last & 15) + 16 * (((g_last & 15) + lean_sf * fb_src + 15) >> 4) + (n_stages - 1) * lean_sf * fb_src;
+                        if (g_first < 0 || lo < 0 || (uint64_t)hi > b->src_arena_bytes) w.flags |= kWorkChecked;
+                    }
                 }
                 work.push_back(w);
             }
@@ -244,7 +261,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             u.n_blocks = w.n_blocks;
             u.flags = w.flags | (w.first_block == 0 ? (uint32_t)kWorkFirst : 0u);
             u.plane = w.plane;
-            u.pad = 0;
+            u.src_plane_stride = planar ? seg_plane_stride[w.seg] : 0u;
             lean_units.push_back(u);
         }
     }
@@ -279,7 +296,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     p.coef = flt->d_coef;
     p.src_arena_bytes = b->src_arena_bytes;
     p.L = L; p.M = M; p.L_blk = L_blk; p.M_blk = M_blk;
-    p.channels = ch; p.sb = sb; p.db = db;
+    p.channels = ch; p.sb = sb; p.db = db;              // (a planar batch: launch_src_lean picks its instantiation by b->src_planar)
     p.src_le = src_le;
     p.dst_le = dst_le;
     return OHGPU_OK;

@@ -47,7 +47,7 @@ typedef struct {
     uint8_t  dst_bits;
     uint8_t  dst_endian;
     uint8_t  flags;
-    uint8_t  reserved[8];
+    uint8_t  reserved[8];   /* (the device path's src_plane_stride: a planar source is, here, ohp_flac_pack followed by this) */
 } ohp_src_msg_desc;
 
 int ohp_msg_process(const ohp_msg_desc* d, const uint8_t* src_base, uint8_t* dst_base);

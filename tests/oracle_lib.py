@@ -34,7 +34,7 @@ SRC_MSG_DESC = np.dtype([
     ("dst_offset", "<u8"), ("n_frames", "<u4"),
     ("ramp_start", "<u2"), ("ramp_end", "<u2"), ("attenuation", "<u2"),
     ("channels", "u1"), ("src_bits", "u1"), ("src_endian", "u1"),
-    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1"), ("reserved", "u1", (8,))], align=False)
+    ("dst_bits", "u1"), ("dst_endian", "u1"), ("flags", "u1"), ("src_plane_stride", "<u8")], align=False)
 assert MSG_DESC.itemsize == 32 and SRC_MSG_DESC.itemsize == 64
 
 

@@ -109,3 +109,40 @@ def test_flac_to_ramped_messages_without_resampling(ctx, name, dst_bits):
     assert O.msg_process_batch(descs, packed_ref, want) == 0
     assert np.array_equal(got, want)
     ctx.batch_destroy(b); ctx.free(d_packed); ctx.free(d_out)
+
+
+@pytest.mark.parametrize("name", ["s24_stereo_44k1_b4096_l8", "s24_stereo_44k1_b576_l0", "s16_stereo_44k1_b1152_l5"])
+def test_flac_planes_to_resampled_ramped_s24_in_one_pass(ctx, name):
+    """Config 5 as bench.py runs it since round 2: ONE batch, ONE pass.  The resampler's descriptors point at the decoder's
+    planes (OHGPU_FLAG_SRC_PLANAR32); there is no FLAC_PACK batch, no packed arena.  Expected: the oracle's composition of
+    the three rows -- the planes packed as Flac.cpp:379-417 packs them, then resampled and ramped."""
+    info, _stream, frames, md5_ok = FW.load(name)
+    assert md5_ok
+    ch, bits, n_in, n_streams = info["channels"], info["bits"], info["frames"], 16
+    planes, pcm = plane_arena(frames, n_streams, 97)
+    packed_ref = FW.pack_be(pcm.reshape(-1, ch), bits)
+    L, M, coef = capi.src_design(44100, 48000, 32, 9.0, 20000.0)
+    ref = O.Src(44100, 48000, 32, 9.0, 20000.0)
+    h = ctx.src_create(L, M, 32, coef)
+    out_total = ref.out_frames(n_in)
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 20 * O.JIFFIES_PER_MS, 40 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, n_in, L, M, 240, ch, bits, O.ENDIAN_BIG, 24, O.ENDIAN_BIG, sched)
+    want = np.zeros(dbytes, dtype=np.uint8)
+    assert ref.process_batch(descs, packed_ref, want) == 0
+    fused = descs.copy().view(capi.SRC_MSG_DESC)
+    per_packed, per_planes = n_in * ch * (bits // 8), ch * n_in * 4
+    fused["src_offset"] = (descs["src_offset"] // per_packed) * per_planes             # the stream's plane 0
+    fused["src_plane_stride"] = n_in * 4
+    fused["flags"] |= capi.FLAG_SRC_PLANAR32
+    src = planes.view(np.uint8).reshape(-1)
+    d_src, d_out = ctx.upload(src), ctx.malloc(dbytes)
+    sb = ctx.src_batch(h, fused, src.size, dbytes)
+    ctx.src_run(sb, d_src, d_out)                                          # the step's only launch sequence: this batch
+    got = ctx.download(d_out, dbytes)
+    assert np.array_equal(got, want)
+    plan, bi = ctx.src_plan(sb), ctx.batch_info(sb)
+    assert plan["block_kernel_out_frames"] > 0.9 * n_streams * out_total   # whole blocks straight from the planes on the block kernel
+    assert plan["generic_pieces"] <= 2 * n_streams                         # only a stream's block-unaligned ends are left over
+    assert bi["src_bytes_touched"] >= n_streams * n_in * ch * 4 * 0.99     # what is read is the planes (4 bytes a subsample), nothing packed
+    ctx.batch_destroy(sb); ctx.src_destroy(h); ctx.free(d_src); ctx.free(d_out)

@@ -499,7 +499,7 @@ def test_src_block_kernel_irregular_message_tilings(ctx, seed):
             ramp = RAMPS[int(rng.integers(0, len(RAMPS)))]
             flags = O.FLAG_RAMP if rng.random() < 0.6 else 0
             if rng.random() > 0.03:                                     # (a few messages are simply not asked for)
-                rows.append((s_pos, 0, in_frames, m, d_base + m * 6, n, ramp[0], ramp[1], 256, 2, 24, LE, 24, BE, flags, [0] * 8))
+                rows.append((s_pos, 0, in_frames, m, d_base + m * 6, n, ramp[0], ramp[1], 256, 2, 24, LE, 24, BE, flags, 0))
             m += n
         s_pos += in_frames * 6
         d_pos = d_base + out_total * 6 + int(rng.integers(0, 9))
