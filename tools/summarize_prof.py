@@ -22,13 +22,23 @@ def short(name):
     return name[-60:]
 
 
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: of several runs of one pass keep the latest."""
+    by_dir = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
 def main():
     tag = sys.argv[1]
     what = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 10 --warmup 3 --no-cpu"   # the profiled command
     latest = len(sys.argv) > 3 and sys.argv[3] == "--latest"           # this run is bench.py's default workload: feed roofline.traffic
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     out = {"tag": tag, "kernels": {}, "counters": {}}
-    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for f in newest(os.path.join(src, "trace", "**", "*kernel_trace.csv")):
         per = defaultdict(list)
         for r in csv.DictReader(open(f)):
             per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -36,14 +46,14 @@ def main():
             v.sort()
             out["kernels"][k] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": v[0], "max_us": v[-1],
                                  "median_us": v[len(v) // 2]}
-    for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(src, "pmc*", "**", "*counter_collection.csv")):
         acc = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
             for c, v in cs.items():
                 out["counters"].setdefault(k, {})[c] = sum(v) / len(v)
-    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    stats = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1, sort_keys=True)
     with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as md:
