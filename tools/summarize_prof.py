@@ -64,6 +64,9 @@ def main():
             md.write(f"| {k} | {v['calls']} | {v['avg_us']:.1f} | {v['median_us']:.1f} | {v['min_us']:.1f} | {v['max_us']:.1f} |\n")
         if stats:
             md.write("\n## rocprofv3 --stats (verbatim)\n\n```\n" + open(stats[0]).read() + "```\n")
+        notes = os.path.join(ROOT, "profiles", f"{tag}_notes.md")      # hand-written reading of the numbers, kept next to them
+        if os.path.exists(notes):
+            md.write("\n" + open(notes).read().rstrip() + "\n")
         md.write("\n## PMC counters (mean per dispatch)\n\n")
         for k, cs in out["counters"].items():
             md.write(f"### {k}\n\n| counter | value |\n|---|---|\n")
