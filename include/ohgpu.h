@@ -300,7 +300,9 @@ uint64_t ohgpu_src_out_frames(uint32_t L, uint32_t M, uint64_t in_frames);
 int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
 /* A batch may be run any number of times, one launch at a time (it owns device-side work counters): launches of the same
- * batch must be ordered, e.g. by issuing them on one stream.  Different batches are independent. */
+ * batch on one stream queue behind each other; a launch on ANOTHER stream while the previous one has not finished returns
+ * OHGPU_ERR_INVALID (nothing is launched).  Different batches are independent.  The same holds for
+ * ohgpu_flywheel_batch_run (the batch owns Burg's workspace). */
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
 
 /* Host-buffer convenience (a live pipeline's 5 ms cadence): H2D, run, D2H, sync.  dst_host bytes that no message

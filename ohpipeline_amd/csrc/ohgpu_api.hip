@@ -334,10 +334,27 @@ int ohgpu_pcm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     return OHGPU_OK;
 }
 
+// Batches with per-launch device state (see ohgpu_batch::last_done): refuse a launch on another stream while the previous one
+// has not finished; remember this one.
+static int claim_single_launch(const ohgpu_batch* b, hipStream_t s, const char* who)
+{
+    if (b->last_done != nullptr && b->last_stream != s && hipEventQuery(b->last_done) == hipErrorNotReady)
+        return set_error(OHGPU_ERR_INVALID, "%s: the batch is still running on another stream (its unit counters / workspace serve one "
+                         "launch at a time: wait for it, use the same stream, or create a second batch)", who);
+    if (b->last_done == nullptr && hipEventCreateWithFlags(&b->last_done, hipEventDisableTiming) != hipSuccess) {
+        b->last_done = nullptr;
+        return set_error(OHGPU_ERR_DEVICE, "%s: hipEventCreate failed", who);
+    }
+    b->last_stream = s;
+    return OHGPU_OK;
+}
+static void launched(const ohgpu_batch* b, hipStream_t s) { if (b->last_done) (void)hipEventRecord(b->last_done, s); }
+
 int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
 {
     CTX_GUARD("ohgpu_batch_destroy");
     if (!batch) return OHGPU_OK;
+    if (batch->last_done) hipEventDestroy(batch->last_done);
     if (batch->d_descs) hipFree(batch->d_descs);
     if (batch->kind == kBatchSrc) free_src_fast(batch);
     if (batch->kind == kBatchPcm) free_pcm_line(batch);
@@ -514,7 +531,11 @@ int ohgpu_flywheel_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const voi
     if (!batch || batch->kind != kBatchFlywheel) return set_error(OHGPU_ERR_INVALID, "ohgpu_flywheel_batch_run: not a flywheel batch");
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_flywheel_batch_run: null arena pointer");
-    OHGPU_HIP_TRY(launch_flywheel(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int claim = claim_single_launch(batch, s, "ohgpu_flywheel_batch_run");       // (Burg's workspace is the batch's)
+    if (claim != OHGPU_OK) return claim;
+    OHGPU_HIP_TRY(launch_flywheel(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+    launched(batch, s);
     return OHGPU_OK;
 }
 
@@ -743,12 +764,15 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     hipStream_t s = pick_stream(ctx, stream);
     const bool aligned = ((uintptr_t)src_base & 15u) == 0;          // the staging loads move aligned 16-byte pieces of the arena
     if (ctx->variant != 1 && batch->fast.enabled && aligned) {
+        const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
+        if (claim != OHGPU_OK) return claim;
         // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
         if (batch->fast.lean && (ctx->variant == 0 || batch->src_planar))      // (round 1's kernel does not read planes)
             OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         else
             OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+        launched(batch, s);
     } else {
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->d_descs, batch->n, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
     }

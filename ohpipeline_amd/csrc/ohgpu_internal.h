@@ -244,6 +244,11 @@ struct ohgpu_batch {
     ohgpu::FlywheelPlan fly;      // kBatchFlywheel only
     ohgpu::FmtLinePlan fmtline;   // kBatchFmt only
     ohgpu::OhmPlan ohm;           // kBatchOhm only
+    // A resampled batch's unit counters and a flywheel batch's workspace belong to ONE launch at a time.  Launches on the same
+    // stream queue behind each other; a launch on another stream while the last one is still running is refused
+    // (ohgpu_*_batch_run, OHGPU_ERR_INVALID) instead of silently sharing them.
+    mutable hipStream_t last_stream = nullptr;
+    mutable hipEvent_t  last_done = nullptr;
 };
 
 namespace ohgpu {

@@ -133,3 +133,34 @@ def test_planar_descriptors_are_validated(ctx):
     with pytest.raises(capi.OhGpuError):
         ctx.src_batch(h, e, arena_bytes, dst_bytes)
     ctx.src_destroy(h)
+
+
+def test_a_batch_serves_one_launch_at_a_time(ctx):
+    """The block kernels' unit counters (and a flywheel batch's workspace) belong to the batch: a second launch on another
+    stream while the first is still running must be refused, not run with shared counters; the same stream queues."""
+    L, M, coef = capi.src_design(44100, 48000, 32, BETA, F_PASS)
+    h = ctx.src_create(L, M, 32, coef)
+    streams, frames = 64, 44100 * 4
+    rng = np.random.default_rng(5)
+    arena, stride, per_stream, _ = planes_and_packed(rng, 1, frames, 16, 0)
+    arena = np.tile(arena, streams)
+    d, dst_bytes, _ = descs_for(streams, frames, L, M, 16, 240, True, stride, per_stream)
+    d_src, d_dst = ctx.upload(arena), ctx.malloc(dst_bytes)
+    b = ctx.src_batch(h, d, arena.size, dst_bytes)
+    s2 = ctx.stream_create()
+    try:
+        for _ in range(8):
+            ctx.src_run(b, d_src, d_dst)                                  # queued on the context's stream
+        with pytest.raises(capi.OhGpuError) as err:
+            ctx.src_run(b, d_src, d_dst, stream=s2)                       # ...and still running there
+        assert err.value.code == capi.ERR_INVALID
+        ctx.sync()
+        ctx.src_run(b, d_src, d_dst, stream=s2)                           # once it has finished, any stream will do
+        ctx.sync(s2)
+        first = ctx.download(d_dst, dst_bytes)
+        ctx.src_run(b, d_src, d_dst)
+        ctx.sync()
+        assert np.array_equal(first, ctx.download(d_dst, dst_bytes))
+    finally:
+        ctx.stream_destroy(s2)
+        ctx.batch_destroy(b); ctx.src_destroy(h); ctx.free(d_src); ctx.free(d_dst)

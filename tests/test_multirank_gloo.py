@@ -43,3 +43,28 @@ def test_partition_by_bytes_is_contiguous_complete_and_even():
         if total >= 4 * world:
             shares = [sum(w[a:b]) for a, b in zip(cuts, cuts[1:])]
             assert max(shares) - min(shares) <= 2 * max(w), (total, world, shares)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 4])
+def test_bench_runs_under_the_launcher_with_two_ranks_on_a_gpu(config):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks
+    sharing the box's one GPU (`local_rank % device_count`): rendezvous, per-rank contexts, the barrier and the max over ranks,
+    one JSON line from rank 0 with the whole job's throughput.  The launcher starts before anything touches the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", str(config), "--steps", "2", "--warmup", "1",
+           "--seconds", "0.3", "--streams", "24" if config == 4 else "6", "--sustain", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                               # rank 0 alone reports
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["unit"] == "Msamples/s"
+    assert res["scaling"] == ("strong" if config == 4 else "weak")
+    if config == 3:                                                      # weak: every rank brought its own 6 streams
+        assert abs(res["value"] * res["ms_per_step"] * 1e3 / (2 * 6 * round(0.3 * 44100)) - 1.0) < 0.01   # (both figures are rounded)
+    assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None    # (the CPU leg runs at N = 1 only)
