@@ -384,7 +384,7 @@ def main():
     ap.add_argument("--rate-in", type=int, default=44100, help="config 3: input rate (the headline is 44100)")
     args = ap.parse_args()
     if args.seconds is None:
-        args.seconds = {3: 10.0, 4: 4.0, 5: 4.0}[args.config]
+        args.seconds = 10.0                                    # (every configuration: 10 s of audio per stream)
     if args.streams is None:
         args.streams = 2048 if args.config == 4 else 256
 
