@@ -375,7 +375,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json configs[config-1]: 3 = the headline")
-    ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: 10 s for config 3, 4 s for configs 4 and 5)")
+    ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: 10 s)")
     ap.add_argument("--streams", type=int, default=None, help="config 3/5: streams per GPU (256); config 4: streams in all (2048)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 2 round 1's block kernel)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / check, end_to_end and cadence legs (profiling runs)")
