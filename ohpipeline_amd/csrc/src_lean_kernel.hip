@@ -420,7 +420,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         constexpr int r = NCR - 1 - decltype(rc)::value;
         lean_issue_f64<r * 128>(cf[r], coef_lane);
     }, std::make_integer_sequence<int, NCR>{});
-    uint64_t raw = 0;
+    uint64_t rawp[2] = {0, 0};
 
     // ---- warm-up: the T advances before the block's first output only fill the window.  Stages 0 and 1 are issued together;
     // from then on stage q + 1 is issued when stage q begins (into the buffer stage q - 1 was read from), here and in the loop.
@@ -451,7 +451,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     }
     STAMP(st_warm)
     // The coefficient reads above were issued before the warm-up's waits: they have landed.  From here on, in issue order:
-    //   per advance:  X (raw sample)
+    //   per advance:  X (raw sample; of the NEXT advance where that lies in the same stage -- see the loop)
     //   per output:   W  S  16 taps(c[NCR-1])  C'[NCR-1]   W  16 taps(c[NCR-2])  C'[NCR-2] ...
     //                 W  unpack  16 taps(c[0])  C'[0]   round, clamp, (ramp,) pack
     // Every W awaits a reload C'[r] issued one output earlier (the last one the raw sample X as well).  After C'[r] come at
@@ -477,26 +477,31 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
             // ---- advance: this channel's sample of the next input frame enters slot s ----
             tl += L;
             const int tle = tl < t_end ? tl : t_end;
-            if (!(t < tle)) {
-                // no output needs it yet (M > L), or the block is done: read, wait and convert in ONE statement (a register must
-                // not be touched between a load's issue and its wait, and across statements the compiler may copy it)
-                constexpr int sp = s % SF, ph = sp % PH;
-                uint32_t lo, hi;
-                asm volatile("ds_read_b32 %[lo], %[addr] offset:%[o0]\n\t"
-                             "ds_read_b32 %[hi], %[addr] offset:%[o1]\n\t"
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             ".if %[pl]\n\tv_lshlrev_b32 %[lo], %[sel], %[lo]\n\t.else\n\tv_perm_b32 %[lo], %[hi], %[lo], %[sel]\n\t.endif\n\t"
-                             "v_cvt_f64_i32 %[d], %[lo]"
-                             : [lo] "=&v"(lo), [hi] "=&v"(hi), [d] "=v"(win[s])
-                             : [addr] "v"(in_addr[(s / SF) & 1][ph]), [o0] "i"(FB_SRC * (sp - ph)), [o1] "i"(FB_SRC * (sp - ph) + 4),
-                               [sel] "v"(in_sel[(s % SF) % PH]), [pl] "i"(PL ? 1 : 0) : "memory");
-            } else {
+            // The raw sample of advance s lands in rawp[s & 1].  It is read ONE ADVANCE AHEAD wherever the next advance lies in
+            // the same stage (15 of 16, 7 of 8): an advance that emits nothing -- every second one at 96 -> 48 kHz -- then finds
+            // its sample there instead of waiting out an LDS round trip.  Not across a stage's end (the next stage may not have
+            // landed) and so never across the trip's back-edge (T is a whole number of stages): an in-flight register must not
+            // be loop-carried.  Neither arm below touches the register the look-ahead is aimed at.
+            constexpr int sp = s % SF, ph = sp % PH;
+            constexpr bool had_ahead = sp != 0, look_ahead = sp != SF - 1;
 #ifndef OHGPU_DIAG_NO_X
-                {
-                    constexpr int sp = s % SF, ph = sp % PH;
-                    lean_issue_2xu32<FB_SRC * (sp - ph) / 4>(raw, in_addr[(s / SF) & 1][ph]);
-                }
+            if constexpr (!had_ahead) lean_issue_2xu32<FB_SRC * (sp - ph) / 4>(rawp[s & 1], in_addr[(s / SF) & 1][ph]);
+            if constexpr (look_ahead) {
+                constexpr int sn = sp + 1, phn = sn % PH;
+                lean_issue_2xu32<FB_SRC * (sn - phn) / 4>(rawp[(s + 1) & 1], in_addr[(s / SF) & 1][phn]);
+            }
 #endif
+            if (!(t < tle)) {
+                // no output needs it yet (M > L), or the block is done: wait for the sample (everything but the look-ahead just
+                // issued) and convert, in ONE statement
+                uint32_t w;
+                asm volatile("s_waitcnt lgkmcnt(%[n])\n\t"
+                             ".if %[pl]\n\tv_lshlrev_b32 %[w], %[sel], %[lo]\n\t.else\n\tv_perm_b32 %[w], %[hi], %[lo], %[sel]\n\t.endif\n\t"
+                             "v_cvt_f64_i32 %[d], %[w]"
+                             : [w] "=&v"(w), [d] "=&v"(win[s])
+                             : [hi] "v"((uint32_t)(rawp[s & 1] >> 32)), [lo] "v"((uint32_t)rawp[s & 1]), [n] "i"(look_ahead ? 1 : 0),
+                               [sel] "v"(in_sel[sp % PH]), [pl] "i"(PL ? 1 : 0) : "memory");
+            } else {
                 do {
                 // ---- emit the outputs whose newest input frame is this one ----
                 uint32_t cp;
@@ -515,7 +520,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                     constexpr int r = NCR - 1 - decltype(rc)::value;          // highest taps (oldest samples) first, the newest sample last
                     // (no register operands: the statements keep their order among themselves, and an operand written right in front
                     // of a statement that reads it gets that statement an s_nop)
-                    if constexpr (r == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw) : "i"(NCR - 1) : "memory");   // (the raw sample passes through its wait)
+                    if constexpr (r == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(rawp[s & 1]) : "i"(NCR - 1) : "memory");   // (the raw sample passes through its wait)
                     else asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(NCR - 1) : "memory");
                     // Consecutive statements that touch the accumulator are padded apart with an s_nop by the compiler (the gfx940 dst_sel forwarding hazard, assumed of every inline asm)
                     // unless an instruction of its own lies between them: the output is counted in front of its first taps and t
@@ -535,13 +540,13 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 #define W_(k) win[(s - (16 * r + (k)) + 2 * T) % T]
 #ifndef OHGPU_DIAG_NO_TAPS
                     if constexpr (r == 0)
-                        lean_taps16_unpack<PL>(acc, cf[0], raw, in_sel[(s % SF) % PH], win[s], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
+                        lean_taps16_unpack<PL>(acc, cf[0], rawp[s & 1], in_sel[(s % SF) % PH], win[s], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                            W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1));
                     else
                         lean_taps16(acc, cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                     W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1), W_(0));
 #else
-                    if constexpr (r == 0) win[s] = lean_unpack<PL>(raw, in_sel[(s % SF) % PH]);
+                    if constexpr (r == 0) win[s] = lean_unpack<PL>(rawp[s & 1], in_sel[(s % SF) % PH]);
 #endif
 #undef W_
 #ifndef OHGPU_DIAG_NO_COEF
