@@ -63,8 +63,10 @@ __device__ __forceinline__ void group_store(uint8_t* p, const typename GroupVec<
 
 // SB / DB: bytes per source / destination subsample when the whole batch has one layout (immediates instead of
 // scalar registers in every shift and multiply), 0 = read them from each chunk's record.
+// (Same-depth instantiations fit 64 registers and are held to them -- eight waves per SIMD: +4 % on plain S24, same box; the
+// depth-changing ones would spill, and S32 -> S24 lost 7 % when forced.)
 template <int SB, int DB>
-__global__ __launch_bounds__(kLineWaves * 64) void pcm_line_kernel(const PcmChunk* __restrict__ chunks, const uint32_t n_chunks,
+__global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu((SB == DB && SB != 4) ? 8 : 1, 8))) void pcm_line_kernel(const PcmChunk* __restrict__ chunks, const uint32_t n_chunks,
                                                                   const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                   const uint16_t* __restrict__ ramp_table)
 {
