@@ -64,7 +64,8 @@ def taps_for(rate_in):
 class Group:
     """Streams that share a filter and a layout: one source arena, one destination arena, one batch, one launch per step."""
 
-    def __init__(self, capi, rate_in, channels, stream_ids, in_frames, src_bits=BITS, src_endian=None, planar=False):
+    def __init__(self, capi, rate_in, channels, stream_ids, in_frames, src_bits=BITS, src_endian=None, planar=False,
+                 dst_bits=BITS, dst_endian=None):
         self.rate_in, self.channels, self.stream_ids, self.in_frames = rate_in, channels, list(stream_ids), in_frames
         self.planar = planar                                  # config 5: the source is the FLAC decoder's TInt32 planes (OHGPU_FLAG_SRC_PLANAR32)
         self.taps = taps_for(rate_in)
@@ -73,7 +74,9 @@ class Group:
         self.n_msgs = (self.out_total + OUT_FRAMES_PER_MSG - 1) // OUT_FRAMES_PER_MSG
         self.src_bits = src_bits
         self.src_endian = capi.ENDIAN_LITTLE if src_endian is None else src_endian
-        self.fb_src, self.fb_dst = (channels * 4 if planar else channels * src_bits // 8), channels * BITS // 8
+        self.dst_bits = dst_bits                              # (the bench's own groups write S24 big endian; tests vary it)
+        self.dst_endian = capi.ENDIAN_BIG if dst_endian is None else dst_endian
+        self.fb_src, self.fb_dst = (channels * 4 if planar else channels * src_bits // 8), channels * dst_bits // 8
         n = len(self.stream_ids)
         self.src_bytes, self.dst_bytes = n * in_frames * self.fb_src, n * self.out_total * self.fb_dst
         self.descs = self._descs(capi)
@@ -119,7 +122,7 @@ class Group:
             d["flags"] |= capi.FLAG_SRC_PLANAR32
             d["src_plane_stride"] = self.in_frames * 4
         d["channels"], d["src_bits"], d["src_endian"] = self.channels, self.src_bits, self.src_endian
-        d["dst_bits"], d["dst_endian"] = BITS, capi.ENDIAN_BIG
+        d["dst_bits"], d["dst_endian"] = self.dst_bits, self.dst_endian
         return d
 
     def fill_noise(self):

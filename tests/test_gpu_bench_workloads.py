@@ -61,3 +61,52 @@ def test_config4_groups_are_bit_exact(ctx, variant):
 def test_config3_group_is_bit_exact(ctx):
     args = argparse.Namespace(config=3, streams=24, seconds=1.0, rate_in=44100, channels=2)
     run_groups(ctx, bench.build_groups(capi, args, 0, 1)[0])
+
+
+def lean_instantiations():
+    """(T, channels, source bytes, source LE, destination bytes, destination LE) of every block-kernel instantiation the library
+    is built with, read from the list the kernels are instantiated from (csrc/src_block_common.h)."""
+    import re
+    text = open(os.path.join(ROOT, "ohpipeline_amd", "csrc", "src_block_common.h")).read()
+    text = text[text.index("#else", text.index("OHGPU_DIAG_ONE_KERNEL")):]
+    found = re.findall(r"X\((\d+), (\d+), (\d+), (true|false), (\d+), (true|false)\)", text)
+    return sorted(set((int(t), int(c), int(s), sl == "true", int(d), dl == "true") for t, c, s, sl, d, dl in found))
+
+
+def noise_le(stream_id, n_subsamples, bits):
+    """bench.py's seeded full-scale noise at another depth, little endian (the top bytes of the same LCG words)."""
+    x = bench.lcg_block((0x9E3779B9 * (stream_id + 1)) & bench.MASK, n_subsamples)
+    b = np.empty((x.size, bits // 8), dtype=np.uint8)
+    for k in range(bits // 8):
+        b[:, k] = (x >> (8 * (4 - bits // 8 + k))) & 0xFF
+    return b
+
+
+@pytest.mark.parametrize("inst", lean_instantiations(), ids=lambda i: "T%d_ch%d_s%d%s_d%d%s" % (i[0], i[1], i[2], "le" if i[3] else "be", i[4], "le" if i[5] else "be"))
+def test_every_block_kernel_instantiation_on_the_bench_workload(ctx, inst):
+    """One bench-shaped group per instantiation -- the host model's 50 ms / 500 ms ramp schedule, 5 ms messages, full-scale
+    noise, enough streams for workgroups of several waves -- on the lean kernel and (packed sources) on round 1's."""
+    T, ch, sb, src_le, db, dst_le = inst
+    planar = sb == 4
+    rate = 96000 if T == 64 else 44100
+    src_bits = 16 if planar else sb * 8
+    n_streams = 24 if ch == 2 else 12
+    g = bench.Group(capi, rate, ch, range(900, 900 + n_streams), int(round(0.7 * rate)), src_bits=src_bits,
+                    src_endian=capi.ENDIAN_LITTLE if src_le else capi.ENDIAN_BIG, planar=planar,
+                    dst_bits=db * 8, dst_endian=capi.ENDIAN_LITTLE if dst_le else capi.ENDIAN_BIG)
+    assert g.taps == T
+    per = g.in_frames * ch
+    if planar:                                                           # the decoder's planes, and the oracle's packed composition
+        v = [(noise_le(sid, per, 16).view("<i2").astype(np.int32).reshape(g.in_frames, ch)) for sid in g.stream_ids]
+        g.src = np.ascontiguousarray(np.stack([x.T for x in v])).reshape(-1).view(np.uint8)
+        g.oracle_src = np.concatenate([x.reshape(-1).astype(">i2").view(np.uint8) for x in v])
+        g.oracle_descs["src_endian"] = capi.ENDIAN_BIG
+    else:
+        le = [noise_le(sid, per, src_bits) for sid in g.stream_ids]
+        g.src = np.concatenate([(x if src_le else x[:, ::-1]).reshape(-1) for x in le])
+    for variant in ((0,) if planar else (0, 2)):
+        ctx.set_kernel_variant(variant)
+        try:
+            run_groups(ctx, [g])
+        finally:
+            ctx.set_kernel_variant(0)
