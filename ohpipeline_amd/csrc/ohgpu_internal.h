@@ -129,17 +129,23 @@ inline void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)
 
 // ---- line kernel of the PCM message path (csrc/pcm_line_kernel.hip) ----
 struct PcmChunk {             // one wave's share of a message: subsamples [q0, q0 + nq); 64 bytes = one scalar load
-    uint64_t src_off, dst_off;    // byte offsets of the chunk's first source / destination byte in the arenas
-    uint32_t q0, nq;
+    // ---- the first 16 bytes are what it takes to START a chunk (issue its loads): the uniform path fetches them for the
+    // next trip's chunks ahead of time and the whole record only once the audio is on its way (PcmChunkHead) ----
+    uint64_t src_off;             // byte offset of the chunk's first source byte in the arena
+    uint32_t nq;
+    uint8_t  channels, sb, db, flags;   // bytes per subsample; kChunk* bits
+    uint64_t dst_off;             // byte offset of the chunk's first destination byte
+    uint32_t q0;
     uint32_t n_frames;            // of the whole message (ramp)
     uint16_t ramp_start, ramp_end;
     uint32_t attenuation;
-    uint8_t  channels, sb, db, flags;   // bytes per subsample; kChunk* bits
     uint32_t m_ch, m_n1;          // x / d == umulhi(x, m) >> s for x < 2^31 (m == 0: d == 1); d = channels, n_frames - 1
     uint8_t  s_ch, s_n1, pad8[2];
     uint32_t plain_sel;           // v_perm_b32 selector of the plain path: source bytes -> destination bytes in memory order
     uint32_t pad[2];
 };
+struct PcmChunkHead { uint64_t src_off; uint32_t nq; uint8_t channels, sb, db, flags; };
+static_assert(sizeof(PcmChunkHead) == 16, "the head of a chunk record");
 static_assert(sizeof(PcmChunk) == 64, "chunk record = one 64-byte scalar load");
 enum { kChunkRamp = 1, kChunkSilence = 2, kChunkZeroLsb = 4, kChunkSrcLe = 8, kChunkDstLe = 16 };
 struct PcmLinePlan {

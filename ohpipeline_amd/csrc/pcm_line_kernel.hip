@@ -205,8 +205,9 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
         uint32_t grp_sel[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};    // plain path: selector of destination dword j over source dwords {2pr+1, 2pr}
         uint32_t grp_for = 0xffffffffu;                               // the per-subsample selector they were derived from
         auto is_silence = [](const PcmChunk& c) __attribute__((always_inline)) -> bool { return (c.flags & kChunkSilence) != 0; };
-        auto load_head = [&](const PcmChunk& c, bool on, Vec& a, Vec& b) __attribute__((always_inline)) {
-            if (!on || is_silence(c)) return;
+        auto head_of = [&](uint32_t i) __attribute__((always_inline)) -> PcmChunkHead { return *(const PcmChunkHead*)&chunks[i]; };
+        auto load_head = [&](const PcmChunkHead& c, bool on, Vec& a, Vec& b) __attribute__((always_inline)) {
+            if (!on || (c.flags & kChunkSilence)) return;
             const uint32_t n_grp = c.nq >> 2;
             const uint8_t* const sp = src + c.src_off;
             if (lane < n_grp) group_load<SB>(a, sp + (size_t)lane * (4 * SB));
@@ -334,18 +335,22 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
                 for (int bq = 0; bq < DB; bq++) dp[(size_t)q * DB + bq] = (uint8_t)(v >> (8 * bq));
             }
         };
-        PcmChunk c0 = chunks[chunk];
+        // (Scalar registers are the scarce thing here: two whole records per chunk in flight -- this trip's and the next one's --
+        // were 64 of them and spilled into vector lanes inside the loops.  A trip needs 16 bytes of a record to issue its
+        // loads; those are fetched one trip ahead, the whole records while the audio is on its way.)
+        PcmChunkHead h0 = head_of(chunk);
         bool has1 = chunk + stride < n_chunks;
-        PcmChunk c1 = chunks[has1 ? chunk + stride : chunk];
+        PcmChunkHead h1 = head_of(has1 ? chunk + stride : chunk);
         while (true) {
             Vec a0 = {}, b0 = {}, a1 = {}, b1 = {};
-            load_head(c0, true, a0, b0);
-            load_head(c1, has1, a1, b1);
-            // the next trip's records, while this trip's audio is on its way
+            load_head(h0, true, a0, b0);
+            load_head(h1, has1, a1, b1);
+            const PcmChunk c0 = chunks[chunk];
+            const PcmChunk c1 = chunks[has1 ? chunk + stride : chunk];
             const uint32_t next = chunk + 2 * stride;
             const bool more = next < n_chunks, more1 = next + stride < n_chunks;
-            const PcmChunk n0 = chunks[more ? next : chunk];
-            const PcmChunk n1 = chunks[more1 ? next + stride : chunk];
+            const PcmChunkHead n0 = head_of(more ? next : chunk);
+            const PcmChunkHead n1 = head_of(more1 ? next + stride : chunk);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : : "memory");
             if (is_silence(c0)) generic_chunk(c0, nullptr);
             else if (is_plain(c0)) plain_chunk(c0, a0, b0);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
             }
             if (!more) break;
             chunk = next;
-            c0 = n0; c1 = n1; has1 = more1;
+            h0 = n0; h1 = n1; has1 = more1;
         }
         return;
     }
