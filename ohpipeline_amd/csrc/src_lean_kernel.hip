@@ -238,8 +238,11 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     uint32_t unit = blockIdx.x * n_waves + wave;
     LeanUnit wk = units[unit < n_work ? unit : 0u];
     while (unit < n_work) {
+    // The next unit is claimed LATE -- at this unit's last stage boundary, with a stage's worth of outputs still to go to cover
+    // the atomic's latency: a unit claimed at the start of the one before it is a unit nobody else can take for that long, and
+    // the launch ends when the slowest such pair does.
     uint32_t claim = 0;
-    if (lane == 0) claim = atomicAdd(unit_counter, 1u);
+    bool claimed = false;
 #ifdef OHGPU_DIAG_STAMP
     st_mark = __builtin_amdgcn_s_memtime(); st_units++;
 #endif
@@ -468,6 +471,10 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                     const int q = (g * T + s) / SF;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage q has landed (this wave issued all of it)
                     if ((q + 1) * SF < total) issue_stage(q + 1);
+                    else if (!claimed) {
+                        if (lane == 0) claim = atomicAdd(unit_counter, 1u);
+                        claimed = true;
+                    }
                     STAMP(st_stage)
                 }
                 issue_store();
@@ -664,6 +671,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         }, std::make_integer_sequence<int, T>{});
     }
     STAMP(st_out)
+    if (!claimed && lane == 0) claim = atomicAdd(unit_counter, 1u);          // (a unit too short for a stage boundary of its own)
     // the next unit's descriptor is fetched while the last lines are written back
     unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     const LeanUnit next_wk = units[unit < n_work ? unit : n_work - 1u];
