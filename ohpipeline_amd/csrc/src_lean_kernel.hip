@@ -469,7 +469,9 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 STAMP(st_out)
                 if constexpr ((s % SF) == 0) {
                     const int q = (g * T + s) / SF;
+#ifndef OHGPU_DIAG_NO_STAGE_WAIT                                       // (diagnostic: wrong audio, the wait's share of the time)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage q has landed (this wave issued all of it)
+#endif
                     if ((q + 1) * SF < total) issue_stage(q + 1);
                     else if (!claimed) {
                         if (lane == 0) claim = atomicAdd(unit_counter, 1u);
