@@ -62,7 +62,9 @@ __device__ __forceinline__ uint32_t ramp_index_magic(uint32_t ramp_start, int32_
 {
     uint32_t ramp = ramp_start;
     if (n_frames != 1) {
-        const int32_t prod = (int32_t)i * total;                       // TInt arithmetic, Msg.cpp:835
+        // TInt arithmetic, Msg.cpp:835.  Both factors fit 24 bits (i < 2^17: validation; |total| <= 2^16), so the full-rate
+        // 24-bit multiply gives the same 32-bit product as the quarter-rate 32-bit one.
+        const int32_t prod = __mul24((int)i, (int)total);
         const uint32_t mag = udiv_magic((uint32_t)(prod < 0 ? -prod : prod), m, s);
         ramp = ramp_start - (uint32_t)(prod < 0 ? -(int32_t)mag : (int32_t)mag);   // C division truncates toward zero
     }
