@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "ohgpu_internal.h"
@@ -42,23 +43,54 @@ template <> struct GroupVec<3> { typedef uint32_t type __attribute__((ext_vector
 template <> struct GroupVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
 
 template <int N>
-__device__ __forceinline__ void group_load(typename GroupVec<N>::type& v, const uint8_t* p)
+__device__ __forceinline__ void group_load(typename GroupVec<N>::type& v, const uint8_t* base, uint32_t off)
 {
-    if constexpr (N == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    else if constexpr (N == 3) asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    // (wave-uniform 64-bit base in scalar registers + a 32-bit lane offset: no 64-bit address arithmetic per lane)
+    if constexpr (N == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    else if constexpr (N == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void group_put(uint8_t* base, uint32_t off, const typename GroupVec<N>::type& o)
+{
+    if constexpr (N == 2) asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(off), "v"(o), "s"(base) : "memory");
+    else if constexpr (N == 3) asm volatile("global_store_dwordx3 %0, %1, %2 nt" : : "v"(off), "v"(o), "s"(base) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(off), "v"(o), "s"(base) : "memory");
 }
 template <int NI, int NO>
-__device__ __forceinline__ void group_store(uint8_t* p, const typename GroupVec<NI>::type& in, const uint32_t (&sel)[4][2])
+__device__ __forceinline__ void group_store(uint8_t* base, uint32_t off, const typename GroupVec<NI>::type& in, const uint32_t (&sel)[4][2])
 {
     const uint32_t i0 = in[0], i1 = in[1], i2 = NI > 2 ? in[2] : 0u, i3 = NI > 3 ? in[3 < NI ? 3 : 0] : 0u;
     typename GroupVec<NO>::type o;
 #pragma unroll
     for (int j = 0; j < NO; j++)
         o[j] = __builtin_amdgcn_perm(i1, i0, sel[j][0]) | (NI > 2 ? __builtin_amdgcn_perm(i3, i2, sel[j][1]) : 0u);
-    if constexpr (NO == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(o) : "memory");
-    else if constexpr (NO == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(p), "v"(o) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(o) : "memory");
+    group_put<NO>(base, off, o);
+}
+
+// ---- selectors of the ramped group path (xform_chunk's common case).  RampApplicator reads a subsample's top 16 bits and
+// writes those two bytes back with zeros below them (Msg.cpp:840-895), so a ramped subsample is: ONE v_perm_b32 that lifts
+// its two most significant bytes (either byte order) out of the loaded dwords into the top half of a register, one 24-bit
+// multiply by twice the Q15 multiplier (bits 31..16 of the product are (s16 * mult) >> 15), and its share of the ONE
+// v_perm_b32 per destination dword that picks those two product bytes (either byte order) and zeros. ----
+constexpr uint32_t ramp_in_sel(int sb, int k, bool le)
+{
+    const int bi = (k * sb) & 3;                                      // first byte of the subsample in {iw[d + 1], iw[d]}, d = k * sb / 4
+    const int hi = le ? bi + sb - 1 : bi, lo = le ? bi + sb - 2 : bi + 1;
+    return ((uint32_t)hi << 24) | ((uint32_t)lo << 16) | 0x0c0cu;
+}
+constexpr uint32_t ramp_out_sel(int db, int j, bool le)               // destination dword j over the products {r[first + 1], r[first]}, first = 4j / db
+{
+    uint32_t sel = 0;
+    const int first = (4 * j) / db;
+    for (int t = 0; t < 4; t++) {
+        const int B = 4 * j + t, qi = B / db, m = B % db;
+        const int pos = le ? db - 1 - m : m;                           // 0 = most significant byte of the subsample
+        uint32_t code = pos == 0 ? 3u : (pos == 1 ? 2u : 0x0cu);
+        if (code != 0x0cu && qi != first) code += 4u;
+        sel |= code << (8 * t);
+    }
+    return sel;
 }
 
 // SB / DB: bytes per source / destination subsample when the whole batch has one layout (immediates instead of
@@ -71,11 +103,12 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
                                                                   const uint16_t* __restrict__ ramp_table)
 {
     __shared__ uint16_t s_ramp[kRampTableCount];
+    __shared__ uint16_t s_ramp2[kRampTableCount];                       // twice the multiplier (<= 0xfffe): the ramped group path's
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kLineWaves][2][kInBytes];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (uint32_t i = tid; i < kRampTableCount; i += blockDim.x) s_ramp[i] = ramp_table[i];
+    for (uint32_t i = tid; i < kRampTableCount; i += blockDim.x) { s_ramp[i] = ramp_table[i]; s_ramp2[i] = (uint16_t)(2u * ramp_table[i]); }
     __syncthreads();
 
     // Software pipeline over the wave's chunks (chunk, chunk + stride, ...): while chunk i is processed, the input of
@@ -210,8 +243,8 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
             if (!on || (c.flags & kChunkSilence)) return;
             const uint32_t n_grp = c.nq >> 2;
             const uint8_t* const sp = src + c.src_off;
-            if (lane < n_grp) group_load<SB>(a, sp + (size_t)lane * (4 * SB));
-            if (64 + lane < n_grp) group_load<SB>(b, sp + (size_t)(64 + lane) * (4 * SB));
+            if (lane < n_grp) group_load<SB>(a, sp, lane * (4 * SB));
+            if (64 + lane < n_grp) group_load<SB>(b, sp, (64 + lane) * (4 * SB));
         };
         // ---- plain chunk: a fixed byte shuffle (per destination dword: one v_perm_b32 per pair of source dwords, selectors
         // derived from the record's per-subsample selector when the layout changes) ----
@@ -241,12 +274,12 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
             for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {
                 const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
                 if (g0 != 0) {                                          // (the first 128 groups were loaded by the trip)
-                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
-                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
+                    if (ga < n_grp) group_load<SB>(in_a, sp, ga * (4 * SB));
+                    if (gb < n_grp) group_load<SB>(in_b, sp, gb * (4 * SB));
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
                 }
-                if (ga < n_grp) group_store<SB, DB>(dp + (size_t)ga * (4 * DB), in_a, grp_sel);
-                if (gb < n_grp) group_store<SB, DB>(dp + (size_t)gb * (4 * DB), in_b, grp_sel);
+                if (ga < n_grp) group_store<SB, DB>(dp, ga * (4 * DB), in_a, grp_sel);
+                if (gb < n_grp) group_store<SB, DB>(dp, gb * (4 * DB), in_b, grp_sel);
             }
             // the chunk's last 1..3 subsamples: byte by byte
             const uint32_t tail0 = n_grp * 4, tail_bytes = (ck.nq - tail0) * DB;
@@ -285,8 +318,6 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
             auto do_group = [&](uint32_t g, const Vec& in) __attribute__((always_inline)) {
                 uint32_t iw[5] = {in[0], in[1], SB > 2 ? in[2 < SB ? 2 : 0] : 0u, SB > 3 ? in[3 < SB ? 3 : 0] : 0u, 0u};
                 uint32_t ow[5] = {0, 0, 0, 0, 0};
-                uint32_t m_lo = 0, m_hi = 0;
-                if (ramp && stereo_even) { const uint32_t f = (ck.q0 >> 1) + 2 * g; m_lo = ramp_mult(f); m_hi = ramp_mult(f + 1); }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int off = k * SB, o = k * DB;
@@ -294,12 +325,8 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
                     uint32_t w = src_le ? (raw << (32 - 8 * SB)) : (__builtin_bswap32(raw) & ~(SB == 4 ? 0u : (0xffffffffu >> (8 * (SB & 3)))));
                     if (atten) w = attenuate_word(w, ck.attenuation);
                     if (ramp) {
-                        if (stereo_even) {
-                            w = ramp_word(w, k < 2 ? m_lo : m_hi, SB, 2, (uint32_t)(k & 1));
-                        } else {
-                            const uint32_t sub = ck.q0 + 4 * g + k, frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
-                            w = ramp_word(w, ramp_mult(frame), SB, ck.channels, sub - frame * ck.channels);
-                        }
+                        const uint32_t sub = ck.q0 + 4 * g + k, frame = udiv_magic(sub, ck.m_ch, ck.s_ch);
+                        w = ramp_word(w, ramp_mult(frame), SB, ck.channels, sub - frame * ck.channels);
                     }
                     w &= keep;
                     const uint32_t v = dst_le ? (w >> (32 - 8 * DB)) : __builtin_bswap32(w);   // destination bytes in memory order
@@ -309,20 +336,68 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
                 typename GroupVec<DB>::type out;
 #pragma unroll
                 for (int j = 0; j < DB; j++) out[j] = ow[j];
-                uint8_t* const op = dp + (size_t)g * (4 * DB);
-                if constexpr (DB == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
-                else if constexpr (DB == 3) asm volatile("global_store_dwordx3 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(op), "v"(out) : "memory");
+                group_put<DB>(dp, g * (4 * DB), out);
             };
-            for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {
-                const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
-                if (g0 != 0) {                                          // (the first 128 groups were loaded by the trip)
-                    if (ga < n_grp) group_load<SB>(in_a, sp + (size_t)ga * (4 * SB));
-                    if (gb < n_grp) group_load<SB>(in_b, sp + (size_t)gb * (4 * SB));
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
+            // The common ramped chunk -- no attenuation, two bytes or more either side, a group inside two frames (stereo from an
+            // even subsample: frames f, f + 1; three channels or more: frame f up to subsample kb, f + 1 from it) -- without the
+            // general expressions: see ramp_in_sel.  (32-bit six-channel audio gets its channel byte from the general path.)
+            // ramp_index_magic for a message of 3..32768 frames (no special cases: the multiplier exists and frame x |total| is
+            // below 2^31; the quotient's sign is the ramp's, the same for the whole message), then TWICE the Q15 multiplier
+            const uint32_t abs_total = (uint32_t)(total < 0 ? -total : total) & 0x1ffffu;
+            const uint32_t neg_mask = total < 0 ? 0xffffffffu : 0u, ramp_base = (uint32_t)ck.ramp_start + neg_mask;   // start - (+-mag) = (start + m) - (mag ^ m)
+            auto ramp_mult2 = [&](uint32_t frame) __attribute__((always_inline)) -> uint32_t {
+                const uint32_t mag = __umulhi((frame & 0xffffu) * abs_total, ck.m_n1) >> ck.s_n1;     // (masks: operand ranges the compiler can see select the full-rate 24-bit multiplies)
+                const uint32_t ramp16 = (ramp_base - (mag ^ neg_mask)) & 0xffffu;
+                const uint32_t idx = (kRampMax + (1u << 4) - ramp16) >> 5;
+                return s_ramp2[idx < kRampTableCount - 1 ? idx : kRampTableCount - 1];
+            };
+            auto ramped_group = [&](auto stereo_tag, uint32_t g, const Vec& in) __attribute__((always_inline)) {
+                constexpr bool STEREO = decltype(stereo_tag)::value;
+                constexpr int S = SB < 2 ? 2 : SB, D = DB < 2 ? 2 : DB;       // (never instantiated for one-byte subsamples)
+                const uint32_t iw[5] = {in[0], in[1], SB > 2 ? in[2 < SB ? 2 : 0] : 0u, SB > 3 ? in[3 < SB ? 3 : 0] : 0u, 0u};
+                const uint32_t sub0 = ck.q0 + 4 * g;
+                uint32_t f0, kb = 2;
+                if constexpr (STEREO) {
+                    f0 = sub0 >> 1;
+                } else {
+                    f0 = __umulhi(sub0, ck.m_ch) >> ck.s_ch;              // (three channels or more: the multiplier exists)
+                    kb = ck.channels - (sub0 - (f0 & 0xffffu) * (uint32_t)ck.channels);
                 }
-                if (ga < n_grp) do_group(ga, in_a);
-                if (gb < n_grp) do_group(gb, in_b);
+                const uint32_t m0 = ramp_mult2(f0), m1 = ramp_mult2(f0 + 1);
+                uint32_t r[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int d = (k * S) >> 2;
+                    const uint32_t w = __builtin_amdgcn_perm(iw[d + 1], iw[d], src_le ? ramp_in_sel(S, k, true) : ramp_in_sel(S, k, false));
+                    const uint32_t mk = STEREO ? (k < 2 ? m0 : m1) : ((uint32_t)k >= kb ? m1 : m0);
+                    r[k] = (uint32_t)(((int32_t)w >> 16) * (int32_t)mk);
+                }
+                typename GroupVec<DB>::type out;
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    const int first = (4 * j) / D;
+                    out[j] = __builtin_amdgcn_perm(r[first + 1], r[first], dst_le ? ramp_out_sel(D, j, true) : ramp_out_sel(D, j, false));
+                }
+                group_put<DB>(dp, g * (4 * DB), out);
+            };
+            auto all_groups = [&](auto&& one) __attribute__((always_inline)) {
+                for (uint32_t g0 = 0; g0 < n_grp; g0 += 128) {
+                    const uint32_t ga = g0 + lane, gb = g0 + 64 + lane;
+                    if (g0 != 0) {                                      // (the first 128 groups were loaded by the trip)
+                        if (ga < n_grp) group_load<SB>(in_a, sp, ga * (4 * SB));
+                        if (gb < n_grp) group_load<SB>(in_b, sp, gb * (4 * SB));
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_a), "+v"(in_b) : : "memory");
+                    }
+                    if (ga < n_grp) one(ga, in_a);
+                    if (gb < n_grp) one(gb, in_b);
+                }
+            };
+            const bool two_frames = stereo_even || ck.channels >= 3;
+            if (SB >= 2 && DB >= 2 && ramp && !atten && two_frames && !(SB == 4 && ck.channels == 6) && ck.m_n1 != 0 && ck.n_frames <= 32768u) {
+                if (stereo_even) all_groups([&](uint32_t g, const Vec& in) __attribute__((always_inline)) { ramped_group(std::true_type{}, g, in); });
+                else all_groups([&](uint32_t g, const Vec& in) __attribute__((always_inline)) { ramped_group(std::false_type{}, g, in); });
+            } else {
+                all_groups(do_group);
             }
             const uint32_t tail0 = n_grp * 4;                   // the chunk's last 1..3 subsamples, one lane each
             if (lane < ck.nq - tail0) {

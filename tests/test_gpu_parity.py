@@ -152,6 +152,32 @@ def test_pcm_uniform_batches_every_depth_pair(vctx, bits, dbits):
         assert bad.size == 0, f"{bits}->{dbits} se={se} de={de} ch={ch}: {bad.size} mismatches, first at {bad[:5]}"
 
 
+@pytest.mark.parametrize("bits,dbits", list(itertools.product([16, 24, 32], [16, 24, 32])))
+def test_pcm_ramped_groups_every_channel_count(vctx, bits, dbits):
+    """The line kernel's ramped group path (a group of four subsamples inside two frames: two multiplier look-ups, one
+    byte shuffle in, one multiply, one shuffle out per subsample) against the oracle's RampApplicator: every channel count
+    up to eight, both byte orders on both sides, every ramp shape (down, up, flat, partial), messages of 2 frames (no
+    multiplier for the division: general path) to several chunks, ragged tails."""
+    rng = np.random.default_rng(7 * bits + dbits)
+    for ch, (se, de) in itertools.product([2, 3, 4, 5, 6, 7, 8], [(BE, BE), (LE, BE), (BE, LE), (LE, LE)]):
+        rows, parts, sp, dp = [], [], 0, 0
+        for k, n in enumerate([2, 3, 4, 7, 64, 219, 240, 513, 2000]):
+            if n * ch * max(bits, dbits) // 8 > 65536:
+                n = 300
+            for ramp in RAMPS:
+                pad = (k + ramp[0]) % 5
+                nbytes = n * ch * bits // 8
+                parts.append(rng.integers(0, 256, size=pad + nbytes, dtype=np.uint8))
+                rows.append((sp + pad, dp + (k % 3), n, ramp[0], ramp[1], 256, ch, bits, se, dbits, de, O.FLAG_RAMP))
+                sp += pad + nbytes
+                dp += n * ch * dbits // 8 + 5
+        descs = np.array(rows, dtype=O.MSG_DESC)
+        src = np.concatenate(parts)
+        got, want = run_pcm(vctx, descs, src, dp), oracle_pcm(descs, src, dp)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"{bits}->{dbits} ch={ch} se={se} de={de}: {bad.size} mismatches, first at {bad[:5]}"
+
+
 @pytest.mark.parametrize("bits,dbits,ch", [(24, 24, 2), (16, 24, 2), (24, 16, 6), (32, 24, 2), (16, 16, 1), (24, 32, 8)])
 def test_pcm_contiguous_streams_of_mixed_messages(vctx, bits, dbits, ch):
     """Back-to-back messages of one stream -- what the chunk planner merges -- with plain, ramped, silent and (16-bit)
