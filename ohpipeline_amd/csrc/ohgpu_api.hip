@@ -286,6 +286,14 @@ static int upload_batch(ohgpu_ctx* ctx, ohgpu_batch* b, const void* host_descs, 
 int ohgpu_pcm_batch_create(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
 {
+    return pcm_batch_create_prefixed(ctx, descs, n, src_arena_bytes, dst_arena_bytes, nullptr, nullptr, 0, out);
+}
+
+}  // extern "C"
+
+int ohgpu::pcm_batch_create_prefixed(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n, uint64_t src_arena_bytes, uint64_t dst_arena_bytes,
+                                     const MsgPrefix* prefixes, const uint8_t* blob, size_t blob_bytes, ohgpu_batch** out)
+{
     CTX_GUARD("ohgpu_pcm_batch_create");
     if (!out || (n && !descs)) return set_error(OHGPU_ERR_INVALID, "ohgpu_pcm_batch_create: null argument");
     *out = nullptr;
@@ -315,11 +323,13 @@ int ohgpu_pcm_batch_create(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n
         }
     }
     int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_msg_desc));
-    if (err == OHGPU_OK) err = plan_pcm_line(ctx, b, descs, n);
+    if (err == OHGPU_OK) err = plan_pcm_line(ctx, b, descs, n, prefixes, blob, blob_bytes);
     if (err != OHGPU_OK) { if (b->d_descs) hipFree(b->d_descs); delete b; return err; }
     *out = b;
     return OHGPU_OK;
 }
+
+extern "C" {
 
 int ohgpu_pcm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
 {

@@ -140,9 +140,12 @@ struct PcmChunk {             // one wave's share of a message: subsamples [q0, 
     uint16_t ramp_start, ramp_end;
     uint32_t attenuation;
     uint32_t m_ch, m_n1;          // x / d == umulhi(x, m) >> s for x < 2^31 (m == 0: d == 1); d = channels, n_frames - 1
-    uint8_t  s_ch, s_n1, pad8[2];
+    uint8_t  s_ch, s_n1;
+    uint8_t  prefix_bytes;        // bytes the chunk's wave copies from the batch's prefix blob to just before dst_off (0: none) --
+    uint8_t  pad8;                //   a Songcast frame's header, written with the frame's first audio (csrc/ohm_frame_kernel.hip)
     uint32_t plain_sel;           // v_perm_b32 selector of the plain path: source bytes -> destination bytes in memory order
-    uint32_t pad[2];
+    uint32_t prefix_off;          // of those bytes in the blob (a multiple of 4; entries are padded to whole dwords)
+    uint32_t pad;
 };
 struct PcmChunkHead { uint64_t src_off; uint32_t nq; uint8_t channels, sb, db, flags; };
 static_assert(sizeof(PcmChunkHead) == 16, "the head of a chunk record");
@@ -150,9 +153,12 @@ static_assert(sizeof(PcmChunk) == 64, "chunk record = one 64-byte scalar load");
 enum { kChunkRamp = 1, kChunkSilence = 2, kChunkZeroLsb = 4, kChunkSrcLe = 8, kChunkDstLe = 16 };
 struct PcmLinePlan {
     bool     enabled = false;
+    bool     prefixed = false;    // chunks carry prefixes (d_prefix): only this kernel writes them
     uint32_t n_chunks = 0;
     void*    d_chunks = nullptr;
+    void*    d_prefix = nullptr;  // the prefix blob
 };
+struct MsgPrefix { uint32_t off; uint32_t bytes; };   // per message: [off, off + bytes) of the blob goes right before its destination (bytes <= 255; 0: none)
 
 // ---- line kernel of the layout-changing processors (csrc/fmt_line_kernel.hip) ----
 struct FmtChunk {             // 64 bytes = one scalar load
@@ -209,9 +215,10 @@ struct OhmPlan {
     void*    d_selr = nullptr;             // OhmSelRec[n_selr]: ramped / attenuated fragments of wider streams, one pass
     uint32_t n_selr = 0;
     void*    d_scratch = nullptr;
-    void*    d_frames = nullptr;           // OhmFrameRec[n_frames]
+    void*    d_frames = nullptr;           // OhmFrameRec[n_frames], the frames whose header `direct` does not write first
     void*    d_streams = nullptr;          // 64 bytes per stream
     uint32_t n_frames = 0;
+    uint32_t n_unfolded = 0;               // d_frames[0, n_unfolded): headers no audio pass writes (the header kernel's, always)
 };
 
 enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3, kBatchFlywheel = 4, kBatchOhm = 5 };
@@ -272,7 +279,12 @@ int set_error(int code, const char* fmt, ...);
 hipError_t launch_fmt_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_pcm_v1(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
-int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n);
+int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n,
+                  const MsgPrefix* prefixes = nullptr, const uint8_t* blob = nullptr, size_t blob_bytes = 0);
+// ohgpu_pcm_batch_create with a prefix per message (not part of the C ABI: the Songcast frame batch is its one user).
+// (*out)->line.prefixed tells whether the line kernel took them; if not, nobody writes them.
+int pcm_batch_create_prefixed(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n, uint64_t src_arena_bytes, uint64_t dst_arena_bytes,
+                              const MsgPrefix* prefixes, const uint8_t* blob, size_t blob_bytes, ohgpu_batch** out);
 void free_pcm_line(ohgpu_batch* b);
 int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, size_t n);
 void free_fmt_line(ohgpu_batch* b);

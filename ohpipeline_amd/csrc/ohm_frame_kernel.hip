@@ -6,9 +6,13 @@
 //   wider streams: the Sender pack's channel select (fmt_line_kernel), after a PCM pass into a scratch arena when the
 //     fragment is ramped, attenuated or silent (what MsgPlayable::Read would have applied first, Msg.cpp:2753-2786).
 // What is new here is the header: 36 per-frame bytes (OhmHeader + the per-frame part of OhmMsgAudio::Serialise,
-// OhmMsg.cpp:363-413) and the per-stream 22 + codec bytes (GetStreamHeader, :225-241), written by 16 lanes per frame.
+// OhmMsg.cpp:363-413) and the per-stream 22 + codec bytes (GetStreamHeader, :225-241).  A mono / stereo frame's header is
+// assembled on the host when the batch is created and travels as the PREFIX of the frame's first audio message: the wave
+// that writes that audio writes the header in front of it (pcm_line_kernel), one launch for the whole batch.  Every other
+// frame's header (wider streams, frames without audio) is written by ohm_header_kernel, 16 lanes per frame.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -191,6 +195,9 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
     }
 
     std::vector<ohgpu_msg_desc> direct, stage;
+    std::vector<MsgPrefix> direct_prefix;                              // per direct message: the frame header it carries (bytes == 0: none)
+    std::vector<uint8_t> blob;                                         // those headers, each padded to whole dwords
+    std::vector<uint8_t> folded(n_frames, 0);
     std::vector<ohgpu_fmt_desc> select, select_staged;
     std::vector<OhmSelRec> selr;
     uint64_t scratch_bytes = 0, in_frames = 0, src_touched = 0, dst_written = 0;
@@ -267,6 +274,18 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
                 m.dst_offset = at;
                 m.dst_bits = (uint8_t)(wb * 8);
                 direct.push_back(m);
+                // The frame's first audio is this message's: its wave writes the header too (the bytes right before `at`), so a
+                // batch of mono / stereo streams is ONE launch.  The header as it goes on the wire: the record's 36 bytes, then
+                // the stream's (what ohm_header_kernel assembles from the two records for every other frame).
+                MsgPrefix pre = {0, 0};
+                if (at == fr.dst_offset + header_bytes) {
+                    pre.off = (uint32_t)blob.size(); pre.bytes = header_bytes;
+                    blob.insert(blob.end(), h, h + kPerFrameHeader);
+                    blob.insert(blob.end(), &stream_recs[(size_t)fr.stream * 64], &stream_recs[(size_t)fr.stream * 64] + (header_bytes - kPerFrameHeader));
+                    blob.resize((blob.size() + 3) & ~(size_t)3, 0);
+                    folded[f] = 1;
+                }
+                direct_prefix.push_back(pre);
             } else if (plain) {
                 p.src_offset = fg.src_offset;
                 select.push_back(p);
@@ -330,7 +349,21 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
         if (h) OHGPU_HIP_TRY(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
         return OHGPU_OK;
     };
-    if (!direct.empty()) err = ohgpu_pcm_batch_create(ctx, direct.data(), direct.size(), src_arena_bytes, dst_arena_bytes, &plan.direct);
+    if (blob.size() > 0xffffff00ull) {                                  // (prefix offsets are 32-bit: such a batch keeps the header kernel)
+        blob.clear();
+        std::fill(folded.begin(), folded.end(), 0);
+    }
+    if (!direct.empty())
+        err = pcm_batch_create_prefixed(ctx, direct.data(), direct.size(), src_arena_bytes, dst_arena_bytes,
+                                        blob.empty() ? nullptr : direct_prefix.data(), blob.data(), blob.size(), &plan.direct);
+    // frames whose header no audio pass writes first; the rest follow, for the runs in which the line kernel is not the one used
+    const bool folds = plan.direct && plan.direct->line.prefixed;
+    std::vector<OhmFrameRec> ordered;
+    ordered.reserve(n_frames);
+    for (size_t f = 0; f < n_frames; f++) if (!(folds && folded[f])) ordered.push_back(recs[f]);
+    plan.n_unfolded = (uint32_t)ordered.size();
+    for (size_t f = 0; f < n_frames; f++) if (folds && folded[f]) ordered.push_back(recs[f]);
+    recs.swap(ordered);
     if (err == OHGPU_OK && !select.empty())
         err = ohgpu_fmt_batch_create(ctx, select.data(), select.size(), src_arena_bytes, dst_arena_bytes, &plan.select);
     if (err == OHGPU_OK && !stage.empty())
@@ -368,11 +401,15 @@ int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
                            (const uint16_t*)ctx->d_ramp_table, (const uint8_t*)src_base, batch->src_arena_bytes, (uint8_t*)dst_base);
         OHGPU_HIP_TRY(hipGetLastError());
     }
-    const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame * kFramesPerGroup;
-    const uint32_t blocks = (p.n_frames + frames_per_block - 1) / frames_per_block;
-    hipLaunchKernelGGL(ohm_header_kernel, dim3(blocks), dim3(threads), 0, s,
-                       (const OhmFrameRec*)p.d_frames, p.n_frames, (const uint8_t*)p.d_streams, (uint8_t*)dst_base);
-    OHGPU_HIP_TRY(hipGetLastError());
+    // headers: those the direct pass has not written (all of them when the generic kernel ran it, ohgpu_set_kernel_variant(1))
+    const uint32_t n_headers = ctx->variant == 1 ? p.n_frames : p.n_unfolded;
+    if (n_headers) {
+        const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame * kFramesPerGroup;
+        const uint32_t blocks = (n_headers + frames_per_block - 1) / frames_per_block;
+        hipLaunchKernelGGL(ohm_header_kernel, dim3(blocks), dim3(threads), 0, s,
+                           (const OhmFrameRec*)p.d_frames, n_headers, (const uint8_t*)p.d_streams, (uint8_t*)dst_base);
+        OHGPU_HIP_TRY(hipGetLastError());
+    }
     return OHGPU_OK;
 }
 

@@ -95,12 +95,13 @@ constexpr uint32_t ramp_out_sel(int db, int j, bool le)               // destina
 
 // SB / DB: bytes per source / destination subsample when the whole batch has one layout (immediates instead of
 // scalar registers in every shift and multiply), 0 = read them from each chunk's record.
-// (Same-depth instantiations fit 64 registers and are held to them -- eight waves per SIMD: +4 % on plain S24, same box; the
-// depth-changing ones would spill, and S32 -> S24 lost 7 % when forced.)
+// (Every instantiation is held to 64 vector registers -- eight waves per SIMD.  With the group accesses on scalar bases the
+// depth-changing ones need 57..65 by themselves; holding them costs scalar spills into vector lanes and still wins, same box:
+// nothing on plain batches, 3..14 % when every message is ramped.  Round 1's 74-register S32 -> S24 lost 7 % when forced.)
 template <int SB, int DB>
-__global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu((SB == DB && SB != 4) ? 8 : 1, 8))) void pcm_line_kernel(const PcmChunk* __restrict__ chunks, const uint32_t n_chunks,
+__global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void pcm_line_kernel(const PcmChunk* __restrict__ chunks, const uint32_t n_chunks,
                                                                   const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                                  const uint16_t* __restrict__ ramp_table)
+                                                                  const uint16_t* __restrict__ ramp_table, const uint8_t* __restrict__ prefix)
 {
     __shared__ uint16_t s_ramp[kRampTableCount];
     __shared__ uint16_t s_ramp2[kRampTableCount];                       // twice the multiplier (<= 0xfffe): the ramped group path's
@@ -119,6 +120,22 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
     if (chunk >= n_chunks) return;
     auto is_plain = [](const PcmChunk& c) __attribute__((always_inline)) -> bool {
         return !(c.flags & (kChunkRamp | kChunkSilence)) && c.attenuation == OHGPU_UNITY_ATTENUATION;
+    };
+    // A chunk's prefix (a Songcast frame's header in front of the frame's first audio): 4..255 bytes of the batch's blob to just
+    // before the chunk's destination, a dword per lane at any alignment; when the size is not a multiple of four the last
+    // lane's dword is the prefix's LAST four bytes (it overlaps its neighbour's with the same bytes).  Scalar base + lane
+    // offset on both sides: two vector registers per chunk.  The load is in flight until the caller's s_waitcnt.
+    auto prefix_pos = [&](const PcmChunk& c) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t hb = c.prefix_bytes;
+        return lane * 4 + 4 <= hb ? lane * 4 : hb - 4;
+    };
+    auto prefix_load = [&](const PcmChunk& c, bool on, uint32_t pos, uint32_t& v) __attribute__((always_inline)) {
+        const uint8_t* const base = prefix + c.prefix_off;
+        if (on && lane * 4 < c.prefix_bytes) asm volatile("global_load_dword %0, %1, %2" : "+v"(v) : "v"(pos), "s"(base) : "memory");
+    };
+    auto prefix_store = [&](const PcmChunk& c, bool on, uint32_t pos, uint32_t v) __attribute__((always_inline)) {
+        uint8_t* const base = dst + (c.dst_off - c.prefix_bytes);
+        if (on && lane * 4 < c.prefix_bytes) asm volatile("global_store_dword %0, %1, %2" : : "v"(pos), "v"(v), "s"(base) : "memory");
     };
     auto stage_in = [&](const PcmChunk& c, uint32_t buf) __attribute__((always_inline)) -> uint32_t {
         if (c.flags & kChunkSilence) return 0u;
@@ -426,7 +443,13 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
             const bool more = next < n_chunks, more1 = next + stride < n_chunks;
             const PcmChunkHead n0 = head_of(more ? next : chunk);
             const PcmChunkHead n1 = head_of(more1 ? next + stride : chunk);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : : "memory");
+            uint32_t p0 = 0, p1 = 0;                                    // the chunks' prefixes (none: no lane takes part)
+            const uint32_t pp0 = prefix_pos(c0), pp1 = prefix_pos(c1);
+            prefix_load(c0, true, pp0, p0);
+            prefix_load(c1, has1, pp1, p1);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(p0), "+v"(p1) : : "memory");
+            prefix_store(c0, true, pp0, p0);
+            prefix_store(c1, has1, pp1, p1);
             if (is_silence(c0)) generic_chunk(c0, nullptr);
             else if (is_plain(c0)) plain_chunk(c0, a0, b0);
             else xform_chunk(c0, a0, b0);
@@ -459,6 +482,13 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        if (ck.prefix_bytes) {
+            uint32_t pv = 0;
+            const uint32_t pp = prefix_pos(ck);
+            prefix_load(ck, true, pp, pv);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv) : : "memory");
+            prefix_store(ck, true, pp, pv);
+        }
         generic_chunk(ck, (const __attribute__((address_space(3))) uint8_t*)&s_in[wave][buf][0]);
         if (!has_nx) break;
         chunk += stride;
@@ -470,11 +500,13 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
 // ---- host side: chunk list and per-message multipliers ----
 void free_pcm_line(ohgpu_batch* b)
 {
-    if (b->line.d_chunks) hipFree(b->line.d_chunks);
+    if (b->line.d_chunks) (void)hipFree(b->line.d_chunks);
+    if (b->line.d_prefix) (void)hipFree(b->line.d_prefix);
     b->line = PcmLinePlan();
 }
 
-int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n)
+int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n,
+                  const MsgPrefix* prefixes, const uint8_t* blob, size_t blob_bytes)
 {
     (void)ctx;
     b->line = PcmLinePlan();
@@ -505,6 +537,13 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
             }
             c.plain_sel |= selb << (8 * m);
         }
+        const bool has_prefix = prefixes && prefixes[i].bytes != 0 && n_sub > 0;     // (goes with the message's FIRST chunk)
+        if (has_prefix) {
+            if (prefixes[i].bytes < 4u || prefixes[i].bytes > 255u || (prefixes[i].off & 3u) || (uint64_t)prefixes[i].off + ((prefixes[i].bytes + 3u) & ~3u) > blob_bytes ||
+                prefixes[i].bytes > d.dst_offset)
+                return set_error(OHGPU_ERR_INVALID, "message %zu: prefix [%u, +%u) of a %zu-byte blob", i, prefixes[i].off, prefixes[i].bytes, blob_bytes);
+            c.prefix_off = prefixes[i].off; c.prefix_bytes = (uint8_t)prefixes[i].bytes;
+        }
         uint32_t sh;
         magic_u31(d.channels, &c.m_ch, &sh); c.s_ch = (uint8_t)sh;
         magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &c.m_n1, &sh); c.s_n1 = (uint8_t)sh;
@@ -519,7 +558,7 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
             continue;
         }
         if (group_path && n_sub > 0) {
-            if (!chunks.empty() && mergeable) {
+            if (!chunks.empty() && mergeable && !has_prefix) {
                 PcmChunk& p = chunks.back();
                 if (p.flags == c.flags && p.plain_sel == c.plain_sel && (uint64_t)p.nq + n_sub <= kGroupChunkSub &&
                     p.src_off + (uint64_t)p.nq * sb == d.src_offset && p.dst_off + (uint64_t)p.nq * db == d.dst_offset) {
@@ -539,6 +578,7 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
             c.src_off = d.src_offset + q0 * sb;
             c.dst_off = d.dst_offset + q0 * db;
             chunks.push_back(c);
+            c.prefix_bytes = 0;
         }
     }
     if (chunks.empty() || chunks.size() > 0xffffffffull) return OHGPU_OK;
@@ -547,6 +587,15 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
     if (e != hipSuccess) {
         free_pcm_line(b);
         return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "chunk plan upload: %s", hipGetErrorString(e));
+    }
+    if (prefixes && blob_bytes) {
+        e = hipMalloc(&b->line.d_prefix, blob_bytes);
+        if (e == hipSuccess) e = hipMemcpy(b->line.d_prefix, blob, blob_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free_pcm_line(b);
+            return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "prefix blob upload: %s", hipGetErrorString(e));
+        }
+        b->line.prefixed = true;
     }
     b->line.n_chunks = (uint32_t)chunks.size();
     b->line.enabled = true;
@@ -560,7 +609,7 @@ static hipError_t launch_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const 
     uint32_t grid = (b->line.n_chunks + kLineWaves - 1) / kLineWaves;
     if (grid > cus * 8) grid = cus * 8;                                 // 8 workgroups = 32 waves fill a CU
     hipLaunchKernelGGL((pcm_line_kernel<SB, DB>), dim3(grid), dim3(kLineWaves * 64), 0, s,
-                       (const PcmChunk*)b->line.d_chunks, b->line.n_chunks, src, dst, ctx->d_ramp_table);
+                       (const PcmChunk*)b->line.d_chunks, b->line.n_chunks, src, dst, ctx->d_ramp_table, (const uint8_t*)b->line.d_prefix);
     return hipGetLastError();
 }
 

@@ -186,6 +186,23 @@ def test_many_streams_in_one_batch_with_gaps_and_a_halt(ctx):
     check(out, want, w.expected)
 
 
+def test_headers_with_the_generic_kernel(ctx):
+    """A mono / stereo frame's header rides with its first audio through the line kernel; when the generic kernel runs the
+    audio instead (kernel variant 1), ohm_header_kernel has to write every header."""
+    rng = np.random.default_rng(78)
+    w = Workload()
+    for k, (rate, bits, ch) in enumerate([(48000, 24, 2), (44100, 16, 2), (44100, 24, 1), (48000, 24, 6), (48000, 8, 2)]):
+        w.add_stream(rng, rate, bits, ch, 12, codec=b"PCM" * (k % 3), halt_last=(k == 1), gap=k, attenuate=True)
+    ctx.set_kernel_variant(1)
+    try:
+        out, want = w.run(ctx)
+    finally:
+        ctx.set_kernel_variant(0)
+    check(out, want, w.expected)
+    out, want = w.run(ctx)
+    check(out, want, w.expected)
+
+
 def test_uniform_batch_of_plain_stereo_frames(ctx):
     """The shape the throughput figure is quoted on: every frame 5 ms of plain stereo S24 at 48 kHz."""
     rng = np.random.default_rng(5)
