@@ -198,27 +198,31 @@ struct OhmFrameRec {              // 48 bytes: the 36 per-frame header bytes in 
     uint32_t stream_and_bytes;    // bits 0..23: index of the 64-byte stream record (bytes [0, n) = OhmMsgAudio::GetStreamHeader);
                                   // bits 24..31: the whole header's size, 36 + n
 };
-struct OhmSelRec {               // 48 bytes: one fragment of a stream of more than two channels that carries a ramp or an attenuation
+struct OhmSelRec {               // 48 bytes: one audible fragment of a stream of more than two channels (ohm_wide_kernel)
     uint64_t src_off, dst_off;
     uint32_t n_frames;
     uint32_t m_n1;                // x / (n_frames - 1) == umulhi(x, m_n1) >> s_n1 for x < 2^31 (m_n1 == 0: n_frames - 1 <= 1)
-    uint16_t ramp_start, ramp_end, attenuation;
-    uint8_t  channels, sb, first_ch, flags, s_n1, little;
-    uint8_t  pad[12];
+    uint16_t ramp_start, ramp_end, attenuation, pad16;      // (every field inside an aligned dword: the record is read with scalar loads)
+    uint8_t  channels, sb, first_ch, flags;
+    uint8_t  s_n1, little;
+    uint8_t  prefix_bytes;        // the frame's header: [prefix_off, + prefix_bytes) of the batch's blob, written right before dst_off when
+    uint8_t  pad8;                //   the fragment is the frame's first audio (0: it is not)
+    uint32_t prefix_off;          // (a multiple of 4)
+    uint32_t safe_frames;         // frames [0, safe_frames) may be read with one 8-byte load each (it stays inside the source arena)
 };
 static_assert(sizeof(OhmSelRec) == 48, "OhmSelRec");
 struct OhmPlan {
-    ohgpu_batch* direct = nullptr;         // pcm batch: fragments of mono/stereo streams, source -> frames (ramp + depth in one pass)
-    ohgpu_batch* select = nullptr;         // fmt batch: plain fragments of wider streams, source -> frames (channel select)
-    ohgpu_batch* stage = nullptr;          // pcm batch: ramped / silent fragments of wider streams, source -> scratch
+    ohgpu_batch* direct = nullptr;         // pcm batch: fragments of mono/stereo streams, source -> frames (ramp + depth in one pass, headers as prefixes)
+    ohgpu_batch* stage = nullptr;          // pcm batch: silent fragments of wider streams -> scratch
     ohgpu_batch* select_staged = nullptr;  // fmt batch: scratch -> frames
-    void*    d_selr = nullptr;             // OhmSelRec[n_selr]: ramped / attenuated fragments of wider streams, one pass
+    void*    d_selr = nullptr;             // OhmSelRec[n_selr]: audible fragments of wider streams (ohm_wide_kernel: select, attenuation, ramp, header)
     uint32_t n_selr = 0;
+    void*    d_wide_prefix = nullptr;      // their frames' headers
     void*    d_scratch = nullptr;
-    void*    d_frames = nullptr;           // OhmFrameRec[n_frames], the frames whose header `direct` does not write first
-    void*    d_streams = nullptr;          // 64 bytes per stream
+    void*    d_frames = nullptr;           // OhmFrameRec[n_frames] for ohm_header_kernel: [0, n_unfolded) the headers no audio pass writes,
+    void*    d_streams = nullptr;          //   then, up to n_unfolded_generic, those `direct` writes unless the generic kernel runs it
     uint32_t n_frames = 0;
-    uint32_t n_unfolded = 0;               // d_frames[0, n_unfolded): headers no audio pass writes (the header kernel's, always)
+    uint32_t n_unfolded = 0, n_unfolded_generic = 0;
 };
 
 enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3, kBatchFlywheel = 4, kBatchOhm = 5 };

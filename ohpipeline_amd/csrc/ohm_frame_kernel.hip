@@ -3,24 +3,32 @@
 // A frame = header + audio.  The audio of every fragment is an ordinary message for the kernels that already exist:
 //   mono / stereo streams: one PCM message (ramp, attenuation, 32 -> 24 bit) written straight into the frame -- the
 //     Sender's pack of such a stream IS the depth conversion (Sender.cpp:351-377 keeps min(bytes, 3) leading bytes);
-//   wider streams: the Sender pack's channel select (fmt_line_kernel), after a PCM pass into a scratch arena when the
-//     fragment is ramped, attenuated or silent (what MsgPlayable::Read would have applied first, Msg.cpp:2753-2786).
+//   wider streams: ohm_wide_kernel -- the Sender pack's channel select with the playable's attenuation and ramp, one pass
+//     over the two channels that go on the wire; silent fragments (MsgPlayableSilence's channel-id bytes, Msg.cpp:2874-2893)
+//     take a PCM pass into a scratch arena and fmt_line_kernel's select.
 // What is new here is the header: 36 per-frame bytes (OhmHeader + the per-frame part of OhmMsgAudio::Serialise,
 // OhmMsg.cpp:363-413) and the per-stream 22 + codec bytes (GetStreamHeader, :225-241).  A mono / stereo frame's header is
 // assembled on the host when the batch is created and travels as the PREFIX of the frame's first audio message: the wave
-// that writes that audio writes the header in front of it (pcm_line_kernel), one launch for the whole batch.  Every other
-// frame's header (wider streams, frames without audio) is written by ohm_header_kernel, 16 lanes per frame.
+// that writes that audio writes the header in front of it (pcm_line_kernel), one launch for the whole batch; ohm_wide_kernel
+// does the same for the wider streams' frames.  Every other frame's header (frames without audio, frames that begin with
+// silence on a wider stream) is written by ohm_header_kernel, 16 lanes per frame.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "ohgpu_internal.h"
 #include "pcm_device.h"
 
 namespace ohgpu {
+
+template <uint32_t N> struct GroupOut;
+template <> struct GroupOut<1> { typedef uint32_t type __attribute__((ext_vector_type(1))); };
+template <> struct GroupOut<2> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct GroupOut<3> { typedef uint32_t type __attribute__((ext_vector_type(3))); };
 
 static constexpr uint32_t kPerFrameHeader = 36;        // OhmHeader::kHeaderBytes (8) + kPerFrameBytes (28), OhmMsg.cpp:368
 static constexpr uint32_t kStreamFixed = 22;           // GetStreamHeader without the codec name
@@ -71,36 +79,166 @@ ohm_header_kernel(const OhmFrameRec* __restrict__ frames, uint32_t n_frames, con
     }
 }
 
-// Ramped / attenuated fragments of streams with more than two channels: what MsgPlayablePcm::ReadBlock (attenuation, then
-// RampApplicator; Msg.cpp:2736-2786) and Sender::DoProcessFragment (two channels, <= 3 leading bytes; Sender.cpp:351-377)
-// do to the two channels that go on the wire, in one pass: a wave per fragment, a lane per wire subsample.
-__global__ void __launch_bounds__(256)
-ohm_select_ramp_kernel(const OhmSelRec* __restrict__ recs, uint32_t n_recs, const uint16_t* __restrict__ ramp_table,
-                       const uint8_t* __restrict__ src, uint64_t src_arena_bytes, uint8_t* __restrict__ dst)
+// Audible fragments of streams with more than two channels: what MsgPlayablePcm::ReadBlock (attenuation, then
+// RampApplicator; Msg.cpp:2736-2786) and Sender::DoProcessFragment (two channels from FirstChannelToSend, <= 3 leading bytes
+// each; Sender.cpp:351-377) do to the two channels that go on the wire, in one pass -- and the frame's header in front of
+// them when the fragment is the frame's first audio (the prefix scheme of pcm_line_kernel).  A wave per fragment; a lane
+// = TWO frames: one 8-byte load per frame (the two wire subsamples lie next to each other; any alignment, scalar base +
+// lane offset), 4 x WB output bytes in ONE store.  256 frames' loads -- four per lane -- are issued before any is used.
+//   plain:   the wire bytes are a byte shuffle of the loaded ones, one v_perm_b32 per subsample;
+//   ramped:  RampApplicator reads the top 16 bits and writes two bytes back over zeros: one v_perm_b32 lifts them into the
+//            top half of a register, one 24-bit multiply by twice the Q15 multiplier, one v_perm_b32 takes the product's
+//            two bytes (pcm_line_kernel's ramped group path; one multiplier look-up per frame);
+//   attenuated (16-bit audio, RAOP): pcm_device.h's general expressions.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+ohm_wide_kernel(const OhmSelRec* __restrict__ recs, uint32_t n_recs, const uint16_t* __restrict__ ramp_table,
+                const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint8_t* __restrict__ prefix)
 {
-    const uint32_t lane = threadIdx.x & 63, waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_recs; i += waves) {
+    __shared__ uint16_t s_ramp2[kRampTableCount];                       // twice the multiplier
+    __shared__ uint16_t s_ramp[kRampTableCount];
+    for (uint32_t i = threadIdx.x; i < kRampTableCount; i += 256) { s_ramp[i] = ramp_table[i]; s_ramp2[i] = (uint16_t)(2u * ramp_table[i]); }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, waves = gridDim.x * 4;     // (launched with 256 threads: literal, so that the record index stays scalar)
+    typedef uint32_t V2 __attribute__((ext_vector_type(2)));
+    for (uint32_t i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); i < n_recs; i += waves) {
         const OhmSelRec r = recs[i];
-        const uint32_t sb = r.sb, wb = sb < 3 ? sb : 3;
+        // (the record's byte fields come through a vector load: back to scalar registers, the loads' base has to be one)
+        const uint32_t sb = __builtin_amdgcn_readfirstlane(r.sb), ch = __builtin_amdgcn_readfirstlane(r.channels), n = r.n_frames;
+        const uint32_t first_ch = __builtin_amdgcn_readfirstlane(r.first_ch);
+        const uint8_t* const sp = src + r.src_off + first_ch * sb;                  // frame f's two wire subsamples start at sp + f * ch * sb
+        uint8_t* const dp = dst + r.dst_off;
+        const uint32_t fb = ch * sb;
+        const bool ramp = (r.flags & OHGPU_FLAG_RAMP) != 0, atten = r.attenuation != OHGPU_UNITY_ATTENUATION;
         const int32_t total = (int32_t)r.ramp_start - (int32_t)r.ramp_end;
-        for (uint32_t q = lane; q < r.n_frames * 2; q += 64) {
-            const uint32_t f = q >> 1, c = r.first_ch + (q & 1);
-            const uint64_t at = r.src_off + ((uint64_t)f * r.channels + c) * sb;
-            const uint8_t* p = src + at;
-            uint32_t w = 0;                                              // left-justified, most significant byte first
-            if (at + 4 <= src_arena_bytes) {                             // one (unaligned) dword load; the bytes beyond the subsample are dropped
-                uint32_t v;
-                __builtin_memcpy(&v, p, 4);
-                w = r.little ? (v << (32 - 8 * sb)) : (__builtin_bswap32(v) & (0xffffffffu << (32 - 8 * sb)));
-            } else {
-                for (uint32_t k = 0; k < sb; k++) w |= (uint32_t)p[r.little ? sb - 1 - k : k] << (24 - 8 * k);
+        // Loads are issued from asm statements and waited for by a later one: between the two the destination register must
+        // not be copied, and a branch or a loop entry in between makes the compiler do exactly that ("the rule
+        // behind the hand-counted waits").  So every load here is UNCONDITIONAL -- lanes with nothing to fetch read a clamped,
+        // valid address and ignore the result -- and load ... wait is always straight-line code.
+        const uint32_t hb = r.prefix_bytes, safe = r.safe_frames;
+        const uint32_t hpos = hb == 0 ? 0u : (lane * 4 + 4 <= hb ? lane * 4 : hb - 4);
+        const uint8_t* const hbase = hb ? prefix + r.prefix_off : (const uint8_t*)ramp_table;  // (the ramp table is always there to be read)
+        const uint8_t* const lbase = safe ? sp : (const uint8_t*)ramp_table;
+        auto load_frame = [&](uint32_t f, V2& v) __attribute__((always_inline)) {   // in flight until the next s_waitcnt
+            const uint32_t off = safe ? (f < safe ? f : safe - 1) * fb : 0u;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(v) : "v"(off), "s"(lbase) : "memory");
+        };
+        auto load_frame_at_the_arena_end = [&](uint32_t f, V2& v) __attribute__((always_inline)) {   // (after the wait) the 8 bytes would
+            if (f >= safe && f < n) {                                    // cross the arena's end: the subsamples' own bytes, one by one
+                uint32_t lo = 0, hi = 0;
+                for (uint32_t k = 0; k < 2 * sb; k++) {
+                    const uint32_t byte = sp[(size_t)f * fb + k];
+                    if (k < 4) lo |= byte << (8 * k); else hi |= byte << (8 * (k - 4));
+                }
+                v[0] = lo; v[1] = hi;
             }
-            if (r.attenuation != OHGPU_UNITY_ATTENUATION) w = attenuate_word(w, r.attenuation);
-            if (r.flags & OHGPU_FLAG_RAMP)
-                w = ramp_word(w, ramp_table[ramp_index_magic(r.ramp_start, total, f, r.n_frames, r.m_n1, r.s_n1)], sb, r.channels, c);
-            uint8_t* o = dst + r.dst_off + (size_t)q * wb;
-            for (uint32_t k = 0; k < wb; k++) o[k] = (uint8_t)(w >> (24 - 8 * k));
+        };
+        // ---- the header and the first 256 frames ----
+        uint32_t hv = 0;
+        V2 a0 = {}, a1 = {}, b0 = {}, b1 = {};
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(hv) : "v"(hpos), "s"(hbase) : "memory");
+        load_frame(2 * lane, a0); load_frame(2 * lane + 1, a1);
+        load_frame(2 * (lane + 64), b0); load_frame(2 * (lane + 64) + 1, b1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(hv) : : "memory");
+        if (lane * 4 < hb) {
+            uint8_t* const obase = dp - hb;
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(hpos), "v"(hv), "s"(obase) : "memory");
         }
+        auto body = [&](auto wb_tag) __attribute__((always_inline)) {
+            constexpr uint32_t WB = decltype(wb_tag)::value;
+            typedef typename GroupOut<WB>::type Out;
+            // selectors over {d1, d0}: subsample k's wire bytes in memory order (plain), its two top bytes into the top half (ramp)
+            uint32_t sel_plain[2], sel_top[2];
+#pragma unroll
+            for (uint32_t k = 0; k < 2; k++) {
+                uint32_t a = 0, b = 0;
+                const uint32_t o = k * sb;
+#pragma unroll
+                for (uint32_t m = 0; m < 4; m++) a |= (m < WB ? (r.little ? o + sb - 1 - m : o + m) : 0x0cu) << (8 * m);
+                b = ((r.little ? o + sb - 1 : o) << 24) | ((sb > 1 ? (r.little ? o + sb - 2 : o + 1) : 0x0cu) << 16) | 0x0c0cu;
+                sel_plain[k] = a; sel_top[k] = b;
+            }
+            const uint32_t abs_total = (uint32_t)(total < 0 ? -total : total) & 0x1ffffu;
+            const uint32_t neg_mask = total < 0 ? 0xffffffffu : 0u, ramp_base = (uint32_t)r.ramp_start + neg_mask;
+            const bool fast_ramp = ramp && !atten && r.m_n1 != 0 && n <= 32768u;
+            auto mult2 = [&](uint32_t f) __attribute__((always_inline)) -> uint32_t {       // pcm_line_kernel's ramp_mult2
+                const uint32_t mag = __umulhi((f & 0xffffu) * abs_total, r.m_n1) >> r.s_n1;
+                const uint32_t ramp16 = (ramp_base - (mag ^ neg_mask)) & 0xffffu;
+                const uint32_t idx = (kRampMax + (1u << 4) - ramp16) >> 5;
+                return s_ramp2[idx < kRampTableCount - 1 ? idx : kRampTableCount - 1];
+            };
+            // one frame -> its two subsamples' wire bytes (memory order, first byte low)
+            auto frame_bytes = [&](uint32_t f, const V2& d, uint32_t& v0, uint32_t& v1) __attribute__((always_inline)) {
+                if (fast_ramp) {
+                    const uint32_t m2 = mult2(f);
+                    const uint32_t p0 = (uint32_t)(((int32_t)__builtin_amdgcn_perm(d[1], d[0], sel_top[0]) >> 16) * (int32_t)m2);
+                    const uint32_t p1 = (uint32_t)(((int32_t)__builtin_amdgcn_perm(d[1], d[0], sel_top[1]) >> 16) * (int32_t)m2);
+                    constexpr uint32_t take = WB == 1 ? 0x0c0c0c03u : 0x0c0c0203u;          // product bytes 3, 2, then zeros
+                    v0 = __builtin_amdgcn_perm(0u, p0, take);
+                    v1 = __builtin_amdgcn_perm(0u, p1, take);
+                } else if (!ramp && !atten) {
+                    v0 = __builtin_amdgcn_perm(d[1], d[0], sel_plain[0]);
+                    v1 = __builtin_amdgcn_perm(d[1], d[0], sel_plain[1]);
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 2; k++) {
+                        // left-justified big-endian word of subsample k
+                        uint32_t w = 0;
+                        const uint64_t both = ((uint64_t)d[1] << 32) | d[0];
+                        for (uint32_t m = 0; m < sb; m++) w |= (uint32_t)((both >> (8 * (k * sb + (r.little ? sb - 1 - m : m)))) & 0xffu) << (24 - 8 * m);
+                        if (atten) w = attenuate_word(w, r.attenuation);
+                        if (ramp) w = ramp_word(w, s_ramp[ramp_index_magic(r.ramp_start, total, f, n, r.m_n1, r.s_n1)], sb, ch, first_ch + k);
+                        const uint32_t v = __builtin_bswap32(w) & (0xffffffffu >> (32 - 8 * WB));
+                        if (k == 0) v0 = v; else v1 = v;
+                    }
+                }
+            };
+            auto put_pair = [&](uint32_t g, const V2& da, const V2& db) __attribute__((always_inline)) {   // frames 2g, 2g + 1
+                uint32_t v[4] = {0, 0, 0, 0};
+                frame_bytes(2 * g, da, v[0], v[1]);
+                const bool second = 2 * g + 1 < n;
+                if (second) frame_bytes(2 * g + 1, db, v[2], v[3]);
+                uint32_t ow[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t o = k * WB;
+                    ow[o >> 2] |= v[k] << (8 * (o & 3));
+                    if ((o & 3) + WB > 4) ow[(o >> 2) + 1] |= v[k] >> (32 - 8 * (o & 3));
+                }
+                const uint32_t at = g * (4 * WB);
+                if (second) {
+                    Out out;
+#pragma unroll
+                    for (uint32_t j = 0; j < WB; j++) out[j] = ow[j];
+                    if constexpr (WB == 1) asm volatile("global_store_dword %0, %1, %2" : : "v"(at), "v"(ow[0]), "s"(dp) : "memory");
+                    else if constexpr (WB == 2) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(at), "v"(out), "s"(dp) : "memory");
+                    else asm volatile("global_store_dwordx3 %0, %1, %2" : : "v"(at), "v"(out), "s"(dp) : "memory");
+                } else {                                                 // an odd fragment's last frame
+                    for (uint32_t bq = 0; bq < 2 * WB; bq++) dp[(size_t)at + bq] = (uint8_t)(ow[bq >> 2] >> (8 * (bq & 3)));
+                }
+            };
+            auto put_four = [&](uint32_t g0, V2& fa0, V2& fa1, V2& fb0, V2& fb1) __attribute__((always_inline)) {
+                const uint32_t ga = g0 + lane, gb = ga + 64;
+                if (safe < n) {                                          // (wave-uniform: the arena's last fragment only)
+                    load_frame_at_the_arena_end(2 * ga, fa0); load_frame_at_the_arena_end(2 * ga + 1, fa1);
+                    load_frame_at_the_arena_end(2 * gb, fb0); load_frame_at_the_arena_end(2 * gb + 1, fb1);
+                }
+                if (2 * ga < n) put_pair(ga, fa0, fa1);
+                if (2 * gb < n) put_pair(gb, fb0, fb1);
+            };
+            put_four(0, a0, a1, b0, b1);
+            for (uint32_t g0 = 128; 2 * g0 < n; g0 += 128) {             // fragments of more than 256 frames
+                const uint32_t ga = g0 + lane, gb = ga + 64;
+                V2 c0 = {}, c1 = {}, d0 = {}, d1 = {};
+                load_frame(2 * ga, c0); load_frame(2 * ga + 1, c1);
+                load_frame(2 * gb, d0); load_frame(2 * gb + 1, d1);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1) : : "memory");
+                put_four(g0, c0, c1, d0, d1);
+            }
+        };
+        const uint32_t wb = sb < 3 ? sb : 3;
+        if (wb == 3) body(std::integral_constant<uint32_t, 3>{});
+        else if (wb == 2) body(std::integral_constant<uint32_t, 2>{});
+        else body(std::integral_constant<uint32_t, 1>{});
     }
 }
 
@@ -113,11 +251,11 @@ void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b)
 {
     OhmPlan& p = b->ohm;
     ohgpu_batch_destroy(ctx, p.direct);
-    ohgpu_batch_destroy(ctx, p.select);
     ohgpu_batch_destroy(ctx, p.stage);
     ohgpu_batch_destroy(ctx, p.select_staged);
     if (p.d_scratch) hipFree(p.d_scratch);
     if (p.d_selr) hipFree(p.d_selr);
+    if (p.d_wide_prefix) hipFree(p.d_wide_prefix);
     if (p.d_frames) hipFree(p.d_frames);
     if (p.d_streams) hipFree(p.d_streams);
     p = OhmPlan();
@@ -197,8 +335,9 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
     std::vector<ohgpu_msg_desc> direct, stage;
     std::vector<MsgPrefix> direct_prefix;                              // per direct message: the frame header it carries (bytes == 0: none)
     std::vector<uint8_t> blob;                                         // those headers, each padded to whole dwords
-    std::vector<uint8_t> folded(n_frames, 0);
-    std::vector<ohgpu_fmt_desc> select, select_staged;
+    std::vector<uint8_t> wide_blob;                                    // the same for the wider streams' frames (ohm_wide_kernel)
+    std::vector<uint8_t> folded(n_frames, 0);                          // 1: the header rides with `direct`, 2: with ohm_wide_kernel
+    std::vector<ohgpu_fmt_desc> select_staged;
     std::vector<OhmSelRec> selr;
     uint64_t scratch_bytes = 0, in_frames = 0, src_touched = 0, dst_written = 0;
     for (size_t f = 0; f < n_frames; f++) {
@@ -286,12 +425,9 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
                     folded[f] = 1;
                 }
                 direct_prefix.push_back(pre);
-            } else if (plain) {
-                p.src_offset = fg.src_offset;
-                select.push_back(p);
             } else if (!(fg.flags & OHGPU_FLAG_SILENCE)) {
-                // ramp / attenuation on a wider stream: one pass over the two channels that go on the wire
-                if (ch > OHGPU_MAX_CHANNELS)
+                // a wider stream's audible fragment: one pass over the two channels that go on the wire
+                if (!plain && ch > OHGPU_MAX_CHANNELS)
                     return set_error(OHGPU_ERR_UNSUPPORTED, "ohm fragment %zu: ramp / attenuation on %u channels (MsgPlayable carries at most 8)", gi, ch);
                 if (fg.ramp_start > OHGPU_RAMP_MAX || fg.ramp_end > OHGPU_RAMP_MAX)
                     return set_error(OHGPU_ERR_INVALID, "ohm fragment %zu: ramp [%u..%u] beyond Ramp::kMax", gi, fg.ramp_start, fg.ramp_end);
@@ -302,6 +438,8 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
                 if (fg.src_offset > src_arena_bytes || src_bytes > src_arena_bytes - fg.src_offset)
                     return set_error(OHGPU_ERR_BOUNDS, "ohm fragment %zu: reads [%llu, +%llu) beyond the %llu-byte source arena", gi,
                                      (unsigned long long)fg.src_offset, (unsigned long long)src_bytes, (unsigned long long)src_arena_bytes);
+                if (src_bytes > 0xffffffffull)
+                    return set_error(OHGPU_ERR_INVALID, "ohm fragment %zu: %llu source bytes (the limit is 4 GiB - 1)", gi, (unsigned long long)src_bytes);
                 OhmSelRec sr;
                 memset(&sr, 0, sizeof(sr));
                 sr.src_off = fg.src_offset; sr.dst_off = at; sr.n_frames = fg.n_frames;
@@ -311,6 +449,17 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
                 uint32_t sh = 0;
                 magic_u31(fg.n_frames > 1 ? fg.n_frames - 1 : 1, &sr.m_n1, &sh);
                 sr.s_n1 = (uint8_t)sh;
+                // frames whose 8-byte read (their two wire subsamples and what follows) ends inside the arena
+                const uint64_t first = fg.src_offset + (uint64_t)sr.first_ch * sr.sb, fbytes = (uint64_t)ch * sr.sb;
+                sr.safe_frames = first + 8 > src_arena_bytes ? 0u
+                                 : (uint32_t)std::min<uint64_t>(fg.n_frames, (src_arena_bytes - 8 - first) / fbytes + 1);
+                if (at == fr.dst_offset + header_bytes && wide_blob.size() < 0xffffff00ull) {   // the frame's first audio: the header rides along
+                    sr.prefix_off = (uint32_t)wide_blob.size(); sr.prefix_bytes = (uint8_t)header_bytes;
+                    wide_blob.insert(wide_blob.end(), h, h + kPerFrameHeader);
+                    wide_blob.insert(wide_blob.end(), &stream_recs[(size_t)fr.stream * 64], &stream_recs[(size_t)fr.stream * 64] + (header_bytes - kPerFrameHeader));
+                    wide_blob.resize((wide_blob.size() + 3) & ~(size_t)3, 0);
+                    folded[f] = 2;
+                }
                 selr.push_back(sr);
             } else {
                 if (ch > OHGPU_MAX_CHANNELS)
@@ -351,21 +500,21 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
     };
     if (blob.size() > 0xffffff00ull) {                                  // (prefix offsets are 32-bit: such a batch keeps the header kernel)
         blob.clear();
-        std::fill(folded.begin(), folded.end(), 0);
+        for (auto& x : folded) if (x == 1) x = 0;
     }
     if (!direct.empty())
         err = pcm_batch_create_prefixed(ctx, direct.data(), direct.size(), src_arena_bytes, dst_arena_bytes,
                                         blob.empty() ? nullptr : direct_prefix.data(), blob.data(), blob.size(), &plan.direct);
-    // frames whose header no audio pass writes first; the rest follow, for the runs in which the line kernel is not the one used
+    // ohm_header_kernel's list: first the frames whose header no audio pass writes, then those `direct` writes (the header kernel
+    // takes them too in the runs in which the generic kernel does `direct`'s work); ohm_wide_kernel always writes its own.
     const bool folds = plan.direct && plan.direct->line.prefixed;
     std::vector<OhmFrameRec> ordered;
     ordered.reserve(n_frames);
-    for (size_t f = 0; f < n_frames; f++) if (!(folds && folded[f])) ordered.push_back(recs[f]);
+    for (size_t f = 0; f < n_frames; f++) if (folded[f] == 0 || (folded[f] == 1 && !folds)) ordered.push_back(recs[f]);
     plan.n_unfolded = (uint32_t)ordered.size();
-    for (size_t f = 0; f < n_frames; f++) if (folds && folded[f]) ordered.push_back(recs[f]);
+    for (size_t f = 0; f < n_frames; f++) if (folded[f] == 1 && folds) ordered.push_back(recs[f]);
+    plan.n_unfolded_generic = (uint32_t)ordered.size();
     recs.swap(ordered);
-    if (err == OHGPU_OK && !select.empty())
-        err = ohgpu_fmt_batch_create(ctx, select.data(), select.size(), src_arena_bytes, dst_arena_bytes, &plan.select);
     if (err == OHGPU_OK && !stage.empty())
         err = ohgpu_pcm_batch_create(ctx, stage.data(), stage.size(), src_arena_bytes, scratch_bytes, &plan.stage);
     if (err == OHGPU_OK && !select_staged.empty())
@@ -373,6 +522,7 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
     if (err == OHGPU_OK) err = dev_copy(&plan.d_scratch, nullptr, scratch_bytes);
     if (err == OHGPU_OK) err = dev_copy(&plan.d_selr, selr.data(), selr.size() * sizeof(OhmSelRec));
     plan.n_selr = (uint32_t)selr.size();
+    if (err == OHGPU_OK) err = dev_copy(&plan.d_wide_prefix, wide_blob.data(), wide_blob.size());
     if (err == OHGPU_OK) err = dev_copy(&plan.d_frames, recs.data(), recs.size() * sizeof(OhmFrameRec));
     if (err == OHGPU_OK) err = dev_copy(&plan.d_streams, stream_recs.data(), stream_recs.size());
     if (err != OHGPU_OK) { free_ohm(ctx, b); delete b; return err; }
@@ -391,18 +541,18 @@ int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     int err = OHGPU_OK;
     if (p.direct) err = ohgpu_pcm_batch_run(ctx, p.direct, src_base, dst_base, s);
-    if (err == OHGPU_OK && p.select) err = ohgpu_fmt_batch_run(ctx, p.select, src_base, dst_base, s);
     if (err == OHGPU_OK && p.stage) err = ohgpu_pcm_batch_run(ctx, p.stage, src_base, p.d_scratch, s);
     if (err == OHGPU_OK && p.select_staged) err = ohgpu_fmt_batch_run(ctx, p.select_staged, p.d_scratch, dst_base, s);
     if (err != OHGPU_OK) return err;
     if (p.n_selr) {
-        const uint32_t blocks = (p.n_selr + 3) / 4 < 4096u ? (p.n_selr + 3) / 4 : 4096u;
-        hipLaunchKernelGGL(ohm_select_ramp_kernel, dim3(blocks), dim3(256), 0, s, (const OhmSelRec*)p.d_selr, p.n_selr,
-                           (const uint16_t*)ctx->d_ramp_table, (const uint8_t*)src_base, batch->src_arena_bytes, (uint8_t*)dst_base);
+        const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
+        const uint32_t blocks = (p.n_selr + 3) / 4 < cus * 8 ? (p.n_selr + 3) / 4 : cus * 8;          // 8 workgroups = 32 waves fill a CU
+        hipLaunchKernelGGL(ohm_wide_kernel, dim3(blocks), dim3(256), 0, s, (const OhmSelRec*)p.d_selr, p.n_selr,
+                           (const uint16_t*)ctx->d_ramp_table, (const uint8_t*)src_base, (uint8_t*)dst_base, (const uint8_t*)p.d_wide_prefix);
         OHGPU_HIP_TRY(hipGetLastError());
     }
     // headers: those the direct pass has not written (all of them when the generic kernel ran it, ohgpu_set_kernel_variant(1))
-    const uint32_t n_headers = ctx->variant == 1 ? p.n_frames : p.n_unfolded;
+    const uint32_t n_headers = ctx->variant == 1 ? p.n_unfolded_generic : p.n_unfolded;
     if (n_headers) {
         const uint32_t threads = 256, frames_per_block = threads / kLanesPerFrame * kFramesPerGroup;
         const uint32_t blocks = (n_headers + frames_per_block - 1) / frames_per_block;

@@ -155,10 +155,13 @@ def test_stereo_and_mono_streams(ctx, rate, bits, ch):
     check(out, want, w.expected)
 
 
-@pytest.mark.parametrize("rate,bits,ch", [(48000, 24, 6), (44100, 16, 6), (48000, 32, 8), (44100, 24, 4), (48000, 16, 3)])
+@pytest.mark.parametrize("rate,bits,ch", [(48000, 24, 6), (44100, 16, 6), (48000, 32, 8), (44100, 24, 4), (48000, 16, 3),
+                                          (96000, 24, 6), (192000, 24, 6), (192000, 16, 4), (176400, 8, 3)])
 def test_wider_streams_select_the_first_two_channels(ctx, rate, bits, ch):
     """Channel select after the ramp / silence the playable carries; 16-bit 6-channel silence shows the channel-id bytes of
-    MsgPlayableSilence::ReadBlock (Msg.cpp:2877) in the second wire channel."""
+    MsgPlayableSilence::ReadBlock (Msg.cpp:2877) in the second wire channel.  The high rates give fragments of several
+    hundred frames (ohm_wide_kernel's second and later rounds of 256), the stream's last fragment ends with the arena (its
+    last frames are read byte by byte)."""
     w = Workload()
     w.add_stream(np.random.default_rng(ch * 1000 + bits), rate, bits, ch, 40, codec=b"WAV", attenuate=True)
     out, want = w.run(ctx)
