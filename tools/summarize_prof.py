@@ -15,7 +15,7 @@ def short(name):
     name = name.split("(")[0]
     if "src_lean_kernel" in name:                                      # keep the instantiation: <T, channels, src bytes, src LE, dst bytes, dst LE>
         return "src_lean_kernel" + name[name.index("src_lean_kernel") + len("src_lean_kernel"):].replace(" ", "")
-    for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_line_kernel", "pcm_msg_kernel_v1", "fmt_line_kernel", "fmt_kernel_v1", "flywheel_kernel", "ohm_header_kernel", "ohm_select_ramp_kernel",
+    for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_line_kernel", "pcm_msg_kernel_v1", "fmt_line_kernel", "fmt_kernel_v1", "flywheel_kernel", "ohm_header_kernel", "ohm_wide_kernel", "ohm_select_ramp_kernel",
               "unpack_stereo_kernel", "flac_stereo_kernel"):
         if k in name:
             return k
