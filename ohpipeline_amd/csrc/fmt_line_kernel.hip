@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void flac_stereo_kernel(const FmtChunk* __rest
 // ---- host side ----
 void free_fmt_line(ohgpu_batch* b)
 {
-    if (b->fmtline.d_chunks) hipFree(b->fmtline.d_chunks);
+    if (b->fmtline.d_chunks) (void)hipFree(b->fmtline.d_chunks);
+    if (b->fmtline.d_wide) (void)hipFree(b->fmtline.d_wide);
     b->fmtline = FmtLinePlan();
 }
 
@@ -227,6 +228,31 @@ int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, s
             b->channels = descs[0].channels; b->src_bits = sbits; b->dst_bits = dbits;
             b->src_endian = b->dst_endian = OHGPU_ENDIAN_BIG;
             return plan_pcm_line(ctx, b, msgs.data(), n);                // -> b->line; ohgpu_fmt_batch_run launches it
+        }
+    }
+    // A batch of Songcast packs that all drop channels (streams wider than stereo) is the plain case of ohm_wide_kernel: a lane
+    // per two frames, one 8-byte load per frame, no staging (csrc/ohm_frame_kernel.hip).
+    {
+        bool wide = n > 0;
+        for (size_t i = 0; i < n && wide; i++)
+            wide = descs[i].kind == OHGPU_FMT_SENDER_PACK && descs[i].channels > 2 &&
+                   (uint64_t)descs[i].n_frames * descs[i].channels * (descs[i].src_bits / 8) <= 0xffffffffull;
+        if (wide) {
+            std::vector<OhmSelRec> recs;
+            for (size_t i = 0; i < n; i++)
+                if (descs[i].n_frames)
+                    recs.push_back(wide_record(descs[i].src_offset, descs[i].dst_offset, descs[i].n_frames, descs[i].channels, descs[i].src_bits / 8,
+                                               false, b->src_arena_bytes));
+            if (!recs.empty()) {
+                hipError_t e = hipMalloc(&b->fmtline.d_wide, recs.size() * sizeof(OhmSelRec));
+                if (e == hipSuccess) e = hipMemcpy(b->fmtline.d_wide, recs.data(), recs.size() * sizeof(OhmSelRec), hipMemcpyHostToDevice);
+                if (e != hipSuccess) {
+                    free_fmt_line(b);
+                    return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "record upload: %s", hipGetErrorString(e));
+                }
+                b->fmtline.n_wide = (uint32_t)recs.size();
+                return OHGPU_OK;
+            }
         }
     }
     // Uniform stereo batches of a11 (16/24/32-bit) or a14 take the register-only kernels: one record per descriptor.

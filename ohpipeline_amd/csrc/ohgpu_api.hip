@@ -485,6 +485,9 @@ int ohgpu_fmt_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_fmt_batch_run: null arena pointer");
     if (ctx->variant != 1 && batch->line.enabled)                       // stereo Songcast packs planned onto the PCM line kernel
         OHGPU_HIP_TRY(launch_pcm_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
+    else if (ctx->variant != 1 && batch->fmtline.n_wide)                // Songcast packs of wider streams
+        OHGPU_HIP_TRY(launch_ohm_wide(ctx, batch->fmtline.d_wide, batch->fmtline.n_wide, (const uint8_t*)src_base, (uint8_t*)dst_base, nullptr,
+                                      pick_stream(ctx, stream)));
     else if (ctx->variant != 1 && batch->fmtline.enabled)
         OHGPU_HIP_TRY(launch_fmt_line(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, pick_stream(ctx, stream)));
     else

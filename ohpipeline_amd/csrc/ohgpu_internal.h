@@ -181,6 +181,8 @@ struct FmtLinePlan {
     uint8_t  group_bytes = 0;     // its source (a11) / destination (a14) bytes per subsample
     uint32_t n_chunks = 0;
     void*    d_chunks = nullptr;
+    uint32_t n_wide = 0;          // a batch of Sender packs that all drop channels: OhmSelRec[n_wide] for ohm_wide_kernel
+    void*    d_wide = nullptr;
 };
 
 // ---- FlywheelRamper (csrc/flywheel_kernel.hip) ----
@@ -293,6 +295,9 @@ void free_pcm_line(ohgpu_batch* b);
 int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, size_t n);
 void free_fmt_line(ohgpu_batch* b);
 hipError_t launch_fmt_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+// csrc/ohm_frame_kernel.hip: the two wire channels of streams wider than stereo (Sender::DoProcessFragment), one record per fragment
+OhmSelRec wide_record(uint64_t src_off, uint64_t dst_off, uint32_t n_frames, uint32_t channels, uint32_t sb, bool little, uint64_t src_arena_bytes);
+hipError_t launch_ohm_wide(const ohgpu_ctx* ctx, const void* d_recs, uint32_t n_recs, const uint8_t* src, uint8_t* dst, const uint8_t* prefix, hipStream_t s);
 int plan_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_flywheel_desc* descs, size_t n);
 void free_flywheel(ohgpu_batch* b);
 hipError_t launch_flywheel(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);

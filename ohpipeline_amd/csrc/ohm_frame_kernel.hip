@@ -242,6 +242,34 @@ ohm_wide_kernel(const OhmSelRec* __restrict__ recs, uint32_t n_recs, const uint1
     }
 }
 
+// A plain record (no ramp, unity attenuation, no header); the callers add what their fragment carries.
+OhmSelRec wide_record(uint64_t src_off, uint64_t dst_off, uint32_t n_frames, uint32_t channels, uint32_t sb, bool little, uint64_t src_arena_bytes)
+{
+    OhmSelRec sr;
+    memset(&sr, 0, sizeof(sr));
+    sr.src_off = src_off; sr.dst_off = dst_off; sr.n_frames = n_frames;
+    sr.ramp_start = sr.ramp_end = OHGPU_RAMP_MAX; sr.attenuation = OHGPU_UNITY_ATTENUATION;
+    sr.channels = (uint8_t)channels; sr.sb = (uint8_t)sb; sr.first_ch = (uint8_t)(channels < 10 ? 0 : 8);   // Sender::FirstChannelToSend, Sender.cpp:351-354
+    sr.little = little ? 1 : 0;
+    uint32_t sh = 0;
+    magic_u31(n_frames > 1 ? n_frames - 1 : 1, &sr.m_n1, &sh);
+    sr.s_n1 = (uint8_t)sh;
+    // frames whose 8-byte read (their two wire subsamples and what follows) ends inside the arena
+    const uint64_t first = src_off + (uint64_t)sr.first_ch * sb, fbytes = (uint64_t)channels * sb;
+    sr.safe_frames = first + 8 > src_arena_bytes ? 0u : (uint32_t)std::min<uint64_t>(n_frames, (src_arena_bytes - 8 - first) / fbytes + 1);
+    return sr;
+}
+
+hipError_t launch_ohm_wide(const ohgpu_ctx* ctx, const void* d_recs, uint32_t n_recs, const uint8_t* src, uint8_t* dst, const uint8_t* prefix, hipStream_t s)
+{
+    if (n_recs == 0) return hipSuccess;
+    const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
+    const uint32_t blocks = (n_recs + 3) / 4 < cus * 8 ? (n_recs + 3) / 4 : cus * 8;                  // 8 workgroups = 32 waves fill a CU
+    hipLaunchKernelGGL(ohm_wide_kernel, dim3(blocks), dim3(256), 0, s, (const OhmSelRec*)d_recs, n_recs,
+                       (const uint16_t*)ctx->d_ramp_table, src, dst, prefix);
+    return hipGetLastError();
+}
+
 static inline void put_be(uint8_t* p, uint64_t v, uint32_t n)
 {
     for (uint32_t i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * (n - 1 - i)));
@@ -440,19 +468,9 @@ int ohgpu_ohm_batch_create(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
                                      (unsigned long long)fg.src_offset, (unsigned long long)src_bytes, (unsigned long long)src_arena_bytes);
                 if (src_bytes > 0xffffffffull)
                     return set_error(OHGPU_ERR_INVALID, "ohm fragment %zu: %llu source bytes (the limit is 4 GiB - 1)", gi, (unsigned long long)src_bytes);
-                OhmSelRec sr;
-                memset(&sr, 0, sizeof(sr));
-                sr.src_off = fg.src_offset; sr.dst_off = at; sr.n_frames = fg.n_frames;
+                OhmSelRec sr = wide_record(fg.src_offset, at, fg.n_frames, ch, s.src_bits / 8, little, src_arena_bytes);
                 sr.ramp_start = fg.ramp_start; sr.ramp_end = fg.ramp_end; sr.attenuation = fg.attenuation;
-                sr.channels = (uint8_t)ch; sr.sb = (uint8_t)(s.src_bits / 8); sr.first_ch = (uint8_t)(ch < 10 ? 0 : 8);
-                sr.flags = fg.flags; sr.little = little ? 1 : 0;
-                uint32_t sh = 0;
-                magic_u31(fg.n_frames > 1 ? fg.n_frames - 1 : 1, &sr.m_n1, &sh);
-                sr.s_n1 = (uint8_t)sh;
-                // frames whose 8-byte read (their two wire subsamples and what follows) ends inside the arena
-                const uint64_t first = fg.src_offset + (uint64_t)sr.first_ch * sr.sb, fbytes = (uint64_t)ch * sr.sb;
-                sr.safe_frames = first + 8 > src_arena_bytes ? 0u
-                                 : (uint32_t)std::min<uint64_t>(fg.n_frames, (src_arena_bytes - 8 - first) / fbytes + 1);
+                sr.flags = fg.flags;
                 if (at == fr.dst_offset + header_bytes && wide_blob.size() < 0xffffff00ull) {   // the frame's first audio: the header rides along
                     sr.prefix_off = (uint32_t)wide_blob.size(); sr.prefix_bytes = (uint8_t)header_bytes;
                     wide_blob.insert(wide_blob.end(), h, h + kPerFrameHeader);
@@ -544,13 +562,7 @@ int ohgpu_ohm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (err == OHGPU_OK && p.stage) err = ohgpu_pcm_batch_run(ctx, p.stage, src_base, p.d_scratch, s);
     if (err == OHGPU_OK && p.select_staged) err = ohgpu_fmt_batch_run(ctx, p.select_staged, p.d_scratch, dst_base, s);
     if (err != OHGPU_OK) return err;
-    if (p.n_selr) {
-        const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
-        const uint32_t blocks = (p.n_selr + 3) / 4 < cus * 8 ? (p.n_selr + 3) / 4 : cus * 8;          // 8 workgroups = 32 waves fill a CU
-        hipLaunchKernelGGL(ohm_wide_kernel, dim3(blocks), dim3(256), 0, s, (const OhmSelRec*)p.d_selr, p.n_selr,
-                           (const uint16_t*)ctx->d_ramp_table, (const uint8_t*)src_base, (uint8_t*)dst_base, (const uint8_t*)p.d_wide_prefix);
-        OHGPU_HIP_TRY(hipGetLastError());
-    }
+    OHGPU_HIP_TRY(launch_ohm_wide(ctx, p.d_selr, p.n_selr, (const uint8_t*)src_base, (uint8_t*)dst_base, (const uint8_t*)p.d_wide_prefix, s));
     // headers: those the direct pass has not written (all of them when the generic kernel ran it, ohgpu_set_kernel_variant(1))
     const uint32_t n_headers = ctx->variant == 1 ? p.n_unfolded_generic : p.n_unfolded;
     if (n_headers) {

@@ -62,6 +62,42 @@ def test_sender_pack(ctx):
         assert nb.value == out_bytes and np.array_equal(got, want), (sb, ch, n)
 
 
+def test_sender_pack_batches_of_wider_streams(ctx):
+    """Batches in which every pack drops channels run ohm_wide_kernel's plain path (a lane per two frames): every depth,
+    3..10 channels, one frame to several rounds of 256, odd source and destination offsets, the last descriptor ending with
+    the source arena (its last frames are read byte by byte), and untouched bytes between the outputs."""
+    rng = np.random.default_rng(41)
+    for sb in (1, 2, 3, 4):
+        rows, parts, sp, dp, want_parts = [], [], 0, 0, []
+        for k, (ch, n) in enumerate([(3, 1), (6, 240), (8, 241), (10, 33), (4, 1000), (5, 2), (7, 513), (6, 3), (3, 77)]):
+            pad = k % 4
+            a = rng.integers(0, 256, size=n * ch * sb, dtype=np.uint8)
+            parts += [rng.integers(0, 256, size=pad, dtype=np.uint8), a]
+            out_bytes = n * 2 * min(sb, 3)
+            rows.append((sp + pad, dp + (k % 3), n, ch, sb * 8))
+            w = np.zeros(out_bytes, dtype=np.uint8)
+            nb = C.c_uint32(0)
+            assert O.lib().ohp_sender_pack(a.ctypes.data_as(C.c_void_p), a.size, ch, sb, w.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0
+            want_parts.append((dp + (k % 3), w))
+            sp += pad + a.size
+            dp += out_bytes + 5
+        d = np.zeros(len(rows), dtype=capi.FMT_DESC)
+        for i, (so, do, n, ch, bits) in enumerate(rows):
+            d["kind"][i], d["src_offset"][i], d["dst_offset"][i], d["n_frames"][i], d["channels"][i], d["src_bits"][i] = capi.FMT_SENDER_PACK, so, do, n, ch, bits
+        src = np.concatenate(parts)
+        got = run_fmt(ctx, d, src, dp)
+        want = np.full(dp, 0xA5, dtype=np.uint8)
+        for off, w in want_parts:
+            want[off:off + w.size] = w
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (sb, bad[:5])
+        ctx.set_kernel_variant(1)                                        # the byte kernel agrees
+        try:
+            assert np.array_equal(run_fmt(ctx, d, src, dp), want)
+        finally:
+            ctx.set_kernel_variant(0)
+
+
 def test_flac_pack(ctx):
     """a14: planar TInt32 -> packed BE interleaved 8/16/24; 32-bit is unsupported as in the reference (Flac.cpp:379-417)."""
     rng = np.random.default_rng(5)

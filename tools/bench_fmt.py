@@ -21,12 +21,13 @@ def main():
     a = ap.parse_args()
     from ohpipeline_amd import capi
     ctx = capi.Context(0)
-    n, f, ch = a.descs, a.frames, 2
-    cases = [("a11 unpack to planar (S24 stereo -> 2 x S32 planes)", capi.FMT_UNPACK_PLANAR, 24, 0, f * ch * 3, f * ch * 4),
-             ("a13 Songcast sender pack (S32 stereo -> S24)", capi.FMT_SENDER_PACK, 32, 0, f * ch * 4, f * ch * 3),
-             ("a14 FLAC packer (2 x TInt32 planes -> S24 interleaved)", capi.FMT_FLAC_PACK, 32, 24, f * ch * 4, f * ch * 3)]
+    n, f = a.descs, a.frames
+    cases = [("a11 unpack to planar (S24 stereo -> 2 x S32 planes)", capi.FMT_UNPACK_PLANAR, 2, 24, 0, f * 2 * 3, f * 2 * 4),
+             ("a13 Songcast sender pack (S32 stereo -> S24)", capi.FMT_SENDER_PACK, 2, 32, 0, f * 2 * 4, f * 2 * 3),
+             ("a13 Songcast sender pack (S24 six channels -> two)", capi.FMT_SENDER_PACK, 6, 24, 0, f * 6 * 3, f * 2 * 3),
+             ("a14 FLAC packer (2 x TInt32 planes -> S24 interleaved)", capi.FMT_FLAC_PACK, 2, 32, 24, f * 2 * 4, f * 2 * 3)]
     rng = np.random.default_rng(1)
-    for name, kind, sbits, dbits, in_b, out_b in cases:
+    for name, kind, ch, sbits, dbits, in_b, out_b in cases:
         d = np.zeros(n, dtype=capi.FMT_DESC)
         d["kind"], d["channels"], d["src_bits"], d["dst_bits"], d["n_frames"] = kind, ch, sbits, dbits, f
         d["src_offset"] = np.arange(n, dtype=np.uint64) * in_b
