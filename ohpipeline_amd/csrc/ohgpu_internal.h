@@ -151,10 +151,12 @@ struct PcmChunkHead { uint64_t src_off; uint32_t nq; uint8_t channels, sb, db, f
 static_assert(sizeof(PcmChunkHead) == 16, "the head of a chunk record");
 static_assert(sizeof(PcmChunk) == 64, "chunk record = one 64-byte scalar load");
 enum { kChunkRamp = 1, kChunkSilence = 2, kChunkZeroLsb = 4, kChunkSrcLe = 8, kChunkDstLe = 16 };
+constexpr uint32_t kLineLists = 10;   // chunk lists of a plan: [0] the general path, [1 + (sb - 2) * 3 + (db - 2)] the 16/24/32-bit layouts
 struct PcmLinePlan {
     bool     enabled = false;
     bool     prefixed = false;    // chunks carry prefixes (d_prefix): only this kernel writes them
     uint32_t n_chunks = 0;
+    uint32_t list_first[kLineLists] = {}, list_count[kLineLists] = {};   // d_chunks[list_first[k], + list_count[k]): one launch each
     void*    d_chunks = nullptr;
     void*    d_prefix = nullptr;  // the prefix blob
 };

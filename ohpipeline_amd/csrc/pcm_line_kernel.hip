@@ -510,8 +510,14 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
 {
     (void)ctx;
     b->line = PcmLinePlan();
-    std::vector<PcmChunk> chunks;
-    bool mergeable = false;                                             // the last chunk is a group-path chunk
+    // One chunk list per layout: messages of 16/24/32-bit audio on both sides go to the list of their (source, destination)
+    // depth pair and run the instantiation that has those depths as immediates and works in registers (whatever their channel
+    // counts and byte orders: those are per chunk); everything else -- 8-bit audio on either side -- to list 0, the general
+    // staged path.  A batch is as many launches as it has non-empty lists: one 8-bit stream no longer sends 2047 others down
+    // the slow path.
+    std::vector<PcmChunk> lists[kLineLists];
+    std::vector<PcmChunk>* last_list = nullptr;                         // the previous message's
+    bool mergeable = false;                                             // ... and its last chunk is a group-path chunk
     for (size_t i = 0; i < n; i++) {
         const ohgpu_msg_desc& d = descs[i];
         const uint64_t n_sub = (uint64_t)d.n_frames * d.channels;
@@ -549,7 +555,11 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
         magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &c.m_n1, &sh); c.s_n1 = (uint8_t)sh;
         // Plain messages of a uniform batch run the group path, which needs no staging buffer: such a message is one chunk,
         // and it is appended to the previous chunk when it continues it in both arenas (a stream's consecutive messages).
-        const bool registers_only = b->uniform && sb >= 2 && sb <= 4 && db >= 2 && db <= 4 && !(d.flags & OHGPU_FLAG_SILENCE);
+        const bool fast_layout = sb >= 2 && sb <= 4 && db >= 2 && db <= 4;
+        std::vector<PcmChunk>& chunks = lists[fast_layout ? 1 + (sb - 2) * 3 + (db - 2) : 0];
+        if (&chunks != last_list) mergeable = false;
+        last_list = &chunks;
+        const bool registers_only = fast_layout && !(d.flags & OHGPU_FLAG_SILENCE);
         const bool group_path = registers_only && !(d.flags & OHGPU_FLAG_RAMP) && d.attenuation == OHGPU_UNITY_ATTENUATION;
         if (registers_only && !group_path && n_sub > 0) {                // ramped / attenuated: one chunk per message, no staging
             c.q0 = 0; c.nq = (uint32_t)n_sub; c.src_off = d.src_offset; c.dst_off = d.dst_offset;
@@ -581,9 +591,16 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
             c.prefix_bytes = 0;
         }
     }
-    if (chunks.empty() || chunks.size() > 0xffffffffull) return OHGPU_OK;
-    hipError_t e = hipMalloc(&b->line.d_chunks, chunks.size() * sizeof(PcmChunk));
-    if (e == hipSuccess) e = hipMemcpy(b->line.d_chunks, chunks.data(), chunks.size() * sizeof(PcmChunk), hipMemcpyHostToDevice);
+    std::vector<PcmChunk> all;
+    for (uint32_t k = 0; k < kLineLists; k++) {
+        b->line.list_first[k] = (uint32_t)all.size();
+        b->line.list_count[k] = (uint32_t)lists[k].size();
+        all.insert(all.end(), lists[k].begin(), lists[k].end());
+        if (all.size() > 0xffffffffull) return OHGPU_OK;
+    }
+    if (all.empty()) return OHGPU_OK;
+    hipError_t e = hipMalloc(&b->line.d_chunks, all.size() * sizeof(PcmChunk));
+    if (e == hipSuccess) e = hipMemcpy(b->line.d_chunks, all.data(), all.size() * sizeof(PcmChunk), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         free_pcm_line(b);
         return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "chunk plan upload: %s", hipGetErrorString(e));
@@ -597,31 +614,37 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
         }
         b->line.prefixed = true;
     }
-    b->line.n_chunks = (uint32_t)chunks.size();
+    b->line.n_chunks = (uint32_t)all.size();
     b->line.enabled = true;
     return OHGPU_OK;
 }
 
 template <int SB, int DB>
-static hipError_t launch_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+static hipError_t launch_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32_t first, uint32_t count, const uint8_t* src, uint8_t* dst, hipStream_t s)
 {
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
-    uint32_t grid = (b->line.n_chunks + kLineWaves - 1) / kLineWaves;
+    uint32_t grid = (count + kLineWaves - 1) / kLineWaves;
     if (grid > cus * 8) grid = cus * 8;                                 // 8 workgroups = 32 waves fill a CU
     hipLaunchKernelGGL((pcm_line_kernel<SB, DB>), dim3(grid), dim3(kLineWaves * 64), 0, s,
-                       (const PcmChunk*)b->line.d_chunks, b->line.n_chunks, src, dst, ctx->d_ramp_table, (const uint8_t*)b->line.d_prefix);
+                       (const PcmChunk*)b->line.d_chunks + first, count, src, dst, ctx->d_ramp_table, (const uint8_t*)b->line.d_prefix);
     return hipGetLastError();
 }
 
 hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
 {
-    if (b->uniform) {
-        const uint32_t sb = b->src_bits / 8, db = b->dst_bits / 8;
-#define X(S, D) if (sb == S && db == D) return launch_line<S, D>(ctx, b, src, dst, s);
+    for (uint32_t k = 0; k < kLineLists; k++) {
+        const uint32_t first = b->line.list_first[k], count = b->line.list_count[k];
+        if (count == 0) continue;
+        hipError_t e = hipSuccess;
+        switch (k) {
+        case 0: e = launch_line<0, 0>(ctx, b, first, count, src, dst, s); break;
+#define X(S, D) case 1 + (S - 2) * 3 + (D - 2): e = launch_line<S, D>(ctx, b, first, count, src, dst, s); break;
         X(2, 2) X(2, 3) X(2, 4) X(3, 2) X(3, 3) X(3, 4) X(4, 2) X(4, 3) X(4, 4)
 #undef X
+        }
+        if (e != hipSuccess) return e;
     }
-    return launch_line<0, 0>(ctx, b, src, dst, s);
+    return hipSuccess;
 }
 
 }  // namespace ohgpu

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--all-ramped", action="store_true", help="every message carries a ramp (worst case for RampApplicator, a7)")
+    ap.add_argument("--mix", action="store_true", help="streams cycle through six layouts (stereo S24, S16->S24, S32->S24, six-channel S24, S16, S24->S32): "
+                                                       "one batch, one launch per layout")
+    ap.add_argument("--mix-8bit", action="store_true", help="with --mix: every 64th stream is 8-bit (the general staged path, in the same batch)")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (one thread) on a bounded sample of the streams")
     a = ap.parse_args()
@@ -43,24 +46,36 @@ def main():
     jps = 56448000 // 48000
     sched = np.array(hostmodel.stream_ramp_schedule([int(c) * jps for c in count], 50 * 56448, 500 * 56448), dtype=np.int64)
     d = np.zeros(a.streams * n_msgs, dtype=capi.MSG_DESC)
-    src_stream = a.frames * ch * sb + a.misalign
-    dst_stream = a.frames * ch * db + a.misalign
+    layouts = [(ch, a.src_bits, a.dst_bits)]
+    if a.mix:
+        layouts = [(2, 24, 24), (2, 16, 24), (2, 32, 24), (6, 24, 24), (2, 16, 16), (2, 24, 32)]
+    src_pos = dst_pos = 0
+    algo = 0
+    stream_dst_end = []
     for s in range(a.streams):
+        lch, lsbits, ldbits = layouts[s % len(layouts)]
+        if a.mix and a.mix_8bit and s % 64 == 63:
+            lch, lsbits, ldbits = 2, 8, 8
+        lsb, ldb = lsbits // 8, ldbits // 8
         sl = slice(s * n_msgs, (s + 1) * n_msgs)
-        d["src_offset"][sl] = s * src_stream + a.misalign + first * ch * sb
-        d["dst_offset"][sl] = s * dst_stream + a.misalign + first * ch * db
+        d["src_offset"][sl] = src_pos + a.misalign + first * lch * lsb
+        d["dst_offset"][sl] = dst_pos + a.misalign + first * lch * ldb
         d["n_frames"][sl] = count
         d["flags"][sl] = sched[:, 0]
         d["ramp_start"][sl] = sched[:, 1]
         d["ramp_end"][sl] = sched[:, 2]
+        d["channels"][sl], d["src_bits"][sl], d["dst_bits"][sl] = lch, lsbits, ldbits
+        src_pos += a.frames * lch * lsb + a.misalign
+        dst_pos += a.frames * lch * ldb + a.misalign
+        algo += a.frames * lch * (lsb + ldb)
+        stream_dst_end.append(dst_pos)
     if a.all_ramped:
         d["flags"] = capi.FLAG_RAMP
         d["ramp_start"], d["ramp_end"] = 16384, 3000
     d["attenuation"] = a.attenuation
-    d["channels"], d["src_bits"], d["dst_bits"] = ch, a.src_bits, a.dst_bits
     d["src_endian"] = capi.ENDIAN_BIG if a.src_endian == "big" else capi.ENDIAN_LITTLE
     d["dst_endian"] = capi.ENDIAN_BIG if a.dst_endian == "big" else capi.ENDIAN_LITTLE
-    src_bytes, dst_bytes = a.streams * src_stream, a.streams * dst_stream
+    src_bytes, dst_bytes = src_pos, dst_pos
     rng = np.random.default_rng(1234)
     src = rng.integers(0, 256, size=src_bytes, dtype=np.uint8)
 
@@ -81,25 +96,26 @@ def main():
     ctx.sync()
     ms = sorted(ctx.elapsed_ms(e0, e1) for e0, e1 in ev)
     avg = sum(ms) / len(ms)
-    algo = a.streams * a.frames * ch * (sb + db)
     out = dict(metric="PCM message path GB/s", ms_avg=round(avg, 4), ms_min=round(ms[0], 4),
                gbps=round(algo / avg / 1e6, 1), frac_of_8TBps=round(algo / avg / 1e6 / 8000.0, 4),
                msamples_per_s=round(a.streams * a.frames / avg / 1e3, 1), algorithmic_bytes=algo,
                config=dict(streams=a.streams, frames=a.frames, msg_frames=a.msg_frames, channels=ch, src_bits=a.src_bits,
                            dst_bits=a.dst_bits, src_endian=a.src_endian, dst_endian=a.dst_endian,
-                           attenuation=a.attenuation, all_ramped=a.all_ramped, misalign=a.misalign, variant=a.variant, msgs=int(d.size)))
+                           attenuation=a.attenuation, all_ramped=a.all_ramped, misalign=a.misalign, variant=a.variant, msgs=int(d.size),
+                           mix=bool(a.mix), mix_8bit=bool(a.mix and a.mix_8bit)))
     if a.check:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ctypes as C
         import oracle_lib as O
-        k = min(a.streams, 3) * n_msgs
+        n_chk = min(a.streams, 64 if a.mix else 3)
+        k = n_chk * n_msgs
         part = np.ascontiguousarray(d[:k]).view(O.MSG_DESC) if d.dtype != O.MSG_DESC else np.ascontiguousarray(d[:k])
         ref = np.full(dst_bytes, 0xEE, dtype=np.uint8)
         rc = O.lib().ohp_msg_process_batch(part.ctypes.data_as(C.c_void_p), part.size, src.ctypes.data_as(C.c_void_p),
                                             ref.ctypes.data_as(C.c_void_p))
         assert rc == 0
         got = ctx.download(d_dst, dst_bytes)
-        n = min(a.streams, 3) * dst_stream
+        n = stream_dst_end[n_chk - 1]
         out["check"] = "ok" if np.array_equal(got[:n], ref[:n]) else "MISMATCH"
     if a.cpu:
         import time
