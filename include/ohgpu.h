@@ -297,6 +297,8 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t taps_per_p
 int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src);
 /* ceil(in_frames * L / M): output frames available once in_frames input frames have arrived */
 uint64_t ohgpu_src_out_frames(uint32_t L, uint32_t M, uint64_t in_frames);
+/* The messages of one batch may differ in layout (channels, depths, byte orders, packed or planar source): the batch is
+ * planned per layout and runs one launch sequence per layout, messages of a stream in the order given. */
 int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
 /* A batch may be run any number of times, one launch at a time (it owns device-side work counters): launches of the same

@@ -364,6 +364,7 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
 {
     CTX_GUARD("ohgpu_batch_destroy");
     if (!batch) return OHGPU_OK;
+    for (ohgpu_batch* part : batch->parts) ohgpu_batch_destroy(ctx, part);
     if (batch->last_done) hipEventDestroy(batch->last_done);
     if (batch->d_descs) hipFree(batch->d_descs);
     if (batch->kind == kBatchSrc) free_src_fast(batch);
@@ -750,8 +751,34 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         }
     }
     int err = upload_batch(ctx, b, dev.data(), n * sizeof(DevSrcDesc));
-    if (err == OHGPU_OK) err = plan_src_fast(ctx, b, descs, n, dev);
+    if (err == OHGPU_OK && b->uniform) err = plan_src_fast(ctx, b, descs, n, dev);
+    if (err == OHGPU_OK && !b->uniform) {
+        // Mixed layouts (channel counts, depths, byte orders, planar or packed sources): the block kernels are instantiated per
+        // layout, so the batch becomes one uniform batch per layout, messages in their given order.  (More than 32 layouts: the
+        // generic kernel takes the whole batch, as it did for every mixed batch before.)
+        auto key = [](const ohgpu_src_msg_desc& d) -> uint64_t {
+            return (uint64_t)d.channels | ((uint64_t)d.src_bits << 8) | ((uint64_t)d.dst_bits << 16) | ((uint64_t)d.src_endian << 24) |
+                   ((uint64_t)d.dst_endian << 32) | ((uint64_t)((d.flags & OHGPU_FLAG_SRC_PLANAR32) ? 1 : 0) << 40);
+        };
+        std::vector<uint64_t> keys;
+        std::vector<std::vector<ohgpu_src_msg_desc>> groups;
+        for (size_t i = 0; i < n && keys.size() <= 32; i++) {
+            const uint64_t k = key(descs[i]);
+            size_t g = 0;
+            while (g < keys.size() && keys[g] != k) g++;
+            if (g == keys.size()) { keys.push_back(k); groups.emplace_back(); }
+            groups[g].push_back(descs[i]);
+        }
+        if (keys.size() <= 32) {
+            for (size_t g = 0; g < groups.size() && err == OHGPU_OK; g++) {
+                ohgpu_batch* part = nullptr;
+                err = ohgpu_src_batch_create(ctx, src, groups[g].data(), groups[g].size(), src_arena_bytes, dst_arena_bytes, &part);
+                if (err == OHGPU_OK) b->parts.push_back(part);
+            }
+        }
+    }
     if (err != OHGPU_OK) {
+        for (ohgpu_batch* part : b->parts) ohgpu_batch_destroy(ctx, part);
         if (b->d_descs) hipFree(b->d_descs);
         delete b;
         return err;
@@ -763,6 +790,17 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
 int ohgpu_src_batch_plan(const ohgpu_batch* b, uint64_t* block_kernel_out_frames, uint64_t* generic_pieces)
 {
     if (!b || b->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_plan: not a src batch");
+    if (!b->parts.empty()) {
+        uint64_t fast = 0, pieces = 0;
+        for (const ohgpu_batch* part : b->parts) {
+            uint64_t f = 0, p = 0;
+            ohgpu_src_batch_plan(part, &f, &p);
+            fast += f; pieces += p;
+        }
+        if (block_kernel_out_frames) *block_kernel_out_frames = fast;
+        if (generic_pieces) *generic_pieces = pieces;
+        return OHGPU_OK;
+    }
     if (block_kernel_out_frames) *block_kernel_out_frames = b->fast.enabled ? b->fast.fast_out_frames : 0;
     if (generic_pieces) *generic_pieces = b->fast.enabled ? b->fast.n_rem : b->n;
     return OHGPU_OK;
@@ -775,6 +813,13 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (batch->n == 0) return OHGPU_OK;
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
     hipStream_t s = pick_stream(ctx, stream);
+    if (ctx->variant != 1 && !batch->parts.empty()) {               // one uniform batch per layout
+        for (const ohgpu_batch* part : batch->parts) {
+            const int err = ohgpu_src_batch_run(ctx, part, src_base, dst_base, s);
+            if (err != OHGPU_OK) return err;
+        }
+        return OHGPU_OK;
+    }
     const bool aligned = ((uintptr_t)src_base & 15u) == 0;          // the staging loads move aligned 16-byte pieces of the arena
     if (ctx->variant != 1 && batch->fast.enabled && aligned) {
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)

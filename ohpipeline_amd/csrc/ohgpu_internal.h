@@ -265,6 +265,9 @@ struct ohgpu_batch {
     ohgpu::FlywheelPlan fly;      // kBatchFlywheel only
     ohgpu::FmtLinePlan fmtline;   // kBatchFmt only
     ohgpu::OhmPlan ohm;           // kBatchOhm only
+    // kBatchSrc whose messages differ in layout: one uniform batch per layout (each with its own block-kernel plan), run one
+    // after the other; this batch keeps every descriptor for the generic kernel (ohgpu_set_kernel_variant(1)).
+    std::vector<ohgpu_batch*> parts;
     // A resampled batch's unit counters and a flywheel batch's workspace belong to ONE launch at a time.  Launches on the same
     // stream queue behind each other; a launch on another stream while the last one is still running is refused
     // (ohgpu_*_batch_run, OHGPU_ERR_INVALID) instead of silently sharing them.

@@ -461,6 +461,53 @@ def test_src_config4_mix_runs_on_the_block_kernel(ctx):
         ctx.src_destroy(h)
 
 
+def test_src_one_batch_of_mixed_layouts_runs_on_the_block_kernels(ctx):
+    """One resampled batch whose streams differ in channel count, depth and byte order: planned as one uniform batch per layout
+    (each on its block kernel where one is instantiated), interleaved in the caller's order, bit-exact; the generic kernel
+    (variant 1) agrees."""
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    layouts = [(2, 24, LE, 24, BE), (6, 24, LE, 24, BE), (2, 16, BE, 24, BE), (8, 24, BE, 24, LE), (2, 24, LE, 24, BE), (2, 32, LE, 32, BE)]
+    in_frames, out_frames = 5880, 6400
+    n_msgs = (out_frames + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 30 * O.JIFFIES_PER_MS, 50 * O.JIFFIES_PER_MS)
+    per_stream, src_parts, sp, dp = [], [], 0, 0
+    for sid, (ch, sbits, se, dbits, de) in enumerate(layouts):
+        d, sbytes, dbytes, _, _ = W.src_stream_descs(1, in_frames, ref.L, ref.M, 240, ch, sbits, se, dbits, de, sched)
+        d = d.copy()
+        d["src_offset"] += sp
+        d["dst_offset"] += dp
+        per_stream.append(d)
+        src_parts.append(W.noise_pcm(sid, in_frames, ch, sbits, se))
+        assert src_parts[-1].size == sbytes
+        sp += sbytes + (-sbytes) % 16
+        src_parts.append(np.zeros((-sbytes) % 16, dtype=np.uint8))
+        dp += dbytes + 3
+    # message k of every stream, then message k + 1: layouts alternate from one descriptor to the next
+    descs = np.concatenate([np.stack([d[k] for d in per_stream]) for k in range(n_msgs)])
+    src = np.concatenate(src_parts)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dp)
+    ctx.memset(d_dst, 0xA5, dp)
+    b = ctx.src_batch(h, descs, src.size, dp)
+    plan = ctx.src_plan(b)
+    # (the block kernels are instantiated for 24-bit output of 16/24-bit... sources as the configs need them: the S16 and S32
+    # streams' parts go to the generic kernel message by message, the other four streams' to their block kernels)
+    assert plan["block_kernel_out_frames"] == 4 * out_frames and plan["generic_pieces"] == 2 * n_msgs, plan
+    ctx.src_run(b, d_src, d_dst)
+    got = ctx.download(d_dst, dp)
+    want = oracle_src(ref, descs, src, dp)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}"
+    ctx.set_kernel_variant(1)
+    try:
+        ctx.memset(d_dst, 0xA5, dp)
+        ctx.src_run(b, d_src, d_dst)
+        assert np.array_equal(ctx.download(d_dst, dp), want)
+    finally:
+        ctx.set_kernel_variant(0)
+    ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
+
+
 @pytest.mark.parametrize("rate,taps,ch", [(44100, 32, 6), (96000, 64, 6), (44100, 32, 8), (44100, 32, 2)])
 def test_src_workgroups_of_several_waves(ctx, rate, taps, ch):
     """Enough units that every workgroup runs several waves side by side (bench.py's config 4 at full size found what the small
