@@ -2,6 +2,9 @@
 // No exception crosses this boundary; every failure is a negative code plus ohgpu_last_error().
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <utility>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -388,6 +391,20 @@ int ohgpu_batch_info(const ohgpu_batch* b, uint64_t* n_msgs, uint64_t* in_frames
     return OHGPU_OK;
 }
 
+// Do the messages' outputs tile [0, total) exactly?  Then the host-buffer calls need not upload the destination first (they
+// do so to keep the bytes no message covers as the caller gave them).
+static bool outputs_tile(std::vector<std::pair<uint64_t, uint64_t>>& ranges, uint64_t total)
+{
+    std::sort(ranges.begin(), ranges.end());
+    uint64_t pos = 0;
+    for (const auto& r : ranges) {
+        if (r.second == 0) continue;
+        if (r.first != pos) return false;
+        pos += r.second;
+    }
+    return pos == total;
+}
+
 int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
                            const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes)
 {
@@ -399,7 +416,10 @@ int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n
     err = ohgpu_malloc(ctx, src_bytes, &d_src);
     if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
     if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);  // bytes no message covers stay as given
+    std::vector<std::pair<uint64_t, uint64_t>> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = {descs[i].dst_offset, (uint64_t)descs[i].n_frames * descs[i].channels * (descs[i].dst_bits / 8)};
+    if (err == OHGPU_OK && dst_bytes && !outputs_tile(out, dst_bytes))
+        err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);  // bytes no message covers stay as given
     if (err == OHGPU_OK) err = ohgpu_pcm_batch_run(ctx, b, d_src, d_dst, nullptr);
     if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
     if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
@@ -848,7 +868,10 @@ int ohgpu_src_process_host(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
     err = ohgpu_malloc(ctx, src_bytes, &d_src);
     if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
     if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);
+    std::vector<std::pair<uint64_t, uint64_t>> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = {descs[i].dst_offset, (uint64_t)descs[i].n_frames * descs[i].channels * (descs[i].dst_bits / 8)};
+    if (err == OHGPU_OK && dst_bytes && !outputs_tile(out, dst_bytes))
+        err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);  // bytes no message covers stay as given
     if (err == OHGPU_OK) err = ohgpu_src_batch_run(ctx, b, d_src, d_dst, nullptr);
     if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
     if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);

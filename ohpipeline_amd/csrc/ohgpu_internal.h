@@ -104,8 +104,9 @@ struct SrcFastPlan {
     uint32_t ring_bytes = 0;      // bytes of packed output a block row's LDS ring holds
     bool     lean = false;        // the batch runs on src_lean_kernel (round 2) rather than src_block_kernel
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
-    void*    d_planes = nullptr;  // uint16 [n_planes][plane_stride / 2]: RampApplicator's multiplier per output frame of every ramped unit
-    uint32_t plane_stride = 0;    // bytes per plane: rows * L_blk entries and one load group of slack
+    void*    d_planes = nullptr;  // uint16: RampApplicator's multiplier per output frame of every ramped unit, [blocks of the unit][L_blk]
+    uint32_t plane_stride = 0;    // the unit of SrcWork::plane / LeanUnit::plane in bytes (16: planes are as long as their units)
+    void*    d_slab = nullptr;    // the one allocation the arrays below live in
     void*    d_segs = nullptr;
     void*    d_msgs = nullptr;
     void*    d_work = nullptr;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <utility>
 #include <vector>
 
 #include "ohgpu_internal.h"
@@ -17,27 +18,37 @@ namespace ohgpu {
 void free_src_fast(ohgpu_batch* b)
 {
     SrcFastPlan& f = b->fast;
-    if (f.d_segs) hipFree(f.d_segs);
-    if (f.d_msgs) hipFree(f.d_msgs);
-    if (f.d_work) hipFree(f.d_work);
-    if (f.d_lean_units) hipFree(f.d_lean_units);
-    if (f.d_rem) hipFree(f.d_rem);
-    if (f.d_counter) hipFree(f.d_counter);
-    if (f.d_planes) hipFree(f.d_planes);
+    if (f.d_slab) (void)hipFree(f.d_slab);                            // (every d_* below points into it)
     f = SrcFastPlan();
 }
 
-template <typename V>
-static int upload_vec(const std::vector<V>& v, void** dptr)
-{
-    *dptr = nullptr;
-    if (v.empty()) return OHGPU_OK;
-    hipError_t e = hipMalloc(dptr, v.size() * sizeof(V));
-    if (e == hipSuccess) e = hipMemcpy(*dptr, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE,
-                                          "block plan upload: %s", hipGetErrorString(e));
-    return OHGPU_OK;
-}
+// A plan's device arrays live in ONE allocation, filled by ONE copy: at a live pipeline's cadence (a batch per 5 ms period,
+// ohgpu_src_process_host) the seven allocations, seven synchronous copies and seven frees of round 1 were most of the call.
+struct Slab {
+    std::vector<uint8_t> host;
+    std::vector<std::pair<void**, size_t>> at;                         // where each array's device pointer goes, and its offset
+    template <typename V>
+    void add(const std::vector<V>& v, void** dptr)
+    {
+        *dptr = nullptr;
+        if (v.empty()) return;
+        const size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + v.size() * sizeof(V));
+        memcpy(host.data() + off, v.data(), v.size() * sizeof(V));
+        at.emplace_back(dptr, off);
+    }
+    int upload(void** slab)
+    {
+        *slab = nullptr;
+        if (host.empty()) return OHGPU_OK;
+        hipError_t e = hipMalloc(slab, host.size());
+        if (e == hipSuccess) e = hipMemcpy(*slab, host.data(), host.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE,
+                                              "block plan upload: %s", hipGetErrorString(e));
+        for (auto& a : at) *a.first = (uint8_t*)*slab + a.second;
+        return OHGPU_OK;
+    }
+};
 
 // RampApplicator's multiplier for frame i of a message of n frames (OpenHome/Media/Pipeline/Msg.cpp:826-837): the ramp value
 // moves from `start` towards `end` by C integer division (truncation toward zero, the numerator may be negative), is cast
@@ -202,10 +213,14 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 w.flags = ramped ? kWorkRamped : 0u;
                 w.plane = 0; w.pad = 0;
                 if (ramped && lean) {
-                    const size_t per = (size_t)rows * L_blk + 8;
-                    w.plane = (uint32_t)(planes.size() / per);
-                    planes.resize(planes.size() + per, 0xffffu);
-                    uint16_t* pl = planes.data() + (size_t)w.plane * per;
+                    // (as many rows as the unit has blocks -- a live pipeline's batch of one message per stream has one -- in
+                    // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16)
+                    const size_t per = (((size_t)w.n_blocks * L_blk + 8) + 7) & ~(size_t)7;
+                    if (planes.size() / 8 + per / 8 > 0xffffffffull) return OHGPU_OK;
+                    w.plane = (uint32_t)(planes.size() / 8);
+                    const size_t at = planes.size();
+                    planes.resize(at + per, 0xffffu);
+                    uint16_t* pl = planes.data() + at;
                     for (uint32_t m = mi; m < sg.msg_end && msgs[m].out0 < u_hi; m++) {
                         const SegMsg& sm = msgs[m];
                         if (!(sm.flags & OHGPU_FLAG_RAMP)) continue;
@@ -244,6 +259,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         i = e;
     }
     if (work.empty()) return OHGPU_OK;
+    if (!planes.empty()) planes.resize(planes.size() + (size_t)rows * L_blk + 8, 0xffffu);   // (lanes without a block read their row's place too)
     // Longest first: the waves claim units in this order, and the kernel ends when the last unit does.  With the ramped
     // units where the streams put them (each stream's fade-out is its last units) the launch ended on a few long units
     // with most of the chip idle.
@@ -266,13 +282,15 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         }
     }
 
-    int err = upload_vec(segs, &f.d_segs);
-    if (err == OHGPU_OK) err = upload_vec(msgs, &f.d_msgs);
-    if (err == OHGPU_OK) err = upload_vec(work, &f.d_work);
-    if (err == OHGPU_OK && lean) err = upload_vec(lean_units, &f.d_lean_units);
-    if (err == OHGPU_OK) err = upload_vec(rem, &f.d_rem);
-    if (err == OHGPU_OK) err = upload_vec(planes.empty() ? std::vector<uint16_t>(4, 0xffffu) : planes, &f.d_planes);
-    if (err == OHGPU_OK) err = upload_vec(std::vector<uint32_t>(2, 0u), &f.d_counter);   // {units claimed, waves finished}: zero between launches
+    Slab slab;
+    slab.add(segs, &f.d_segs);
+    slab.add(msgs, &f.d_msgs);
+    slab.add(work, &f.d_work);
+    if (lean) slab.add(lean_units, &f.d_lean_units);
+    slab.add(rem, &f.d_rem);
+    slab.add(planes.empty() ? std::vector<uint16_t>(4, 0xffffu) : planes, &f.d_planes);
+    slab.add(std::vector<uint32_t>(2, 0u), &f.d_counter);            // {units claimed, waves finished}: zero between launches
+    int err = slab.upload(&f.d_slab);
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
     f.enabled = true;
     f.T = T;
@@ -285,7 +303,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.lean = lean;
     f.lean_coef_lds_bytes = lean_coef;
     f.lean_wave_lds_bytes = lean_wave_lds;
-    f.plane_stride = (uint32_t)(((size_t)rows * L_blk + 8) * sizeof(uint16_t));
+    f.plane_stride = 16;                                              // SrcWork::plane counts 16-byte pieces
     f.lean_max_waves = lean_max_waves;
     f.fast_out_frames = fast_frames;
     SrcFastParams& p = f.params;

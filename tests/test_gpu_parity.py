@@ -286,6 +286,42 @@ def test_pcm_process_host_round_trip(ctx):
     assert np.array_equal(dst, oracle_pcm(descs, src, dst.size))
 
 
+def test_process_host_keeps_the_bytes_no_message_covers(ctx):
+    """The host-buffer calls write the messages' outputs and nothing else: with gaps between the outputs the destination is
+    uploaded first, with outputs that tile it exactly (any order) that copy is skipped -- same result either way."""
+    rng = np.random.default_rng(12)
+    for gap in (0, 5):
+        rows, parts, sp, dp = [], [], 0, 0
+        for k in range(7):
+            n = 100 + 13 * k
+            parts.append(rng.integers(0, 256, size=n * 6, dtype=np.uint8))
+            rows.append((sp, dp, n, 16384, 0, 256, 2, 24, LE, 24, BE, O.FLAG_RAMP if k % 2 else 0))
+            sp += n * 6
+            dp += n * 6 + gap
+        descs = np.array(rows[::-1], dtype=O.MSG_DESC)                    # (not in destination order)
+        src = np.concatenate(parts)
+        dst = np.full(dp, 0x5A, dtype=np.uint8)
+        ctx.pcm_process_host(descs, src, dst)
+        want = np.full(dp, 0x5A, dtype=np.uint8)
+        assert O.msg_process_batch(descs, src, want) == 0
+        assert np.array_equal(dst, want), gap
+    # the resampler's call: one 5 ms message per stream, outputs back to back / with a hole after each
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    in_frames = 4410
+    src = np.concatenate([W.noise_pcm(s, in_frames, 2, 24, LE) for s in range(3)])
+    d, sbytes, dbytes, out_total, _ = W.src_stream_descs(3, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, None)
+    pick = np.ascontiguousarray(d[5::(out_total + 239) // 240][:3]).copy()      # message 5 of every stream
+    for hole in (0, 7):
+        pick["dst_offset"] = np.arange(3, dtype=np.uint64) * (240 * 6 + hole)
+        total = 3 * (240 * 6 + hole)
+        dst = np.full(total, 0x5A, dtype=np.uint8)
+        ctx.src_process_host(h, pick, src, dst)
+        want = np.full(total, 0x5A, dtype=np.uint8)
+        assert ref.process_batch(pick, src, want) == 0
+        assert np.array_equal(dst, want), hole
+    ctx.src_destroy(h)
+
+
 def test_config1_stream_s16le_ramp_s24(vctx):
     """BASELINE config 1: 1 stream stereo S16LE 44.1 kHz, 220-frame msgs, up-ramp 50 ms / down-ramp 500 ms, S16->S24."""
     frames = 44100
