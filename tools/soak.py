@@ -57,6 +57,10 @@ def main():
             try:
                 F.test_flywheel_batch_matches_oracle(ctx)
                 M.test_line_kernel_equals_byte_kernel_on_mixed_batches(ctx)
+                M.test_sender_pack_batches_of_wider_streams(ctx)
+                pair = [(16, 16), (24, 24), (32, 24), (16, 24), (24, 32), (32, 32), (24, 16), (16, 32), (32, 16)][(seed // 10) % 9]
+                P.test_pcm_ramped_groups_every_channel_count(ctx, *pair)
+                P.test_pcm_uniform_batches_every_depth_pair(ctx, *pair)
             finally:
                 np.random.default_rng = real_rng
             counts["flywheel"] += 1
