@@ -87,7 +87,9 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(32, 6, 3, true, 3, false)     \
     X(32, 6, 3, false, 3, false)    \
     X(32, 8, 3, true, 3, false)     \
-    X(32, 8, 3, false, 3, false)
+    X(32, 8, 3, false, 3, false)    \
+    X(32, 4, 3, false, 3, false)    \
+    X(32, 6, 2, false, 3, false)
 #define OHGPU_BLOCK_KERNELS_3(X)    \
     X(64, 2, 3, true, 3, false)     \
     X(64, 6, 3, true, 3, false)     \
