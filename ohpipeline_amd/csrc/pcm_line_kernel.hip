@@ -17,6 +17,7 @@
 //     per-message multipliers computed on the host (exact for operands < 2^31, which validation guarantees).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -508,8 +509,15 @@ void free_pcm_line(ohgpu_batch* b)
 int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, size_t n,
                   const MsgPrefix* prefixes, const uint8_t* blob, size_t blob_bytes)
 {
-    (void)ctx;
     b->line = PcmLinePlan();
+    // How many of a stream's consecutive plain messages share a chunk: enough chunks for every wave of the launch to take a few
+    // dozen (the launch ends on whole chunks), no more than eight messages each (a chunk's record is read once; one message
+    // per chunk made 512 000 stereo messages 6 % slower than two, eight per chunk 5 % slower -- tools/bench_pcm.py, same box).
+    size_t n_plain = 0;
+    for (size_t i = 0; i < n; i++)
+        n_plain += !(descs[i].flags & (OHGPU_FLAG_RAMP | OHGPU_FLAG_SILENCE)) && descs[i].attenuation == OHGPU_UNITY_ATTENUATION;
+    const size_t waves = (size_t)(ctx->num_cus > 0 ? ctx->num_cus : 256) * 8 * kLineWaves;
+    const uint32_t merge_msgs = (uint32_t)std::min<size_t>(8, std::max<size_t>(1, (n_plain + 16 * waves) / (32 * waves)));
     // One chunk list per layout: messages of 16/24/32-bit audio on both sides go to the list of their (source, destination)
     // depth pair and run the instantiation that has those depths as immediates and works in registers (whatever their channel
     // counts and byte orders: those are per chunk); everything else -- 8-bit audio on either side -- to list 0, the general
@@ -570,13 +578,14 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
         if (group_path && n_sub > 0) {
             if (!chunks.empty() && mergeable && !has_prefix) {
                 PcmChunk& p = chunks.back();
-                if (p.flags == c.flags && p.plain_sel == c.plain_sel && (uint64_t)p.nq + n_sub <= kGroupChunkSub &&
+                if (p.flags == c.flags && p.plain_sel == c.plain_sel && (uint64_t)p.nq + n_sub <= kGroupChunkSub && p.host_msgs < merge_msgs &&
                     p.src_off + (uint64_t)p.nq * sb == d.src_offset && p.dst_off + (uint64_t)p.nq * db == d.dst_offset) {
                     p.nq += (uint32_t)n_sub;
+                    p.host_msgs++;
                     continue;
                 }
             }
-            c.q0 = 0; c.nq = (uint32_t)n_sub; c.src_off = d.src_offset; c.dst_off = d.dst_offset;
+            c.q0 = 0; c.nq = (uint32_t)n_sub; c.src_off = d.src_offset; c.dst_off = d.dst_offset; c.host_msgs = 1;
             chunks.push_back(c);
             mergeable = true;
             continue;
