@@ -1,7 +1,16 @@
 // pcm_line_kernel.hip -- the tuned kernel of the PCM message path: unpack ->
 // attenuate -> ramp | silence -> pack, any depth / byte order / channel count / alignment, line-coalesced.
 //
-// HBM-bound byte work (about 0.5 integer op per byte), so the design is about memory instructions, not arithmetic:
+// HBM-bound byte work (about 0.5 integer op per byte), so the design is about memory instructions, not arithmetic.
+// Two paths share the chunk records and the launch:
+//   REGISTERS (16/24/32-bit audio on both sides: pcm_line_kernel<SB, DB>, one launch per depth pair of the batch).  A
+//     chunk is a message or a run of a stream's plain messages; lane = a GROUP of four subsamples -- one unaligned
+//     8/12/16-byte load on a scalar base, one store; a trip of the wave's loop issues the first 128 groups of TWO chunks
+//     before it touches either.  Plain: a byte shuffle.  Ramped: shuffle -> 24-bit multiply -> shuffle (RampApplicator
+//     uses a subsample's top 16 bits and writes two bytes back), two multiplier look-ups per group.  Attenuated and the
+//     rest: pcm_device.h's expressions on the same groups.  A chunk may carry a PREFIX (a Songcast frame's header) that its
+//     wave writes in front of the audio.
+//   STAGED (8-bit audio, silence: pcm_line_kernel<0, 0> and generic_chunk), described first:
 //   * A message is cut into CHUNKS of <= 512 subsamples (host, at batch creation), each described by one 64-byte
 //     record that a single scalar load fetches; one wave owns a chunk at a time.
 //   * In: the aligned 16-byte pieces that cover the chunk's source bytes go straight to LDS
