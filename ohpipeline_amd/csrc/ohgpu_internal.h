@@ -146,7 +146,7 @@ struct PcmChunk {             // one wave's share of a message: subsamples [q0, 
     uint8_t  pad8;                //   a Songcast frame's header, written with the frame's first audio (csrc/ohm_frame_kernel.hip)
     uint32_t plain_sel;           // v_perm_b32 selector of the plain path: source bytes -> destination bytes in memory order
     uint32_t prefix_off;          // of those bytes in the blob (a multiple of 4; entries are padded to whole dwords)
-    uint32_t host_msgs;           // (planner only: messages merged into the chunk)
+    uint32_t pad;
 };
 struct PcmChunkHead { uint64_t src_off; uint32_t nq; uint8_t channels, sb, db, flags; };
 static_assert(sizeof(PcmChunkHead) == 16, "the head of a chunk record");

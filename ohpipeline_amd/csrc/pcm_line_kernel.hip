@@ -585,18 +585,40 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
             continue;
         }
         if (group_path && n_sub > 0) {
+            // A stream's consecutive plain messages are one run of bytes: they are appended to the open chunk, and the run is cut
+            // into chunks of about merge_msgs messages -- NOT at the message boundaries but where the destination is 64-byte
+            // aligned (and, if possible, a whole number of groups in): a boundary inside a 64-byte sector makes two waves write
+            // parts of it at different times.  48 kHz messages (1440 bytes of S24 stereo) end on such boundaries anyway; 44.1 kHz
+            // ones (1320 bytes) do not, and ran 15 % slower until the cuts moved.
+            const uint32_t target = (uint32_t)std::min<uint64_t>(kGroupChunkSub, (uint64_t)merge_msgs * n_sub);
+            bool appended = false;
             if (!chunks.empty() && mergeable && !has_prefix) {
                 PcmChunk& p = chunks.back();
-                if (p.flags == c.flags && p.plain_sel == c.plain_sel && (uint64_t)p.nq + n_sub <= kGroupChunkSub && p.host_msgs < merge_msgs &&
+                if (p.flags == c.flags && p.plain_sel == c.plain_sel && (uint64_t)p.nq + n_sub <= 0xffffffffull &&
                     p.src_off + (uint64_t)p.nq * sb == d.src_offset && p.dst_off + (uint64_t)p.nq * db == d.dst_offset) {
                     p.nq += (uint32_t)n_sub;
-                    p.host_msgs++;
-                    continue;
+                    appended = true;
                 }
             }
-            c.q0 = 0; c.nq = (uint32_t)n_sub; c.src_off = d.src_offset; c.dst_off = d.dst_offset; c.host_msgs = 1;
-            chunks.push_back(c);
-            mergeable = true;
+            if (!appended) {
+                c.q0 = 0; c.nq = (uint32_t)n_sub; c.src_off = d.src_offset; c.dst_off = d.dst_offset;
+                chunks.push_back(c);
+                mergeable = true;
+            }
+            while (chunks.back().nq >= target + target / 4) {           // (what stays open is less than a chunk and a quarter)
+                PcmChunk rest = chunks.back();
+                uint32_t cut = target & ~3u, second_best = 0;
+                for (uint32_t q = target; q + 128 > target && q > target / 2; q--) {
+                    if ((rest.dst_off + (uint64_t)q * db) % 64 != 0) continue;
+                    if (q % 4 == 0) { second_best = q; break; }
+                    if (!second_best) second_best = q;
+                }
+                if (second_best) cut = second_best;
+                if (cut == 0) break;
+                chunks.back().nq = cut;
+                rest.src_off += (uint64_t)cut * sb; rest.dst_off += (uint64_t)cut * db; rest.nq -= cut; rest.prefix_bytes = 0;
+                chunks.push_back(rest);
+            }
             continue;
         }
         mergeable = false;
