@@ -586,10 +586,10 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
         }
         if (group_path && n_sub > 0) {
             // A stream's consecutive plain messages are one run of bytes: they are appended to the open chunk, and the run is cut
-            // into chunks of about merge_msgs messages -- NOT at the message boundaries but where the destination is 64-byte
-            // aligned (and, if possible, a whole number of groups in): a boundary inside a 64-byte sector makes two waves write
-            // parts of it at different times.  48 kHz messages (1440 bytes of S24 stereo) end on such boundaries anyway; 44.1 kHz
-            // ones (1320 bytes) do not, and ran 15 % slower until the cuts moved.
+            // into chunks of about merge_msgs messages -- NOT at the message boundaries but where the destination is 128-byte
+            // aligned (and, if possible, a whole number of groups in): a boundary inside a line makes two waves write parts of
+            // it at different times.  48 kHz messages (1440 bytes of S24 stereo) end on 64-byte boundaries anyway; 44.1 kHz
+            // ones (1320 bytes) do not, and ran 15 % slower until the cuts moved (64-byte cuts: +13 %, 128-byte: another 1..4 %).
             const uint32_t target = (uint32_t)std::min<uint64_t>(kGroupChunkSub, (uint64_t)merge_msgs * n_sub);
             bool appended = false;
             if (!chunks.empty() && mergeable && !has_prefix) {
@@ -608,8 +608,8 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
             while (chunks.back().nq >= target + target / 4) {           // (what stays open is less than a chunk and a quarter)
                 PcmChunk rest = chunks.back();
                 uint32_t cut = target & ~3u, second_best = 0;
-                for (uint32_t q = target; q + 128 > target && q > target / 2; q--) {
-                    if ((rest.dst_off + (uint64_t)q * db) % 64 != 0) continue;
+                for (uint32_t q = target; q + 256 > target && q > target / 2; q--) {
+                    if ((rest.dst_off + (uint64_t)q * db) % 128 != 0) continue;
                     if (q % 4 == 0) { second_best = q; break; }
                     if (!second_best) second_best = q;
                 }
