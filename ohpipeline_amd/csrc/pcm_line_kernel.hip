@@ -440,19 +440,23 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
         // (Scalar registers are the scarce thing here: two whole records per chunk in flight -- this trip's and the next one's --
         // were 64 of them and spilled into vector lanes inside the loops.  A trip needs 16 bytes of a record to issue its
         // loads; those are fetched one trip ahead, the whole records while the audio is on its way.)
+        // (a trip's two chunks are NEIGHBOURS in the list -- usually in memory too: the line two messages or two datagrams share
+        // is then written by one wave within one trip, not by two waves at different times)
+        chunk *= 2;
+        if (chunk >= n_chunks) return;
         PcmChunkHead h0 = head_of(chunk);
-        bool has1 = chunk + stride < n_chunks;
-        PcmChunkHead h1 = head_of(has1 ? chunk + stride : chunk);
+        bool has1 = chunk + 1 < n_chunks;
+        PcmChunkHead h1 = head_of(has1 ? chunk + 1 : chunk);
         while (true) {
             Vec a0 = {}, b0 = {}, a1 = {}, b1 = {};
             load_head(h0, true, a0, b0);
             load_head(h1, has1, a1, b1);
             const PcmChunk c0 = chunks[chunk];
-            const PcmChunk c1 = chunks[has1 ? chunk + stride : chunk];
+            const PcmChunk c1 = chunks[has1 ? chunk + 1 : chunk];
             const uint32_t next = chunk + 2 * stride;
-            const bool more = next < n_chunks, more1 = next + stride < n_chunks;
+            const bool more = next < n_chunks, more1 = next + 1 < n_chunks;
             const PcmChunkHead n0 = head_of(more ? next : chunk);
-            const PcmChunkHead n1 = head_of(more1 ? next + stride : chunk);
+            const PcmChunkHead n1 = head_of(more1 ? next + 1 : chunk);
             uint32_t p0 = 0, p1 = 0;                                    // the chunks' prefixes (none: no lane takes part)
             const uint32_t pp0 = prefix_pos(c0), pp1 = prefix_pos(c1);
             prefix_load(c0, true, pp0, p0);
