@@ -4,15 +4,20 @@
     python bench.py --gpus 1 --steps 5 --warmup 2                  # configs[2], the headline (default)
     python bench.py --config 4                                      # configs[3]: 2048 mixed streams (44.1/96 -> 48 kHz, 2/6/8 channels)
     python bench.py --config 5                                      # configs[4]: FLAC frames -> pack -> resample -> ramp -> S24
+    python bench.py --gpus N                                        # N > 1 without a launcher: bench.py starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                      # ... or is started as one of them (WORLD_SIZE set)
 
 A "step" is one pass of the hot path over the whole batch a rank owns: every launch the batch needs (one fused
 resample->ramp->pack launch per filter/layout group; config 5 also the FLAC pack), inputs and descriptors already resident in
 HBM.  Streams shard across ranks with no collective.  Rank 0 prints ONE JSON line with `roofline` (HIP events around every
 launch of the step, on the launch stream), `cpu_baseline` (the CPU oracle timed on this host's cores, and the full-size
 bit-exact check of the GPU's output against it) and `cadence` (one 5 ms message per stream per call, the live regime).
-The CPU oracle (oracle/, tests/oracle_lib.py) is used only for the `cpu_baseline` leg, never on the measured path.
+The default line (config 3, one GPU) also carries `configs`: BASELINE configs[3] and configs[4] run in the same process at
+their full size (`--no-extra-configs` skips them), each with its own ms_per_step, roofline fraction and bit-exact check.
+`plan_ms` is the wall time of ohgpu_src_batch_create for the step's batches (the plan is made once and reused by every launch).
+The CPU oracle (oracle/, tests/oracle_lib.py) is used only for the `cpu_baseline` leg, never on the measured path.  A run
+whose check fails prints the line with `value` null and exits 1.
 """
 import argparse
 import json
@@ -126,17 +131,24 @@ class Group:
         return d
 
     def fill_noise(self):
+        from concurrent.futures import ThreadPoolExecutor
         self.src = np.empty(self.src_bytes, dtype=np.uint8)
         per = self.in_frames * self.fb_src
-        for k, sid in enumerate(self.stream_ids):
-            self.src[k * per:(k + 1) * per] = noise_s24le(sid, self.in_frames * self.channels)
+
+        def one(k):
+            self.src[k * per:(k + 1) * per] = noise_s24le(self.stream_ids[k], self.in_frames * self.channels)
+        with ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0))))) as ex:     # (numpy releases the GIL in these passes)
+            list(ex.map(one, range(len(self.stream_ids))))
 
     def attach(self, ctx):
         self.h = ctx.src_create(self.L, self.M, self.taps, self.coef)
         self.d_src = self.d_src_external if self.d_src_external is not None else ctx.upload(self.src)
         self.d_dst = ctx.malloc(self.dst_bytes)
         ctx.memset(self.d_dst, 0, self.dst_bytes)
-        self.batch = ctx.src_batch(self.h, self.descs, self.src_bytes, self.dst_bytes)
+        ctx.sync()
+        t0 = time.perf_counter()
+        self.batch = ctx.src_batch(self.h, self.descs, self.src_bytes, self.dst_bytes)    # validation, plan, upload (synchronous)
+        self.plan_ms = (time.perf_counter() - t0) * 1e3
         self.info, self.plan = ctx.batch_info(self.batch), ctx.src_plan(self.batch)
 
     def detach(self, ctx):
@@ -206,66 +218,120 @@ def pin_and_call(cpu, fn, *a):
     return fn(*a)
 
 
-def cpu_baseline(groups, got_by_group):
+def physical_cpus(cpus):
+    """One logical CPU per physical core among `cpus` (the kernel's thread_siblings_list): SURVEY.md 8d(ii) asks for one pinned
+    worker per PHYSICAL core."""
+    seen, out = set(), []
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                sib = f.read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out
+
+
+def cpu_baseline(groups, got_by_group, light=False):
     """Times the CPU oracle (restatement of the reference path + the resampler's integer model, gcc -O2) on this host: the same
-    descriptors and input, streams statically partitioned over pinned threads, scratch buffers allocated once per job
-    (ohp_src_msg_process_batch_steady); median of three passes.  Its output is the bit-exact check of the GPU's."""
+    descriptors and input, streams statically partitioned over pinned threads -- ONE PER PHYSICAL CORE the process may run on
+     -- scratch buffers allocated once per job (ohp_src_msg_process_batch_steady); median of three passes
+    (`light`: one pass, no side figures).  Beside it: the same step on 16 threads (a one-GPU box's CPU share, what rounds 1-2
+    reported) and on one thread.  Its output is the bit-exact check of the GPU's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle_lib as O
-    cpus = sorted(os.sched_getaffinity(0))
-    threads = max(1, min(len(cpus), int(os.environ.get("OHGPU_BENCH_CPU_THREADS", "16"))))
+    allowed = sorted(os.sched_getaffinity(0))
+    phys = physical_cpus(allowed)
+    if os.environ.get("OHGPU_BENCH_CPU_THREADS"):
+        phys = phys[:max(1, int(os.environ["OHGPU_BENCH_CPU_THREADS"]))]
     lib = O.lib()
-    jobs, outs, frames = [], [], 0
+    outs = [np.zeros(g.dst_bytes, dtype=np.uint8) for g in groups]
+    frames = sum(len(g.stream_ids) * g.in_frames for g in groups)
+    refs = []
     for g in groups:
         ref = O.Src(g.rate_in, RATE_OUT, g.taps, BETA, F_PASS)
         assert np.array_equal(ref.coef_q28, g.coef)
-        dst = np.zeros(g.dst_bytes, dtype=np.uint8)
-        outs.append(dst)
-        n = len(g.stream_ids)
-        frames += n * g.in_frames
-        bounds = np.linspace(0, n, min(2 * threads, n) + 1).astype(int)
-        for t in range(len(bounds) - 1):
-            if bounds[t + 1] > bounds[t]:
-                part = np.ascontiguousarray(g.oracle_descs[bounds[t] * g.n_msgs:bounds[t + 1] * g.n_msgs])
-                jobs.append((ref, part, g.src if g.oracle_src is None else g.oracle_src, dst, (bounds[t + 1] - bounds[t]) * g.in_frames * g.channels))
-    jobs.sort(key=lambda j: -j[4])                                       # longest first over the pinned threads
+        refs.append(ref)
 
-    def run(kj):
-        k, (ref, part, src, dst, _) = kj
-        return pin_and_call(cpus[k % threads], lib.ohp_src_msg_process_batch_steady, ref.h, part.ctypes.data_as(C.c_void_p), part.size,
-                            src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+    def timed(cpus, passes):
+        threads = len(cpus)
+        jobs = []
+        for g, ref, dst in zip(groups, refs, outs):
+            n = len(g.stream_ids)
+            bounds = np.linspace(0, n, min(2 * threads, n) + 1).astype(int)
+            for t in range(len(bounds) - 1):
+                if bounds[t + 1] > bounds[t]:
+                    part = np.ascontiguousarray(g.oracle_descs[bounds[t] * g.n_msgs:bounds[t + 1] * g.n_msgs])
+                    jobs.append((ref, part, g.src if g.oracle_src is None else g.oracle_src, dst,
+                                 (bounds[t + 1] - bounds[t]) * g.in_frames * g.channels * g.taps))
+        jobs.sort(key=lambda j: -j[4])                                   # longest first over the pinned threads
 
-    times = []
-    with ThreadPoolExecutor(threads) as ex:
+        def run(kj):
+            k, (ref, part, src, dst, _) = kj
+            return pin_and_call(cpus[k % threads], lib.ohp_src_msg_process_batch_steady, ref.h, part.ctypes.data_as(C.c_void_p), part.size,
+                                src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+        times = []
+        with ThreadPoolExecutor(threads) as ex:
+            for _ in range(passes):
+                t0 = time.perf_counter()
+                rcs = list(ex.map(run, enumerate(jobs)))
+                times.append(time.perf_counter() - t0)
+                assert all(r == 0 for r in rcs)
+        return sorted(times)[len(times) // 2], len(jobs), sum(times) * threads
+
+    passes = 1 if light else 3
+    dt, n_jobs, core_s = timed(phys, passes)
+    ok = all(np.array_equal(a, b) for a, b in zip(got_by_group, outs))
+    base = dict(value=round(frames / dt / 1e6, 3), unit="Msamples/s", cores=len(phys), kind="port",
+                host_cores_online=os.cpu_count(), host_cores_allowed=len(allowed), host_physical_cores_allowed=len(physical_cpus(allowed)),
+                sample=f"the whole step, median of {passes} pass(es): {frames} input frames in {n_jobs} jobs, one pinned thread per physical core "
+                       f"({len(phys)}; gcc -O2 oracle, scratch allocated once per job; {dt:.2f} s per pass, {core_s:.0f} core-seconds in all)")
+    if not light:
+        if len(phys) > 16:
+            dt16, _, _ = timed(phys[:16], 3)
+            base["threads_16"] = round(frames / dt16 / 1e6, 3)
+        # one thread alone (SURVEY.md 8d(i)): the first streams of the first group, about a second of work
+        g0 = groups[0]
+        n_one = max(1, min(len(g0.stream_ids), 8))
+        one_part = np.ascontiguousarray(g0.oracle_descs[:n_one * g0.n_msgs])
+        g0_src = g0.src if g0.oracle_src is None else g0.oracle_src
+        one = []
         for _ in range(3):
             t0 = time.perf_counter()
-            rcs = list(ex.map(run, enumerate(jobs)))
-            times.append(time.perf_counter() - t0)
-            assert all(r == 0 for r in rcs)
-    dt = sorted(times)[1]
-    # one thread alone (SURVEY.md 8d): the first streams of the first group, about a second of work
-    g0 = groups[0]
-    ref0 = jobs[0][0] if False else O.Src(g0.rate_in, RATE_OUT, g0.taps, BETA, F_PASS)
-    n_one = max(1, min(len(g0.stream_ids), 8))
-    one_part = np.ascontiguousarray(g0.oracle_descs[:n_one * g0.n_msgs])
-    g0_src = g0.src if g0.oracle_src is None else g0.oracle_src
-    one = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        rc = lib.ohp_src_msg_process_batch_steady(ref0.h, one_part.ctypes.data_as(C.c_void_p), one_part.size,
-                                                  g0_src.ctypes.data_as(C.c_void_p), outs[0].ctypes.data_as(C.c_void_p))
-        one.append(time.perf_counter() - t0)
-        assert rc == 0
-    ok = all(np.array_equal(a, b) for a, b in zip(got_by_group, outs))
-    base = dict(value=round(frames / dt / 1e6, 3), unit="Msamples/s", cores=threads, kind="port",
-                host_cores_online=os.cpu_count(), host_cores_allowed=len(cpus),
-                single_thread=round(n_one * g0.in_frames / sorted(one)[1] / 1e6, 3),
-                sample=f"the whole step, median of 3 passes: {frames} input frames in {len(jobs)} jobs on {threads} pinned threads "
-                       f"(gcc -O2 oracle, scratch allocated once per job; {dt:.2f} s per pass, {sum(times) * threads:.0f} core-seconds in all)")
+            rc = pin_and_call(phys[0], lib.ohp_src_msg_process_batch_steady, refs[0].h, one_part.ctypes.data_as(C.c_void_p), one_part.size,
+                              g0_src.ctypes.data_as(C.c_void_p), outs[0].ctypes.data_as(C.c_void_p))
+            one.append(time.perf_counter() - t0)
+            assert rc == 0
+        try:
+            os.sched_setaffinity(0, set(allowed))
+        except OSError:
+            pass
+        base["single_thread"] = round(n_one * g0.in_frames / sorted(one)[1] / 1e6, 3)
     return base, ("bit-exact vs oracle" if ok else "MISMATCH")
+
+
+def rank_check(groups, got_first):
+    """Multi-rank runs: every rank checks the first stream of each of its groups against the oracle (a cheap check; the whole
+    step is checked at N = 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
+    import oracle_lib as O
+    for g, got in zip(groups, got_first):
+        ref = O.Src(g.rate_in, RATE_OUT, g.taps, BETA, F_PASS)
+        part = np.ascontiguousarray(g.oracle_descs[:g.n_msgs])
+        src = g.src if g.oracle_src is None else g.oracle_src
+        want = np.zeros(g.out_total * g.fb_dst, dtype=np.uint8)
+        rc = O.lib().ohp_src_msg_process_batch_steady(ref.h, part.ctypes.data_as(C.c_void_p), part.size, src.ctypes.data_as(C.c_void_p),
+                                                      want.ctypes.data_as(C.c_void_p))
+        if rc != 0 or not np.array_equal(got, want):
+            return False
+    return True
 
 
 def cadence(ctx, capi, g, calls=200):
@@ -372,37 +438,42 @@ def end_to_end(ctx, capi, g):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json configs[config-1]: 3 = the headline")
-    ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: 10 s)")
-    ap.add_argument("--streams", type=int, default=None, help="config 3/5: streams per GPU (256); config 4: streams in all (2048)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 2 round 1's block kernel)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / check, end_to_end and cadence legs (profiling runs)")
-    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the warm-up and the timed steps, so that they see the clock the chip holds under this load")
-    ap.add_argument("--channels", type=int, default=2, help="config 3: channels per stream (the headline is stereo)")
-    ap.add_argument("--rate-in", type=int, default=44100, help="config 3: input rate (the headline is 44100)")
-    args = ap.parse_args()
-    if args.seconds is None:
-        args.seconds = 10.0                                    # (every configuration: 10 s of audio per stream)
-    if args.streams is None:
-        args.streams = 2048 if args.config == 4 else 256
+def source_fingerprint():
+    """sha256 over the sources of the kernel the headline times (what a stored profile must have been taken from)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("src_lean_kernel.hip", "src_block_common.h", "src_plan.cpp", "ohgpu_internal.h"):
+        with open(os.path.join(ROOT, "ohpipeline_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch  # noqa: F401  (torch.distributed is plumbing: barrier + max over ranks)
-        import torch.distributed as dist
-        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
 
-    from ohpipeline_amd import capi
-    ctx = capi.Context(local_rank % max(capi.device_count(), 1) if world > 1 else 0)   # fewer GPUs than ranks (a rehearsal): shared
-    ctx.set_kernel_variant(args.variant)
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: start the N ranks as a CHILD process -- before this
+    process has imported the C ABI or touched HIP, and never by exec -- relay rank 0's JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.exit(proc.returncode if proc.returncode != 0 or lines else 1)
+
+
+def measure(capi, ctx, args, rank, world, dist, light=False):
+    """One workload (args.config) on this rank's share: sustain, warm-up, `steps` timed steps between barriers, the result line
+    as a dict (rank 0; None elsewhere) and whether every check passed.  `light` (the extra configs of the default line): no
+    cadence / end_to_end legs, one CPU pass."""
     flac = None
     if args.config == 5:
         import bench_flac
@@ -448,6 +519,7 @@ def main():
     barrier()
     frames_all = float(sum(len(g.stream_ids) * g.in_frames for g in groups))
     subs_all = float(sum(len(g.stream_ids) * g.in_frames * g.channels for g in groups))
+    checks_ok = True
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -456,13 +528,23 @@ def main():
         tot = torch.tensor([frames_all, subs_all], dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         frames_all, subs_all = float(tot[0]), float(tot[1])
+        if not args.no_cpu:
+            first = [ctx.download(g.d_dst, g.out_total * g.fb_dst) for g in groups]
+            okt = torch.tensor([1.0 if rank_check(groups, first) else 0.0], dtype=torch.float64)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            checks_ok = bool(okt.item() > 0.5)
 
     # per-launch kernel time (HIP events on the launch stream), this rank
     grp_ms = [float(np.mean([ctx.elapsed_ms(ev[k][i][0], ev[k][i][1]) for k in range(args.steps)])) for i in range(n_ev)]
+    for row in ev:
+        for pair in row:
+            for e in pair:
+                ctx.event_destroy(e)
     kernel_ms = float(sum(grp_ms[:len(groups)]))
     alg_bytes = float(sum(g.algorithmic_bytes for g in groups))
     flops = float(sum(g.flops for g in groups))
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    plan_ms = float(sum(g.plan_ms for g in groups))
 
     result = None
     if rank == 0:
@@ -488,6 +570,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "plan_ms": round(plan_ms, 3),                    # ohgpu_src_batch_create for the step's batches: once, reused by every launch
             "msubsamples_per_s": round(subs_all * args.steps / elapsed / 1e6, 3),   # frames x channels
             "higher_is_better": True,
             "scaling": scaling,
@@ -500,6 +583,7 @@ def main():
                        "groups": [{"rate_in": g.rate_in, "channels": g.channels, "src_bits": g.src_bits, "streams": len(g.stream_ids),
                                    "taps_per_phase": g.taps, "frames_per_stream": g.in_frames, "msgs": int(g.info["n_msgs"]),
                                    "kernel_ms": round(grp_ms[i], 4), "gbps": round(g.algorithmic_bytes / (grp_ms[i] * 1e-3) / 1e9, 1),
+                                   "plan_ms": round(g.plan_ms, 3),
                                    "block_kernel_out_frames": g.plan["block_kernel_out_frames"], "generic_pieces": g.plan["generic_pieces"]}
                                   for i, g in enumerate(groups)],
                        "sharding": f"streams over {world} rank(s), no collective"},
@@ -517,40 +601,118 @@ def main():
         if flac is not None:
             result["config"]["flac"] = flac.report(grp_ms[-1])
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and args.config == 3:
+        if os.path.exists(pmc) and args.config == 3 and world == 1:
+            # `traffic` is a counter measurement of THIS workload taken in separate --pmc passes (tools/profile_bench.sh), not of
+            # this run: it is quoted only while the kernel's sources are the ones that profile was taken from
             try:
                 p = json.load(open(pmc))
                 if p.get("streams_per_gpu") == args.streams and p.get("frames_per_stream") == groups[0].in_frames \
-                        and p.get("kernel_variant") == args.variant:
+                        and p.get("kernel_variant") == args.variant and p.get("source_sha16") == source_fingerprint():
                     result["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
-                    result["roofline"]["traffic_source"] = p.get("source")
+                    result["roofline"]["traffic_source"] = "stored profile, not this run: " + str(p.get("source"))
             except Exception:
                 pass
         if world == 1 and not args.no_cpu:
             got = [ctx.download(g.d_dst, g.dst_bytes) for g in groups]
-            try:                                             # (reported extras: never let them cost the headline line)
-                if args.config == 3:
-                    result["end_to_end"] = end_to_end(ctx, capi, groups[0])
-                result["cadence"] = None if head.planar else cadence(ctx, capi, head)    # (the live regime is measured on the packed layouts)
-            except Exception as e:
-                result["extras_error"] = f"{type(e).__name__}: {e}"
-            base, check = cpu_baseline(groups, got)
+            if not light:
+                try:                                         # (reported extras: never let them cost the headline line)
+                    if args.config == 3:
+                        result["end_to_end"] = end_to_end(ctx, capi, groups[0])
+                        result["end_to_end"]["plan_ms"] = round(plan_ms, 3)
+                        result["end_to_end"]["ms_per_step_with_plan"] = round(result["end_to_end"]["ms_per_step"] + plan_ms, 3)
+                    result["cadence"] = None if head.planar else cadence(ctx, capi, head)    # (the live regime is measured on the packed layouts)
+                except Exception as e:
+                    result["extras_error"] = f"{type(e).__name__}: {e}"
+            base, check = cpu_baseline(groups, got, light=light)
             result["cpu_baseline"] = base
             result["check"] = check
+            checks_ok = checks_ok and check == "bit-exact vs oracle"
             if flac is not None:
                 result["check_flac_decode"] = flac.check(ctx)
+                checks_ok = checks_ok and result["check_flac_decode"].startswith("lossless")
         else:
             result["cpu_baseline"] = None
+            if world > 1 and not args.no_cpu:
+                result["check"] = ("bit-exact vs oracle: first stream of every group on every rank" if checks_ok else "MISMATCH")
     for g in groups:
         g.detach(ctx)
     if flac is not None:
         flac.close(ctx)
+    return result, checks_ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json configs[config-1]: 3 = the headline")
+    ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: 10 s)")
+    ap.add_argument("--streams", type=int, default=None, help="config 3/5: streams per GPU (256); config 4: streams in all (2048)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 2 round 1's block kernel)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / check, end_to_end and cadence legs (profiling runs)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="the default line without its `configs` object (configs[3] and configs[4] at full size)")
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the warm-up and the timed steps, so that they see the clock the chip holds under this load")
+    ap.add_argument("--channels", type=int, default=2, help="config 3: channels per stream (the headline is stereo)")
+    ap.add_argument("--rate-in", type=int, default=44100, help="config 3: input rate (the headline is 44100)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                                     # (does not return; nothing of HIP or the C ABI has been loaded yet)
+    explicit = args.seconds is not None or args.streams is not None
+    if args.seconds is None:
+        args.seconds = 10.0                                    # (every configuration: 10 s of audio per stream)
+    if args.streams is None:
+        args.streams = 2048 if args.config == 4 else 256
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch  # noqa: F401  (torch.distributed is plumbing: barrier + max over ranks)
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+
+    from ohpipeline_amd import capi
+    ctx = capi.Context(local_rank % max(capi.device_count(), 1) if world > 1 else 0)   # fewer GPUs than ranks (a rehearsal): shared
+    ctx.set_kernel_variant(args.variant)
+    result, ok = measure(capi, ctx, args, rank, world, dist)
+    # The default line (config 3, one GPU, sizes untouched) also carries BASELINE configs[3] and configs[4], at their full size
+    # (2048 streams x 10 s; 256 FLAC streams x 10 s), same process, each with its own sustain phase, steps and whole-step check.
+    if rank == 0 and world == 1 and args.config == 3 and not explicit and not args.no_extra_configs and not args.no_cpu \
+            and args.channels == 2 and args.rate_in == 44100:
+        result["configs"] = {}
+        for cfg in (4, 5):
+            t0 = time.perf_counter()
+            try:
+                sub = argparse.Namespace(**vars(args))
+                sub.config, sub.streams, sub.sustain = cfg, (2048 if cfg == 4 else 256), 0.5
+                r, sub_ok = measure(capi, ctx, sub, rank, world, dist, light=True)
+                ok = ok and sub_ok
+                entry = {"metric": r["metric"], "workload": r["config"]["workload"], "value": r["value"], "ms_per_step": r["ms_per_step"],
+                         "kernel_avg_ms": r["roofline"]["kernel_avg_ms"], "plan_ms": r["plan_ms"], "frac": r["roofline"]["frac"],
+                         "fp64_frac": r["roofline"]["fp64_frac"], "achieved_gbps": r["roofline"]["achieved"], "scaling": r["scaling"],
+                         "check": r.get("check"), "cpu_baseline": {k: r["cpu_baseline"][k] for k in ("value", "cores")},
+                         "groups": [{k: g[k] for k in ("rate_in", "channels", "src_bits", "streams", "taps_per_phase", "kernel_ms", "gbps", "generic_pieces")}
+                                    for g in r["config"]["groups"]]}
+                if "check_flac_decode" in r:
+                    entry["check_flac_decode"] = r["check_flac_decode"]
+                    entry["host_decode"] = r["config"]["flac"]["host_decode"]
+            except Exception as e:                             # (an extra config never costs the headline line; a failed CHECK does)
+                entry = {"error": f"{type(e).__name__}: {e}"}
+            entry["wall_s"] = round(time.perf_counter() - t0, 1)
+            result["configs"][str(cfg)] = entry
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if not ok:
+            result["value"] = None                             # a fast result that differs from the oracle's is not a result
         print(json.dumps(result))
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

@@ -256,6 +256,9 @@ class Context:
         check(lib().ohgpu_event_create(self._h, C.byref(e)))
         return e
 
+    def event_destroy(self, event):
+        check(lib().ohgpu_event_destroy(self._h, event))
+
     def record(self, event, stream=None):
         check(lib().ohgpu_event_record(self._h, event, stream))
 

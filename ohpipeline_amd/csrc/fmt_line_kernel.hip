@@ -85,11 +85,7 @@ __global__ __launch_bounds__(kFmtWaves * 64) void fmt_line_kernel(const FmtChunk
                     v = subsample(upos) | (subsample(upos + 1) << 8) | (subsample(upos + 2) << 16) | (subsample(upos + 3) << 24);
                 }
                 if (pos >= 0 && (uint32_t)pos + 4 <= len) {
-#ifdef OHGPU_EXP_STORE_PLAIN
-                    *(uint32_t*)(obase + (size_t)k * 4) = v;
-#else
                     __builtin_nontemporal_store(v, (uint32_t*)(obase + (size_t)k * 4));       // written once, never read here
-#endif
                 } else {                                                // first / last dword of the chunk: only its own bytes
                     const uint32_t skip = pos < 0 ? (uint32_t)(-pos) : 0u;
                     for (uint32_t b = skip; b < 4; b++) {

@@ -50,6 +50,11 @@ static double bessel_i0(double x)
 //   L/M = rate_out/rate_in reduced, N = L*T prototype taps, Kaiser(beta)-windowed sinc,
 //   stop edge f_stop = rate_out - f_pass, cutoff midway, DC gain L, Q28 rounding half up,
 //   polyphase order coef[p*T + k] = h[p + k*L].
+//   An integer decimator (L = 1) gets an ODD length, N = T - 1, centred on a tap (a type I linear-phase filter, whole-sample
+//   delay), stored with coef[T - 1] = 0.  For 2:1 (96 -> 48 kHz: cutoff midway between 20 and 28 kHz = exactly a quarter of the
+//   input rate) that prototype is a HALF-BAND filter: sinc(d / 2) vanishes at every even distance d from the centre, so every
+//   second coefficient is exactly zero after the Q28 rounding and an output needs T / 2 products plus the centre tap
+//   (src_lean_kernel's half-band instantiations; any other kernel just multiplies by the zeros).
 int design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, double f_pass,
                std::vector<int32_t>* coef_q28, uint32_t* L_out, uint32_t* M_out)
 {
@@ -60,7 +65,7 @@ int design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, dou
     *L_out = L;
     *M_out = M;
     if (coef_q28 == nullptr) return OHGPU_OK;
-    const uint32_t N = L * T;
+    const uint32_t N = (L == 1 && T > 1) ? T - 1 : L * T;
     double f_stop = (double)rate_out - f_pass;
     if (f_stop > (double)rate_in - f_pass && rate_out > 2 * rate_in) f_stop = (double)rate_in - f_pass;
     const double fs_up = (double)L * (double)rate_in;
@@ -81,12 +86,12 @@ int design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, dou
         sum += h[n];
     }
     const double scale = (double)L / sum;
-    coef_q28->assign(N, 0);
+    coef_q28->assign((size_t)L * T, 0);
     int64_t worst = 0;
     for (uint32_t p = 0; p < L; p++) {
         int64_t sabs = 0;
         for (uint32_t k = 0; k < T; k++) {
-            const double v = h[p + k * L] * scale;
+            const double v = (p + k * L < N) ? h[p + k * L] * scale : 0.0;
             const int32_t q = (int32_t)std::floor(v * 268435456.0 + 0.5);
             (*coef_q28)[p * T + k] = q;
             sabs += q < 0 ? -(int64_t)q : (int64_t)q;

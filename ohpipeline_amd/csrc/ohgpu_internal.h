@@ -71,12 +71,21 @@ struct LeanUnit {             // the lean kernel's own view of a unit (same orde
     int64_t  src_row0;        // source arena offset of row 0's input frame at advance -T: seg.src_base + (first_block * M_blk - T) * fb_src
     int64_t  dst_row0;        // destination arena offset of row 0's first output byte: seg.dst_base + first_block * L_blk * fb_dst
     uint32_t n_blocks;
-    uint32_t flags;           // kWorkRamped | kWorkChecked | kWorkFirst
+    uint32_t flags;           // kWorkRamped | kWorkChecked | kWorkFirst; bits 8..15: blocks per ROW (a row = that many consecutive blocks)
     uint32_t plane;
     uint32_t src_plane_stride; // planar source: bytes between the channels' planes (the planner keeps such a batch off this kernel
                                // unless every plane of a unit is within 4 GiB of its first)
 };
-static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24 && sizeof(LeanUnit) == 32, "plan layouts");
+struct RampJob {              // ramp_plane_kernel: frames [i0, i0 + count) of one ramped message go to entries [plane_entry, + count) of the planes
+    uint64_t plane_entry;     // index of the first uint16 entry
+    uint32_t i0, count;
+    uint32_t n;               // the message's frames (RampApplicator's iNumSamples)
+    uint32_t m_n1;            // x / (n - 1) == umulhi(x, m_n1) >> s_n1 for x < 2^31 (m_n1 == 0: n - 1 <= 1)
+    uint16_t ramp_start, ramp_end;
+    uint8_t  s_n1;
+    uint8_t  pad[3];
+};
+static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24 && sizeof(LeanUnit) == 32 && sizeof(RampJob) == 32, "plan layouts");
 
 struct SrcFastParams {        // kernel argument block
     const SrcSeg*  segs;
@@ -98,6 +107,7 @@ struct SrcFastPlan {
     uint32_t T = 0;               // taps per phase
     SrcFastParams params{};
     uint32_t n_work = 0;
+    uint32_t n_lean = 0;          // LeanUnit count (a lean unit may hold several blocks per row: it need not equal n_work)
     uint32_t coef_lds_bytes = 0;  // the coefficient table's share of a workgroup's LDS
     uint32_t wave_lds_bytes = 0;  // per wave: input stages, message table, output ring
     uint32_t max_waves = 0;       // waves per workgroup the LDS allows (<= 12)
@@ -112,6 +122,7 @@ struct SrcFastPlan {
     void*    d_work = nullptr;
     void*    d_lean_units = nullptr;   // LeanUnit [n_work], when `lean`
     void*    d_counter = nullptr; // uint32[2]: units claimed / waves finished by the running launch; the kernel's last wave zeroes them
+    void*    d_ramp_jobs = nullptr; // RampJob[]: what ramp_plane_kernel filled the planes from (kept for the batch's lifetime)
     void*    d_rem = nullptr;     // DevSrcDesc[] the generic kernel finishes (block-unaligned heads and tails)
     size_t   n_rem = 0;
     uint64_t fast_out_frames = 0;
@@ -311,6 +322,7 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+hipError_t launch_ramp_planes(const ohgpu_ctx* ctx, const void* d_jobs, uint32_t n_jobs, void* d_planes, hipStream_t s);   // csrc/ramp_plane_kernel.hip
 bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves);

@@ -166,7 +166,7 @@ __global__ __launch_bounds__((LeanGeom<T, CH, SB, DB>::MAX_WAVES * 64))
 void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                      const double* __restrict__ coef, const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                     const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk, const uint32_t M_blk,
+                     const uint64_t src_arena_bytes, const int L, const int M, const uint32_t L_blk1, const uint32_t M_blk1,
                      const uint32_t ring_bytes, const uint32_t src_shift, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
 {
     static_assert(T % 16 == 0 && T >= 32 && T <= 64, "T / 16 coefficient registers per lane");
@@ -247,6 +247,10 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     st_mark = __builtin_amdgcn_s_memtime(); st_units++;
 #endif
     const uint32_t n_blocks = wk.n_blocks;
+    // A row is `kb` consecutive blocks of its stream (src_plan.cpp: long units first, one-block units for the end of the launch):
+    // the window stays warm from block to block, so a row pays the T warm-up advances and their history once, not per block.
+    const uint32_t kb = (wk.flags >> 8) & 0xffu;
+    const uint32_t L_blk = L_blk1 * kb, M_blk = M_blk1 * kb;           // outputs / input frames per ROW of this unit
     const bool ramped = (wk.flags & kWorkRamped) != 0;                 // wave-uniform
     const bool checked = (wk.flags & kWorkChecked) != 0;               // some staging piece of the unit lies outside the arena
     const bool lane_valid = lane_block && row < n_blocks;
@@ -751,10 +755,10 @@ static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
     auto kernel = src_lean_kernel<T, CH, SB, SRC_LE, DB, DST_LE>;
     const SrcFastPlan& f = b->fast;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
-    uint32_t w = (f.n_work + cus - 1) / cus;
+    uint32_t w = (f.n_lean + cus - 1) / cus;
     if (w < 1) w = 1;
     if (w > f.lean_max_waves) w = f.lean_max_waves;
-    uint32_t g = (f.n_work + w - 1) / w;
+    uint32_t g = (f.n_lean + w - 1) / w;
     if (g > cus) g = cus;
     const uint32_t lds = f.lean_coef_lds_bytes + w * f.lean_wave_lds_bytes;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -766,7 +770,7 @@ static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
     if (stamp_path && hipMalloc((void**)&dbg, n_dbg * 8) == hipSuccess) hipMemsetAsync(dbg, 0, n_dbg * 8, s);
 #endif
     hipLaunchKernelGGL(kernel, dim3(g), dim3(w * 64), lds, s,
-                       (const LeanUnit*)f.d_lean_units, f.n_work, p.coef, (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst,
+                       (const LeanUnit*)f.d_lean_units, f.n_lean, p.coef, (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst,
                        p.src_arena_bytes, (int)p.L, (int)p.M, p.L_blk, p.M_blk, f.ring_bytes, 32u - b->src_bits, (uint32_t*)f.d_counter, dbg);
 #ifdef OHGPU_DIAG_STAMP
     if (dbg) {      // diagnostic build only: wait, sum up, write a text report, never on the product path

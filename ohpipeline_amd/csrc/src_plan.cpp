@@ -37,34 +37,29 @@ struct Slab {
         memcpy(host.data() + off, v.data(), v.size() * sizeof(V));
         at.emplace_back(dptr, off);
     }
+    size_t tail = 0;                                                   // device-only bytes behind the copied part (reserve)
+    std::pair<void**, size_t> tail_at{nullptr, 0};
+    void reserve(size_t bytes, void** dptr)                            // space the device fills itself: allocated, not copied
+    {
+        *dptr = nullptr;
+        if (bytes == 0) return;
+        tail_at = {dptr, (host.size() + 255) & ~(size_t)255};
+        tail = bytes;
+    }
     int upload(void** slab)
     {
         *slab = nullptr;
-        if (host.empty()) return OHGPU_OK;
-        hipError_t e = hipMalloc(slab, host.size());
-        if (e == hipSuccess) e = hipMemcpy(*slab, host.data(), host.size(), hipMemcpyHostToDevice);
+        if (host.empty() && tail == 0) return OHGPU_OK;
+        const size_t total = tail ? tail_at.second + tail : host.size();
+        hipError_t e = hipMalloc(slab, total);
+        if (e == hipSuccess && !host.empty()) e = hipMemcpy(*slab, host.data(), host.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess && tail) *tail_at.first = (uint8_t*)*slab + tail_at.second;
         if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE,
                                               "block plan upload: %s", hipGetErrorString(e));
         for (auto& a : at) *a.first = (uint8_t*)*slab + a.second;
         return OHGPU_OK;
     }
 };
-
-// RampApplicator's multiplier for frame i of a message of n frames (OpenHome/Media/Pipeline/Msg.cpp:826-837): the ramp value
-// moves from `start` towards `end` by C integer division (truncation toward zero, the numerator may be negative), is cast
-// to TUint16, and indexes RampArray.h's 512 entries through (kMax - ramp + 16) >> 5, limited to the last entry.
-static uint16_t ramp_multiplier(const uint16_t table[512], uint32_t start, uint32_t end, uint32_t i, uint32_t n)
-{
-    uint32_t ramp = start;
-    if (n != 1) {
-        const int32_t total = (int32_t)start - (int32_t)end;
-        const int32_t prod = (int32_t)i * total;                       // TInt arithmetic (validated: n <= 131071, |total| <= 16384)
-        ramp = start - (uint32_t)(prod / (int32_t)(n - 1));
-    }
-    ramp &= 0xffffu;
-    const uint32_t idx = (16384u - ramp + 16u) >> 5;
-    return table[idx < 511u ? idx : 511u];
-}
 
 // piece [m_lo, m_hi) of message d (device form dv) for the generic kernel
 static DevSrcDesc make_piece(const ohgpu_src_msg_desc& d, const DevSrcDesc& dv, uint64_t m_lo, uint64_t m_hi,
@@ -84,7 +79,6 @@ static DevSrcDesc make_piece(const ohgpu_src_msg_desc& d, const DevSrcDesc& dv, 
 int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n,
                   const std::vector<DevSrcDesc>& dev)
 {
-    (void)ctx;
     SrcFastPlan& f = b->fast;
     f = SrcFastPlan();
     if (n == 0 || !b->uniform) return OHGPU_OK;
@@ -146,6 +140,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     });
 
     std::vector<SrcSeg> segs;
+    struct SegRun { uint32_t seg; uint64_t blk_lo, blk_hi; uint32_t work_begin; };   // a segment's whole blocks and where its units start in `work`
+    std::vector<SegRun> seg_runs;
     std::vector<uint32_t> seg_plane_stride;             // planar batches: bytes between a segment's planes
     std::vector<SegMsg> msgs;
     std::vector<SrcWork> work;
@@ -153,9 +149,25 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     uint64_t fast_frames = 0;
     // lean kernel: one plane of multipliers per ramped unit -- rows * L_blk entries (uint16, 0xffff = no ramp on that frame)
     // (the kernel loads eight entries at a time; a row is a whole number of loads when L_blk is a multiple of 8, else the slack covers the last one)
-    uint16_t ramp_table[512];
-    build_ramp_table(ramp_table);
-    std::vector<uint16_t> planes;
+    // (the multipliers themselves are computed on the device, csrc/ramp_plane_kernel.hip: the planner only says which message
+    // covers which stretch of which plane)
+    std::vector<RampJob> ramp_jobs;
+    size_t plane_entries = 0;
+
+    // the lean kernel's staging moves, per stage q, the aligned 16-byte pieces that hold each row's frames: does every one of
+    // them lie inside the arena?  (Only a unit at an end of the arena can fail.)  A row is `kb` consecutive blocks.
+    auto unit_leaves_arena = [&](int64_t sbase, uint64_t plane_stride, uint64_t first_block, uint32_t n_rows, uint32_t kb) {
+        const int64_t m_row = (int64_t)M_blk * kb;
+        const int64_t total = m_row + T, n_stages = (total + lean_sf - 1) / lean_sf;
+        for (uint32_t pc = 0; pc < (planar ? ch : 1u); pc++) {              // (planar: every channel's plane is staged on its own)
+            const int64_t g_first = sbase + (int64_t)(pc * plane_stride) + ((int64_t)(first_block * M_blk) - (int64_t)T) * fb_src;
+            const int64_t g_last = g_first + (int64_t)(n_rows - 1) * m_row * fb_src;
+            const int64_t lo = g_first - (g_first & 15);
+            const int64_t hi = g_last - (g_last & 15) + 16 * (((g_last & 15) + lean_sf * fb_src + 15) >> 4) + (n_stages - 1) * lean_sf * fb_src;
+            if (g_first < 0 || lo < 0 || (uint64_t)hi > b->src_arena_bytes) return true;
+        }
+        return false;
+    };
 
     size_t i = 0;
     while (i < n) {
@@ -198,6 +210,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             const uint32_t seg_index = (uint32_t)segs.size();
             segs.push_back(sg);
             seg_plane_stride.push_back((uint32_t)d0.src_plane_stride);
+            seg_runs.push_back(SegRun{seg_index, blk_lo, blk_hi, (uint32_t)work.size()});
             uint32_t mi = msg_begin;                      // message that holds the unit's first output frame
             for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
                 SrcWork w;
@@ -212,35 +225,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                     ramped = (msgs[m].flags & OHGPU_FLAG_RAMP) && msgs[m].out0 + msgs[m].n > u_lo;
                 w.flags = ramped ? kWorkRamped : 0u;
                 w.plane = 0; w.pad = 0;
-                if (ramped && lean) {
-                    // (as many rows as the unit has blocks -- a live pipeline's batch of one message per stream has one -- in
-                    // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16)
-                    const size_t per = (((size_t)w.n_blocks * L_blk + 8) + 7) & ~(size_t)7;
-                    if (planes.size() / 8 + per / 8 > 0xffffffffull) return OHGPU_OK;
-                    w.plane = (uint32_t)(planes.size() / 8);
-                    const size_t at = planes.size();
-                    planes.resize(at + per, 0xffffu);
-                    uint16_t* pl = planes.data() + at;
-                    for (uint32_t m = mi; m < sg.msg_end && msgs[m].out0 < u_hi; m++) {
-                        const SegMsg& sm = msgs[m];
-                        if (!(sm.flags & OHGPU_FLAG_RAMP)) continue;
-                        const uint64_t lo = std::max<uint64_t>(sm.out0, u_lo), hi = std::min<uint64_t>(sm.out0 + sm.n, u_hi);
-                        for (uint64_t fr = lo; fr < hi; fr++)
-                            pl[fr - u_lo] = ramp_multiplier(ramp_table, sm.ramp_start, sm.ramp_end, (uint32_t)(fr - sm.out0), sm.n);
-                    }
-                }
-                // the lean kernel's staging moves, per stage q, the aligned 16-byte pieces that hold each row's eight frames:
-                // does every one of them lie inside the arena?  (Only a unit at an end of the arena can fail.)
-                {
-                    const int64_t total = (int64_t)M_blk + T, n_stages = (total + lean_sf - 1) / lean_sf;
-                    for (uint32_t pc = 0; pc < (planar ? ch : 1u); pc++) {          // (planar: every channel's plane is staged on its own)
-                        const int64_t g_first = sbase + (int64_t)(pc * d0.src_plane_stride) + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
-                        const int64_t g_last = g_first + (int64_t)(w.n_blocks - 1) * M_blk * fb_src;
-                        const int64_t lo = g_first - (g_first & 15);
-                        const int64_t hi = g_last - (g_last & 15) + 16 * (((g_last & 15) + lean_sf * fb_src + 15) >> 4) + (n_stages - 1) * lean_sf * fb_src;
-                        if (g_first < 0 || lo < 0 || (uint64_t)hi > b->src_arena_bytes) w.flags |= kWorkChecked;
-                    }
-                }
+                if (unit_leaves_arena(sbase, d0.src_plane_stride, bk, w.n_blocks, 1)) w.flags |= kWorkChecked;
                 work.push_back(w);
             }
             fast_frames += (blk_hi - blk_lo) * L_blk;
@@ -259,28 +244,101 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         i = e;
     }
     if (work.empty()) return OHGPU_OK;
-    if (!planes.empty()) planes.resize(planes.size() + (size_t)rows * L_blk + 8, 0xffffu);   // (lanes without a block read their row's place too)
-    // Longest first: the waves claim units in this order, and the kernel ends when the last unit does.  With the ramped
-    // units where the streams put them (each stream's fade-out is its last units) the launch ended on a few long units
-    // with most of the chip idle.
-    std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {     // ramped first, partly filled units last
-        return ((x.flags & kWorkRamped) ? 3u : 1u) * x.n_blocks > ((y.flags & kWorkRamped) ? 3u : 1u) * y.n_blocks;
-    });
-
+    // ---- the lean kernel's units.  A unit is `rows` rows; a row is `kb` CONSECUTIVE blocks of its stream.  With kb = 1 (round
+    // 2) every block pays a filter length of warm-up advances and re-reads that much history (32 frames per 147), and every
+    // 160 outputs a unit set-up; a row of kb blocks pays them once.  But long units make the end of the launch coarse -- round
+    // 2 measured uniformly longer blocks as a loss for exactly that reason -- so only the FIRST part of the work is cut into
+    // long units, claimed first, and about `tail_rounds` rounds of one-block units are left for the waves to level out on.
+    // Ramped units stay one block long (a long unit would run the ramp path for all its outputs).
     std::vector<LeanUnit> lean_units;
     if (lean) {
-        lean_units.reserve(work.size());
-        for (const SrcWork& w : work) {
-            LeanUnit u;
-            u.src_row0 = segs[w.seg].src_base + ((int64_t)(w.first_block * M_blk) - (int64_t)T) * fb_src;
-            u.dst_row0 = segs[w.seg].dst_base + (int64_t)(w.first_block * L_blk) * fb_dst;
-            u.n_blocks = w.n_blocks;
-            u.flags = w.flags | (w.first_block == 0 ? (uint32_t)kWorkFirst : 0u);
-            u.plane = w.plane;
-            u.src_plane_stride = planar ? seg_plane_stride[w.seg] : 0u;
-            lean_units.push_back(u);
+        const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * lean_max_waves;
+        double tail_rounds = 2.5;
+        uint32_t kb_max = 8;
+#ifdef OHGPU_DIAG
+        if (const char* e = getenv("OHGPU_DIAG_TAIL_ROUNDS")) tail_rounds = atof(e);       // (diagnostic builds: the long/short split)
+        if (const char* e = getenv("OHGPU_DIAG_KB_MAX")) kb_max = (uint32_t)atoi(e);
+#endif
+        // how many one-block units the plan has, and the share of them to merge
+        const double u1 = (double)work.size(), long_budget = u1 - tail_rounds * waves;
+        uint32_t kb_long = 1;
+        double long_share = 0.0;
+        if (long_budget >= 2.0 * waves && kb_max >= 2) {
+            const uint32_t n_rounds = long_budget > 4.5 * waves ? 2u : 1u;                     // rounds of long units per wave
+            kb_long = (uint32_t)(long_budget / ((double)waves * n_rounds) + 0.5);
+            if (kb_long > kb_max) kb_long = kb_max;
+            if (kb_long < 2) kb_long = 1;
+            long_share = kb_long > 1 ? long_budget / u1 : 0.0;
         }
+        lean_units.reserve(work.size());
+        auto emit = [&](const SegRun& r, uint64_t bk, uint32_t n_rows, uint32_t kb, const SrcWork* w1) -> bool {
+            LeanUnit u;
+            u.src_row0 = segs[r.seg].src_base + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
+            u.dst_row0 = segs[r.seg].dst_base + (int64_t)(bk * L_blk) * fb_dst;
+            u.n_blocks = n_rows;
+            u.flags = (kb << 8) | (bk == 0 ? (uint32_t)kWorkFirst : 0u);
+            u.plane = 0;
+            u.src_plane_stride = planar ? seg_plane_stride[r.seg] : 0u;
+            if (w1) u.flags |= w1->flags & (kWorkRamped | kWorkChecked);
+            else if (unit_leaves_arena(segs[r.seg].src_base, u.src_plane_stride, bk, n_rows, kb)) u.flags |= kWorkChecked;
+            if (u.flags & kWorkRamped) {
+                // one plane of multipliers per ramped unit -- n_rows * L_blk entries (uint16, 0xffff = no ramp on that frame), in
+                // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16
+                const SrcSeg& sg = segs[r.seg];
+                const uint64_t u_lo = bk * L_blk, u_hi = (bk + n_rows) * L_blk;
+                const size_t per = (((size_t)n_rows * L_blk + 8) + 7) & ~(size_t)7;
+                if (plane_entries / 8 + per / 8 > 0xffffffffull) return false;
+                u.plane = (uint32_t)(plane_entries / 8);
+                for (uint32_t m = w1->msg_first; m < sg.msg_end && msgs[m].out0 < u_hi; m++) {
+                    const SegMsg& sm = msgs[m];
+                    if (!(sm.flags & OHGPU_FLAG_RAMP)) continue;
+                    const uint64_t lo = std::max<uint64_t>(sm.out0, u_lo), hi = std::min<uint64_t>(sm.out0 + sm.n, u_hi);
+                    if (hi <= lo) continue;
+                    RampJob j;
+                    memset(&j, 0, sizeof(j));
+                    j.plane_entry = plane_entries + (lo - u_lo);
+                    j.i0 = (uint32_t)(lo - sm.out0); j.count = (uint32_t)(hi - lo); j.n = sm.n;
+                    j.m_n1 = sm.m_n1; j.s_n1 = sm.s_n1; j.ramp_start = sm.ramp_start; j.ramp_end = sm.ramp_end;
+                    ramp_jobs.push_back(j);
+                }
+                plane_entries += per;
+            }
+            lean_units.push_back(u);
+            return true;
+        };
+        for (const SegRun& r : seg_runs) {
+            const uint32_t n_units = (uint32_t)((r.blk_hi - r.blk_lo + rows - 1) / rows);
+            uint32_t k = 0;
+            while (k < n_units) {
+                const SrcWork& w1 = work[r.work_begin + k];
+                // a run of plain, full one-block units: its first `long_share` goes out as long units
+                uint32_t run = 0;
+                while (kb_long > 1 && k + run < n_units && !(work[r.work_begin + k + run].flags & kWorkRamped) &&
+                       work[r.work_begin + k + run].n_blocks == rows) run++;
+                const uint32_t n_long = kb_long > 1 ? (uint32_t)(long_share * run / kb_long + 0.5) : 0u;
+                if (n_long > 0 && n_long * kb_long <= run) {
+                    for (uint32_t q = 0; q < n_long; q++)
+                        if (!emit(r, w1.first_block + (uint64_t)q * kb_long * rows, rows, kb_long, nullptr)) return OHGPU_OK;
+                    k += n_long * kb_long;
+                    for (uint32_t q = n_long * kb_long; q < run; q++, k++)
+                        if (!emit(r, work[r.work_begin + k].first_block, rows, 1, &work[r.work_begin + k])) return OHGPU_OK;
+                    continue;
+                }
+                if (!emit(r, w1.first_block, w1.n_blocks, 1, &w1)) return OHGPU_OK;
+                k++;
+            }
+        }
+        if (plane_entries) plane_entries += (size_t)rows * L_blk + 8;                             // (lanes without a block read their row's place too)
+        // Longest first: the waves claim units in this order, and the kernel ends when the last unit does.
+        std::stable_sort(lean_units.begin(), lean_units.end(), [](const LeanUnit& x, const LeanUnit& y) {
+            auto cost = [](const LeanUnit& u) { return ((u.flags & kWorkRamped) ? 6u : 5u) * ((u.flags >> 8) & 0xffu) * u.n_blocks; };
+            return cost(x) > cost(y);
+        });
     }
+    // (round 1's kernel, variant 2, keeps one-block units; ramped first, partly filled units last)
+    std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {
+        return ((x.flags & kWorkRamped) ? 3u : 1u) * x.n_blocks > ((y.flags & kWorkRamped) ? 3u : 1u) * y.n_blocks;
+    });
 
     Slab slab;
     slab.add(segs, &f.d_segs);
@@ -288,13 +346,22 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     slab.add(work, &f.d_work);
     if (lean) slab.add(lean_units, &f.d_lean_units);
     slab.add(rem, &f.d_rem);
-    slab.add(planes.empty() ? std::vector<uint16_t>(4, 0xffffu) : planes, &f.d_planes);
     slab.add(std::vector<uint32_t>(2, 0u), &f.d_counter);            // {units claimed, waves finished}: zero between launches
+    slab.add(ramp_jobs, &f.d_ramp_jobs);
+    slab.reserve((plane_entries ? plane_entries : 8) * sizeof(uint16_t), &f.d_planes);
     int err = slab.upload(&f.d_slab);
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
+    {   // the planes: preset to "no ramp", then RampApplicator's multiplier for every frame of a ramped message (device)
+        hipStream_t s0 = ctx ? ctx->stream : nullptr;
+        hipError_t e = hipMemsetAsync(f.d_planes, 0xff, (plane_entries ? plane_entries : 8) * sizeof(uint16_t), s0);
+        if (e == hipSuccess && ctx) e = launch_ramp_planes(ctx, f.d_ramp_jobs, (uint32_t)ramp_jobs.size(), f.d_planes, s0);
+        if (e == hipSuccess) e = hipStreamSynchronize(s0);
+        if (e != hipSuccess) { free_src_fast(b); return set_error(OHGPU_ERR_DEVICE, "ramp planes: %s", hipGetErrorString(e)); }
+    }
     f.enabled = true;
     f.T = T;
     f.n_work = (uint32_t)work.size();
+    f.n_lean = (uint32_t)lean_units.size();
     f.n_rem = rem.size();
     f.coef_lds_bytes = coef_lds;
     f.wave_lds_bytes = wave_lds;

@@ -74,67 +74,59 @@ MsgAudio::MsgAudio(TUint aSampleRate, TUint aBitDepth, TUint aChannels)
 {
 }
 
+// The three functions below are the message algebra of Msg.cpp:1949-2046 restated: what they must DO is fixed by the reference
+// (its suites run against them, tests/cpp/test_host.cpp), how they are written is this file's own.
 MsgAudio* MsgAudio::Split(TUint aJiffies)
 {
-    ASSERT(aJiffies > 0);
-    ASSERT(aJiffies < iSize);
-    MsgAudio* remaining = Allocate();
-    remaining->iOffset = iOffset + aJiffies;
-    remaining->iSize = iSize - aJiffies;
-    if (iRamp.IsEnabled()) {
-        remaining->iRamp = iRamp.Split(aJiffies, iSize);
-    }
-    else {
-        remaining->iRamp.Reset();
-    }
+    ASSERT(aJiffies != 0 && aJiffies < iSize);                     // both ends keep audio
+    MsgAudio* tail = Allocate();
+    tail->iOffset = iOffset + aJiffies;
+    tail->iSize = iSize - aJiffies;
+    tail->iRamp = iRamp.IsEnabled() ? iRamp.Split(aJiffies, iSize) : Media::Ramp();   // (Ramp::Split shortens iRamp to the head's share)
     iSize = aJiffies;
-    SplitCompleted(*remaining);
-    return remaining;
+    SplitCompleted(*tail);
+    return tail;
 }
 
 MsgAudio* MsgAudio::Clone()
 {
-    MsgAudio* clone = Allocate();
-    clone->iSize = iSize;
-    clone->iOffset = iOffset;
-    clone->iRamp = iRamp;
-    return clone;
+    MsgAudio* twin = Allocate();
+    twin->iOffset = iOffset;
+    twin->iSize = iSize;
+    twin->iRamp = iRamp;
+    return twin;
 }
 
 TUint MsgAudio::SetRamp(TUint aStart, TUint& aRemainingDuration, Ramp::EDirection aDirection, MsgAudio*& aSplit)
 {
-    const TUint remainingDuration = aRemainingDuration;
-    aSplit = nullptr;
     ASSERT(aDirection == Ramp::EUp || aDirection == Ramp::EDown);
-    if (iRamp.IsEnabled() && iRamp.Direction() == Ramp::EMute) {      // a muted message stays muted (Msg.cpp:1997-2002)
-        if (aDirection == Ramp::EDown) {
-            aRemainingDuration = 0;
-        }
+    aSplit = nullptr;
+    const bool fadingOut = aDirection == Ramp::EDown;
+    if (iRamp.IsEnabled() && iRamp.Direction() == Ramp::EMute) {
+        // muted audio stays muted, and a fade-out that has reached silence has nothing left to do (Msg.cpp:1997-2002)
+        if (fadingOut) aRemainingDuration = 0;
         return iRamp.End();
     }
-    Media::Ramp split;
-    TUint splitPos;
-    if (iRamp.Set(aStart, iSize, remainingDuration, aDirection, split, splitPos)) {
-        if (splitPos == 0) {
-            iRamp = split;
+    // Ramp::Set merges the requested ramp with the one already here.  Where the two lines cross it reports the position and
+    // the ramp of the part behind it; that part becomes a message of its own.
+    Media::Ramp behindCrossing;
+    TUint crossAt = 0;
+    const bool crossed = iRamp.Set(aStart, iSize, aRemainingDuration, aDirection, behindCrossing, crossAt);
+    TUint handedBack = 0;
+    if (crossed && crossAt == 0) {
+        iRamp = behindCrossing;                                    // the other line is the lower one from the first jiffy on
+    }
+    else if (crossed && crossAt != iSize) {
+        const Media::Ramp head = iRamp;                            // (Split rescales both halves; the pair Set computed is the one that counts)
+        aSplit = Split(crossAt);
+        iRamp = head;
+        aSplit->iRamp = behindCrossing;
+        if (!fadingOut && behindCrossing.Direction() != aDirection) {
+            handedBack = aSplit->iSize;                            // the tail still runs the old way: its length is not progress (Msg.cpp:2032-2034)
         }
-        else if (splitPos != iSize) {
-            const Media::Ramp first = iRamp;       // Split() rescales ramps; put the intended pair back afterwards
-            aSplit = Split(splitPos);
-            iRamp = first;
-            aSplit->iRamp = split;
-        }
     }
-    aRemainingDuration -= iSize;
-    if (aSplit != nullptr && aSplit->iRamp.Direction() != aDirection && aDirection == Ramp::EUp) {
-        aRemainingDuration += aSplit->iSize;       // the tail runs the other way: roughly compensate (Msg.cpp:2032-2034)
-    }
-    if (aDirection == Ramp::EDown && iRamp.End() == Ramp::kMin) {
-        aRemainingDuration = 0;
-    }
-    else if (aDirection == Ramp::EUp && iRamp.End() == Ramp::kMax) {
-        aRemainingDuration = 0;
-    }
+    const TUint target = fadingOut ? Ramp::kMin : Ramp::kMax;
+    aRemainingDuration = (iRamp.End() == target) ? 0 : aRemainingDuration - iSize + handedBack;
     return iRamp.End();
 }
 
@@ -183,11 +175,9 @@ void MsgAudioPcm::SplitCompleted(MsgAudio& aRemaining)
 
 void MsgAudioPcm::Aggregate(MsgAudioPcm* aMsg)
 {
-    ASSERT(aMsg->iSampleRate == iSampleRate);
-    ASSERT(aMsg->iBitDepth == iBitDepth);
-    ASSERT(aMsg->iNumChannels == iNumChannels);
-    ASSERT(aMsg->iTrackOffset == iTrackOffset + Jiffies());          // must logically follow this one
-    ASSERT(!iRamp.IsEnabled() && !aMsg->iRamp.IsEnabled());          // no ramps allowed
+    // same format, the audio that directly follows this one, no ramp on either (Msg.cpp:2167-2172)
+    ASSERT(aMsg->iSampleRate == iSampleRate && aMsg->iBitDepth == iBitDepth && aMsg->iNumChannels == iNumChannels);
+    ASSERT(aMsg->iTrackOffset == iTrackOffset + Jiffies() && !iRamp.IsEnabled() && !aMsg->iRamp.IsEnabled());
     ASSERT(iAudioData != nullptr && aMsg->iAudioData != nullptr);
     iAudioData->Aggregate(*aMsg->iAudioData);
     iSize += aMsg->Jiffies();
@@ -196,35 +186,34 @@ void MsgAudioPcm::Aggregate(MsgAudioPcm* aMsg)
 
 MsgPlayable* MsgAudioPcm::CreatePlayable()
 {
-    const TUint jiffiesPerSample = Jiffies::PerSample(iSampleRate);
-    TUint offsetJiffies = iOffset;
-    const TUint offsetBytes = Jiffies::ToBytes(offsetJiffies, jiffiesPerSample, iNumChannels, iBitDepth);
-    TUint sizeJiffies = iSize + (iOffset - offsetJiffies);           // offset and size round down to whole samples
-    const TUint sizeBytes = Jiffies::ToBytes(sizeJiffies, jiffiesPerSample, iNumChannels, iBitDepth);
+    // Msg.cpp:2234-2262 in frames: the window [iOffset, iOffset + iSize) of the audio, both ends rounded DOWN to whole samples
+    // (Jiffies::ToBytes), is what a playable reads; a muted message plays silence of that length instead.
+    const TUint perSample = Jiffies::PerSample(iSampleRate);
+    const TUint frameBytes = (iBitDepth / 8) * iNumChannels;
+    const TUint firstFrame = iOffset / perSample;
+    const TUint endFrame = static_cast<TUint>((static_cast<TUint64>(iOffset) + iSize) / perSample);
     PlayableWork work;
     work.sampleRate = iSampleRate;
     work.bitDepth = iBitDepth;
     work.channels = iNumChannels;
-    work.sizeBytes = sizeBytes;
-    work.frames = sizeBytes / ((iBitDepth / 8) * iNumChannels);
-    if (iRamp.Direction() != Ramp::EMute) {
-        work.offsetBytes = offsetBytes;
+    work.frames = endFrame - firstFrame;
+    work.sizeBytes = work.frames * frameBytes;
+    work.silence = iRamp.Direction() == Ramp::EMute;               // (and then no ramp, no attenuation, no source)
+    if (!work.silence) {
+        work.offsetBytes = firstFrame * frameBytes;
         work.attenuation = iAttenuation;
         work.ramp = iRamp;
-        if (iResampled != nullptr) {
-            work.resampled = true;
+        work.resampled = iResampled != nullptr;
+        if (work.resampled) {
             work.stream = iResampled;
-            work.outFrame0 = iResampledFrame0 + offsetJiffies / jiffiesPerSample;
+            work.outFrame0 = iResampledFrame0 + firstFrame;
         }
         else {
             work.audio = iAudioData;
         }
     }
-    else {                                                           // muted: silence of the same length, no ramp
-        work.silence = true;
-    }
     MsgPlayable* playable = new MsgPlayable(iFactory, work, iSize);
-    RemoveRef();
+    RemoveRef();                                                   // the playable stands in for this message from here on
     return playable;
 }
 
@@ -280,30 +269,26 @@ MsgPlayable::MsgPlayable(MsgFactory& aFactory, const PlayableWork& aWork, TUint 
 
 MsgPlayable* MsgPlayable::Split(TUint aBytes)
 {
-    ASSERT(aBytes <= iWork.sizeBytes);
-    ASSERT(aBytes != 0);
+    // Msg.cpp:2591-2624: the driver cuts a playable to its period.  The head keeps aBytes; the ramp is divided in proportion to
+    // BYTES here (jiffies in MsgAudio::Split).
+    ASSERT(aBytes != 0 && aBytes <= iWork.sizeBytes);
     if (aBytes == iWork.sizeBytes) {
-        return nullptr;
+        return nullptr;                                            // nothing behind the cut
     }
-    const TUint bytesPerSample = (iWork.bitDepth / 8) * iWork.channels;
-    const TUint numSamples = aBytes / bytesPerSample;
-    const TUint splitJiffies = numSamples * Jiffies::PerSample(iWork.sampleRate);
-    PlayableWork rest = iWork;
-    rest.offsetBytes = iWork.offsetBytes + aBytes;
-    rest.sizeBytes = iWork.sizeBytes - aBytes;
-    rest.frames = rest.sizeBytes / bytesPerSample;
-    rest.outFrame0 = iWork.outFrame0 + numSamples;
-    if (iWork.ramp.IsEnabled()) {
-        rest.ramp = iWork.ramp.Split(aBytes, iWork.sizeBytes);       // bytes are the unit here (Msg.cpp:2611-2613)
-    }
-    else {
-        rest.ramp.Reset();
-    }
-    MsgPlayable* remaining = new MsgPlayable(iFactory, rest, iJiffies - splitJiffies);
+    const TUint frameBytes = (iWork.bitDepth / 8) * iWork.channels;
+    const TUint headFrames = aBytes / frameBytes;
+    const TUint headJiffies = headFrames * Jiffies::PerSample(iWork.sampleRate);
+    PlayableWork tail = iWork;
+    tail.offsetBytes += aBytes;
+    tail.sizeBytes -= aBytes;
+    tail.frames = tail.sizeBytes / frameBytes;
+    tail.outFrame0 += headFrames;
+    tail.ramp = iWork.ramp.IsEnabled() ? iWork.ramp.Split(aBytes, iWork.sizeBytes) : Media::Ramp();
+    MsgPlayable* rest = new MsgPlayable(iFactory, tail, iJiffies - headJiffies);
     iWork.sizeBytes = aBytes;
-    iWork.frames = numSamples;
-    iJiffies = splitJiffies;
-    return remaining;
+    iWork.frames = headFrames;
+    iJiffies = headJiffies;
+    return rest;
 }
 
 void MsgPlayable::Read(IPcmProcessor& aProcessor)

@@ -714,7 +714,9 @@ int ohp_src_design(ohp_src* s, uint32_t rate_in, uint32_t rate_out, uint32_t T, 
     if (rate_in == 0 || rate_out == 0 || T == 0) return OHP_ERR_ASSERT;
     const uint32_t g = gcd_u32(rate_in, rate_out);
     const uint32_t L = rate_out / g, M = rate_in / g;
-    const uint32_t N = L * T;
+    /* an integer decimator (L = 1) gets an odd length, T - 1, centred on a tap, stored with coef[T - 1] = 0 (for 2:1 with the
+     * cutoff at a quarter of the input rate that is a half-band filter: every second coefficient rounds to exactly zero) */
+    const uint32_t N = (L == 1 && T > 1) ? T - 1 : L * T;
     s->L = L; s->M = M; s->T = T; s->beta = beta; s->rate_in = rate_in; s->rate_out = rate_out;
     s->f_pass = f_pass;
     s->f_stop = (double)rate_out - f_pass;
@@ -725,8 +727,8 @@ int ohp_src_design(ohp_src* s, uint32_t rate_in, uint32_t rate_out, uint32_t T, 
     const double centre = 0.5 * (double)(N - 1);
     const double i0b = bessel_i0(beta);
     double* h = (double*)malloc(sizeof(double) * N);
-    s->coef_q28 = (int32_t*)malloc(sizeof(int32_t) * N);
-    s->coef_f64 = (double*)malloc(sizeof(double) * N);
+    s->coef_q28 = (int32_t*)malloc(sizeof(int32_t) * L * T);
+    s->coef_f64 = (double*)malloc(sizeof(double) * L * T);
     if (!h || !s->coef_q28 || !s->coef_f64) { free(h); ohp_src_free(s); return OHP_ERR_ASSERT; }
     double sum = 0.0;
     for (uint32_t n = 0; n < N; n++) {
@@ -744,7 +746,7 @@ int ohp_src_design(ohp_src* s, uint32_t rate_in, uint32_t rate_out, uint32_t T, 
     for (uint32_t p = 0; p < L; p++) {
         int64_t sabs = 0;
         for (uint32_t k = 0; k < T; k++) {
-            const double v = h[p + k * L] * scale;
+            const double v = (p + k * L < N) ? h[p + k * L] * scale : 0.0;
             const int32_t q = (int32_t)floor(v * 268435456.0 + 0.5);
             s->coef_f64[p * T + k] = v;
             s->coef_q28[p * T + k] = q;

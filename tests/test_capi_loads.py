@@ -133,6 +133,7 @@ def test_the_shipped_library_is_not_a_diagnostic_build():
             code = line.split("//")[0]
             s = code.strip()
             if s.startswith(("#ifdef", "#ifndef", "#if ")):
+                assert "OHGPU_EXP" not in s, f"{name}:{no}: an experiment switch outside the OHGPU_DIAG family: {s}"
                 inside = bool(depth_diag and depth_diag[-1])
                 depth_diag.append(inside or ("OHGPU_DIAG" in s and not s.startswith("#ifndef")) or
                                   (s.startswith("#ifndef") and "OHGPU_DIAG" in s and False))
@@ -140,7 +141,7 @@ def test_the_shipped_library_is_not_a_diagnostic_build():
                 depth_diag.pop()
             elif s.startswith(("#else", "#elif")):
                 pass                                      # (the other arm of a DIAG guard is product code, but it names no hook)
-            elif "getenv" in code or re.search(r"OHGPU_DIAG_\w+", code):
+            elif "getenv" in code or re.search(r"OHGPU_(DIAG|EXP)_\w+", code):
                 if s.startswith("#define STAMP") or "#ifndef OHGPU_DIAG" in s:
                     continue
                 assert depth_diag and depth_diag[-1], f"{name}:{no}: a diagnostic hook outside #ifdef OHGPU_DIAG*: {s}"

@@ -68,3 +68,32 @@ def test_bench_runs_under_the_launcher_with_two_ranks_on_a_gpu(config):
     if config == 3:                                                      # weak: every rank brought its own 6 streams
         assert abs(res["value"] * res["ms_per_step"] * 1e3 / (2 * 6 * round(0.3 * 44100)) - 1.0) < 0.01   # (both figures are rounded)
     assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None    # (the CPU leg runs at N = 1 only)
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_when_asked_for_two_gpus():
+    """`python bench.py --gpus 2` as the driver types it, no launcher around it: bench.py starts the two ranks itself (a child
+    torch.distributed.run, before this process has loaded the C ABI), relays rank 0's line and the child's exit code.  Two
+    ranks share the box's one GPU here; every rank checks its first stream against the oracle."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--seconds", "0.3", "--streams", "6", "--sustain", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["sharding"].startswith("streams over 2 rank(s)")
+    assert res["check"].startswith("bit-exact vs oracle")
+
+
+def test_bench_gpus_flag_is_acted_on_before_anything_touches_the_gpu():
+    """Static: the launcher branch of bench.main() comes before the first import of the C ABI (an exec or a fork after HIP is
+    initialised takes the box down; a child process started earlier does not)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert "launch_ranks(args)" in main
+    assert main.index("launch_ranks(args)") < main.index("from ohpipeline_amd import capi")
+    body = src[src.index("def launch_ranks("):src.index("def measure(")]
+    assert "subprocess.run(" in body and "os.exec" not in body and "capi" not in body
