@@ -641,6 +641,10 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
     if (!s) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_create: out of host memory");
     s->L = L; s->M = M; s->T = T;
     s->max_sum_abs = max_sum_abs;
+    // a half-band 2:1 decimator (what ohgpu_src_design makes for 96 -> 48 kHz): of its odd taps only the centre one is not zero
+    s->halfband = L == 1 && M == 2 && T == 64 && coef_q28[T - 1] == 0;
+    for (uint32_t k = 1; k < T && s->halfband; k += 2)
+        if (k != T / 2 - 1 && coef_q28[k] != 0) s->halfband = false;
     hipError_t e = hipMalloc((void**)&s->d_coef, n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_coef_q28, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(s->d_coef, cd.data(), n * sizeof(double), hipMemcpyHostToDevice);

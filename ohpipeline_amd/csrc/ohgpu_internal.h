@@ -257,6 +257,8 @@ struct ohgpu_ctx {
 struct ohgpu_src {
     uint32_t L, M, T;
     int64_t  max_sum_abs;         // largest sum|c| over the phases, Q28 (the lean kernel's rounding bias needs < 2^29)
+    bool     halfband;            // L = 1, M = 2, T = 64 and every odd tap but tap T/2 - 1 zero (host_design.cpp's 2:1 decimator): the
+                                  // lean kernel's half-band instantiations multiply by the 33 taps that are not
     double*  d_coef;              // [L][T] exact integer-valued doubles (Q28)
     int32_t* d_coef_q28;          // [L][T] int32
 };
@@ -323,7 +325,7 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_ramp_planes(const ohgpu_ctx* ctx, const void* d_jobs, uint32_t n_jobs, void* d_planes, hipStream_t s);   // csrc/ramp_plane_kernel.hip
-bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
+bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);

@@ -106,4 +106,14 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(32, 2, 4, true, 3, false)      \
     X(32, 2, 4, true, 3, true)
 #endif
-#define OHGPU_BLOCK_PARTS 3
+// the lean kernel's half-band instantiations (a filter with ohgpu_src::halfband: T = 64 stored, 33 products per output), part 4.
+// Each has a plain T = 64 twin in the list above, which serves every other 64-tap filter of the same layout.
+#ifdef OHGPU_DIAG_ONE_KERNEL
+#define OHGPU_LEAN_HB_KERNELS(X)
+#else
+#define OHGPU_LEAN_HB_KERNELS(X)     \
+    X(64, 2, 3, true, 3, false)      \
+    X(64, 6, 3, true, 3, false)      \
+    X(64, 8, 3, true, 3, false)
+#endif
+#define OHGPU_BLOCK_PARTS 4

@@ -127,6 +127,13 @@ __device__ __forceinline__ double lean_unpack(const uint64_t words, const uint32
                  : "=&v"(w), "=v"(d) : "v"((uint32_t)(words >> 32)), "v"((uint32_t)words), "v"(sel), "i"(PL ? 1 : 0));
     return d;
 }
+// ... and without the conversion: sample x 256 as an integer (the half-band kernel's delay line keeps the odd frames that way)
+__device__ __forceinline__ uint32_t lean_unpack_raw(const uint64_t words, const uint32_t sel)
+{
+    uint32_t w;
+    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(w) : "v"((uint32_t)(words >> 32)), "v"((uint32_t)words), "v"(sel));
+    return w;
+}
 // selector of lean_unpack for a subsample whose first byte sits `sh` bytes into the low word ({hi, lo} = bytes 7..0):
 // result bytes 3..(4-SB) = the subsample most significant byte first, the rest zero (0x0c)
 template <int SB, bool LE>
@@ -146,13 +153,21 @@ __device__ __forceinline__ uint32_t lean_unpack_sel(uint32_t sh)
 // SB == 4 stands for the PLANAR source of OHGPU_FLAG_SRC_PLANAR32 (a packed 32-bit source is not on this kernel): every
 // channel of a block is a staging row of its own, of 4-byte frames -- lane = (block, channel) reads ITS row -- so the rows
 // staged are BPW * CH; everything downstream of the unpack is the packed layout's.
-template <int T, int CH, int SB, int DB>
+// HB: the half-band 2:1 decimator (host_design.cpp: L = 1, M = 2, a 63-tap prototype stored as T = 64 with every odd tap but the
+// centre exactly zero).  T stays the filter's stored length -- the trip, the warm-up and the history are 64 input frames -- but
+// the window holds only the T / 2 EVEN-parity frames the T / 2 non-zero outer taps meet (an output is due on every even
+// frame), and the odd-parity frames wait, packed, in a delay line of T / 4 registers for the centre tap, T / 2 - 1 frames later.
+#ifndef OHGPU_LEAN_MAX_WAVES_T32
+#define OHGPU_LEAN_MAX_WAVES_T32 0                       // (experiments: waves per workgroup of the 32-slot-window kernels)
+#endif
+template <int T, int CH, int SB, int DB, bool HB = false>
 struct LeanGeom {
     static constexpr bool PL = SB == 4;
     static constexpr int BPW = 64 / CH;
     static constexpr int ROWS = BPW;
     static constexpr int IN_ROWS = PL ? BPW * CH : BPW;   // staged rows
-    static constexpr int MAX_WAVES = T <= 32 ? 12 : 8;   // three per SIMD (what the LDS left by the coefficient table allows with 16-frame stages), two when the window alone is 128 registers
+    static constexpr int TW = HB ? T / 2 : T;            // window slots = taps that meet the window
+    static constexpr int MAX_WAVES = OHGPU_LEAN_MAX_WAVES_T32 > 0 && TW <= 32 ? OHGPU_LEAN_MAX_WAVES_T32 : (TW <= 32 ? 12 : 8);  // three per SIMD (what the LDS left by the coefficient table allows with 16-frame stages), two when the window alone is 128 registers
     static constexpr int FB_SRC = PL ? 4 : CH * SB, FB_DST = CH * DB;     // bytes per frame of a staged row
     static constexpr int SF = lean_stage_frames(CH);      // frames per stage
     static constexpr int IN_BLOCKS = PL ? lean_in_blocks_planar(CH) : lean_in_blocks(CH, SB);
@@ -161,8 +176,8 @@ struct LeanGeom {
     static constexpr bool DUMMY = (64 % CH) != 0;         // the lanes beyond the last whole block store into a ring of their own
 };
 
-template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
-__global__ __launch_bounds__((LeanGeom<T, CH, SB, DB>::MAX_WAVES * 64))
+template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool HB = false>
+__global__ __launch_bounds__((LeanGeom<T, CH, SB, DB, HB>::MAX_WAVES * 64))
 void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                      const double* __restrict__ coef, const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
@@ -170,9 +185,11 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                      const uint32_t ring_bytes, const uint32_t src_shift, uint32_t* __restrict__ unit_counter, uint64_t* __restrict__ dbg)
 {
     static_assert(T % 16 == 0 && T >= 32 && T <= 64, "T / 16 coefficient registers per lane");
-    constexpr bool PL = LeanGeom<T, CH, SB, DB>::PL;       // planar TInt32 source (src_shift = 32 - its bit depth)
-    static_assert(!PL || (SRC_LE && !LeanGeom<T, CH, SB, DB>::DUMMY), "planar instantiations: host-endian planes, channel counts that divide 64");
-    using G = LeanGeom<T, CH, SB, DB>;
+    constexpr bool PL = LeanGeom<T, CH, SB, DB, HB>::PL;       // planar TInt32 source (src_shift = 32 - its bit depth)
+    static_assert(!PL || (SRC_LE && !LeanGeom<T, CH, SB, DB, HB>::DUMMY), "planar instantiations: host-endian planes, channel counts that divide 64");
+    static_assert(!HB || (T == 64 && !PL), "the half-band kernel: 63 taps stored as 64, packed sources");
+    using G = LeanGeom<T, CH, SB, DB, HB>;
+    constexpr int TW = G::TW;                               // window slots (HB: the even-parity frames only)
 #ifdef OHGPU_DIAG_STAMP
     // diagnostic build: shader-clock stamps per phase, summed per wave, written to dbg[wave][8] at the end (never read by the kernel)
     uint64_t st_setup = 0, st_warm = 0, st_stage = 0, st_drain = 0, st_out = 0, st_units = 0, st_mark = 0;
@@ -181,7 +198,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 #else
 #define STAMP(acc)
 #endif
-    constexpr int NCR = T / 16;
+    constexpr int NCR = TW / 16;
     constexpr int BPW = G::BPW, ROWS = G::ROWS, IN_ROWS = G::IN_ROWS;
     constexpr int FB_SRC = G::FB_SRC, FB_DST = G::FB_DST;
     constexpr int IN_BLOCKS = G::IN_BLOCKS, IN_STRIDE = G::IN_STRIDE, IN_ITERS = G::IN_ITERS, SF = G::SF;
@@ -199,7 +216,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     const uint32_t lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_waves = blockDim.x >> 6;
-    const uint32_t table_bytes = (uint32_t)L * T * 8;
+    const uint32_t table_bytes = (uint32_t)L * TW * 8;
 #ifndef OHGPU_LEAN_RING_PAD
 #define OHGPU_LEAN_RING_PAD 4
 #endif
@@ -210,11 +227,13 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 
     // ---- coefficient table -> LDS once per workgroup, scaled by 2^-36 (exact): the window holds samples x 256, so the
     // accumulator is in sample units with 28 fraction bits.
-    for (uint32_t i = tid; i < (uint32_t)L * T; i += blockDim.x)
-        ((__attribute__((address_space(3))) double*)(lds_u8_t)smem)[i] = coef[i] * (1.0 / 68719476736.0);
+    // (HB: the table is the T / 2 outer taps -- the even ones -- and the centre tap, the one odd tap that is not zero, is a scalar)
+    for (uint32_t i = tid; i < (uint32_t)L * TW; i += blockDim.x)
+        ((__attribute__((address_space(3))) double*)(lds_u8_t)smem)[i] = coef[HB ? 2 * i : i] * (1.0 / 68719476736.0);
     __syncthreads();
+    const double centre_tap = HB ? coef[T / 2 - 1] * (1.0 / 68719476736.0) : 0.0;      // (wave-uniform: a scalar load)
     const uint32_t coef_lane = (uint32_t)(uintptr_t)((lds_u8_t)smem + (lane & 15) * 8);
-    const uint32_t coef_lane_L = coef_lane + (uint32_t)L * (T * 8);     // + (phase - L) * T * 8, modulo 2^32
+    const uint32_t coef_lane_L = coef_lane + (uint32_t)L * (TW * 8);    // + (phase - L) * TW * 8, modulo 2^32
     uint8_t* const wsmem = smem + table_bytes + wave * wave_lds;
     const lds_u8_t lds = (lds_u8_t)wsmem;
     const uint32_t wave_lds_addr = (uint32_t)(uintptr_t)lds;
@@ -379,7 +398,8 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         }
     };
 
-    double win[T];                            // (every slot is written by the warm-up before it is read)
+    double win[TW];                           // (every slot is written by the warm-up before it is read)
+    uint32_t dly[HB ? T / 4 : 1];             // HB: the last T / 4 odd-parity frames as sample x 256 integers (the centre tap's delay line)
 
     // (wave-uniform scalars; the loop's control flow is kept to single compares -- the scalar unit serves the CU's four SIMDs
     // one instruction per cycle between them, and round 2's first cut of this loop, with compound conditions, issued as many
@@ -448,13 +468,25 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 lean_issue_2xu32<FB_SRC * (sp - ph) / 4>(r4[sp & 3], in_addr[q & 1][ph]);
             }, std::make_integer_sequence<int, 4>{});
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]) : : "memory");
+            if constexpr (HB) {               // frame a_lin = SF q + 4 h + k: even ones into the window, odd ones into the delay line
 #pragma unroll
-            for (int k = 0; k < 4; k++) win[SF * q + 4 * h + k] = lean_unpack<PL>(r4[k], in_sel[(4 * h + k) % PH]);
+                for (int k = 0; k < 4; k += 2) {
+                    win[((SF * q + 4 * h + k) / 2) % TW] = lean_unpack<PL>(r4[k], in_sel[(4 * h + k) % PH]);
+                    dly[((SF * q + 4 * h + k + 1) / 2) % (T / 4)] = lean_unpack_raw(r4[k + 1], in_sel[(4 * h + k + 1) % PH]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) win[SF * q + 4 * h + k] = lean_unpack<PL>(r4[k], in_sel[(4 * h + k) % PH]);
+            }
         }, std::make_integer_sequence<int, SF / 4>{});
     }, std::make_integer_sequence<int, T / SF>{});
     if (any_first) {
 #pragma unroll
-        for (int s = 0; s < T; s++) win[s] = first_block ? 0.0 : win[s];
+        for (int s = 0; s < TW; s++) win[s] = first_block ? 0.0 : win[s];
+        if constexpr (HB) {
+#pragma unroll
+            for (int s = 0; s < T / 4; s++) dly[s] = first_block ? 0u : dly[s];
+        }
     }
     STAMP(st_warm)
     // The coefficient reads above were issued before the warm-up's waits: they have landed.  From here on, in issue order:
@@ -496,6 +528,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
             // landed) and so never across the trip's back-edge (T is a whole number of stages): an in-flight register must not
             // be loop-carried.  Neither arm below touches the register the look-ahead is aimed at.
             constexpr int sp = s % SF, ph = sp % PH;
+            constexpr int ws = HB ? s / 2 : s;                          // the window slot of this advance's frame (HB: even frames only)
             constexpr bool had_ahead = sp != 0, look_ahead = sp != SF - 1;
 #ifndef OHGPU_DIAG_NO_X
             if constexpr (!had_ahead) lean_issue_2xu32<FB_SRC * (sp - ph) / 4>(rawp[s & 1], in_addr[(s / SF) & 1][ph]);
@@ -504,14 +537,22 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 lean_issue_2xu32<FB_SRC * (sn - phn) / 4>(rawp[(s + 1) & 1], in_addr[(s / SF) & 1][phn]);
             }
 #endif
-            if (!(t < tle)) {
+            if constexpr (HB && (s & 1) != 0) {
+                // half-band, an odd-parity frame: no output is ever due on it and no outer tap ever meets it.  It waits, as
+                // sample x 256, for the centre tap of the output T / 4 outputs on: wait for the sample and unpack, ONE statement
+                // (the slot it takes is the one the previous output's centre tap has just read)
+                asm volatile("s_waitcnt lgkmcnt(%[n])\n\tv_perm_b32 %[w], %[hi], %[lo], %[sel]"
+                             : [w] "=&v"(dly[(s / 2) % (T / 4)])
+                             : [hi] "v"((uint32_t)(rawp[s & 1] >> 32)), [lo] "v"((uint32_t)rawp[s & 1]), [n] "i"(look_ahead ? 1 : 0),
+                               [sel] "v"(in_sel[sp % PH]) : "memory");
+            } else if (!(t < tle)) {
                 // no output needs it yet (M > L), or the block is done: wait for the sample (everything but the look-ahead just
                 // issued) and convert, in ONE statement
                 uint32_t w;
                 asm volatile("s_waitcnt lgkmcnt(%[n])\n\t"
                              ".if %[pl]\n\tv_lshlrev_b32 %[w], %[sel], %[lo]\n\t.else\n\tv_perm_b32 %[w], %[hi], %[lo], %[sel]\n\t.endif\n\t"
                              "v_cvt_f64_i32 %[d], %[w]"
-                             : [w] "=&v"(w), [d] "=&v"(win[s])
+                             : [w] "=&v"(w), [d] "=&v"(win[ws])
                              : [hi] "v"((uint32_t)(rawp[s & 1] >> 32)), [lo] "v"((uint32_t)rawp[s & 1]), [n] "i"(look_ahead ? 1 : 0),
                                [sel] "v"(in_sel[sp % PH]), [pl] "i"(PL ? 1 : 0) : "memory");
             } else {
@@ -521,14 +562,27 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 // the accumulator starts at the rounding bias; the next output's phase: pu += M mod L, and -L again on a carry; its
                 // coefficient row
                 double acc;
+                if constexpr (HB) {
+                    // ... and, half-band, the centre tap at once: the odd frame T / 2 - 1 back, out of the delay line (a fixed
+                    // phase: the coefficient row never moves)
+                    double mid;
+                    asm volatile("v_mov_b64 %[acc], %[bias]\n\t"
+                                 "v_cvt_f64_i32 %[mid], %[dl]\n\t"
+                                 "v_lshl_add_u32 %[cp], %[pu], %[sh], %[cl]\n\t"
+                                 "v_fmac_f64 %[acc], %[cen], %[mid]"
+                                 : [acc] "=&v"(acc), [cp] "=&v"(cp), [mid] "=&v"(mid)
+                                 : [bias] "s"(bias), [pu] "s"(pu), [sh] "i"(TW == 32 ? 8 : 9), [cl] "v"(coef_lane_L),
+                                   [dl] "v"(dly[(s / 2) % (T / 4)]), [cen] "s"(centre_tap));
+                } else {
                 asm volatile("v_mov_b64 %[acc], %[bias]\n\t"
                              "s_add_u32 %[pu], %[pu], %[mr]\n\t"
                              "s_cselect_b32 vcc_lo, %[nl], 0\n\t"
                              "s_add_u32 %[pu], %[pu], vcc_lo\n\t"
                              "v_lshl_add_u32 %[cp], %[pu], %[sh], %[cl]"
                              : [acc] "=v"(acc), [pu] "+s"(pu), [cp] "=v"(cp)
-                             : [bias] "s"(bias), [mr] "s"((uint32_t)Mr), [nl] "s"(0u - (uint32_t)L), [sh] "i"(T == 32 ? 8 : 9), [cl] "v"(coef_lane_L)
+                             : [bias] "s"(bias), [mr] "s"((uint32_t)Mr), [nl] "s"(0u - (uint32_t)L), [sh] "i"(TW == 32 ? 8 : 9), [cl] "v"(coef_lane_L)
                              : "vcc", "scc");
+                }
                 static_for([&](auto rc) __attribute__((always_inline)) {
                     constexpr int r = NCR - 1 - decltype(rc)::value;          // highest taps (oldest samples) first, the newest sample last
                     // (no register operands: the statements keep their order among themselves, and an operand written right in front
@@ -550,16 +604,16 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         t += M;
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#define W_(k) win[(s - (16 * r + (k)) + 2 * T) % T]
+#define W_(k) win[(ws - (16 * r + (k)) + 2 * TW) % TW]
 #ifndef OHGPU_DIAG_NO_TAPS
                     if constexpr (r == 0)
-                        lean_taps16_unpack<PL>(acc, cf[0], rawp[s & 1], in_sel[(s % SF) % PH], win[s], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
+                        lean_taps16_unpack<PL>(acc, cf[0], rawp[s & 1], in_sel[(s % SF) % PH], win[ws], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                            W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1));
                     else
                         lean_taps16(acc, cf[r], W_(15), W_(14), W_(13), W_(12), W_(11), W_(10), W_(9), W_(8),
                                     W_(7), W_(6), W_(5), W_(4), W_(3), W_(2), W_(1), W_(0));
 #else
-                    if constexpr (r == 0) win[s] = lean_unpack<PL>(rawp[s & 1], in_sel[(s % SF) % PH]);
+                    if constexpr (r == 0) win[ws] = lean_unpack<PL>(rawp[s & 1], in_sel[(s % SF) % PH]);
 #endif
 #undef W_
 #ifndef OHGPU_DIAG_NO_COEF
@@ -707,20 +761,25 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*
 #define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
 #define X_DECLARE(t, c, s_, sl, d, dl) extern template __global__ void src_lean_kernel<t, c, s_, sl, d, dl>(OHGPU_LEAN_ARGS);
+#define X_DEFINE_HB(t, c, s_, sl, d, dl) template __global__ void src_lean_kernel<t, c, s_, sl, d, dl, true>(OHGPU_LEAN_ARGS);
+#define X_DECLARE_HB(t, c, s_, sl, d, dl) extern template __global__ void src_lean_kernel<t, c, s_, sl, d, dl, true>(OHGPU_LEAN_ARGS);
 #if defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 2
 OHGPU_BLOCK_KERNELS_2(X_DEFINE)
 #elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 3
 OHGPU_BLOCK_KERNELS_3(X_DEFINE)
 OHGPU_LEAN_PLANAR_KERNELS(X_DEFINE)
+#elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 4
+OHGPU_LEAN_HB_KERNELS(X_DEFINE_HB)
 #elif defined(OHGPU_BLOCK_PART)
 OHGPU_BLOCK_KERNELS_2(X_DECLARE)
 OHGPU_BLOCK_KERNELS_3(X_DECLARE)
 OHGPU_LEAN_PLANAR_KERNELS(X_DECLARE)
+OHGPU_LEAN_HB_KERNELS(X_DECLARE_HB)
 #endif
 
 #if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
 // Geometry the planner needs (must match the kernel's constexprs).  Returns false when the layout does not fit the CU's LDS.
-bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
+bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves)
 {   // (sb == 4: the planar source, LeanGeom)
@@ -734,12 +793,13 @@ bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_
     *rows = bpw;
     *in_blocks = inb;
     *ring_bytes = rb;
-    *coef_lds_bytes = L * T * 8;
+    const uint32_t tw = halfband ? T / 2 : T;              // (LeanGeom::TW: the taps the LDS table holds)
+    *coef_lds_bytes = L * tw * 8;
     *wave_lds_bytes = (2 * ((in_rows * inb * 16 + 127u) & ~127u) + ((bpw * (rb + OHGPU_LEAN_RING_PAD) + 15) & ~15u) + ((64 % ch) ? rb + 64u : 0u) + 127u) & ~127u;
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
-    const uint32_t cap = T <= 32 ? 12u : 8u;
+    const uint32_t cap = tw <= 32 ? (OHGPU_LEAN_MAX_WAVES_T32 > 0 ? (uint32_t)OHGPU_LEAN_MAX_WAVES_T32 : 12u) : 8u;
     if (w > cap) w = cap;
     if (w < 4) return false;
 #ifdef OHGPU_DIAG
@@ -749,10 +809,10 @@ bool src_lean_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_
     return true;
 }
 
-template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
+template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE, bool HB = false>
 static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
 {
-    auto kernel = src_lean_kernel<T, CH, SB, SRC_LE, DB, DST_LE>;
+    auto kernel = src_lean_kernel<T, CH, SB, SRC_LE, DB, DST_LE, HB>;
     const SrcFastPlan& f = b->fast;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     uint32_t w = (f.n_lean + cus - 1) / cus;
@@ -814,6 +874,13 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
         prm.src_le = 1;
         OHGPU_LEAN_PLANAR_KERNELS(X)
         return hipErrorInvalidValue;
+    }
+    if (b->src->halfband) {                                // the 2:1 decimator: 33 products per output instead of 64
+#define XHB(t, c, s_, sl, d, dl)                                                                                          \
+    if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
+        return launch_lean_one<t, c, s_, sl, d, dl, true>(ctx, b, prm, s);
+        OHGPU_LEAN_HB_KERNELS(XHB)
+#undef XHB
     }
     OHGPU_BLOCK_KERNELS(X)
 #undef X

@@ -101,7 +101,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // the lean kernel (round 2): same blocks, rows and ring; its rounding bias needs sum|c| < 2^29 in every phase
     uint32_t lean_rows = 0, lean_inb = 0, lean_sf = 8, lean_ring = 0, lean_coef = 0, lean_wave_lds = 0, lean_max_waves = 0;
     const bool lean = flt->max_sum_abs < ((int64_t)1 << 29) &&
-                      src_lean_geometry(L, T, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
+                      src_lean_geometry(L, T, flt->halfband, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
                       lean_rows == rows && lean_ring == ring;
     if (planar && !lean) return OHGPU_OK;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines

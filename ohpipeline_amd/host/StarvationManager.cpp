@@ -331,6 +331,11 @@ TBool StarvationManager::Draining(TUint aLane) const
     return iLanes.at(aLane)->draining.load();
 }
 
+TBool StarvationManager::Finished(TUint aLane) const
+{
+    return iLanes.at(aLane)->finished;
+}
+
 TBool StarvationManager::DrainRequested(TUint aLane) const
 {
     return iLanes.at(aLane)->startDrain.load();
@@ -424,16 +429,22 @@ void StarvationManager::RescueNow(Lane& aLane)
     iRescueLaunches++;
 }
 
-void StarvationManager::Prepare(Lane& aLane, RescueBatch& aBatch)
-{   // :622-646
+TBool StarvationManager::Prepare(Lane& aLane, RescueBatch& aBatch, TBool aMayBlock)
+{   // :622-646.  Returns false when the lane sits this period out (its occupancy gate is still shut and the caller may not wait).
     if (aLane.finished) {
-        return;
+        return true;
     }
     TBool dry;
     {
         std::unique_lock<std::mutex> lock(aLane.m);
         if (aLane.gateJiffies > 0 && aLane.drains == 0 && aLane.halts == 0) {
-            aLane.arrival.wait(lock, [&aLane] { return aLane.jiffies >= aLane.gateJiffies || aLane.drains > 0 || aLane.halts > 0; });
+            auto open = [&aLane] { return aLane.jiffies >= aLane.gateJiffies || aLane.drains > 0 || aLane.halts > 0; };
+            if (aMayBlock) {
+                aLane.arrival.wait(lock, open);
+            }
+            else if (!open()) {
+                return false;                                // one gated stream does not hold the other lanes' period up
+            }
             aLane.gateJiffies = 0;
         }
         dry = aLane.inbox.empty();
@@ -452,10 +463,12 @@ void StarvationManager::Prepare(Lane& aLane, RescueBatch& aBatch)
             QueueRescue(aLane, aBatch);
         }
     }
+    return true;
 }
 
-Msg* StarvationManager::Next(Lane& aLane)
-{   // :648-673
+Msg* StarvationManager::Next(Lane& aLane, TBool aMayBlock)
+{   // :648-673.  aMayBlock == false (Tick): a lane with nothing to hand over -- halted, starting or flushing with an empty
+    // inbox; a lane that could still play would have been rescued by Prepare -- returns nullptr instead of waiting for its feeder.
     if (aLane.finished) {
         return nullptr;
     }
@@ -476,6 +489,9 @@ Msg* StarvationManager::Next(Lane& aLane)
                 return iFactory.CreateMsgHalt();
             }
             wasFlushing = aLane.state == LaneState::Flushing;
+            if (!aMayBlock && aLane.inbox.empty()) {
+                return nullptr;                              // no message this period
+            }
             aLane.arrival.wait(lock, [&aLane] { return !aLane.inbox.empty(); });
             msg = aLane.inbox.front();
             aLane.inbox.pop_front();
@@ -636,17 +652,21 @@ Msg* StarvationManager::Handle(Lane& aLane, Msg* aMsg)
 
 void StarvationManager::Tick(std::vector<Msg*>& aOut)
 {
+    // Nothing in a tick waits for a feeder: the reference gives every pipeline a StarvationRamper and a driver thread of its
+    // own, so an idle pipeline blocks nobody else; here the lanes share the tick, and one that has nothing to say this period
+    // (halted or not yet started with an empty inbox, or held at its occupancy gate) just says nothing -- nullptr.
     RescueBatch batch(iFactory);
-    for (auto& lane : iLanes) {
-        Prepare(*lane, batch);
+    std::vector<TBool> takesPart(iLanes.size());
+    for (size_t i = 0; i < iLanes.size(); i++) {
+        takesPart[i] = Prepare(*iLanes[i], batch, false);
     }
     if (batch.Count() > 0) {
         batch.Run();                                     // every lane that ran dry in this tick, together
         iRescueLaunches++;
     }
     aOut.clear();
-    for (auto& lane : iLanes) {
-        aOut.push_back(Next(*lane));
+    for (size_t i = 0; i < iLanes.size(); i++) {
+        aOut.push_back(takesPart[i] ? Next(*iLanes[i], false) : nullptr);
     }
 }
 
@@ -654,12 +674,12 @@ Msg* StarvationManager::Pull(TUint aLane)
 {
     Lane& lane = *iLanes.at(aLane);
     RescueBatch batch(iFactory);
-    Prepare(lane, batch);
+    Prepare(lane, batch, true);                          // (one lane, its own caller: blocks as the reference's Pull does)
     if (batch.Count() > 0) {
         batch.Run();
         iRescueLaunches++;
     }
-    return Next(lane);
+    return Next(lane, true);
 }
 
 } // namespace Media

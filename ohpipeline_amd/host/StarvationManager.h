@@ -81,8 +81,9 @@ public:
     ~StarvationManager();
     TUint AddLane(const LaneConfig& aConfig);
     TUint LaneCount() const { return (TUint)iLanes.size(); }
-    /** One driver period for every lane: aOut[i] is lane i's next message (the call blocks until every lane has one);
-     *  nullptr for a lane whose MsgQuit has already gone out. */
+    /** One driver period for every lane: aOut[i] is lane i's next message, or nullptr when the lane has none this period --
+     *  its inbox is empty and it is not playing (halted, starting, flushing: a lane that IS playing is rescued instead), it is
+     *  held at its occupancy gate, or its MsgQuit has already gone out (Finished()).  Never waits for a feeder. */
     void Tick(std::vector<Msg*>& aOut);
     /** One driver period for one lane (what IPipelineElementUpstream::Pull is to the reference). */
     Msg* Pull(TUint aLane);
@@ -94,12 +95,13 @@ public: // inspection (the reference's suite reads these as a friend)
     TBool IsEmpty(TUint aLane) const;
     TUint SizeInJiffies(TUint aLane) const;
     TBool Draining(TUint aLane) const;
+    TBool Finished(TUint aLane) const;                   // the lane's MsgQuit has gone out
     TBool DrainRequested(TUint aLane) const;             // DrainAllAudio() called, not yet seen by a tick
     TUint64 RescueLaunches() const { return iRescueLaunches.load(); }   // device rescues so far (one per tick that needed any)
 private:
     struct Lane;
-    void Prepare(Lane& aLane, RescueBatch& aBatch);      // tick step 1
-    Msg* Next(Lane& aLane);                              // tick step 3
+    TBool Prepare(Lane& aLane, RescueBatch& aBatch, TBool aMayBlock);   // tick step 1; false: the lane sits this period out
+    Msg* Next(Lane& aLane, TBool aMayBlock);             // tick step 3
     Msg* Handle(Lane& aLane, Msg* aMsg);                 // one message leaving the inbox; nullptr = consumed
     void QueueRescue(Lane& aLane, RescueBatch& aBatch);  // the lane's last millisecond -> a request
     void RescueNow(Lane& aLane);                         // a rescue decided while dequeuing (drain, flush): a batch of one

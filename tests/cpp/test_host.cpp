@@ -715,6 +715,86 @@ public:
     std::atomic<TUint> iStarted{0}, iStopped{0};
 };
 
+// An idle stream must not hold the others' period up (the reference has one StarvationRamper and one driver thread per
+// pipeline: a halted pipeline blocks only itself).  Lane 0 plays; lane 1 was halted by its source and then hears nothing;
+// lane 2 is held at an occupancy gate its feeder cannot reach.  Every tick must come back with lane 0's message.  No device
+// work: nothing here runs dry while it is playing.
+static void SuiteIdleLaneDoesNotStallTheTick(MsgFactory& aFactory)
+{
+    const TUint kAudio = 4;
+    std::vector<std::unique_ptr<ScriptedSource>> sources;
+    CountingObserver observer;
+    StarvationManager manager(aFactory);
+    for (TUint l = 0; l < 3; l++) {
+        sources.emplace_back(new ScriptedSource());
+        StarvationManager::LaneConfig cfg;
+        cfg.upstream = sources.back().get(); cfg.observer = &observer;
+        cfg.sizeJiffies = 100 * Jiffies::kPerMs; cfg.rampUpJiffies = 50 * Jiffies::kPerMs; cfg.maxStreamCount = 10;
+        TEST(manager.AddLane(cfg) == l);
+        sources[l]->Push(aFactory.CreateMsgMode(ModeInfo()));
+        DecodedStreamInfo info;
+        info.iStreamId = 7 + l; info.iBitDepth = 16; info.iSampleRate = 44100; info.iNumChannels = 2;
+        sources[l]->Push(aFactory.CreateMsgDecodedStream(info));
+    }
+    std::vector<TByte> pcm(4 * 88, 0x11);                    // 2 ms of 44.1 kHz stereo S16
+    TUint fed = 0;
+    for (TUint m = 0; m < kAudio; m++) {
+        MsgAudioPcm* audio = aFactory.CreateMsgAudioPcm(Brn(pcm.data(), (TUint)pcm.size()), 2, 44100, 16, AudioDataEndian::Big, 0);
+        fed += audio->Jiffies();
+        sources[0]->Push(audio);
+    }
+    sources[0]->Push(aFactory.CreateMsgHalt());              // lane 0 ends in a halt of its own: it never runs dry while playing
+    sources[1]->Push(aFactory.CreateMsgHalt());
+    while (manager.SizeInJiffies(0) != fed || manager.IsEmpty(1) || manager.IsEmpty(2)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));   // (the halts carry no jiffies: give the feeders a moment to pass them on)
+    std::vector<Msg*> out;
+    auto kinds = [&](MsgKind a, bool b_null, MsgKind b, bool c_null, MsgKind c) {
+        manager.Tick(out);
+        TEST(out.size() == 3);
+        TEST(out[0] != nullptr && KindOf(out[0]) == a);
+        TEST(b_null ? out[1] == nullptr : (out[1] != nullptr && KindOf(out[1]) == b));
+        TEST(c_null ? out[2] == nullptr : (out[2] != nullptr && KindOf(out[2]) == c));
+        for (Msg* m : out) if (m != nullptr) m->RemoveRef();
+    };
+    kinds(MsgKind::Mode, false, MsgKind::Mode, false, MsgKind::Mode);
+    kinds(MsgKind::DecodedStream, false, MsgKind::DecodedStream, false, MsgKind::DecodedStream);
+    manager.WaitForOccupancy(2, 10 * Jiffies::kPerMs);      // lane 2: a gate nothing will open for a while
+    kinds(MsgKind::AudioPcm, false, MsgKind::Halt, true, MsgKind::Halt);
+    for (TUint m = 1; m < kAudio; m++) {
+        kinds(MsgKind::AudioPcm, true, MsgKind::Halt, true, MsgKind::Halt);   // lane 1 halted and silent, lane 2 gated: lane 0 still gets its period
+    }
+    TEST(manager.State(1) == LaneState::Halted && manager.RescueLaunches() == 0);
+    kinds(MsgKind::Halt, true, MsgKind::Halt, true, MsgKind::Halt);
+    // the idle lanes wake when something arrives: 12 ms of silence open lane 2's gate (silence never makes a lane "playing", so
+    // it cannot run dry into a rescue), a quit ends each lane
+    TUint fed2 = 0;
+    for (TUint m = 0; m < 3; m++) {
+        TUint size = 4 * Jiffies::kPerMs;
+        MsgSilence* silence = aFactory.CreateMsgSilence(size, 44100, 16, 2);
+        fed2 += silence->Jiffies();
+        sources[2]->Push(silence);
+    }
+    for (TUint l = 0; l < 3; l++) sources[l]->Push(aFactory.CreateMsgQuit());
+    while (manager.SizeInJiffies(2) != fed2) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    TUint quits = 0, silence2 = 0;
+    for (TUint t = 0; t < 20000 && quits < 3; t++) {
+        manager.Tick(out);
+        for (TUint l = 0; l < 3; l++) {
+            if (out[l] == nullptr) continue;
+            const MsgKind k = KindOf(out[l]);
+            TEST(k == MsgKind::Quit || (l == 2 && k == MsgKind::Silence));
+            quits += k == MsgKind::Quit;
+            silence2 += k == MsgKind::Silence;
+            out[l]->RemoveRef();
+        }
+        if (quits < 3) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    TEST(quits == 3 && silence2 == 3 && manager.RescueLaunches() == 0);
+    for (TUint l = 0; l < 3; l++) TEST(manager.Finished(l));
+    manager.Tick(out);
+    TEST(out[0] == nullptr && out[1] == nullptr && out[2] == nullptr);
+}
+
 static void SuiteManyLanesStarveTogetherGpu(MsgFactory& aFactory)
 {
     const TUint kLanes = 64, kMsgs = 3;
@@ -771,14 +851,16 @@ static void SuiteManyLanesStarveTogetherGpu(MsgFactory& aFactory)
         // the driver's next periods: 1 ms of extrapolated audio per lane and tick (20 of them, 21 where a millisecond is not a
         // whole number of frames), then the lane's halt; a lane that has passed its quit on has nothing more to give
         std::vector<TUint> halted(kLanes, 0), quit(kLanes, 0);
-        for (TUint t = 0; t < 23; t++) {
+        auto all_quit = [&] { for (TUint l = 0; l < kLanes; l++) if (!quit[l]) return false; return true; };
+        for (TUint t = 0; t < 23 || (!all_quit() && t < 20000); t++) {   // (a tick waits for no feeder: a halted lane's quit may take a few more periods to arrive)
+            if (t >= 23) std::this_thread::sleep_for(std::chrono::milliseconds(1));
             manager.Tick(out);
             if (t == 0) {                                    // (the sources end only now: a lane whose quit is in sight is not rescued)
                 for (TUint l = 0; l < kLanes; l++) sources[l]->Push(aFactory.CreateMsgQuit());
             }
             TEST(out.size() == kLanes);
             for (TUint l = 0; l < kLanes; l++) {
-                if (out[l] == nullptr) { TEST(quit[l] == 1); continue; }
+                if (out[l] == nullptr) { TEST(quit[l] == 1 || (halted[l] == 1 && !manager.Finished(l))); continue; }   // done, or halted and waiting for its feeder
                 const MsgKind kind = KindOf(out[l]);
                 if (kind == MsgKind::AudioPcm) {
                     TEST(!halted[l] && manager.State(l) == LaneState::FlywheelRamping);
@@ -1699,6 +1781,7 @@ int main(int argc, char** argv)
             aggregator.Run();
             SuiteStarvationRamper starvation(control);
             starvation.RunControl();
+            SuiteIdleLaneDoesNotStallTheTick(control);
         }
         if (gpu) {
             MsgFactory f(0);

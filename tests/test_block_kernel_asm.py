@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ohpipeline_amd", "csrc")
 OUTDIR = os.path.join(ROOT, "ohpipeline_amd", "build")
 
+PARTS = (1, 2, 3, 4)              # OHGPU_BLOCK_PARTS (csrc/src_block_common.h); part 4 = the lean kernel's half-band instantiations
 SCALAR_MEM = re.compile(r"^\s*(s_load|s_buffer_load|s_memtime|s_memrealtime|s_scratch_load|s_store|s_atomic|s_dcache)")
 COUNTED_WAIT = re.compile(r"s_waitcnt lgkmcnt\(([1-9]\d*)\)")
 
@@ -42,8 +43,8 @@ def _compile(stem, prefix):
             subprocess.run(cmd, check=True, capture_output=True, timeout=1500)
         return open(out).read().split("\n")
 
-    with ThreadPoolExecutor(3) as ex:
-        texts = list(ex.map(compile_part, (1, 2, 3)))
+    with ThreadPoolExecutor(4) as ex:
+        texts = list(ex.map(compile_part, PARTS))
     found = {}
     for text in texts:
         name, body = None, []
@@ -70,8 +71,16 @@ def block():
     return _compile("src_block_kernel", "src_block_kernel")
 
 
+def _halfband(name):
+    """The lean kernel's seventh template argument: the half-band 2:1 decimator (T = 64 stored, T / 2 taps meet the window)."""
+    m = re.search(r"src_lean_kernelILi\d+ELi\d+ELi\d+ELb\dELi\d+ELb\dELb(\d)E", name)
+    return bool(m and m.group(1) == "1")
+
+
 def _taps_of(name):
-    return int(re.search(r"kernelILi(\d+)E", name).group(1))
+    """DPP taps per output: the filter's T, or T / 2 for a half-band instantiation (its centre tap is a plain v_fmac_f64)."""
+    t = int(re.search(r"kernelILi(\d+)E", name).group(1))
+    return t // 2 if _halfband(name) else t
 
 
 @pytest.mark.parametrize("which", ["lean", "block"])
@@ -94,11 +103,14 @@ def test_no_scratch_and_no_valu_exec_writes(which, request):
 def test_lean_kernels_keep_three_waves_per_simd(lean):
     """The 32-tap instantiations are launched with up to twelve waves per workgroup: at most 168 registers (and no spills:
     test_no_scratch_and_no_valu_exec_writes)."""
-    for part in (1, 2, 3):
+    seen_halfband = 0
+    for part in PARTS:
         text = open(os.path.join(OUTDIR, f"src_lean_kernel.test.{part}.s")).read()
         for m in re.finditer(r"\.name:\s+(_ZN5ohgpu15src_lean_kernelILi(\d+)E\w+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
-            if int(m.group(2)) <= 32:
+            if int(m.group(2)) <= 32 or _halfband(m.group(1)):     # (a half-band kernel's window is 32 frames too: that is its point)
                 assert int(m.group(3)) <= 168, (m.group(1), m.group(3))
+                seen_halfband += _halfband(m.group(1))
+    assert seen_halfband >= 3
 
 
 def tap_waits(body):
