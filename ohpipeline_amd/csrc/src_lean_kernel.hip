@@ -194,6 +194,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     // diagnostic build: shader-clock stamps per phase, summed per wave, written to dbg[wave][8] at the end (never read by the kernel)
     uint64_t st_setup = 0, st_warm = 0, st_stage = 0, st_drain = 0, st_out = 0, st_units = 0, st_mark = 0;
     const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+    const uint64_t st_begin_real = __builtin_amdgcn_s_memrealtime();          // (100 MHz: the shader clock = ticks / real ticks * 100 MHz)
 #define STAMP(acc) { const uint64_t n_ = __builtin_amdgcn_s_memtime(); acc += n_ - st_mark; st_mark = n_; }
 #else
 #define STAMP(acc)
@@ -742,9 +743,10 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     }   // units
 #ifdef OHGPU_DIAG_STAMP
     if (dbg != nullptr && lane == 0) {
-        uint64_t* o = dbg + (size_t)(blockIdx.x * n_waves + wave) * 8;
+        uint64_t* o = dbg + (size_t)(blockIdx.x * n_waves + wave) * 10;
         o[0] = st_setup; o[1] = st_warm; o[2] = st_stage; o[3] = st_drain; o[4] = st_out; o[5] = st_units;
         o[6] = st_begin; o[7] = __builtin_amdgcn_s_memtime();
+        o[8] = st_begin_real; o[9] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     // The counters reset themselves: a wave reports in after its last claim, and the last wave of the grid zeroes both.
@@ -826,7 +828,7 @@ static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
     uint64_t* dbg = nullptr;
 #ifdef OHGPU_DIAG_STAMP
     const char* stamp_path = getenv("OHGPU_DIAG_STAMP_FILE");
-    const size_t n_dbg = (size_t)g * w * 8;
+    const size_t n_dbg = (size_t)g * w * 10;
     if (stamp_path && hipMalloc((void**)&dbg, n_dbg * 8) == hipSuccess) hipMemsetAsync(dbg, 0, n_dbg * 8, s);
 #endif
     hipLaunchKernelGGL(kernel, dim3(g), dim3(w * 64), lds, s,
@@ -839,15 +841,17 @@ static hipError_t launch_lean_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
         hipMemcpy(h.data(), dbg, n_dbg * 8, hipMemcpyDeviceToHost);
         hipFree(dbg);
         if (FILE* fo = fopen(stamp_path, "w")) {
-            double sum[6] = {0, 0, 0, 0, 0, 0}, t0 = 1e300, t1 = 0, life = 0, last_min = 1e300;
-            for (size_t i = 0; i < n_dbg; i += 8) {
+            double sum[6] = {0, 0, 0, 0, 0, 0}, t0 = 1e300, t1 = 0, life = 0, last_min = 1e300, life_real = 0;
+            for (size_t i = 0; i < n_dbg; i += 10) {
                 for (int k = 0; k < 6; k++) sum[k] += (double)h[i + k];
                 if ((double)h[i + 6] < t0) t0 = (double)h[i + 6];
                 if ((double)h[i + 7] > t1) t1 = (double)h[i + 7];
                 if ((double)h[i + 7] < last_min) last_min = (double)h[i + 7];
                 life += (double)(h[i + 7] - h[i + 6]);
+                life_real += (double)(h[i + 9] - h[i + 8]);
             }
-            const double nw = (double)(n_dbg / 8);
+            const double nw = (double)(n_dbg / 10);
+            fprintf(fo, "shader clock over the waves' lives: %.3f GHz (s_memtime / s_memrealtime at 100 MHz)\n", life / life_real * 0.1);
             fprintf(fo, "waves %.0f (grid %u x %u), units %.0f; kernel span %.0f ticks, first wave done at %.0f; mean wave life %.0f\n", nw, g, w, sum[5], t1 - t0, last_min - t0, life / nw);
             fprintf(fo, "mean ticks per wave: set-up %.0f warm-up %.0f stage wait+issue %.0f drain %.0f outputs %.0f | per unit: %.0f %.0f %.0f %.0f %.0f\n",
                     sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw,

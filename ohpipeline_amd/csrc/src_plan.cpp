@@ -253,18 +253,21 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     std::vector<LeanUnit> lean_units;
     if (lean) {
         const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * lean_max_waves;
-        double tail_rounds = 2.5;
-        uint32_t kb_max = 8;
+        // (same-box A/B on the headline workload, tools/exp_units.sh: one block per row everywhere 0.489-0.496 ms; long units of
+        // 3 blocks with 2.5 rounds left 0.484-0.485; of 4 blocks with 1.5 or 0.6 rounds left 0.476)
+        double tail_rounds = 1.5;
+        uint32_t kb_max = 8, long_rounds = 0;
 #ifdef OHGPU_DIAG
         if (const char* e = getenv("OHGPU_DIAG_TAIL_ROUNDS")) tail_rounds = atof(e);       // (diagnostic builds: the long/short split)
         if (const char* e = getenv("OHGPU_DIAG_KB_MAX")) kb_max = (uint32_t)atoi(e);
+        if (const char* e = getenv("OHGPU_DIAG_LONG_ROUNDS")) long_rounds = (uint32_t)atoi(e);
 #endif
         // how many one-block units the plan has, and the share of them to merge
         const double u1 = (double)work.size(), long_budget = u1 - tail_rounds * waves;
         uint32_t kb_long = 1;
         double long_share = 0.0;
         if (long_budget >= 2.0 * waves && kb_max >= 2) {
-            const uint32_t n_rounds = long_budget > 4.5 * waves ? 2u : 1u;                     // rounds of long units per wave
+            const uint32_t n_rounds = long_rounds ? long_rounds : (long_budget > 4.5 * waves ? 2u : 1u);   // rounds of long units per wave
             kb_long = (uint32_t)(long_budget / ((double)waves * n_rounds) + 0.5);
             if (kb_long > kb_max) kb_long = kb_max;
             if (kb_long < 2) kb_long = 1;

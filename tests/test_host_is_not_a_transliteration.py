@@ -25,15 +25,38 @@ OWN_DESIGN = [
 ]
 
 
-@pytest.mark.parametrize("mine,theirs", OWN_DESIGN, ids=[m for m, _ in OWN_DESIGN])
-def test_overlap_with_the_reference_stays_low(mine, theirs):
+# The files that MIRROR a reference interface so that the adapter can stand where the reference classes stand (same class
+# names, method signatures and member names -- INTEGRATION.md 2): their declarations and signature lines cannot differ, their
+# bodies can and must.  Each has a cap a little above what its signatures alone cost, so that a body copied from the reference
+# shows: round 2's Msg.cpp held five of the reference's functions line for line (24 %), now restated (cap 15 %).
+MIRRORS = [
+    ("ohpipeline_amd/host/Msg.cpp", ["Media/Pipeline/Msg.cpp", "Media/Pipeline/Msg.h"], 0.15),
+    ("ohpipeline_amd/host/Msg.h", ["Media/Pipeline/Msg.cpp", "Media/Pipeline/Msg.h"], 0.40),
+    ("ohpipeline_amd/host/Ramp.cpp", ["Media/Pipeline/Msg.cpp", "Media/Pipeline/Msg.h"], 0.42),
+    ("ohpipeline_amd/host/Ramp.h", ["Media/Pipeline/Msg.cpp", "Media/Pipeline/Msg.h"], 0.65),
+    ("ohpipeline_amd/host/DecodedAudioAggregator.cpp", ["Media/Pipeline/DecodedAudioAggregator.cpp", "Media/Codec/CodecController.cpp"], 0.30),
+]
+
+
+def overlap_share(mine, theirs):
     import overlap
     own = overlap.significant(os.path.join(ROOT, mine))
     ref = set()
     for t in theirs:
         ref.update(overlap.significant(os.path.join(REF, t)))
-    share = sum(1 for l in own if l in ref) / max(1, len(own))
+    return sum(1 for l in own if l in ref) / max(1, len(own))
+
+
+@pytest.mark.parametrize("mine,theirs", OWN_DESIGN, ids=[m for m, _ in OWN_DESIGN])
+def test_overlap_with_the_reference_stays_low(mine, theirs):
+    share = overlap_share(mine, theirs)
     assert share < 0.20, f"{mine}: {100 * share:.1f} % of its significant lines are in {theirs}"
+
+
+@pytest.mark.parametrize("mine,theirs,cap", MIRRORS, ids=[m for m, _, _ in MIRRORS])
+def test_interface_mirrors_share_signatures_not_bodies(mine, theirs, cap):
+    share = overlap_share(mine, theirs)
+    assert share < cap, f"{mine}: {100 * share:.1f} % of its significant lines are in {theirs} (cap {100 * cap:.0f} %)"
 
 
 def test_the_deleted_mirrors_stay_deleted():

@@ -7,6 +7,8 @@ import json
 import os
 import sys
 
+import time
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,6 +20,8 @@ def main():
     ap.add_argument("--descs", type=int, default=262144)
     ap.add_argument("--frames", type=int, default=240, help="frames per descriptor (a 5 ms message)")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the timed ones (untimed), so that they see the clock the chip holds under this load")
+    ap.add_argument("--case", type=int, default=-1, help="run only this case (profiling runs)")
     a = ap.parse_args()
     from ohpipeline_amd import capi
     ctx = capi.Context(0)
@@ -27,6 +31,8 @@ def main():
              ("a13 Songcast sender pack (S24 six channels -> two)", capi.FMT_SENDER_PACK, 6, 24, 0, f * 6 * 3, f * 2 * 3),
              ("a14 FLAC packer (2 x TInt32 planes -> S24 interleaved)", capi.FMT_FLAC_PACK, 2, 32, 24, f * 2 * 4, f * 2 * 3)]
     rng = np.random.default_rng(1)
+    if a.case >= 0:
+        cases = cases[a.case:a.case + 1]
     for name, kind, ch, sbits, dbits, in_b, out_b in cases:
         d = np.zeros(n, dtype=capi.FMT_DESC)
         d["kind"], d["channels"], d["src_bits"], d["dst_bits"], d["n_frames"] = kind, ch, sbits, dbits, f
@@ -37,7 +43,11 @@ def main():
         src = rng.integers(0, 256, size=n * in_b, dtype=np.uint8)
         d_src, d_dst = ctx.upload(src), ctx.malloc(n * out_b)
         b = ctx.fmt_batch(d, src.size, n * out_b)
-        for _ in range(3):
+        t1 = time.perf_counter()
+        ctx.fmt_run(b, d_src, d_dst)
+        ctx.sync()
+        one = max(time.perf_counter() - t1, 1e-4)
+        for _ in range(int(min(a.sustain / one, 20000)) + 3):               # steady state first (bench.py does the same)
             ctx.fmt_run(b, d_src, d_dst)
         ctx.sync()
         ev = [(ctx.event(), ctx.event()) for _ in range(a.steps)]

@@ -46,12 +46,16 @@ def main():
     ap.add_argument("--packets", type=int, default=256)
     ap.add_argument("--samples", type=int, default=240)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the timed ones (untimed), so that they see the clock the chip holds under this load")
+    ap.add_argument("--case", type=int, default=-1, help="run only this case (profiling runs)")
     a = ap.parse_args()
     from ohpipeline_amd import capi
     ctx = capi.Context(0)
     rng = np.random.default_rng(1)
     cases = [("stereo S24 plain", 2, 24, False), ("stereo S32 -> S24 plain", 2, 32, False), ("stereo S24 ramped", 2, 24, True),
              ("6-channel S24 plain (channel select)", 6, 24, False), ("6-channel S24 ramped (select + ramp in one pass)", 6, 24, True)]
+    if a.case >= 0:
+        cases = cases[a.case:a.case + 1]
     for name, ch, bits, ramped in cases:
         streams, frames, frags, src_bytes, dst_bytes = build(capi, a.streams, a.packets, a.samples, ch, bits, ramped)
         src = rng.integers(0, 256, size=src_bytes, dtype=np.uint8)
@@ -59,7 +63,11 @@ def main():
         t0 = time.perf_counter()
         b = ctx.ohm_batch(streams, frames, frags, src_bytes, dst_bytes)
         plan_ms = (time.perf_counter() - t0) * 1e3
-        for _ in range(3):
+        t1 = time.perf_counter()
+        ctx.ohm_run(b, d_src, d_dst)
+        ctx.sync()
+        one = max(time.perf_counter() - t1, 1e-4)
+        for _ in range(int(min(a.sustain / one, 20000)) + 3):               # steady state first (bench.py does the same)
             ctx.ohm_run(b, d_src, d_dst)
         ctx.sync()
         ev = [(ctx.event(), ctx.event()) for _ in range(a.steps)]

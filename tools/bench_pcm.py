@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the timed ones (untimed), so that they see the clock the chip holds under this load")
     ap.add_argument("--all-ramped", action="store_true", help="every message carries a ramp (worst case for RampApplicator, a7)")
     ap.add_argument("--mix", action="store_true", help="streams cycle through six layouts (stereo S24, S16->S24, S32->S24, six-channel S24, S16, S24->S32): "
                                                        "one batch, one launch per layout")
@@ -85,7 +86,12 @@ def main():
     d_dst = ctx.malloc(dst_bytes)
     ctx.memset(d_dst, 0xEE, dst_bytes)
     batch = ctx.pcm_batch(d, src_bytes, dst_bytes)
-    for _ in range(a.warmup):
+    import time
+    t0 = time.perf_counter()
+    ctx.pcm_run(batch, d_src, d_dst)
+    ctx.sync()
+    one = max(time.perf_counter() - t0, 1e-4)
+    for _ in range(int(min(a.sustain / one, 20000)) + a.warmup):          # steady state first (bench.py does the same)
         ctx.pcm_run(batch, d_src, d_dst)
     ctx.sync()
     ev = [(ctx.event(), ctx.event()) for _ in range(a.steps)]
@@ -101,7 +107,7 @@ def main():
                msamples_per_s=round(a.streams * a.frames / avg / 1e3, 1), algorithmic_bytes=algo,
                config=dict(streams=a.streams, frames=a.frames, msg_frames=a.msg_frames, channels=ch, src_bits=a.src_bits,
                            dst_bits=a.dst_bits, src_endian=a.src_endian, dst_endian=a.dst_endian,
-                           attenuation=a.attenuation, all_ramped=a.all_ramped, misalign=a.misalign, variant=a.variant, msgs=int(d.size),
+                           attenuation=a.attenuation, all_ramped=a.all_ramped, misalign=a.misalign, variant=a.variant, msgs=int(d.size), sustain_s=a.sustain,
                            mix=bool(a.mix), mix_8bit=bool(a.mix and a.mix_8bit)))
     if a.check:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
