@@ -849,7 +849,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
         if (claim != OHGPU_OK) return claim;
         // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
-        if (batch->fast.lean && (ctx->variant == 0 || batch->src_planar))      // (round 1's kernel does not read planes)
+        if (batch->fast.lean && (ctx->variant == 0 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts)
             OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         else
             OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));

@@ -113,6 +113,7 @@ struct SrcFastPlan {
     uint32_t max_waves = 0;       // waves per workgroup the LDS allows (<= 12)
     uint32_t ring_bytes = 0;      // bytes of packed output a block row's LDS ring holds
     bool     lean = false;        // the batch runs on src_lean_kernel (round 2) rather than src_block_kernel
+    bool     lean_only = false;   // ... and round 1's kernel has no instantiation for its layout (variant 2 then runs the lean kernel too)
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
     void*    d_planes = nullptr;  // uint16: RampApplicator's multiplier per output frame of every ramped unit, [blocks of the unit][L_blk]
     uint32_t plane_stride = 0;    // the unit of SrcWork::plane / LeanUnit::plane in bytes (16: planes are as long as their units)
@@ -329,6 +330,7 @@ bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint3
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
+bool src_lean_only_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                         uint32_t* rows, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);
 

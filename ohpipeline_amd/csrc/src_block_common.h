@@ -49,7 +49,8 @@ static constexpr uint32_t kRampLdsBytes = 1024;         // RampArray.h's 512 Q15
 // frames per stage: stereo rows take OHGPU_LEAN_STAGE_FRAMES at a time (each row's request then covers most of a 128-byte
 // line: with 8 frames -- 48 bytes of a 6-byte-frame row -- every line was requested by three or four stages and fetched
 // from memory 1.8 times), wider frames 8
-static constexpr int lean_stage_frames(int ch) { return ch == 2 ? OHGPU_LEAN_STAGE_FRAMES : 8; }
+// (mono: 16 frames too -- a stage must advance every row by whole 16-byte pieces, and 8 frames of 3 bytes do not)
+static constexpr int lean_stage_frames(int ch) { return ch <= 2 ? OHGPU_LEAN_STAGE_FRAMES : 8; }
 static constexpr int lean_in_blocks(int ch, int sb)
 {
     const int n = (lean_stage_frames(ch) * ch * sb + 14) / 16 + 1;
@@ -98,13 +99,13 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(32, 2, 2, false, 2, false)
 #endif
 #define OHGPU_BLOCK_KERNELS(X) OHGPU_BLOCK_KERNELS_1(X) OHGPU_BLOCK_KERNELS_2(X) OHGPU_BLOCK_KERNELS_3(X)
-// the lean kernel's planar-source instantiations (source bytes 4 = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32), compiled with part 3
+// the lean kernel's planar-source instantiations (source bytes 0 = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32), compiled with part 3
 #ifdef OHGPU_DIAG_ONE_KERNEL
 #define OHGPU_LEAN_PLANAR_KERNELS(X)
 #else
 #define OHGPU_LEAN_PLANAR_KERNELS(X) \
-    X(32, 2, 4, true, 3, false)      \
-    X(32, 2, 4, true, 3, true)
+    X(32, 2, 0, true, 3, false)      \
+    X(32, 2, 0, true, 3, true)
 #endif
 // the lean kernel's half-band instantiations (a filter with ohgpu_src::halfband: T = 64 stored, 33 products per output), part 4.
 // Each has a plain T = 64 twin in the list above, which serves every other 64-tap filter of the same layout.
@@ -116,4 +117,19 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(64, 6, 3, true, 3, false)      \
     X(64, 8, 3, true, 3, false)
 #endif
-#define OHGPU_BLOCK_PARTS 4
+// layouts only the lean kernel is instantiated for (round 1's kernel, variant 2, leaves them to the generic one): packed 32-bit
+// stereo sources, mono (64 blocks per wave), wide little-endian outputs.  Part 5.
+#ifdef OHGPU_DIAG_ONE_KERNEL
+#define OHGPU_LEAN_ONLY_KERNELS(X)
+#else
+#define OHGPU_LEAN_ONLY_KERNELS(X)   \
+    X(32, 2, 4, true, 3, false)      \
+    X(32, 2, 4, false, 3, false)     \
+    X(32, 1, 3, true, 3, false)      \
+    X(32, 1, 3, false, 3, false)     \
+    X(32, 1, 2, true, 3, false)      \
+    X(32, 1, 2, false, 3, false)     \
+    X(32, 6, 3, true, 3, true)       \
+    X(32, 8, 3, true, 3, true)
+#endif
+#define OHGPU_BLOCK_PARTS 5

@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t lean_unpack_sel(uint32_t sh)
     return sel;
 }
 
-// SB == 4 stands for the PLANAR source of OHGPU_FLAG_SRC_PLANAR32 (a packed 32-bit source is not on this kernel): every
+// SB == 0 stands for the PLANAR source of OHGPU_FLAG_SRC_PLANAR32 (SB == 4 is a packed 32-bit source): every
 // channel of a block is a staging row of its own, of 4-byte frames -- lane = (block, channel) reads ITS row -- so the rows
 // staged are BPW * CH; everything downstream of the unpack is the packed layout's.
 // HB: the half-band 2:1 decimator (host_design.cpp: L = 1, M = 2, a 63-tap prototype stored as T = 64 with every odd tap but the
@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t lean_unpack_sel(uint32_t sh)
 #endif
 template <int T, int CH, int SB, int DB, bool HB = false>
 struct LeanGeom {
-    static constexpr bool PL = SB == 4;
+    static constexpr bool PL = SB == 0;
     static constexpr int BPW = 64 / CH;
     static constexpr int ROWS = BPW;
     static constexpr int IN_ROWS = PL ? BPW * CH : BPW;   // staged rows
@@ -377,7 +377,8 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
             }
             // (the reads are awaited HERE, by every lane: left to the compiler the wait sits inside the stores' lane mask, a wave
             // that skips a pass leaves its reads pending, and the compiler then opens the output loop that follows with lgkmcnt(0))
-            static_assert(DRAIN_ITERS <= 2, "one wait for every pass's reads");
+            // (LDS reads return in order: the last pass's registers name the wait for all of them)
+            static_assert(DRAIN_ITERS <= 4, "one wait for every pass's reads");
             if constexpr (DRAIN_ITERS == 1) asm volatile("" : "+v"(v4[0]));
             else asm volatile("" : "+v"(v4[0]), "+v"(v4[DRAIN_ITERS - 1]));
 #pragma unroll
@@ -772,11 +773,14 @@ OHGPU_BLOCK_KERNELS_3(X_DEFINE)
 OHGPU_LEAN_PLANAR_KERNELS(X_DEFINE)
 #elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 4
 OHGPU_LEAN_HB_KERNELS(X_DEFINE_HB)
+#elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 5
+OHGPU_LEAN_ONLY_KERNELS(X_DEFINE)
 #elif defined(OHGPU_BLOCK_PART)
 OHGPU_BLOCK_KERNELS_2(X_DECLARE)
 OHGPU_BLOCK_KERNELS_3(X_DECLARE)
 OHGPU_LEAN_PLANAR_KERNELS(X_DECLARE)
 OHGPU_LEAN_HB_KERNELS(X_DECLARE_HB)
+OHGPU_LEAN_ONLY_KERNELS(X_DECLARE)
 #endif
 
 #if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
@@ -784,8 +788,8 @@ OHGPU_LEAN_HB_KERNELS(X_DECLARE_HB)
 bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves)
-{   // (sb == 4: the planar source, LeanGeom)
-    const bool planar = sb == 4;
+{   // (sb == 0: the planar source, LeanGeom)
+    const bool planar = sb == 0;
     const uint32_t bpw = 64 / ch;
     const uint32_t fb_dst = ch * db;
     const uint32_t inb = planar ? (uint32_t)lean_in_blocks_planar((int)ch) : (uint32_t)lean_in_blocks((int)ch, (int)sb);
@@ -873,8 +877,8 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
 #define X(t, c, s_, sl, d, dl)                                                                                            \
     if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
         return launch_lean_one<t, c, s_, sl, d, dl>(ctx, b, prm, s);
-    if (b->src_planar) {                                   // (SB == 4 is the planar layout, whatever the samples' depth)
-        prm.sb = 4;
+    if (b->src_planar) {                                   // (SB == 0 is the planar layout, whatever the samples' depth)
+        prm.sb = 0;
         prm.src_le = 1;
         OHGPU_LEAN_PLANAR_KERNELS(X)
         return hipErrorInvalidValue;
@@ -887,8 +891,20 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
 #undef XHB
     }
     OHGPU_BLOCK_KERNELS(X)
+    OHGPU_LEAN_ONLY_KERNELS(X)
 #undef X
     return hipErrorInvalidValue;
+}
+
+// Layouts this kernel is instantiated for and round 1's is not (src_block_common.h: mono, packed 32-bit sources, wide
+// little-endian outputs): the planner then makes a lean-only plan.
+bool src_lean_only_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le)
+{
+#define X(t, c, s_, sl, d, dl) \
+    if (T == t && ch == c && sb == s_ && (src_le != 0) == sl && db == d && (dst_le != 0) == dl) return true;
+    OHGPU_LEAN_ONLY_KERNELS(X)
+#undef X
+    return false;
 }
 #endif   // host code: part 1 (or the single translation unit)
 

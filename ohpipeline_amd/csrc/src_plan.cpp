@@ -88,22 +88,26 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const uint32_t src_le = (b->src_endian == OHGPU_ENDIAN_LITTLE && sb > 1) ? 1 : 0;
     const uint32_t dst_le = (b->dst_endian == OHGPU_ENDIAN_LITTLE) ? 1 : 0;
     // a planar source (OHGPU_FLAG_SRC_PLANAR32) is, per channel, a stream of 4-byte frames: the lean kernel alone reads it
-    // (stereo to S24); a packed 32-bit source stays on the generic kernel
+    // (stereo to S24).  Mono, packed 32-bit sources and wide little-endian outputs are lean-only layouts too (round 3):
+    // round 1's kernel has no instantiation for them, so such a plan runs on the lean kernel whatever the variant.
     const bool planar = b->src_planar;
-    if (planar ? !(T == 32 && ch == 2 && sb != 4 && db == 3) : (sb == 4 || !src_block_supported(T, ch, sb, src_le, db, dst_le))) return OHGPU_OK;
+    const bool block_ok = !planar && src_block_supported(T, ch, sb, src_le, db, dst_le);
+    const bool lean_only = planar ? (T == 32 && ch == 2 && sb != 4 && db == 3) : (!block_ok && src_lean_only_supported(T, ch, sb, src_le, db, dst_le));
+    if (!block_ok && !lean_only) return OHGPU_OK;
     const uint32_t sb_geo = planar ? 3u : sb;                           // (round 1's geometry: only its rows and ring are used)
-    const uint32_t sb_lean = planar ? 4u : sb;                          // (LeanGeom: 4 = planar)
+    const uint32_t sb_lean = planar ? 0u : sb;                          // (LeanGeom: 0 = planar)
     const uint32_t fb_src = planar ? 4u : ch * sb, fb_dst = ch * db;    // (planar: a plane's frame)
     // the ring is drained every four advances: #{j : a <= floor(j*M/L) < a+4} <= ceil(4L/M) outputs arrive in between
     const uint32_t out_per_drain = (4 * L + M - 1) / M;
     uint32_t rows = 0, ring = 0, coef_lds = 0, wave_lds = 0, max_waves = 0;
-    if (!src_block_geometry(L, T, ch, sb_geo, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
+    if ((block_ok || planar) && !src_block_geometry(L, T, ch, sb_geo, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
     // the lean kernel (round 2): same blocks, rows and ring; its rounding bias needs sum|c| < 2^29 in every phase
     uint32_t lean_rows = 0, lean_inb = 0, lean_sf = 8, lean_ring = 0, lean_coef = 0, lean_wave_lds = 0, lean_max_waves = 0;
-    const bool lean = flt->max_sum_abs < ((int64_t)1 << 29) &&
-                      src_lean_geometry(L, T, flt->halfband, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves) &&
-                      lean_rows == rows && lean_ring == ring;
-    if (planar && !lean) return OHGPU_OK;
+    bool lean = flt->max_sum_abs < ((int64_t)1 << 29) &&
+                src_lean_geometry(L, T, flt->halfband, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves);
+    if (lean && !block_ok && !planar) { rows = lean_rows; ring = lean_ring; }     // (no geometry of round 1's to agree with)
+    lean = lean && lean_rows == rows && lean_ring == ring;
+    if (lean_only && !lean) return OHGPU_OK;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
     uint32_t min_blk = 128;
 #ifdef OHGPU_DIAG
@@ -371,6 +375,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.max_waves = max_waves;
     f.ring_bytes = ring;
     f.lean = lean;
+    f.lean_only = lean_only;
     f.lean_coef_lds_bytes = lean_coef;
     f.lean_wave_lds_bytes = lean_wave_lds;
     f.plane_stride = 16;                                              // SrcWork::plane counts 16-byte pieces

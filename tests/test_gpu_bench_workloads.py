@@ -64,13 +64,23 @@ def test_config3_group_is_bit_exact(ctx):
 
 
 def lean_instantiations():
-    """(T, channels, source bytes, source LE, destination bytes, destination LE) of every block-kernel instantiation the library
-    is built with, read from the list the kernels are instantiated from (csrc/src_block_common.h)."""
+    """(T, channels, source bytes, source LE, destination bytes, destination LE, list) of every block-kernel instantiation the
+    library is built with, read from the lists the kernels are instantiated from (csrc/src_block_common.h).  `list` tells what
+    runs it: "block" = both block kernels, "planar" (source bytes 0: the TInt32 planes), "halfband" and "lean_only" = the lean
+    kernel alone.  A half-band instantiation has a plain T = 64 twin in the block list, which the bench's own 96 -> 48 kHz
+    filter never reaches any more (it IS half-band): test_plain_64_tap_kernels_still_run covers those."""
     import re
     text = open(os.path.join(ROOT, "ohpipeline_amd", "csrc", "src_block_common.h")).read()
-    text = text[text.index("#else", text.index("OHGPU_DIAG_ONE_KERNEL")):]
-    found = re.findall(r"X\((\d+), (\d+), (\d+), (true|false), (\d+), (true|false)\)", text)
-    return sorted(set((int(t), int(c), int(s), sl == "true", int(d), dl == "true") for t, c, s, sl, d, dl in found))
+    out = set()
+    for macro, kind in (("OHGPU_BLOCK_KERNELS_1", "block"), ("OHGPU_BLOCK_KERNELS_2", "block"), ("OHGPU_BLOCK_KERNELS_3", "block"),
+                        ("OHGPU_LEAN_PLANAR_KERNELS", "planar"), ("OHGPU_LEAN_HB_KERNELS", "halfband"), ("OHGPU_LEAN_ONLY_KERNELS", "lean_only")):
+        defs = [m.end() for m in re.finditer(r"#define %s\(X\)" % macro, text)]
+        body = text[defs[-1]:]                                           # (the last definition: the one behind the diagnostic #else)
+        body = body[:body.index("\n#")]
+        for t, c, s_, sl, d, dl in re.findall(r"X\((\d+), (\d+), (\d+), (true|false), (\d+), (true|false)\)", body):
+            out.add((int(t), int(c), int(s_), sl == "true", int(d), dl == "true", kind))
+    assert len(out) >= 30
+    return sorted(out)
 
 
 def noise_le(stream_id, n_subsamples, bits):
@@ -82,15 +92,17 @@ def noise_le(stream_id, n_subsamples, bits):
     return b
 
 
-@pytest.mark.parametrize("inst", lean_instantiations(), ids=lambda i: "T%d_ch%d_s%d%s_d%d%s" % (i[0], i[1], i[2], "le" if i[3] else "be", i[4], "le" if i[5] else "be"))
+@pytest.mark.parametrize("inst", lean_instantiations(), ids=lambda i: "T%d_ch%d_s%d%s_d%d%s_%s" % (i[0], i[1], i[2], "le" if i[3] else "be", i[4], "le" if i[5] else "be", i[6]))
 def test_every_block_kernel_instantiation_on_the_bench_workload(ctx, inst):
     """One bench-shaped group per instantiation -- the host model's 50 ms / 500 ms ramp schedule, 5 ms messages, full-scale
-    noise, enough streams for workgroups of several waves -- on the lean kernel and (packed sources) on round 1's."""
-    T, ch, sb, src_le, db, dst_le = inst
-    planar = sb == 4
+    noise, enough streams for workgroups of several waves -- on the lean kernel and (the layouts it has) on round 1's.  The
+    whole batch must be on the block kernel: a uniform batch of any of these layouts leaves nothing but block-unaligned ends
+    to the generic one."""
+    T, ch, sb, src_le, db, dst_le, kind = inst
+    planar = kind == "planar"
     rate = 96000 if T == 64 else 44100
     src_bits = 16 if planar else sb * 8
-    n_streams = 24 if ch == 2 else 12
+    n_streams = 24 if ch <= 2 else 12
     g = bench.Group(capi, rate, ch, range(900, 900 + n_streams), int(round(0.7 * rate)), src_bits=src_bits,
                     src_endian=capi.ENDIAN_LITTLE if src_le else capi.ENDIAN_BIG, planar=planar,
                     dst_bits=db * 8, dst_endian=capi.ENDIAN_LITTLE if dst_le else capi.ENDIAN_BIG)
@@ -104,9 +116,41 @@ def test_every_block_kernel_instantiation_on_the_bench_workload(ctx, inst):
     else:
         le = [noise_le(sid, per, src_bits) for sid in g.stream_ids]
         g.src = np.concatenate([(x if src_le else x[:, ::-1]).reshape(-1) for x in le])
-    for variant in ((0,) if planar else (0, 2)):
+    for variant in ((0, 2) if kind == "block" else (0,)):
         ctx.set_kernel_variant(variant)
         try:
             run_groups(ctx, [g])
         finally:
             ctx.set_kernel_variant(0)
+    # nothing but the streams' block-unaligned ends went to the generic kernel (at most a head and a tail message piece per stream
+    # and message it cuts): the layout is on the fast path
+    assert g.plan["block_kernel_out_frames"] >= 0.9 * len(g.stream_ids) * g.out_total, g.plan
+
+
+def test_plain_64_tap_kernels_still_run(ctx):
+    """The T = 64 instantiations serve every 64-tap filter that is NOT half-band.  The bench's own 96 -> 48 kHz design is
+    (host_design.cpp), so take it and break the property -- one odd tap set to a non-zero value, in the oracle's table and in
+    the library's alike: ohgpu_src_create must then choose the plain kernel, and the audio must still be the integer model's."""
+    g = bench.Group(capi, 96000, 2, range(40, 52), 67200)
+    ref = O.Src(g.rate_in, bench.RATE_OUT, g.taps, bench.BETA, bench.F_PASS)
+    assert g.taps == 64 and all(ref.coef_q28[k] == 0 for k in range(1, 64, 2) if k != 31)       # half-band as designed
+    table = np.ctypeslib.as_array(O.lib().ohp_src_coef_q28(ref.h), shape=(64,))                   # (the oracle's own table, in place)
+    table[5] = 12345
+    coef = np.array(table, dtype=np.int32)
+    per = g.in_frames * g.channels
+    le = [noise_le(sid, per, 24) for sid in g.stream_ids]
+    g.src = np.concatenate([x.reshape(-1) for x in le])
+    h = ctx.src_create(g.L, g.M, g.taps, coef)
+    d_src, d_dst = ctx.upload(g.src), ctx.malloc(g.dst_bytes)
+    ctx.memset(d_dst, 0, g.dst_bytes)
+    b = ctx.src_batch(h, g.descs, g.src_bytes, g.dst_bytes)
+    ctx.src_run(b, d_src, d_dst)
+    got = ctx.download(d_dst, g.dst_bytes)
+    want = np.zeros(g.dst_bytes, dtype=np.uint8)
+    assert ref.process_batch(g.descs, g.src, want) == 0
+    assert ctx.src_plan(b)["block_kernel_out_frames"] > 0
+    assert np.array_equal(got, want)
+    ctx.batch_destroy(b)
+    ctx.src_destroy(h)
+    ctx.free(d_src)
+    ctx.free(d_dst)
