@@ -257,10 +257,13 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     std::vector<LeanUnit> lean_units;
     if (lean) {
         const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * lean_max_waves;
-        // (same-box A/B on the headline workload, tools/exp_units.sh: one block per row everywhere 0.489-0.496 ms; long units of
-        // 3 blocks with 2.5 rounds left 0.484-0.485; of 4 blocks with 1.5 or 0.6 rounds left 0.476)
-        double tail_rounds = 1.5;
-        uint32_t kb_max = 8, long_rounds = 0;
+        // Same-box A/Bs on the headline workload (tools/exp_units3.sh, three alternating passes, +-0.1 % within a box): one block
+        // per row everywhere 0.4955 ms; ONE round of long units of 8 blocks with one round of one-block units kept 0.4832;
+        // 6 blocks with two rounds kept 0.4995; two rounds of 4 blocks 0.5025; three rounds of 2 blocks 0.4933.  What a long
+        // row saves is small (a unit's set-up and warm-up are 7 % of a one-block unit; the history it does not re-read is
+        // 18 % of the reads); what decides is how the schedule's last units fall, so: one long unit per wave, the rest short.
+        double tail_rounds = 1.0;
+        uint32_t kb_max = 8, long_rounds = 1;
 #ifdef OHGPU_DIAG
         if (const char* e = getenv("OHGPU_DIAG_TAIL_ROUNDS")) tail_rounds = atof(e);       // (diagnostic builds: the long/short split)
         if (const char* e = getenv("OHGPU_DIAG_KB_MAX")) kb_max = (uint32_t)atoi(e);

@@ -83,6 +83,9 @@ def main():
                "write_size_kib": c["WRITE_SIZE"], "kernel_avg_us_trace": out["kernels"][dom]["avg_us"],
                "source": f"profiles/{tag}_summary.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes",
                "streams_per_gpu": 256, "frames_per_stream": 441000, "kernel_variant": 0}
+        sys.path.insert(0, ROOT)
+        import bench                                                   # (the kernel sources this profile was taken from: bench.py quotes
+        pmc["source_sha16"] = bench.source_fingerprint()               #  `traffic` only while they are unchanged)
         if latest:                                                     # bench.py reads this one for roofline.traffic
             json.dump(pmc, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1, sort_keys=True)
         out["hbm_traffic"] = pmc
