@@ -500,12 +500,16 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
             dist.barrier()
 
     # steady state first: about `sustain` seconds of launches (untimed), so that the timed steps see the clock the chip holds
-    t0 = time.perf_counter()
+    # (by the clock, in bursts: the first step of a process is no measure of the others -- under a profiler it is ten times as long)
     step()
     ctx.sync()
-    one = max(time.perf_counter() - t0, 1e-4)
-    for _ in range(int(min(args.sustain / one, 20000))):
-        step()
+    t0 = time.perf_counter()
+    launched = 0
+    while time.perf_counter() - t0 < args.sustain and launched < 200000:
+        for _ in range(16):
+            step()
+        ctx.sync()
+        launched += 16
     for _ in range(args.warmup):
         step()
     barrier()

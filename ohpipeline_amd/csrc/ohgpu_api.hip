@@ -838,9 +838,15 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
     hipStream_t s = pick_stream(ctx, stream);
     if (ctx->variant != 1 && !batch->parts.empty()) {               // one uniform batch per layout
+        // "nothing is launched" on refusal holds for the whole batch: every part is asked first whether it is free (a part still
+        // running on another stream refuses), and only then does the first one launch
+        for (const ohgpu_batch* part : batch->parts)
+            if (part->last_done != nullptr && part->last_stream != s && hipEventQuery(part->last_done) == hipErrorNotReady)
+                return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: a part of the batch is still running on another stream (its unit counters "
+                                 "serve one launch at a time: wait for it, use the same stream, or create a second batch); nothing was launched");
         for (const ohgpu_batch* part : batch->parts) {
             const int err = ohgpu_src_batch_run(ctx, part, src_base, dst_base, s);
-            if (err != OHGPU_OK) return err;
+            if (err != OHGPU_OK) return err;                        // (a device error: the destination may be partly written, as for any failed launch)
         }
         return OHGPU_OK;
     }

@@ -320,11 +320,28 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
             const uint32_t m0v = wave_lds_addr + buf + (uint32_t)(it * 64) * 16;
             if (!checked) {
                 const uint64_t sbase = (uint64_t)(uintptr_t)src + (uint64_t)stage_off;
+#if defined(OHGPU_DIAG_DMA_POLICY_ID) && OHGPU_DIAG_DMA_POLICY_ID == 1     // (diagnostic builds: a cache policy on the staging loads)
+#define LEAN_DMA_POLICY " nt"
+#elif defined(OHGPU_DIAG_DMA_POLICY_ID) && OHGPU_DIAG_DMA_POLICY_ID == 2
+#define LEAN_DMA_POLICY " sc1"
+#elif defined(OHGPU_DIAG_DMA_POLICY_ID) && OHGPU_DIAG_DMA_POLICY_ID == 3
+#define LEAN_DMA_POLICY " sc0 sc1"
+#elif defined(OHGPU_DIAG_DMA_POLICY_ID) && OHGPU_DIAG_DMA_POLICY_ID == 4
+#define LEAN_DMA_POLICY " sc0"
+#else
+#define LEAN_DMA_POLICY ""
+#endif
                 if (last_partial) {
-                    asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
-                                 : : "v"(piece_off[it]), "s"(sbase), "s"(m0v), "s"((1ull << (kTail & 63)) - 1ull) : "memory", "m0");
+                    // (the lanes beyond the last piece are masked off for this one instruction; EXEC is saved and put back, not
+                    // assumed full: the statement then holds in whatever control flow a compiler leaves around it)
+                    uint64_t keep;
+                    asm volatile("s_mov_b64 %[keep], exec\n\ts_and_b64 exec, %[keep], %[mask]\n\ts_mov_b32 m0, %[m0v]\n\ts_nop 0\n\t"
+                                 "global_load_lds_dwordx4 %[off], %[base]" LEAN_DMA_POLICY "\n\ts_mov_b64 exec, %[keep]"
+                                 : [keep] "=&s"(keep)
+                                 : [off] "v"(piece_off[it]), [base] "s"(sbase), [m0v] "s"(m0v), [mask] "s"((1ull << (kTail & 63)) - 1ull)
+                                 : "memory", "m0", "scc");
                 } else {
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" LEAN_DMA_POLICY
                                  : : "v"(piece_off[it]), "s"(sbase), "s"(m0v) : "memory", "m0");
                 }
             } else {

@@ -31,6 +31,9 @@ public:
 // millisecond (FlywheelRamper.cpp:45-131), RampGenerator cuts the 32-bit blocks back to the stream's depth and ramps them
 // down from where the stream's ramp stood (:281-364).  Here: every request in the same four passes.
 static std::atomic<TUint64> gFlywheelLaunches{0};
+static std::atomic<TUint64> gRescueFailures{0};
+
+TUint64 RescueBatch::Failures() { return gRescueFailures.load(); }
 
 TUint64 RescueBatch::FlywheelLaunches()
 {
@@ -152,7 +155,14 @@ void RescueBatch::Run()
     if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
     for (void* d : {dIn, dPlanar, dRamp, dOut}) if (d) ohgpu_free(ctx, d);
     for (ohgpu_batch* b : {ub, fb, pb}) if (b) ohgpu_batch_destroy(ctx, b);
-    ASSERT(err == OHGPU_OK);
+    if (err != OHGPU_OK) {
+        // The device let the rescue down (out of memory, a failed launch).  Nothing is thrown across the other lanes' period:
+        // the starving lanes get no extrapolated audio, so their next message is the halt that would have followed it and they
+        // ramp up from silence when audio returns -- an audible cut on those streams instead of a dead tick for all of them.
+        gRescueFailures++;
+        iRequests.clear();
+        return;
+    }
     // every block becomes a message that continues the stream's ramp downwards (a ramp already at its minimum: muted)
     for (size_t i = 0; i < n; i++) {
         const RescueRequest& rq = iRequests[i];

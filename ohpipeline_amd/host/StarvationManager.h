@@ -60,6 +60,8 @@ public:
     void Run();
     /** Extrapolation launches (ohgpu_flywheel_batch_run calls) by every batch of this process so far. */
     static TUint64 FlywheelLaunches();
+    /** Rescues the device failed (their lanes went straight to the halt: RescueBatch::Run never throws for a device error). */
+    static TUint64 Failures();
 private:
     MsgFactory& iFactory;
     std::vector<RescueRequest> iRequests;

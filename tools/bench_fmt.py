@@ -43,13 +43,13 @@ def main():
         src = rng.integers(0, 256, size=n * in_b, dtype=np.uint8)
         d_src, d_dst = ctx.upload(src), ctx.malloc(n * out_b)
         b = ctx.fmt_batch(d, src.size, n * out_b)
-        t1 = time.perf_counter()
         ctx.fmt_run(b, d_src, d_dst)
         ctx.sync()
-        one = max(time.perf_counter() - t1, 1e-4)
-        for _ in range(int(min(a.sustain / one, 20000)) + 3):               # steady state first (bench.py does the same)
-            ctx.fmt_run(b, d_src, d_dst)
-        ctx.sync()
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < a.sustain:                         # steady state first, by the clock (bench.py does the same)
+            for _ in range(16):
+                ctx.fmt_run(b, d_src, d_dst)
+            ctx.sync()
         ev = [(ctx.event(), ctx.event()) for _ in range(a.steps)]
         for e0, e1 in ev:
             ctx.record(e0); ctx.fmt_run(b, d_src, d_dst); ctx.record(e1)

@@ -63,13 +63,13 @@ def main():
         t0 = time.perf_counter()
         b = ctx.ohm_batch(streams, frames, frags, src_bytes, dst_bytes)
         plan_ms = (time.perf_counter() - t0) * 1e3
-        t1 = time.perf_counter()
         ctx.ohm_run(b, d_src, d_dst)
         ctx.sync()
-        one = max(time.perf_counter() - t1, 1e-4)
-        for _ in range(int(min(a.sustain / one, 20000)) + 3):               # steady state first (bench.py does the same)
-            ctx.ohm_run(b, d_src, d_dst)
-        ctx.sync()
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < a.sustain:                         # steady state first, by the clock (bench.py does the same)
+            for _ in range(16):
+                ctx.ohm_run(b, d_src, d_dst)
+            ctx.sync()
         ev = [(ctx.event(), ctx.event()) for _ in range(a.steps)]
         for e0, e1 in ev:
             ctx.record(e0); ctx.ohm_run(b, d_src, d_dst); ctx.record(e1)

@@ -87,11 +87,14 @@ def main():
     ctx.memset(d_dst, 0xEE, dst_bytes)
     batch = ctx.pcm_batch(d, src_bytes, dst_bytes)
     import time
-    t0 = time.perf_counter()
     ctx.pcm_run(batch, d_src, d_dst)
     ctx.sync()
-    one = max(time.perf_counter() - t0, 1e-4)
-    for _ in range(int(min(a.sustain / one, 20000)) + a.warmup):          # steady state first (bench.py does the same)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < a.sustain:                            # steady state first, by the clock (bench.py does the same)
+        for _ in range(16):
+            ctx.pcm_run(batch, d_src, d_dst)
+        ctx.sync()
+    for _ in range(a.warmup):
         ctx.pcm_run(batch, d_src, d_dst)
     ctx.sync()
     ev = [(ctx.event(), ctx.event()) for _ in range(a.steps)]
