@@ -12,6 +12,7 @@ TARGET=${OHGPU_PROFILE_TARGET:-$R/bench.py}                      # e.g. tools/be
 if [ "$TARGET" = "$R/bench.py" ]; then BENCH_ARGS="--steps 10 --warmup 3 --no-cpu $*"; else BENCH_ARGS="$*"; fi
 echo "== kernel trace" | tee "$OUT/log.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$TARGET" $BENCH_ARGS >> "$OUT/log.txt" 2>&1 || echo "trace run failed" | tee -a "$OUT/log.txt"
+if [ -n "${OHGPU_PROFILE_TRACE_ONLY:-}" ]; then echo done; exit 0; fi    # (kernel times only: the line kernels' steady-state summaries)
 i=0
 while IFS= read -r SET; do
   [ -z "$SET" ] && continue
