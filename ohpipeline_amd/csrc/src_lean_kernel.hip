@@ -160,6 +160,15 @@ __device__ __forceinline__ uint32_t lean_unpack_sel(uint32_t sh)
 #ifndef OHGPU_LEAN_MAX_WAVES_T32
 #define OHGPU_LEAN_MAX_WAVES_T32 0                       // (experiments: waves per workgroup of the 32-slot-window kernels)
 #endif
+#ifndef OHGPU_LEAN_MAX_WAVES_WIDE
+#define OHGPU_LEAN_MAX_WAVES_WIDE 12                     // (experiments: ... of those with six channels or more, which need fewer registers)
+#endif
+// waves per workgroup: three per SIMD for a 32-slot window (what the LDS left by the coefficient table allows with 16-frame
+// stages), two when the window alone is 128 registers
+static constexpr int lean_max_waves(int tw, int ch, bool halfband)
+{   // (the half-band kernels carry the delay line: the six-channel one does not fit 128 registers)
+    return tw > 32 ? 8 : (OHGPU_LEAN_MAX_WAVES_T32 > 0 ? OHGPU_LEAN_MAX_WAVES_T32 : (ch >= 6 && !halfband ? OHGPU_LEAN_MAX_WAVES_WIDE : 12));
+}
 template <int T, int CH, int SB, int DB, bool HB = false>
 struct LeanGeom {
     static constexpr bool PL = SB == 0;
@@ -167,7 +176,7 @@ struct LeanGeom {
     static constexpr int ROWS = BPW;
     static constexpr int IN_ROWS = PL ? BPW * CH : BPW;   // staged rows
     static constexpr int TW = HB ? T / 2 : T;            // window slots = taps that meet the window
-    static constexpr int MAX_WAVES = OHGPU_LEAN_MAX_WAVES_T32 > 0 && TW <= 32 ? OHGPU_LEAN_MAX_WAVES_T32 : (TW <= 32 ? 12 : 8);  // three per SIMD (what the LDS left by the coefficient table allows with 16-frame stages), two when the window alone is 128 registers
+    static constexpr int MAX_WAVES = lean_max_waves(TW, CH, HB);
     static constexpr int FB_SRC = PL ? 4 : CH * SB, FB_DST = CH * DB;     // bytes per frame of a staged row
     static constexpr int SF = lean_stage_frames(CH);      // frames per stage
     static constexpr int IN_BLOCKS = PL ? lean_in_blocks_planar(CH) : lean_in_blocks(CH, SB);
@@ -822,7 +831,7 @@ bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint3
     const uint32_t budget = 160 * 1024;
     if (*coef_lds_bytes + *wave_lds_bytes > budget) return false;
     uint32_t w = (budget - *coef_lds_bytes) / *wave_lds_bytes;
-    const uint32_t cap = tw <= 32 ? (OHGPU_LEAN_MAX_WAVES_T32 > 0 ? (uint32_t)OHGPU_LEAN_MAX_WAVES_T32 : 12u) : 8u;
+    const uint32_t cap = (uint32_t)lean_max_waves((int)tw, (int)ch, halfband);
     if (w > cap) w = cap;
     if (w < 4) return false;
 #ifdef OHGPU_DIAG

@@ -134,14 +134,17 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             if ((uint64_t)(ch - 1) * descs[k].src_plane_stride + (uint64_t)(rows + 1) * (M_blk + T) * 4 + 4096 >= (1ull << 32)) return OHGPU_OK;
     }
     auto dst_base_of = [&](const ohgpu_src_msg_desc& d) { return (int64_t)d.dst_offset - (int64_t)(d.out_frame0 * fb_dst); };
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    auto before = [&](uint32_t x, uint32_t y) {
         const int64_t sx = src_base_of(descs[x]), sy = src_base_of(descs[y]);
         if (sx != sy) return sx < sy;
         if (descs[x].src_plane_stride != descs[y].src_plane_stride) return descs[x].src_plane_stride < descs[y].src_plane_stride;
         const int64_t dx = dst_base_of(descs[x]), dy = dst_base_of(descs[y]);
         if (dx != dy) return dx < dy;
         return descs[x].out_frame0 < descs[y].out_frame0;
-    });
+    };
+    // (a caller that lists its streams one after the other, each in time order -- the usual case -- is in order already: one
+    // linear pass instead of a sort of half a million messages)
+    if (!std::is_sorted(order.begin(), order.end(), before)) std::sort(order.begin(), order.end(), before);
 
     std::vector<SrcSeg> segs;
     struct SegRun { uint32_t seg; uint64_t blk_lo, blk_hi; uint32_t work_begin; };   // a segment's whole blocks and where its units start in `work`
