@@ -316,7 +316,15 @@ int ohgpu_src_process_host(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
  * (block-unaligned heads/tails, unsupported layouts) left to the generic kernel. */
 int ohgpu_src_batch_plan(const ohgpu_batch* batch, uint64_t* block_kernel_out_frames, uint64_t* generic_pieces);
 
-/* Kernel selection for A/B measurement (0 = default/best, 1 = baseline "v1" kernels). */
+/* ... and how the block kernel's share was cut: its work units, and how many of them are "long" (every row several
+ * consecutive blocks of its stream: the unit schedule of large batches, ohpipeline_amd/csrc/src_plan.cpp).  Both 0 when the
+ * batch runs on the generic kernel alone. */
+int ohgpu_src_batch_units(const ohgpu_batch* batch, uint64_t* units, uint64_t* long_units);
+
+/* Kernel selection for A/B measurement and tests: 0 = default/best; 1 = baseline "v1" kernels; 2 = round 1's block resampler
+ * kernel where it has the layout; 3 = the default kernels with the resampler's long-row unit schedule forced onto batches of
+ * any size (a resampled batch created while 3 is set cuts every run of plain units into rows of three blocks -- what only a
+ * batch of thousands of units gets otherwise -- so that tests reach that path with small inputs; results are identical). */
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant);
 
 #ifdef __cplusplus

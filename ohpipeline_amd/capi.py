@@ -104,6 +104,7 @@ SYMBOLS = {
     "ohgpu_src_batch_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
+    "ohgpu_src_batch_units": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_src_process_host": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
     "ohgpu_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }
@@ -362,6 +363,11 @@ class Context:
         a, b = C.c_uint64(0), C.c_uint64(0)
         check(lib().ohgpu_src_batch_plan(batch, C.byref(a), C.byref(b)))
         return {"block_kernel_out_frames": int(a.value), "generic_pieces": int(b.value)}
+
+    def src_units(self, batch):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().ohgpu_src_batch_units(batch, C.byref(a), C.byref(b)))
+        return {"units": int(a.value), "long_units": int(b.value)}
 
     def src_run(self, batch, d_src, d_dst, stream=None):
         check(lib().ohgpu_src_batch_run(self._h, batch, d_src, d_dst, stream))

@@ -107,7 +107,7 @@ int ohgpu_device_name(ohgpu_ctx* ctx, char* buf, size_t buf_bytes)
 
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 2) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
+    if (!ctx || variant < 0 || variant > 3) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
     ctx->variant = variant;
     return OHGPU_OK;
 }
@@ -830,6 +830,25 @@ int ohgpu_src_batch_plan(const ohgpu_batch* b, uint64_t* block_kernel_out_frames
     return OHGPU_OK;
 }
 
+int ohgpu_src_batch_units(const ohgpu_batch* b, uint64_t* units, uint64_t* long_units)
+{
+    if (!b || b->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_units: not a src batch");
+    uint64_t u = 0, l = 0;
+    if (!b->parts.empty()) {
+        for (const ohgpu_batch* part : b->parts) {
+            uint64_t pu = 0, pl = 0;
+            ohgpu_src_batch_units(part, &pu, &pl);
+            u += pu; l += pl;
+        }
+    } else if (b->fast.enabled) {
+        u = b->fast.lean ? b->fast.n_lean : b->fast.n_work;
+        l = b->fast.lean ? b->fast.n_long : 0;
+    }
+    if (units) *units = u;
+    if (long_units) *long_units = l;
+    return OHGPU_OK;
+}
+
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
 {
     CTX_GUARD("ohgpu_src_batch_run");
@@ -855,7 +874,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
         if (claim != OHGPU_OK) return claim;
         // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
-        if (batch->fast.lean && (ctx->variant == 0 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts)
+        if (batch->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts)
             OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         else
             OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));

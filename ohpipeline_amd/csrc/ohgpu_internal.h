@@ -107,6 +107,7 @@ struct SrcFastPlan {
     uint32_t T = 0;               // taps per phase
     SrcFastParams params{};
     uint32_t n_work = 0;
+    uint32_t n_long = 0;          // ... of which units whose rows are several blocks long
     uint32_t n_lean = 0;          // LeanUnit count (a lean unit may hold several blocks per row: it need not equal n_work)
     uint32_t coef_lds_bytes = 0;  // the coefficient table's share of a workgroup's LDS
     uint32_t wave_lds_bytes = 0;  // per wave: input stages, message table, output ring

@@ -161,13 +161,18 @@ __device__ __forceinline__ uint32_t lean_unpack_sel(uint32_t sh)
 #define OHGPU_LEAN_MAX_WAVES_T32 0                       // (experiments: waves per workgroup of the 32-slot-window kernels)
 #endif
 #ifndef OHGPU_LEAN_MAX_WAVES_WIDE
-#define OHGPU_LEAN_MAX_WAVES_WIDE 12                     // (experiments: ... of those with six channels or more, which need fewer registers)
+#define OHGPU_LEAN_MAX_WAVES_WIDE 16                     // ... of those with six channels or more: they fit 128 registers, four waves per SIMD
 #endif
-// waves per workgroup: three per SIMD for a 32-slot window (what the LDS left by the coefficient table allows with 16-frame
-// stages), two when the window alone is 128 registers
+// Waves per workgroup.  A 32-slot window: three per SIMD for stereo (134 registers; and what the LDS left by the coefficient
+// table allows with 16-frame stages, 11), FOUR for six channels and more -- those kernels have no pair exchange, fit 128
+// registers and their 8-frame stages leave the LDS room (same-box A/B on config 4, tools/exp_wide16.sh: six channels 1.75 ->
+// 1.67 ms, eight 2.25 -> 2.09 ms).  A half-band kernel carries the delay line on top: the eight-channel one still fits 128
+// registers, the six-channel one does not (it would spill).  Two per SIMD when the window alone is 128 registers (T = 64).
 static constexpr int lean_max_waves(int tw, int ch, bool halfband)
-{   // (the half-band kernels carry the delay line: the six-channel one does not fit 128 registers)
-    return tw > 32 ? 8 : (OHGPU_LEAN_MAX_WAVES_T32 > 0 ? OHGPU_LEAN_MAX_WAVES_T32 : (ch >= 6 && !halfband ? OHGPU_LEAN_MAX_WAVES_WIDE : 12));
+{
+    if (tw > 32) return 8;
+    if (OHGPU_LEAN_MAX_WAVES_T32 > 0) return OHGPU_LEAN_MAX_WAVES_T32;
+    return (ch >= 6 && (!halfband || ch == 8)) ? OHGPU_LEAN_MAX_WAVES_WIDE : 12;
 }
 template <int T, int CH, int SB, int DB, bool HB = false>
 struct LeanGeom {

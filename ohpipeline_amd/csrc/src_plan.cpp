@@ -276,7 +276,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         const double u1 = (double)work.size(), long_budget = u1 - tail_rounds * waves;
         uint32_t kb_long = 1;
         double long_share = 0.0;
-        if (long_budget >= 2.0 * waves && kb_max >= 2) {
+        if (ctx && ctx->variant == 3) {                    // ohgpu_set_kernel_variant(3): the long rows forced, for tests with small batches
+            kb_long = 3;
+            long_share = 1.0;
+        } else if (long_budget >= 2.0 * waves && kb_max >= 2) {
             const uint32_t n_rounds = long_rounds ? long_rounds : (long_budget > 4.5 * waves ? 2u : 1u);   // rounds of long units per wave
             kb_long = (uint32_t)(long_budget / ((double)waves * n_rounds) + 0.5);
             if (kb_long > kb_max) kb_long = kb_max;
@@ -375,6 +378,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.T = T;
     f.n_work = (uint32_t)work.size();
     f.n_lean = (uint32_t)lean_units.size();
+    for (const LeanUnit& u : lean_units) f.n_long += ((u.flags >> 8) & 0xffu) > 1 ? 1u : 0u;
     f.n_rem = rem.size();
     f.coef_lds_bytes = coef_lds;
     f.wave_lds_bytes = wave_lds;

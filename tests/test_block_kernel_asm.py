@@ -103,14 +103,20 @@ def test_no_scratch_and_no_valu_exec_writes(which, request):
 def test_lean_kernels_keep_three_waves_per_simd(lean):
     """The 32-tap instantiations are launched with up to twelve waves per workgroup: at most 168 registers (and no spills:
     test_no_scratch_and_no_valu_exec_writes)."""
-    seen_halfband = 0
+    seen_halfband = seen_wide = 0
     for part in PARTS:
         text = open(os.path.join(OUTDIR, f"src_lean_kernel.test.{part}.s")).read()
         for m in re.finditer(r"\.name:\s+(_ZN5ohgpu15src_lean_kernelILi(\d+)E\w+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
             if int(m.group(2)) <= 32 or _halfband(m.group(1)):     # (a half-band kernel's window is 32 frames too: that is its point)
                 assert int(m.group(3)) <= 168, (m.group(1), m.group(3))
                 seen_halfband += _halfband(m.group(1))
-    assert seen_halfband >= 3
+                # six channels and more are launched with up to SIXTEEN waves per workgroup (lean_max_waves): 128 registers --
+                # all but the six-channel half-band kernel, whose delay line does not fit
+                ch = int(re.search(r"src_lean_kernelILi\d+ELi(\d+)E", m.group(1)).group(1))
+                if ch >= 6 and not (_halfband(m.group(1)) and ch == 6):
+                    assert int(m.group(3)) <= 128, (m.group(1), m.group(3))
+                    seen_wide += 1
+    assert seen_halfband >= 3 and seen_wide >= 8
 
 
 def tap_waits(body):

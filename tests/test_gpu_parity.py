@@ -779,3 +779,79 @@ def test_src_groups_overlapped_on_two_streams(ctx):
     ctx.free(d_src)
     ctx.free(d_dst)
     ctx.src_destroy(h)
+
+
+@pytest.mark.parametrize("layout", ["stereo_s24", "six_s24", "halfband_stereo", "halfband_eight", "mono_s16", "stereo_s32", "planar16"])
+@pytest.mark.parametrize("seed", [11, 12])
+def test_long_row_units_match_the_oracle(ctx, layout, seed):
+    """The unit schedule of large batches -- rows of several consecutive blocks, claimed before the one-block units (round 3,
+    src_plan.cpp) -- on small inputs: ohgpu_set_kernel_variant(3) forces it.  Streams long enough for several units, sparse
+    ramped messages (a ramped unit stays one block long, so long and short units alternate inside a stream), ragged stream
+    ends, one stream that starts mid-way (its first block is not block 0), unsorted descriptors.  Bit-exact against the oracle,
+    and equal to what the default schedule writes."""
+    rng = np.random.default_rng(seed)
+    rate, taps, ch, bits, planar = {"stereo_s24": (44100, 32, 2, 24, False), "six_s24": (44100, 32, 6, 24, False),
+                                    "halfband_stereo": (96000, 64, 2, 24, False), "halfband_eight": (96000, 64, 8, 24, False),
+                                    "mono_s16": (44100, 32, 1, 16, False), "stereo_s32": (44100, 32, 2, 32, False),
+                                    "planar16": (44100, 32, 2, 16, True)}[layout]
+    h, ref = make_src(ctx, rate, 48000, taps)
+    fb_src, fb_dst = (4 if planar else ch * bits // 8), ch * 3
+    rows, src_parts, s_pos, d_pos = [], [], 0, 0
+    n_streams = 5 if ch <= 2 else 3
+    for stream in range(n_streams):
+        in_frames = int(rng.integers(38000, 56000)) * (2 if rate == 96000 else 1) * (2 if ch == 1 else 1)   # (mono blocks are 320 outputs)
+        out_total = ref.out_frames(in_frames)
+        if planar:                                                       # the decoder's TInt32 planes, channel after channel
+            v = W.noise_pcm(700 + 10 * seed + stream, in_frames, ch, bits, LE).view("<i2").astype(np.int32).reshape(in_frames, ch)
+            src_parts.append((np.ascontiguousarray(v.T).reshape(-1).view(np.uint8), v.reshape(-1).astype(">i2").view(np.uint8)))
+        else:
+            x = W.noise_pcm(700 + 10 * seed + stream, in_frames, ch, bits, LE)
+            src_parts.append((x, x))
+        d_base = (d_pos + 63) // 64 * 64
+        m = int(rng.integers(400, 1200)) if stream == 1 else 0           # one stream is asked for from the middle on
+        first = m
+        while m < out_total:
+            n = min(int(rng.choice([240, 240, 240, 480, 200])), out_total - m)
+            ramp = RAMPS[int(rng.integers(0, len(RAMPS)))]
+            flags = O.FLAG_RAMP if rng.random() < 0.008 else 0            # sparse ramps: long runs of plain units between them
+            src_off = s_pos
+            rows.append((src_off, 0, in_frames, m, d_base + (m - first) * fb_dst, n, ramp[0], ramp[1], 256, ch, bits, LE, 24, BE,
+                         flags | (capi.FLAG_SRC_PLANAR32 if planar else 0), in_frames * 4 if planar else 0))
+            m += n
+        s_pos += in_frames * (fb_src * ch if planar else fb_src)
+        d_pos = d_base + (out_total - first) * fb_dst
+    descs = np.array(rows, dtype=O.SRC_MSG_DESC)[rng.permutation(len(rows))]
+    src = np.concatenate([a for a, _ in src_parts])
+    d_src, d_dst = ctx.upload(src), ctx.malloc(d_pos)
+    outs = []
+    for variant in (3, 0):
+        ctx.set_kernel_variant(variant)
+        try:
+            ctx.memset(d_dst, 0xA5, d_pos)
+            b = ctx.src_batch(h, descs, src.size, d_pos)
+            units = ctx.src_units(b)
+            assert units["units"] > 0
+            assert (units["long_units"] > 0) == (variant == 3), (variant, units)     # the forced schedule cut long units, the default did not
+            ctx.src_run(b, d_src, d_dst)
+            outs.append(ctx.download(d_dst, d_pos))
+            ctx.batch_destroy(b)
+        finally:
+            ctx.set_kernel_variant(0)
+    if planar:                                                           # the oracle's composition: the planes packed, then resampled
+        od = descs.copy()
+        per = np.cumsum([0] + [b.size for _, b in src_parts])
+        starts = np.cumsum([0] + [a.size for a, _ in src_parts])
+        for k in range(len(src_parts)):
+            sel = od["src_offset"] == starts[k]
+            od["src_offset"][sel] = per[k]
+        od["flags"] &= ~np.uint8(capi.FLAG_SRC_PLANAR32)
+        od["src_plane_stride"] = 0
+        od["src_endian"] = BE
+        want = oracle_src(ref, od, np.concatenate([b for _, b in src_parts]), d_pos)
+    else:
+        want = oracle_src(ref, descs, src, d_pos)
+    bad = np.nonzero(outs[0] != want)[0]
+    assert bad.size == 0, f"{layout} seed {seed}: {bad.size} mismatches, first {bad[:5]}"
+    assert np.array_equal(outs[0], outs[1])
+    ctx.free(d_src); ctx.free(d_dst)
+    ctx.src_destroy(h)
