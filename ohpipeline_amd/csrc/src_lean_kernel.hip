@@ -649,9 +649,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                     if constexpr (r == 0) win[ws] = lean_unpack<PL>(rawp[s & 1], in_sel[(s % SF) % PH]);
 #endif
 #undef W_
-#ifndef OHGPU_DIAG_NO_COEF
-                    lean_issue_f64<r * 128>(cf[r], cp);
-#endif
+                    lean_issue_f64<r * 128>(cf[r], cp);      // (no ablation switch here: the waits above count this reload)
                 }, std::make_integer_sequence<int, NCR>{});
                 // ---- round, clamp, (ramp,) pack: ONE hand-written statement.  u = trunc(2^24 + 0.5 + sum) clamped to
                 // 2^24 + [-2^23, 2^23 - 1]; its low 24 bits are the S24 value.  Everything that survives the output is an in-place

@@ -25,7 +25,8 @@ def main():
     from ohpipeline_amd import capi
     ctx = capi.Context(0)
     deadline = time.time() + a.minutes * 60
-    seed, counts = a.first_seed - 1, {"src_tilings": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
+    seed, counts = a.first_seed - 1, {"src_tilings": 0, "long_rows": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
+    layouts = ["stereo_s24", "six_s24", "halfband_stereo", "halfband_eight", "mono_s16", "stereo_s32", "planar16"]
     real_rng = np.random.default_rng
     formats = [(48000, 24, 2), (44100, 16, 2), (96000, 32, 2), (44100, 24, 1), (48000, 24, 6), (48000, 32, 8), (44100, 16, 6), (48000, 8, 2), (192000, 24, 2)]
     last = time.time()
@@ -36,6 +37,9 @@ def main():
             last = time.time()
         P.test_src_block_kernel_irregular_message_tilings(ctx, seed)
         counts["src_tilings"] += 1
+        if seed % 4 == 0:                                    # round 3: rows of several blocks, forced onto small batches, by layout
+            P.test_long_row_units_match_the_oracle(ctx, layouts[(seed // 4) % len(layouts)], seed)
+            counts["long_rows"] += 1
         rng = np.random.default_rng(seed)
         w = S.Workload()
         for k in range(int(rng.integers(1, 12))):
