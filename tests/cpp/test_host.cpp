@@ -1046,7 +1046,11 @@ static void SuiteSongcastSenderControl(MsgFactory& aControl)
     TEST(np > 20 && sender.Driver().Frame() == sent && sender.Driver().SampleStart() == s.sampleStart + samples);
     TEST(s.sink.grams.empty());
     TByte b[4] = { 0 };
-    TEST_THROWS(sender.Push(aControl.CreateMsgAudioPcm(Brn(b, 4), 2, 44100, 16, AudioDataEndian::Big, 0)->CreatePlayable()), AssertionFailed);   // Sender.cpp:264-268
+    {   // (a message the element refuses stays the caller's: released here, so that the suite is clean under LeakSanitizer too)
+        Msg* refused = aControl.CreateMsgAudioPcm(Brn(b, 4), 2, 44100, 16, AudioDataEndian::Big, 0)->CreatePlayable();
+        TEST_THROWS(sender.Push(refused), AssertionFailed);                             // Sender.cpp:264-268
+        refused->RemoveRef();
+    }
 
     // the messages that cut a packet short, and what they do to the frame counter
     std::vector<TByte> ms(48 * 4, 0x11);                                               // 1 ms of 48 kHz 16-bit stereo
@@ -1054,7 +1058,11 @@ static void SuiteSongcastSenderControl(MsgFactory& aControl)
     DatagramCollector sink2;
     Av::Sender s2(aControl, sink2, 50);
     s2.SetBatching(0);
-    TEST_THROWS(s2.Push(audio()), AssertionFailed);                                    // audio before any MsgDecodedStream: ASSERT(iSampleRate != 0), Sender.cpp:246
+    {
+        Msg* early = audio();
+        TEST_THROWS(s2.Push(early), AssertionFailed);                                  // audio before any MsgDecodedStream: ASSERT(iSampleRate != 0), Sender.cpp:246
+        early->RemoveRef();
+    }
     DecodedStreamInfo info;
     info.iBitDepth = 16; info.iSampleRate = 48000; info.iNumChannels = 2; info.iSampleStart = 7;
     s2.Push(aControl.CreateMsgDecodedStream(info));
