@@ -35,6 +35,31 @@ static std::atomic<TUint64> gRescueFailures{0};
 
 TUint64 RescueBatch::Failures() { return gRescueFailures.load(); }
 
+RescueArena::~RescueArena()
+{
+    for (void* b : iBuf) {
+        if (b != nullptr) ohgpu_free(iCtx, b);
+    }
+}
+
+void* RescueArena::Get(ohgpu_ctx* aCtx, TUint aWhich, size_t aBytes)
+{
+    ASSERT(aWhich < 4 && (iCtx == nullptr || iCtx == aCtx));
+    iCtx = aCtx;
+    if (aBytes > iCap[aWhich]) {                         // grow with headroom: the next, larger rescue should not allocate again
+        if (iBuf[aWhich] != nullptr) ohgpu_free(aCtx, iBuf[aWhich]);
+        iBuf[aWhich] = nullptr;
+        iCap[aWhich] = 0;
+        const size_t want = std::max<size_t>(2 * aBytes, 64 * 1024);
+        void* fresh = nullptr;
+        if (ohgpu_malloc(aCtx, want, &fresh) != OHGPU_OK) return nullptr;
+        iBuf[aWhich] = fresh;
+        iCap[aWhich] = want;
+        iAllocations++;
+    }
+    return iBuf[aWhich];
+}
+
 TUint64 RescueBatch::FlywheelLaunches()
 {
     return gFlywheelLaunches.load();
@@ -143,17 +168,29 @@ void RescueBatch::Run()
     int err = ohgpu_fmt_batch_create(ctx, unpack.data(), n, packedIn.size(), planarBytes, &ub);
     if (err == OHGPU_OK) err = ohgpu_flywheel_batch_create(ctx, fly.data(), n, planarBytes, rampBytes, &fb);
     if (err == OHGPU_OK && !pack.empty()) err = ohgpu_pcm_batch_create(ctx, pack.data(), pack.size(), rampBytes, outBytes, &pb);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, packedIn.size(), &dIn);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, planarBytes, &dPlanar);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, std::max<size_t>(rampBytes, 16), &dRamp);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, std::max<size_t>(outBytes, 16), &dOut);
+    if (iArena != nullptr) {                             // the manager's persistent buffers
+        const size_t need[4] = { packedIn.size(), planarBytes, std::max<size_t>(rampBytes, 16), std::max<size_t>(outBytes, 16) };
+        void** into[4] = { &dIn, &dPlanar, &dRamp, &dOut };
+        for (TUint k = 0; k < 4 && err == OHGPU_OK; k++) {
+            *into[k] = iArena->Get(ctx, k, need[k]);
+            if (*into[k] == nullptr) err = OHGPU_ERR_NOMEM;
+        }
+    }
+    else {
+        if (err == OHGPU_OK) err = ohgpu_malloc(ctx, packedIn.size(), &dIn);
+        if (err == OHGPU_OK) err = ohgpu_malloc(ctx, planarBytes, &dPlanar);
+        if (err == OHGPU_OK) err = ohgpu_malloc(ctx, std::max<size_t>(rampBytes, 16), &dRamp);
+        if (err == OHGPU_OK) err = ohgpu_malloc(ctx, std::max<size_t>(outBytes, 16), &dOut);
+    }
     if (err == OHGPU_OK) err = ohgpu_memcpy_h2d(ctx, dIn, packedIn.data(), packedIn.size(), nullptr);
     if (err == OHGPU_OK) err = ohgpu_fmt_batch_run(ctx, ub, dIn, dPlanar, nullptr);
     if (err == OHGPU_OK) { err = ohgpu_flywheel_batch_run(ctx, fb, dPlanar, dRamp, nullptr); gFlywheelLaunches++; }
     if (err == OHGPU_OK && pb) err = ohgpu_pcm_batch_run(ctx, pb, dRamp, dOut, nullptr);
     if (err == OHGPU_OK && outBytes) err = ohgpu_memcpy_d2h(ctx, packedOut.data(), dOut, outBytes, nullptr);
     if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
-    for (void* d : {dIn, dPlanar, dRamp, dOut}) if (d) ohgpu_free(ctx, d);
+    if (iArena == nullptr) {
+        for (void* d : {dIn, dPlanar, dRamp, dOut}) if (d) ohgpu_free(ctx, d);
+    }
     for (ohgpu_batch* b : {ub, fb, pb}) if (b) ohgpu_batch_destroy(ctx, b);
     if (err != OHGPU_OK) {
         // The device let the rescue down (out of memory, a failed launch).  Nothing is thrown across the other lanes' period:
@@ -433,7 +470,7 @@ void StarvationManager::QueueRescue(Lane& aLane, RescueBatch& aBatch)
 
 void StarvationManager::RescueNow(Lane& aLane)
 {
-    RescueBatch one(iFactory);
+    RescueBatch one(iFactory, &iArena);
     QueueRescue(aLane, one);
     one.Run();
     iRescueLaunches++;
@@ -665,7 +702,7 @@ void StarvationManager::Tick(std::vector<Msg*>& aOut)
     // Nothing in a tick waits for a feeder: the reference gives every pipeline a StarvationRamper and a driver thread of its
     // own, so an idle pipeline blocks nobody else; here the lanes share the tick, and one that has nothing to say this period
     // (halted or not yet started with an empty inbox, or held at its occupancy gate) just says nothing -- nullptr.
-    RescueBatch batch(iFactory);
+    RescueBatch batch(iFactory, &iArena);
     std::vector<TBool> takesPart(iLanes.size());
     for (size_t i = 0; i < iLanes.size(); i++) {
         takesPart[i] = Prepare(*iLanes[i], batch, false);
@@ -683,7 +720,7 @@ void StarvationManager::Tick(std::vector<Msg*>& aOut)
 Msg* StarvationManager::Pull(TUint aLane)
 {
     Lane& lane = *iLanes.at(aLane);
-    RescueBatch batch(iFactory);
+    RescueBatch batch(iFactory, &iArena);
     Prepare(lane, batch, true);                          // (one lane, its own caller: blocks as the reference's Pull does)
     if (batch.Count() > 0) {
         batch.Run();

@@ -48,13 +48,32 @@ struct RescueRequest {
     std::deque<Msg*>* out = nullptr;                     // receives the 1 ms messages of extrapolated, down-ramped audio
 };
 
+/** The four device buffers a rescue works in (newest frames, planes, extrapolated blocks, packed output), kept from rescue to
+ *  rescue and grown on demand: a rescue happens in the very period in which its lanes starve, and four allocations and frees
+ *  in it were four too many (the advisor's finding).  One per StarvationManager; a RescueBatch without one allocates per run. */
+class RescueArena {
+public:
+    RescueArena() {}
+    ~RescueArena();
+    RescueArena(const RescueArena&) = delete;
+    RescueArena& operator=(const RescueArena&) = delete;
+    /** Buffer `aWhich` (0..3) of at least aBytes on aCtx's device, or nullptr when the device refuses. */
+    void* Get(ohgpu_ctx* aCtx, TUint aWhich, size_t aBytes);
+    TUint64 Allocations() const { return iAllocations; }             // device allocations so far (a steady state makes none)
+private:
+    ohgpu_ctx* iCtx = nullptr;
+    void* iBuf[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t iCap[4] = { 0, 0, 0, 0 };
+    TUint64 iAllocations = 0;
+};
+
 /** Extrapolates every request's audio in one chain of device passes (a7 read, a11, N1, a12) and queues the messages. */
 class RescueBatch {
 public:
     static const TUint kTrainingJiffies = Jiffies::kPerMs * 1;       // StarvationRamper.cpp:374-376
     static const TUint kRampDownJiffies = Jiffies::kPerMs * 20;
 public:
-    explicit RescueBatch(MsgFactory& aFactory) : iFactory(aFactory) {}
+    explicit RescueBatch(MsgFactory& aFactory, RescueArena* aArena = nullptr) : iFactory(aFactory), iArena(aArena) {}
     void Add(RescueRequest&& aRequest) { iRequests.push_back(std::move(aRequest)); }
     TUint Count() const { return (TUint)iRequests.size(); }
     void Run();
@@ -64,6 +83,7 @@ public:
     static TUint64 Failures();
 private:
     MsgFactory& iFactory;
+    RescueArena* iArena;                                  // whose buffers to work in (nullptr: allocated and freed by Run)
     std::vector<RescueRequest> iRequests;
 };
 
@@ -100,6 +120,7 @@ public: // inspection (the reference's suite reads these as a friend)
     TBool Finished(TUint aLane) const;                   // the lane's MsgQuit has gone out
     TBool DrainRequested(TUint aLane) const;             // DrainAllAudio() called, not yet seen by a tick
     TUint64 RescueLaunches() const { return iRescueLaunches.load(); }   // device rescues so far (one per tick that needed any)
+    TUint64 RescueAllocations() const { return iArena.Allocations(); } // device allocations of the rescue buffers so far
 private:
     struct Lane;
     TBool Prepare(Lane& aLane, RescueBatch& aBatch, TBool aMayBlock);   // tick step 1; false: the lane sits this period out
@@ -113,6 +134,7 @@ private:
 private:
     MsgFactory& iFactory;
     std::vector<std::unique_ptr<Lane>> iLanes;
+    RescueArena iArena;                                   // the rescues' device buffers (one tick, one thread)
     std::atomic<TUint64> iRescueLaunches;
 };
 

@@ -715,6 +715,63 @@ public:
     std::atomic<TUint> iStarted{0}, iStopped{0};
 };
 
+// A stream that starves twice: the second rescue works in the device buffers the first one allocated (RescueArena) -- a rescue
+// happens in the period in which its lane has nothing to play, and allocating in it was the advisor's finding.
+static void SuiteRescueBuffersPersistGpu(MsgFactory& aFactory)
+{
+    ScriptedSource source;
+    CountingObserver observer;
+    StarvationManager manager(aFactory);
+    StarvationManager::LaneConfig cfg;
+    cfg.upstream = &source; cfg.observer = &observer;
+    cfg.sizeJiffies = 200 * Jiffies::kPerMs; cfg.rampUpJiffies = 50 * Jiffies::kPerMs; cfg.maxStreamCount = 10;
+    TEST(manager.AddLane(cfg) == 0);
+    source.Push(aFactory.CreateMsgMode(ModeInfo()));
+    DecodedStreamInfo info;
+    info.iStreamId = 3; info.iBitDepth = 16; info.iSampleRate = 48000; info.iNumChannels = 2;
+    source.Push(aFactory.CreateMsgDecodedStream(info));
+    uint32_t x = 9;
+    std::vector<TByte> pcm(4 * 96);                          // 2 ms of 48 kHz stereo S16
+    auto feed = [&](TUint aMsgs) {
+        TUint fed = 0;
+        for (TUint m = 0; m < aMsgs; m++) {
+            for (auto& b : pcm) { x = x * 1664525u + 1013904223u; b = (TByte)(x >> 24); }
+            MsgAudioPcm* audio = aFactory.CreateMsgAudioPcm(Brn(pcm.data(), (TUint)pcm.size()), 2, 48000, 16, AudioDataEndian::Big, 0);
+            fed += audio->Jiffies();
+            source.Push(audio);
+        }
+        while (manager.SizeInJiffies(0) != fed) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    };
+    std::vector<Msg*> out;
+    auto play_until_halt = [&](TUint aAudioBefore) {        // the fed audio, then 20 ms of extrapolated audio, then the halt
+        TUint audio = 0;
+        for (TUint t = 0; t < 200; t++) {
+            manager.Tick(out);
+            TEST(out.size() == 1 && out[0] != nullptr);
+            if (out[0] == nullptr) return;
+            const MsgKind k = KindOf(out[0]);
+            out[0]->RemoveRef();
+            if (k == MsgKind::Halt) { TEST(audio == aAudioBefore + 20); return; }
+            if (k == MsgKind::AudioPcm) audio++;
+        }
+        TEST(false);
+    };
+    feed(3);
+    play_until_halt(3);
+    TEST(manager.RescueLaunches() == 1 && manager.RescueAllocations() == 4);
+    feed(40);                                                // 80 ms: through the 50 ms ramp up and on
+    play_until_halt(40);
+    TEST(manager.RescueLaunches() == 2);
+    TEST(manager.RescueAllocations() == 4);                  // the second rescue allocated nothing
+    source.Push(aFactory.CreateMsgQuit());
+    for (TUint t = 0; t < 20000 && !manager.Finished(0); t++) {
+        manager.Tick(out);
+        if (out[0] != nullptr) out[0]->RemoveRef();
+        else std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    TEST(manager.Finished(0));
+}
+
 // An idle stream must not hold the others' period up (the reference has one StarvationRamper and one driver thread per
 // pipeline: a halted pipeline blocks only itself).  Lane 0 plays; lane 1 was halted by its source and then hears nothing;
 // lane 2 is held at an occupancy gate its feeder cannot reach.  Every tick must come back with lane 0's message.  No device
@@ -875,6 +932,7 @@ static void SuiteManyLanesStarveTogetherGpu(MsgFactory& aFactory)
             }
         }
         TEST(manager.RescueLaunches() == 1);                 // ONE rescue for 64 lanes...
+        TEST(manager.RescueAllocations() == 4);              // ... in the manager's four persistent device buffers (allocated by this first rescue)
         TEST(RescueBatch::FlywheelLaunches() == launches + 1);                     // ...and one flywheel launch on the device
         for (TUint l = 0; l < kLanes; l++) TEST(halted[l] == 1 && quit[l] == 1 && continuity[l].Checked() >= kMsgs + 20);
         TEST(observer.iStarted.load() == 2 * kLanes && observer.iStopped.load() == kLanes);     // buffering at start, playing, buffering again
@@ -1801,6 +1859,7 @@ int main(int argc, char** argv)
             SuiteFlywheelGpu(f);
             SuiteStarvationRescueGpu(f);
             SuiteManyLanesStarveTogetherGpu(f);
+            SuiteRescueBuffersPersistGpu(f);
             SuiteSongcastSenderGpu(f);
             SuiteStarvationRamper starvation(f);
             starvation.RunControl();
