@@ -232,10 +232,15 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t table_bytes = (uint32_t)L * TW * 8;
+    // (No pad between the rows: round 1 put 4 bytes there "so that the rows start in different banks", but the LDS counters are
+    // identical to the last digit at pitches of 100, 108 and 124 bytes -- the ring stores' "conflicts" are the second pass of a
+    // dual-dword operation, not addresses -- and without it the stereo kernel's per-wave LDS is 10 240 bytes: twelve waves per
+    // CU instead of eleven.  Same-box A/B, alternating: a wash on most boxes (0.458-0.479 against 0.468-0.489 ms), 11 % faster
+    // on a box that ran the whole kernel 40 % slow (0.605 against 0.681 ms): the twelfth wave is insurance, not speed.)
 #ifndef OHGPU_LEAN_RING_PAD
-#define OHGPU_LEAN_RING_PAD 4
+#define OHGPU_LEAN_RING_PAD 0
 #endif
-    const uint32_t row_stride = ring_bytes + OHGPU_LEAN_RING_PAD;     // rows start in different banks
+    const uint32_t row_stride = ring_bytes + OHGPU_LEAN_RING_PAD;
     const uint32_t ring_area = (ROWS * row_stride + 15) & ~15u;
     const uint32_t dummy_bytes = G::DUMMY ? ring_bytes + 64u : 0u;    // (their store address moves with ring_pos like everyone's)
     const uint32_t wave_lds = (OFF_RING + ring_area + dummy_bytes + 127u) & ~127u;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -254,38 +255,46 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // ---- the lean kernel's units.  A unit is `rows` rows; a row is `kb` CONSECUTIVE blocks of its stream.  With kb = 1 (round
     // 2) every block pays a filter length of warm-up advances and re-reads that much history (32 frames per 147), and every
     // 160 outputs a unit set-up; a row of kb blocks pays them once.  But long units make the end of the launch coarse -- round
-    // 2 measured uniformly longer blocks as a loss for exactly that reason -- so only the FIRST part of the work is cut into
-    // long units, claimed first, and about `tail_rounds` rounds of one-block units are left for the waves to level out on.
-    // Ramped units stay one block long (a long unit would run the ramp path for all its outputs).
+    // 2 measured uniformly longer blocks as a loss for exactly that reason.  So: ONE LONG UNIT PER WAVE, as long as the plain
+    // work allows (claimed first: every wave starts on one), everything else -- what does not divide, and the ramped units,
+    // which stay one block long because a long unit would run the ramp path for all its outputs -- as one-block units for
+    // the waves to level out on.
     std::vector<LeanUnit> lean_units;
     if (lean) {
         const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * lean_max_waves;
-        // Same-box A/Bs on the headline workload (tools/exp_units3.sh, three alternating passes, +-0.1 % within a box): one block
-        // per row everywhere 0.4955 ms; ONE round of long units of 8 blocks with one round of one-block units kept 0.4832;
-        // 6 blocks with two rounds kept 0.4995; two rounds of 4 blocks 0.5025; three rounds of 2 blocks 0.4933.  What a long
-        // row saves is small (a unit's set-up and warm-up are 7 % of a one-block unit; the history it does not re-read is
-        // 18 % of the reads); what decides is how the schedule's last units fall, so: one long unit per wave, the rest short.
-        double tail_rounds = 1.0;
-        uint32_t kb_max = 8, long_rounds = 1;
+        // Same-box A/Bs on the headline workload, alternating passes, +-0.2 % within a box.  Eleven waves per CU
+        // (tools/exp_units3.sh): one block per row everywhere 0.4955 ms; one long unit of 8 blocks per wave 0.4832; 6 blocks and
+        // two rounds of short units kept 0.4995; two rounds of 4-block units 0.5025; three rounds of 2-block units 0.4933.
+        // Twelve waves (tools/exp_units4.sh): one block per row 0.496; 7-block units for eleven of twelve waves 0.4475; for
+        // EVERY wave (3072 long units for 3072 waves, 0.83 rounds of short ones left) 0.4375; 6-block units 0.50-0.51.  What a
+        // long row saves by itself is small (set-up and warm-up are 7 % of a one-block unit; the history it does not re-read is
+        // 18 % of the reads); what decides is how the schedule's last units fall, and "every wave exactly one long unit, as
+        // long as possible" is the rule that was best at both occupancies.
+        uint32_t kb_max = 8, long_rounds = 0;
+        double tail_rounds = 0.0;                            // (diagnostic: plain work held back from the long units, in rounds of short units)
 #ifdef OHGPU_DIAG
         if (const char* e = getenv("OHGPU_DIAG_TAIL_ROUNDS")) tail_rounds = atof(e);       // (diagnostic builds: the long/short split)
         if (const char* e = getenv("OHGPU_DIAG_KB_MAX")) kb_max = (uint32_t)atoi(e);
         if (const char* e = getenv("OHGPU_DIAG_LONG_ROUNDS")) long_rounds = (uint32_t)atoi(e);
 #endif
-        // how many one-block units the plan has, and the share of them to merge
-        const double u1 = (double)work.size(), long_budget = u1 - tail_rounds * waves;
+        // the plain, full one-block units (the only ones that merge), in runs between ramped or partly filled ones
+        uint64_t plain_total = 0;
+        for (const SrcWork& w : work) plain_total += (!(w.flags & kWorkRamped) && w.n_blocks == rows) ? 1u : 0u;
+        const double plain_avail = (double)plain_total - tail_rounds * waves;
         uint32_t kb_long = 1;
-        double long_share = 0.0;
+        uint64_t long_target = 0;                            // long units to cut, over all segments
         if (ctx && ctx->variant == 3) {                    // ohgpu_set_kernel_variant(3): the long rows forced, for tests with small batches
             kb_long = 3;
-            long_share = 1.0;
-        } else if (long_budget >= 2.0 * waves && kb_max >= 2) {
-            const uint32_t n_rounds = long_rounds ? long_rounds : (long_budget > 4.5 * waves ? 2u : 1u);   // rounds of long units per wave
-            kb_long = (uint32_t)(long_budget / ((double)waves * n_rounds) + 0.5);
+            long_target = ~(uint64_t)0;
+        } else if (plain_avail >= 2.0 * waves && kb_max >= 2) {
+            // rounds of long units: one, unless even 8-block units would leave more than that for a second helping
+            const uint32_t n_rounds = long_rounds ? long_rounds : (uint32_t)std::max(1.0, std::ceil(plain_avail / ((double)waves * kb_max) - 0.25));
+            kb_long = (uint32_t)(plain_avail / ((double)waves * n_rounds));
             if (kb_long > kb_max) kb_long = kb_max;
             if (kb_long < 2) kb_long = 1;
-            long_share = kb_long > 1 ? long_budget / u1 : 0.0;
+            long_target = kb_long > 1 ? (uint64_t)waves * n_rounds : 0;
         }
+        uint64_t long_cut = 0;
         lean_units.reserve(work.size());
         auto emit = [&](const SegRun& r, uint64_t bk, uint32_t n_rows, uint32_t kb, const SrcWork* w1) -> bool {
             LeanUnit u;
@@ -327,12 +336,14 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             uint32_t k = 0;
             while (k < n_units) {
                 const SrcWork& w1 = work[r.work_begin + k];
-                // a run of plain, full one-block units: its first `long_share` goes out as long units
+                // a run of plain, full one-block units: long units from its front, the rest (what does not divide) stays short
                 uint32_t run = 0;
                 while (kb_long > 1 && k + run < n_units && !(work[r.work_begin + k + run].flags & kWorkRamped) &&
                        work[r.work_begin + k + run].n_blocks == rows) run++;
-                const uint32_t n_long = kb_long > 1 ? (uint32_t)(long_share * run / kb_long + 0.5) : 0u;
-                if (n_long > 0 && n_long * kb_long <= run) {
+                // (as many long units as the run holds, until every wave has its one)
+                const uint32_t n_long = kb_long > 1 ? (uint32_t)std::min<uint64_t>(run / kb_long, long_target - long_cut) : 0u;
+                if (n_long > 0) {
+                    long_cut += n_long;
                     for (uint32_t q = 0; q < n_long; q++)
                         if (!emit(r, w1.first_block + (uint64_t)q * kb_long * rows, rows, kb_long, nullptr)) return OHGPU_OK;
                     k += n_long * kb_long;
