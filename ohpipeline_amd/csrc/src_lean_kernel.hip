@@ -270,6 +270,16 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     const uint32_t sel_hi = c == 0 ? ((4 + B1) | (4 + B2) << 8 | B0 << 16 | B1 << 24) : ((4 + B2) | B0 << 8 | B1 << 16 | B2 << 24);
     const uint32_t ring_lane = lane_block ? wave_lds_addr + OFF_RING + row * row_stride + (PAIR ? c * 4 : c * DB)
                                           : wave_lds_addr + OFF_RING + ring_area + (lane & 3) * 16;
+    // Pair mode, no pad between the rows (twelve waves per CU): rows 96 bytes apart start 24 dwords apart, so rows r and r + 8
+    // meet in the same banks and the ring stores of a half-wave collide two by two (SQ_LDS_BANK_CONFLICT 40 M -> 117 M per
+    // launch).  Every second group of eight rows therefore keeps its ring ROTATED by half its length: what the others store at
+    // ring position p it stores at (p + ring / 2) mod ring -- 12 dwords on, clear of its neighbour -- and the write-back reads it
+    // there.  Only where half a ring is a whole number of both frame pairs and 16-byte pieces (ring a multiple of 96 bytes:
+    // every stereo S24 layout the planner makes today); otherwise no rotation.
+    const uint32_t ring_half = (uint32_t)__builtin_amdgcn_readfirstlane((int)((PAIR && ring_bytes % 96u == 0) ? ring_bytes / 2 : 0u));   // (an SGPR operand below)
+    const uint32_t ring_rot = (lane_block && ((row >> 3) & 1u)) ? ring_half : 0u;
+    const uint32_t ring_lane_lo = ring_lane + ring_rot;   // for ring positions below the half ...
+    const uint32_t ring_lane_hi = ring_lane - ring_rot;   // ... and from the half on (position - half)
     const double bias = 16777216.5;                     // 2^24 + 0.5
     const uint32_t clamp_lo = 0x00800000u, clamp_hi = 0x017fffffu;   // 2^24 - 2^23 .. 2^24 + 2^23 - 1
 
@@ -401,7 +411,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         if (frames_stored >= 0) return;
 #endif
         while (drained < (((uint32_t)frames_stored * FB_DST) >> 6)) {
-            uint32_t pos = line_pos + (lane & 3) * 16;
+            uint32_t pos = line_pos + (lane & 3) * 16 + (((lane >> 5) & 1u) ? ring_half : 0u);   // (row = it * 16 + lane / 4: its bit 3 is the lane's bit 5)
             if (pos >= ring_bytes) pos -= ring_bytes;
             // every pass's pieces are read before any is stored: one LDS round trip per line, not one per pass
             u32x4 v4[DRAIN_ITERS];
@@ -464,7 +474,7 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     // The store of the last finished output (pair) is issued by the NEXT output, after its first wait, so that no wait ever
     // covers a store just issued.  It is issued by EVERY output: when nothing new is pending the same bytes go to the same
     // place once more (no branch, and the count of LDS operations per output stays fixed).
-    uint32_t st_addr = ring_lane, st_lo = 0, st_hi = 0;
+    uint32_t st_addr = PAIR ? ring_lane_lo : ring_lane, st_lo = 0, st_hi = 0;
     uint32_t y_even = 0, y_odd = 0;                           // frames whose bytes are in the ring or in the pending store
     auto issue_store = [&]() __attribute__((always_inline)) {
 #ifdef OHGPU_DIAG_NO_RING
@@ -717,8 +727,11 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         "v_med3_u32 %[yo], %[yo], %[clo], %[chi]\n\t"
                         "s_cbranch_scc1 80b\n"
                         "41:\n\t"
+                        "s_cmp_lt_u32 %[rp], %[half]\n\t"           // (the rotated rows' place: + half below the half, - half from it on)
+                        "s_cselect_b64 vcc, -1, 0\n\t"
                         "v_cndmask_b32_e64 %[give], %[ye], %[yo], %[m55]\n\t"
-                        "v_add_u32 %[sta], %[rp], %[rl]\n\t"
+                        "v_cndmask_b32 %[sta], %[rlh], %[rll], vcc\n\t"
+                        "v_add_u32 %[sta], %[rp], %[sta]\n\t"
                         "s_add_u32 %[rp], %[rp], %[step]\n\t"
                         "v_mov_b32_dpp %[got], %[give] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                         "s_cmp_eq_u32 %[rp], %[ring]\n\t"
@@ -730,8 +743,8 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                           [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [moff] "+v"(moff),
                           [give] "=&v"(give), [got] "=&v"(got), [t] "=&v"(t16), [mu] "=&v"(mu)
                         : [acc] "v"(acc), [clo] "s"(clamp_lo), [chi] "v"(clamp_hi), [j] "s"(j), [rf] "s"(ramped_u), [mb] "s"(mbase),
-                          [m55] "s"(0x5555555555555555ull), [rl] "v"(ring_lane), [ring] "s"(ring_bytes), [sl] "v"(sel_lo), [sh] "v"(sel_hi),
-                          [step] "i"(2 * FB_DST)
+                          [m55] "s"(0x5555555555555555ull), [rll] "v"(ring_lane_lo), [rlh] "v"(ring_lane_hi), [half] "s"(ring_half),
+                          [ring] "s"(ring_bytes), [sl] "v"(sel_lo), [sh] "v"(sel_hi), [step] "i"(2 * FB_DST)
                         : "vcc", "scc", "memory");
                 } else {
                     asm volatile(
