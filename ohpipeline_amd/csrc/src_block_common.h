@@ -49,8 +49,9 @@ static constexpr uint32_t kRampLdsBytes = 1024;         // RampArray.h's 512 Q15
 // frames per stage: stereo rows take OHGPU_LEAN_STAGE_FRAMES at a time (each row's request then covers most of a 128-byte
 // line: with 8 frames -- 48 bytes of a 6-byte-frame row -- every line was requested by three or four stages and fetched
 // from memory 1.8 times), wider frames 8
-// (mono: 16 frames too -- a stage must advance every row by whole 16-byte pieces, and 8 frames of 3 bytes do not)
-static constexpr int lean_stage_frames(int ch) { return ch <= 2 ? OHGPU_LEAN_STAGE_FRAMES : 8; }
+// (mono and the odd channel counts: 16 frames too -- a stage must advance every row by whole 16-byte pieces, and 8 frames of
+// 3, 9, 15 or 21 bytes do not)
+static constexpr int lean_stage_frames(int ch) { return (ch <= 2 || (ch & 1)) ? OHGPU_LEAN_STAGE_FRAMES : 8; }
 static constexpr int lean_in_blocks(int ch, int sb)
 {
     const int n = (lean_stage_frames(ch) * ch * sb + 14) / 16 + 1;
@@ -118,7 +119,8 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(64, 8, 3, true, 3, false)
 #endif
 // layouts only the lean kernel is instantiated for (round 1's kernel, variant 2, leaves them to the generic one): packed 32-bit
-// stereo sources, mono (64 blocks per wave), wide little-endian outputs.  Part 5.
+// stereo sources, mono (64 blocks per wave), wide little-endian outputs, and the channel counts that complete 1..8 for S24
+// little-endian sources (Msg.h:171 admits 1 to 8 channels): 3, 4, 5, 7.  Part 5.
 #ifdef OHGPU_DIAG_ONE_KERNEL
 #define OHGPU_LEAN_ONLY_KERNELS(X)
 #else
@@ -130,6 +132,10 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(32, 1, 2, true, 3, false)      \
     X(32, 1, 2, false, 3, false)     \
     X(32, 6, 3, true, 3, true)       \
-    X(32, 8, 3, true, 3, true)
+    X(32, 8, 3, true, 3, true)       \
+    X(32, 3, 3, true, 3, false)      \
+    X(32, 4, 3, true, 3, false)      \
+    X(32, 5, 3, true, 3, false)      \
+    X(32, 7, 3, true, 3, false)
 #endif
 #define OHGPU_BLOCK_PARTS 5
