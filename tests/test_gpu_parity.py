@@ -781,7 +781,7 @@ def test_src_groups_overlapped_on_two_streams(ctx):
     ctx.src_destroy(h)
 
 
-@pytest.mark.parametrize("layout", ["stereo_s24", "six_s24", "halfband_stereo", "halfband_eight", "mono_s16", "stereo_s32", "planar16"])
+@pytest.mark.parametrize("layout", ["stereo_s24", "six_s24", "halfband_stereo", "halfband_eight", "mono_s16", "stereo_s32", "planar16", "five_s24"])
 @pytest.mark.parametrize("seed", [11, 12])
 def test_long_row_units_match_the_oracle(ctx, layout, seed):
     """The unit schedule of large batches -- rows of several consecutive blocks, claimed before the one-block units (round 3,
@@ -793,7 +793,7 @@ def test_long_row_units_match_the_oracle(ctx, layout, seed):
     rate, taps, ch, bits, planar = {"stereo_s24": (44100, 32, 2, 24, False), "six_s24": (44100, 32, 6, 24, False),
                                     "halfband_stereo": (96000, 64, 2, 24, False), "halfband_eight": (96000, 64, 8, 24, False),
                                     "mono_s16": (44100, 32, 1, 16, False), "stereo_s32": (44100, 32, 2, 32, False),
-                                    "planar16": (44100, 32, 2, 16, True)}[layout]
+                                    "planar16": (44100, 32, 2, 16, True), "five_s24": (44100, 32, 5, 24, False)}[layout]
     h, ref = make_src(ctx, rate, 48000, taps)
     fb_src, fb_dst = (4 if planar else ch * bits // 8), ch * 3
     rows, src_parts, s_pos, d_pos = [], [], 0, 0

@@ -26,7 +26,7 @@ def main():
     ctx = capi.Context(0)
     deadline = time.time() + a.minutes * 60
     seed, counts = a.first_seed - 1, {"src_tilings": 0, "long_rows": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
-    layouts = ["stereo_s24", "six_s24", "halfband_stereo", "halfband_eight", "mono_s16", "stereo_s32", "planar16"]
+    layouts = ["stereo_s24", "six_s24", "halfband_stereo", "halfband_eight", "mono_s16", "stereo_s32", "planar16", "five_s24"]
     real_rng = np.random.default_rng
     formats = [(48000, 24, 2), (44100, 16, 2), (96000, 32, 2), (44100, 24, 1), (48000, 24, 6), (48000, 32, 8), (44100, 16, 6), (48000, 8, 2), (192000, 24, 2)]
     last = time.time()
