@@ -593,7 +593,11 @@ void src_lean_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                              : [w] "=&v"(dly[(s / 2) % (T / 4)])
                              : [hi] "v"((uint32_t)(rawp[s & 1] >> 32)), [lo] "v"((uint32_t)rawp[s & 1]), [n] "i"(look_ahead ? 1 : 0),
                                [sel] "v"(in_sel[sp % PH]) : "memory");
+#ifdef OHGPU_DIAG_NO_EXPECT
             } else if (!(t < tle)) {
+#else
+            } else if (__builtin_expect(!(t < tle), 0)) {       // (unlikely: kept out of the line of the outputs, one taken branch less per output)
+#endif
                 // no output needs it yet (M > L), or the block is done: wait for the sample (everything but the look-ahead just
                 // issued) and convert, in ONE statement
                 uint32_t w;
