@@ -166,13 +166,17 @@ __device__ __forceinline__ uint32_t lean_unpack_sel(uint32_t sh)
 // Waves per workgroup.  A 32-slot window: three per SIMD for stereo (134 registers; and what the LDS left by the coefficient
 // table allows with 16-frame stages, 11), FOUR for six channels and more -- those kernels have no pair exchange, fit 128
 // registers and their 8-frame stages leave the LDS room (same-box A/B on config 4, tools/exp_wide16.sh: six channels 1.75 ->
-// 1.67 ms, eight 2.25 -> 2.09 ms).  A half-band kernel carries the delay line on top: the eight-channel one still fits 128
-// registers, the six-channel one does not (it would spill).  Two per SIMD when the window alone is 128 registers (T = 64).
+// 1.67 ms, eight 2.25 -> 2.09 ms).  A half-band kernel carries the delay line on top and stays at three: the six-channel one
+// does not fit 128 registers (it would spill), and the eight-channel one, which just does, measured 2.5 % SLOWER squeezed
+// into them (tools/exp_hb8.sh: 2.98-2.99 against 2.91 ms).  Two per SIMD when the window alone is 128 registers (T = 64).
 static constexpr int lean_max_waves(int tw, int ch, bool halfband)
 {
     if (tw > 32) return 8;
     if (OHGPU_LEAN_MAX_WAVES_T32 > 0) return OHGPU_LEAN_MAX_WAVES_T32;
-    return (ch >= 6 && (!halfband || ch == 8)) ? OHGPU_LEAN_MAX_WAVES_WIDE : 12;
+#ifdef OHGPU_DIAG_HB8_WAVES
+    if (halfband && ch == 8) return OHGPU_DIAG_HB8_WAVES;      // (diagnostic: the eight-channel half-band kernel's occupancy)
+#endif
+    return (ch >= 6 && !halfband) ? OHGPU_LEAN_MAX_WAVES_WIDE : 12;
 }
 template <int T, int CH, int SB, int DB, bool HB = false>
 struct LeanGeom {

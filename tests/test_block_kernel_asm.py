@@ -111,12 +111,12 @@ def test_lean_kernels_keep_three_waves_per_simd(lean):
                 assert int(m.group(3)) <= 168, (m.group(1), m.group(3))
                 seen_halfband += _halfband(m.group(1))
                 # six channels and more are launched with up to SIXTEEN waves per workgroup (lean_max_waves): 128 registers --
-                # all but the six-channel half-band kernel, whose delay line does not fit
+                # but for the half-band kernels, which carry the delay line and stay at twelve
                 ch = int(re.search(r"src_lean_kernelILi\d+ELi(\d+)E", m.group(1)).group(1))
-                if ch >= 6 and not (_halfband(m.group(1)) and ch == 6):
+                if ch >= 6 and not _halfband(m.group(1)):
                     assert int(m.group(3)) <= 128, (m.group(1), m.group(3))
                     seen_wide += 1
-    assert seen_halfband >= 3 and seen_wide >= 8
+    assert seen_halfband >= 3 and seen_wide >= 7
 
 
 def tap_waits(body):
