@@ -21,6 +21,24 @@ ARCH = "gfx950"
 BLOCK_PARTS = 5                     # OHGPU_BLOCK_PARTS in csrc/src_block_common.h
 
 
+# The lean kernel's source leans on this toolchain's behaviour in two places: the internal option in SOURCE_FLAGS, and the
+# block placement behind __builtin_expect in its advance loop; tests/test_block_kernel_asm.py checks the generated code for
+# what the hand-counted waits need, so a different compiler fails those tests rather than silently miscounting -- but say so
+# at build time too.
+EXPECTED_HIP = "7.2"
+
+
+def toolchain_note():
+    try:
+        out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception:
+        return None
+    first = next((l for l in out.splitlines() if l.startswith("HIP version")), "")
+    if EXPECTED_HIP not in first:
+        return f"ohpipeline_amd/build.py: built and measured with HIP {EXPECTED_HIP}.x; this is '{first.strip()}' -- run tests/test_block_kernel_asm.py before trusting the block kernels"
+    return None
+
+
 def hipcc():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -49,6 +67,9 @@ def build(force=False, verbose=False, save_temps=False):
     flags are unchanged), then one link."""
     if not force and not is_stale():
         return LIB_PATH
+    note = toolchain_note()
+    if note:
+        print(note, file=sys.stderr)
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
