@@ -297,6 +297,16 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t taps_per_p
 int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src);
 /* ceil(in_frames * L / M): output frames available once in_frames input frames have arrived */
 uint64_t ohgpu_src_out_frames(uint32_t L, uint32_t M, uint64_t in_frames);
+/* Host only, no device needed: the tables ohgpu_src_create makes for the matrix-pipe resampler kernel (24-bit stereo,
+ * ohpipeline_amd/csrc/src_mfma_kernel.hip) -- the coefficients' balanced base-256 digits as padded rows
+ * [4 digits][L][96] bytes, and one 288-byte record per 16-output step of a block row (A-row offsets, the accumulators'
+ * initial values, the window's first 16-frame chunk).  *block_outputs = outputs per block; steps cover rows of up to
+ * max_blocks_per_row blocks.  Query sizes with NULL buffers.  OHGPU_ERR_UNSUPPORTED when the filter does not fit the
+ * tiling (taps_per_phase != 32, or a ratio whose 16-output tiles need more than 64 input frames).  Tests check the
+ * tables against the integer model on the CPU; the kernel is checked on the device. */
+int ohgpu_src_mfma_tables(uint32_t L, uint32_t M, uint32_t taps_per_phase, const int32_t* coef_q28, uint32_t max_blocks_per_row,
+                          uint8_t* coef_digits, size_t coef_digits_capacity, void* steps, size_t steps_capacity,
+                          size_t* coef_digits_bytes, size_t* steps_bytes, uint32_t* block_outputs);
 /* The messages of one batch may differ in layout (channels, depths, byte orders, packed or planar source): the batch is
  * planned per layout and runs one launch sequence per layout, messages of a stream in the order given. */
 int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
@@ -324,7 +334,8 @@ int ohgpu_src_batch_units(const ohgpu_batch* batch, uint64_t* units, uint64_t* l
 /* Kernel selection for A/B measurement and tests: 0 = default/best; 1 = baseline "v1" kernels; 2 = round 1's block resampler
  * kernel where it has the layout; 3 = the default kernels with the resampler's long-row unit schedule forced onto batches of
  * any size (a resampled batch created while 3 is set cuts every run of plain units into rows of three blocks -- what only a
- * batch of thousands of units gets otherwise -- so that tests reach that path with small inputs; results are identical). */
+ * batch of thousands of units gets otherwise -- so that tests reach that path with small inputs; results are identical);
+ * 4 = round 2's fp64 "lean" block kernel where round 4's matrix-pipe kernel (24-bit stereo) would run, for A/B. */
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant);
 
 #ifdef __cplusplus

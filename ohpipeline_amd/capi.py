@@ -101,6 +101,8 @@ SYMBOLS = {
     "ohgpu_src_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vpp]),
     "ohgpu_src_destroy": (C.c_int, [_vp, _vp]),
     "ohgpu_src_out_frames": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint64]),
+    "ohgpu_src_mfma_tables": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp, C.c_size_t, _vp, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "ohgpu_src_batch_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
@@ -156,6 +158,22 @@ def device_count():
     """GPUs visible to the process (ohgpu_device_count); 0 without one."""
     n = lib().ohgpu_device_count()
     return max(int(n), 0)
+
+
+MF_STEP = np.dtype([("aoff", "<u4", (16,)), ("b0", "<u4", (16,)), ("b1", "<u4", (16,)), ("b2", "<i4", (16,)), ("kc", "<u4"), ("pad", "<u4", (7,))])
+assert MF_STEP.itemsize == 288
+
+
+def src_mfma_tables(L, M, T, coef_q28, max_blocks_per_row=8):
+    """(digits [4][L][96] int8, steps MF_STEP[], outputs per block) -- the matrix-pipe resampler kernel's host tables (no device)."""
+    coef = np.ascontiguousarray(coef_q28, dtype=np.int32)
+    nb, ns, lb = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
+    check(lib().ohgpu_src_mfma_tables(L, M, T, coef.ctypes.data, max_blocks_per_row, None, 0, None, 0, C.byref(nb), C.byref(ns), C.byref(lb)))
+    dig = np.zeros(nb.value, dtype=np.int8)
+    steps = np.zeros(ns.value // MF_STEP.itemsize, dtype=MF_STEP)
+    check(lib().ohgpu_src_mfma_tables(L, M, T, coef.ctypes.data, max_blocks_per_row, dig.ctypes.data, dig.nbytes, steps.ctypes.data, steps.nbytes,
+                                      C.byref(nb), C.byref(ns), C.byref(lb)))
+    return dig.reshape(4, L, 96), steps, lb.value
 
 
 def src_design(rate_in, rate_out, taps_per_phase=32, beta=9.0, f_pass=20000.0):

@@ -107,7 +107,7 @@ int ohgpu_device_name(ohgpu_ctx* ctx, char* buf, size_t buf_bytes)
 
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > 3) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
+    if (!ctx || variant < 0 || variant > 4) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
     ctx->variant = variant;
     return OHGPU_OK;
 }
@@ -615,6 +615,31 @@ uint64_t ohgpu_src_out_frames(uint32_t L, uint32_t M, uint64_t in_frames)
     return (in_frames * L + M - 1) / M;
 }
 
+int ohgpu_src_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, uint32_t max_blocks_per_row,
+                          uint8_t* coef_digits, size_t coef_digits_capacity, void* steps_out, size_t steps_capacity,
+                          size_t* coef_digits_bytes, size_t* steps_bytes, uint32_t* block_outputs)
+{
+    if (!coef_q28 || L == 0 || M == 0 || (uint64_t)L * T > (1u << 22) || max_blocks_per_row == 0 || max_blocks_per_row > 64)
+        return set_error(OHGPU_ERR_INVALID, "ohgpu_src_mfma_tables: bad argument");
+    std::vector<uint8_t> adig;
+    std::vector<MfStep> steps;
+    const uint32_t L_blk = T == 32 ? src_block_outputs(L, 6) : 0;
+    if (L_blk == 0 || !build_mfma_tables(L, M, T, coef_q28, L_blk, max_blocks_per_row, &adig, &steps))
+        return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_mfma_tables: L=%u M=%u T=%u does not fit the 16-output tiling", L, M, T);
+    if (coef_digits_bytes) *coef_digits_bytes = adig.size();
+    if (steps_bytes) *steps_bytes = steps.size() * sizeof(MfStep);
+    if (block_outputs) *block_outputs = L_blk;
+    if (coef_digits) {
+        if (coef_digits_capacity < adig.size()) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_mfma_tables: coef_digits too small");
+        memcpy(coef_digits, adig.data(), adig.size());
+    }
+    if (steps_out) {
+        if (steps_capacity < steps.size() * sizeof(MfStep)) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_mfma_tables: steps too small");
+        memcpy(steps_out, steps.data(), steps.size() * sizeof(MfStep));
+    }
+    return OHGPU_OK;
+}
+
 int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, ohgpu_src** out)
 {
     CTX_GUARD("ohgpu_src_create");
@@ -649,9 +674,23 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_coef_q28, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(s->d_coef, cd.data(), n * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_coef_q28, coef_q28, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    // src_mfma_kernel's digit tables, for the block length the planner gives 24-bit stereo output (rows of up to 8 blocks)
+    std::vector<uint8_t> adig;
+    std::vector<MfStep> steps;
+    const uint32_t mf_L_blk = T == 32 ? src_block_outputs(L, 6) : 0;
+    if (e == hipSuccess && mf_L_blk != 0 && build_mfma_tables(L, M, T, coef_q28, mf_L_blk, 8, &adig, &steps)) {
+        e = hipMalloc((void**)&s->d_mf_adig, adig.size());
+        if (e == hipSuccess) e = hipMalloc((void**)&s->d_mf_steps, steps.size() * sizeof(MfStep));
+        if (e == hipSuccess) e = hipMemcpy(s->d_mf_adig, adig.data(), adig.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->d_mf_steps, steps.data(), steps.size() * sizeof(MfStep), hipMemcpyHostToDevice);
+        s->mf_L_blk = mf_L_blk;
+        s->mf_kb_cap = 8;
+    }
     if (e != hipSuccess) {
         if (s->d_coef) hipFree(s->d_coef);
         if (s->d_coef_q28) hipFree(s->d_coef_q28);
+        if (s->d_mf_adig) hipFree(s->d_mf_adig);
+        if (s->d_mf_steps) hipFree(s->d_mf_steps);
         delete s;
         return set_error(OHGPU_ERR_DEVICE, "ohgpu_src_create: %s", hipGetErrorString(e));
     }
@@ -665,6 +704,8 @@ int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src)
     if (!src) return OHGPU_OK;
     hipFree(src->d_coef);
     hipFree(src->d_coef_q28);
+    if (src->d_mf_adig) hipFree(src->d_mf_adig);
+    if (src->d_mf_steps) hipFree(src->d_mf_steps);
     delete src;
     return OHGPU_OK;
 }
@@ -874,7 +915,9 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
         if (claim != OHGPU_OK) return claim;
         // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
-        if (batch->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts)
+        if (batch->fast.mfma && (ctx->variant == 0 || ctx->variant == 3))                            // 24-bit stereo: the taps on the matrix pipe (round 4)
+            OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+        else if (batch->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts; variant 4: the lean kernel where round 4's would run)
             OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         else
             OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));

@@ -86,6 +86,13 @@ struct RampJob {              // ramp_plane_kernel: frames [i0, i0 + count) of o
     uint8_t  pad[3];
 };
 static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24 && sizeof(LeanUnit) == 32 && sizeof(RampJob) == 32, "plan layouts");
+struct MfStep {               // src_mfma_kernel: one step = 16 consecutive output frames of a row (the same for every row: rows start at phase 0)
+    uint32_t aoff[16];        // output m's A row: byte offset into a digit's table, phase * 96 + (31 + k0 - n0(m))
+    uint32_t b0[16], b1[16], b2[16];   // its accumulators' initial values: bits 0..15, 16..31, 32.. of 32896 * sum(c[phase]) + 2^27
+    uint32_t kc;              // the step's window is input chunks kc .. kc + 3 (a chunk = 16 frames; frame 0 of chunk 0 = the row's frame -32)
+    uint32_t pad[7];
+};
+static_assert(sizeof(MfStep) == 288, "MfStep");
 
 struct SrcFastParams {        // kernel argument block
     const SrcSeg*  segs;
@@ -116,6 +123,10 @@ struct SrcFastPlan {
     bool     lean = false;        // the batch runs on src_lean_kernel (round 2) rather than src_block_kernel
     bool     lean_only = false;   // ... and round 1's kernel has no instantiation for its layout (variant 2 then runs the lean kernel too)
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
+    bool     mfma = false;        // ... and its layout is one src_mfma_kernel (round 4) serves: same units and planes, the filter's digit tables
+    const void* d_mf_adig = nullptr;   // (owned by the ohgpu_src)
+    const void* d_mf_steps = nullptr;
+    uint32_t mf_adig_stride = 0;
     void*    d_planes = nullptr;  // uint16: RampApplicator's multiplier per output frame of every ramped unit, [blocks of the unit][L_blk]
     uint32_t plane_stride = 0;    // the unit of SrcWork::plane / LeanUnit::plane in bytes (16: planes are as long as their units)
     void*    d_slab = nullptr;    // the one allocation the arrays below live in
@@ -263,6 +274,11 @@ struct ohgpu_src {
                                   // lean kernel's half-band instantiations multiply by the 33 taps that are not
     double*  d_coef;              // [L][T] exact integer-valued doubles (Q28)
     int32_t* d_coef_q28;          // [L][T] int32
+    // src_mfma_kernel's tables (T = 32 filters whose ratio the 16-output tiling holds; null otherwise), made for blocks of
+    // mf_L_blk outputs and rows of up to mf_kb_cap blocks
+    uint8_t* d_mf_adig = nullptr; // [4 digits][L][96]
+    ohgpu::MfStep* d_mf_steps = nullptr;
+    uint32_t mf_L_blk = 0, mf_kb_cap = 0;
 };
 
 struct ohgpu_batch {
@@ -326,6 +342,12 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
+hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_kernel.hip
+bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, uint32_t L_blk, uint32_t kb_cap,
+                       std::vector<uint8_t>* adig, std::vector<MfStep>* steps);
+bool src_mfma_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db);
+void src_mfma_geometry(uint32_t* rows, uint32_t* wave_lds_bytes, uint32_t* max_waves);
+uint32_t src_block_outputs(uint32_t L, uint32_t fb_dst);      // outputs per block (0: no block length fits): whole phase periods, >= 128, whole 64-byte lines
 hipError_t launch_ramp_planes(const ohgpu_ctx* ctx, const void* d_jobs, uint32_t n_jobs, void* d_planes, hipStream_t s);   // csrc/ramp_plane_kernel.hip
 bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,

@@ -77,6 +77,17 @@ static DevSrcDesc make_piece(const ohgpu_src_msg_desc& d, const DevSrcDesc& dv, 
     return o;
 }
 
+// a block: whole phase periods (multiple of L), at least `min_blk` outputs, and a whole number of 64-byte output lines
+static uint32_t src_block_outputs_for(uint32_t L, uint32_t fb_dst, uint32_t min_blk)
+{
+    uint32_t L_blk = L * ((min_blk + L - 1) / L);
+    uint32_t k = 1;
+    while (k <= 64 && ((uint64_t)L_blk * k * fb_dst) % 64 != 0) k++;
+    if (k > 64) return 0;
+    return L_blk * k;
+}
+uint32_t src_block_outputs(uint32_t L, uint32_t fb_dst) { return src_block_outputs_for(L, fb_dst, 128); }
+
 int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n,
                   const std::vector<DevSrcDesc>& dev)
 {
@@ -114,13 +125,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
 #ifdef OHGPU_DIAG
     if (const char* e = getenv("OHGPU_DIAG_MIN_BLOCK")) min_blk = (uint32_t)atoi(e);     // (diagnostic builds: longer blocks per lane)
 #endif
-    uint32_t L_blk = L * ((min_blk + L - 1) / L);
-    {
-        uint32_t k = 1;
-        while (k <= 64 && ((uint64_t)L_blk * k * fb_dst) % 64 != 0) k++;
-        if (k > 64) return OHGPU_OK;
-        L_blk *= k;
-    }
+    const uint32_t L_blk = src_block_outputs_for(L, fb_dst, min_blk);
+    if (L_blk == 0) return OHGPU_OK;
     const uint64_t M_blk64 = (uint64_t)L_blk * M / L;
     if (M_blk64 + T > 32000 || M_blk64 < T) return OHGPU_OK;    // a block is at least one filter length of input
     const uint32_t M_blk = (uint32_t)M_blk64;
@@ -259,9 +265,15 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // work allows (claimed first: every wave starts on one), everything else -- what does not divide, and the ramped units,
     // which stay one block long because a long unit would run the ramp path for all its outputs -- as one-block units for
     // the waves to level out on.
+    // src_mfma_kernel (round 4) runs the same units for the layouts it serves, from the filter's digit tables -- made for this
+    // block length and rows of up to mf_kb_cap blocks -- with its own number of waves per CU
+    uint32_t mf_rows = 0, mf_wave_lds = 0, mf_max_waves = 0;
+    src_mfma_geometry(&mf_rows, &mf_wave_lds, &mf_max_waves);
+    const bool mfma = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_adig != nullptr && flt->mf_L_blk == L_blk &&
+                      mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
     std::vector<LeanUnit> lean_units;
     if (lean) {
-        const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * lean_max_waves;
+        const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * (mfma ? mf_max_waves : lean_max_waves);
         // Same-box A/Bs on the headline workload, alternating passes, +-0.2 % within a box.  Eleven waves per CU
         // (tools/exp_units3.sh): one block per row everywhere 0.4955 ms; one long unit of 8 blocks per wave 0.4832; 6 blocks and
         // two rounds of short units kept 0.4995; two rounds of 4-block units 0.5025; three rounds of 2-block units 0.4933.
@@ -277,6 +289,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         if (const char* e = getenv("OHGPU_DIAG_KB_MAX")) kb_max = (uint32_t)atoi(e);
         if (const char* e = getenv("OHGPU_DIAG_LONG_ROUNDS")) long_rounds = (uint32_t)atoi(e);
 #endif
+        if (mfma && kb_max > flt->mf_kb_cap) kb_max = flt->mf_kb_cap;      // (the step table's length)
         // the plain, full one-block units (the only ones that merge), in runs between ramped or partly filled ones
         uint64_t plain_total = 0;
         for (const SrcWork& w : work) plain_total += (!(w.flags & kWorkRamped) && w.n_blocks == rows) ? 1u : 0u;
@@ -401,6 +414,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.lean_wave_lds_bytes = lean_wave_lds;
     f.plane_stride = 16;                                              // SrcWork::plane counts 16-byte pieces
     f.lean_max_waves = lean_max_waves;
+    f.mfma = mfma;
+    f.d_mf_adig = mfma ? flt->d_mf_adig : nullptr;
+    f.d_mf_steps = mfma ? flt->d_mf_steps : nullptr;
+    f.mf_adig_stride = L * 96;
     f.fast_out_frames = fast_frames;
     SrcFastParams& p = f.params;
     memset(&p, 0, sizeof(p));

@@ -1,0 +1,105 @@
+"""The matrix-pipe resampler kernel's host tables (ohpipeline_amd/csrc/src_mfma_kernel.hip, `ohgpu_src_mfma_tables`), on the CPU.
+
+The kernel computes an output as six int8 dot products (offset digits of the samples x balanced digits of the Q28
+coefficients) and recombines them in 32-bit integers.  Everything that decides WHICH bytes meet and what the constants are
+lives in two host-made tables; this test replays the kernel's arithmetic from those tables in numpy -- digit planes, the A rows
+taken from the padded coefficient rows at the recorded offsets, the accumulators' initial values, the recombination -- and
+compares every output of whole block rows with the oracle's integer model.  No GPU: the device code is checked by the `gpu`
+tests; this pins the tables and the arithmetic identity they rely on."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from ohpipeline_amd import capi
+
+SRC_DESC = oracle_lib.SRC_MSG_DESC
+
+
+def oracle_outputs(ref, x, n_out):
+    """x: int32 [frames] (one channel, 24-bit values) -> the first n_out outputs of the integer model, stream starting at frame 0."""
+    raw = np.zeros((x.size, 3), dtype=np.uint8)
+    u = x.astype(np.int64) & 0xFFFFFF
+    raw[:, 0], raw[:, 1], raw[:, 2] = u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF
+    d = np.zeros(1, dtype=SRC_DESC)
+    d["src_offset"], d["src_frame0"], d["src_frames"], d["out_frame0"] = 0, 0, x.size, 0
+    d["dst_offset"], d["n_frames"] = 0, n_out
+    d["ramp_start"], d["ramp_end"], d["attenuation"] = 16384, 16384, 256
+    d["channels"], d["src_bits"], d["src_endian"], d["dst_bits"], d["dst_endian"] = 1, 24, 1, 24, 1
+    out = np.zeros(n_out * 3, dtype=np.uint8)
+    assert ref.process_batch(d, raw.reshape(-1), out) == 0
+    o = out.reshape(-1, 3).astype(np.int64)
+    v = o[:, 0] | (o[:, 1] << 8) | (o[:, 2] << 16)
+    return np.where(v >= 1 << 23, v - (1 << 24), v)
+
+
+def emulate_row(dig, steps, L_blk, kb, frames):
+    """frames: int64 [32 + M_blk kb + slack], frames[32 + k] = input frame k of the row (frames[0..31] its history).
+    Returns the row's L_blk * kb outputs computed the kernel's way."""
+    u = frames & 0xFFFFFF
+    # offset digits of the two low bytes, the signed top byte
+    d = [((u & 0xFF) ^ 0x80).astype(np.uint8).view(np.int8).astype(np.int64),
+         (((u >> 8) & 0xFF) ^ 0x80).astype(np.uint8).view(np.int8).astype(np.int64),
+         ((u >> 16) & 0xFF).astype(np.uint8).view(np.int8).astype(np.int64)]
+    out = np.zeros(L_blk * kb, dtype=np.int64)
+    for t in range(L_blk * kb // 16):
+        st = steps[t]
+        k0 = int(st["kc"]) * 16
+        for m in range(16):
+            aoff = int(st["aoff"][m])
+            p, o = divmod(aoff, 96)
+            a = [dig[j, p, o:o + 64].astype(np.int64) for j in range(4)]
+            win = [dd[k0:k0 + 64] for dd in d]
+            s = [int(st["b0"][m]), 0, int(st["b1"][m]), 0, int(st["b2"][m]), 0]
+            for i in range(3):
+                for j in range(4):
+                    s[i + j] += int(np.dot(a[j], win[i]))
+            assert all(abs(v) < 1 << 22 for v in s), "an accumulator left the range the recombination assumes"
+            t0 = (s[1] << 8) + s[0]
+            uu = (s[3] << 8) + s[2] + (t0 >> 16)
+            w = (s[5] << 8) + s[4] + (uu >> 16)
+            assert abs(t0) < 1 << 31 and abs(uu) < 1 << 31 and abs(w << 4) < 1 << 31
+            y = (w << 4) | ((uu >> 12) & 15)
+            out[16 * t + m] = min(max(y, -(1 << 23)), (1 << 23) - 1)
+    return out
+
+
+@pytest.mark.parametrize("rates", [(44100, 48000), (48000, 44100), (32000, 48000)])
+def test_tables_reproduce_the_integer_model(rates):
+    ref = oracle_lib.Src(*rates)
+    L, M, T = ref.L, ref.M, ref.T
+    dig, steps, L_blk = capi.src_mfma_tables(L, M, T, ref.coef_q28, 8)
+    assert dig.shape == (4, L, 96) and L_blk % 16 == 0 and L_blk % L == 0
+    M_blk = L_blk * M // L
+    assert steps.size == L_blk // 16 * 8
+    # digits: balanced, and they recompose to the coefficients, oldest tap last
+    c = ref.coef_q28.reshape(L, T).astype(np.int64)
+    rec = sum(dig[j, :, 32:64].astype(np.int64) << (8 * j) for j in range(4))
+    assert np.array_equal(rec[:, ::-1], c)
+    assert not dig[:, :, :32].any() and not dig[:, :, 64:].any()
+    rng = np.random.default_rng(7)
+    kb = 3
+    n_in = 2 * M_blk * kb + 64
+    for kind in ("noise", "extremes"):
+        if kind == "noise":
+            x = rng.integers(-(1 << 23), 1 << 23, size=n_in, dtype=np.int64)
+        else:
+            x = rng.choice(np.array([-(1 << 23), (1 << 23) - 1, 0, -1, 1, 0x7FFF80, -0x7FFF80]), size=n_in)
+        want = oracle_outputs(ref, x.astype(np.int32), 2 * L_blk * kb)
+        # row 0 of a stream (zero history) and the row after it (its history = the stream's own frames)
+        for r in range(2):
+            first = r * M_blk * kb
+            frames = np.zeros(32 + M_blk * kb + 80, dtype=np.int64)
+            lo = first - 32
+            src = x[max(lo, 0):first + M_blk * kb + 80]
+            frames[max(-lo, 0):max(-lo, 0) + src.size] = src
+            got = emulate_row(dig, steps, L_blk, kb, frames)
+            assert np.array_equal(got, want[r * L_blk * kb:(r + 1) * L_blk * kb]), (kind, r)
+
+
+def test_unsupported_geometries_are_refused():
+    ref = oracle_lib.Src(96000, 48000, 64)
+    with pytest.raises(capi.OhGpuError):
+        capi.src_mfma_tables(ref.L, ref.M, ref.T, ref.coef_q28, 8)
+    ref = oracle_lib.Src(88200, 48000)                   # 32 taps, but 15 M / L = 27 frames per tile: beyond the 64-frame window
+    with pytest.raises(capi.OhGpuError):
+        capi.src_mfma_tables(ref.L, ref.M, ref.T, ref.coef_q28, 8)
