@@ -679,9 +679,11 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
     std::vector<MfStep> steps;
     const uint32_t mf_L_blk = T == 32 ? src_block_outputs(L, 6) : 0;
     if (e == hipSuccess && mf_L_blk != 0 && build_mfma_tables(L, M, T, coef_q28, mf_L_blk, 8, &adig, &steps)) {
-        e = hipMalloc((void**)&s->d_mf_adig, adig.size());
+        std::vector<uint8_t> amat;
+        build_mfma_images(adig, steps, L, &amat);
+        e = hipMalloc((void**)&s->d_mf_amat, amat.size());
         if (e == hipSuccess) e = hipMalloc((void**)&s->d_mf_steps, steps.size() * sizeof(MfStep));
-        if (e == hipSuccess) e = hipMemcpy(s->d_mf_adig, adig.data(), adig.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->d_mf_amat, amat.data(), amat.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(s->d_mf_steps, steps.data(), steps.size() * sizeof(MfStep), hipMemcpyHostToDevice);
         s->mf_L_blk = mf_L_blk;
         s->mf_kb_cap = 8;
@@ -689,7 +691,7 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
     if (e != hipSuccess) {
         if (s->d_coef) hipFree(s->d_coef);
         if (s->d_coef_q28) hipFree(s->d_coef_q28);
-        if (s->d_mf_adig) hipFree(s->d_mf_adig);
+        if (s->d_mf_amat) hipFree(s->d_mf_amat);
         if (s->d_mf_steps) hipFree(s->d_mf_steps);
         delete s;
         return set_error(OHGPU_ERR_DEVICE, "ohgpu_src_create: %s", hipGetErrorString(e));
@@ -704,7 +706,7 @@ int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src)
     if (!src) return OHGPU_OK;
     hipFree(src->d_coef);
     hipFree(src->d_coef_q28);
-    if (src->d_mf_adig) hipFree(src->d_mf_adig);
+    if (src->d_mf_amat) hipFree(src->d_mf_amat);
     if (src->d_mf_steps) hipFree(src->d_mf_steps);
     delete src;
     return OHGPU_OK;

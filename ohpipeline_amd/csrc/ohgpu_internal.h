@@ -124,9 +124,8 @@ struct SrcFastPlan {
     bool     lean_only = false;   // ... and round 1's kernel has no instantiation for its layout (variant 2 then runs the lean kernel too)
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
     bool     mfma = false;        // ... and its layout is one src_mfma_kernel (round 4) serves: same units and planes, the filter's digit tables
-    const void* d_mf_adig = nullptr;   // (owned by the ohgpu_src)
+    const void* d_mf_amat = nullptr;   // (owned by the ohgpu_src)
     const void* d_mf_steps = nullptr;
-    uint32_t mf_adig_stride = 0;
     void*    d_planes = nullptr;  // uint16: RampApplicator's multiplier per output frame of every ramped unit, [blocks of the unit][L_blk]
     uint32_t plane_stride = 0;    // the unit of SrcWork::plane / LeanUnit::plane in bytes (16: planes are as long as their units)
     void*    d_slab = nullptr;    // the one allocation the arrays below live in
@@ -276,7 +275,7 @@ struct ohgpu_src {
     int32_t* d_coef_q28;          // [L][T] int32
     // src_mfma_kernel's tables (T = 32 filters whose ratio the 16-output tiling holds; null otherwise), made for blocks of
     // mf_L_blk outputs and rows of up to mf_kb_cap blocks
-    uint8_t* d_mf_adig = nullptr; // [4 digits][L][96]
+    uint8_t* d_mf_amat = nullptr; // the steps' A operands, lane-linear: [step][4 digits][64 lanes][16 bytes] (build_mfma_images)
     ohgpu::MfStep* d_mf_steps = nullptr;
     uint32_t mf_L_blk = 0, mf_kb_cap = 0;
 };
@@ -345,6 +344,7 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
 hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_kernel.hip
 bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, uint32_t L_blk, uint32_t kb_cap,
                        std::vector<uint8_t>* adig, std::vector<MfStep>* steps);
+void build_mfma_images(const std::vector<uint8_t>& adig, const std::vector<MfStep>& steps, uint32_t L, std::vector<uint8_t>* amat);
 bool src_mfma_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db);
 void src_mfma_geometry(uint32_t* rows, uint32_t* wave_lds_bytes, uint32_t* max_waves);
 uint32_t src_block_outputs(uint32_t L, uint32_t fb_dst);      // outputs per block (0: no block length fits): whole phase periods, >= 128, whole 64-byte lines

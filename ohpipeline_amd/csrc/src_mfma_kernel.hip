@@ -22,21 +22,25 @@
 //   * DIGIT PLANES in LDS: per wave [digit 3][column tile 4][chunk slot 4][column 16][16 frames] bytes = 12 KB.  A chunk is 16
 //     consecutive input frames; the four slots are a ring over chunk index (a tile's window is exactly four chunks: its K run
 //     starts on a chunk boundary).  The B operand of lane (g = lane / 16, n = lane % 16) is ONE ds_read_b128: chunk kc + g,
-//     column n -- conflict-free, the hardware's 16-lane groups take complementary columns from two chunks.
-//   * THE SPLIT: lane (row = lane / 2, half = lane % 2) loads the 48 bytes of its row's 8 frames of the chunk straight from
-//     memory (three unaligned 16-byte loads; no staging buffer), transposes them into six plane dwords pairs with a two-level
-//     v_perm_b32 network (2 permutes per plane dword, compile-time selectors), flips the offset digits' top bits and writes six
-//     ds_write_b64.  The next chunk's loads are issued before the permutes of this one.
-//   * COEFFICIENT DIGITS: per digit and phase a 96-byte row [32 zeros | the phase's 32 digit bytes, oldest tap last | 32 zeros]
-//     (global memory, 61 KB for L = 160: L1/L2 resident).  Output m of a step meets input frame k0 + k with tap
-//     n0(m) + 32 - k0 - k, so its A row is the 64 bytes of its phase's row from offset 31 + k0 - n0(m) on: lane (m, g) makes
-//     ONE unaligned 16-byte load per digit and step, shared by the four column tiles.
+//     column n -- conflict-free.
+//   * EVERY GLOBAL ACCESS IS LANE-CONTIGUOUS.  The vector memory path handles a wave's access per lane unless neighbouring
+//     lanes touch neighbouring bytes: the first version of this kernel -- every lane fetching its own 48 bytes, 12-byte stores
+//     per lane, 16-byte coefficient rows per lane -- kept the texture addresser busy 98 % of a 0.70 ms launch (179 L1 accesses
+//     per load instruction, TA_TA_BUSY = the launch).  So a chunk of the 32 rows (32 x 96 bytes) is fetched as 192 pieces of
+//     16 bytes in row-major order -- six neighbouring lanes per row, three instructions -- into a 3 KB STAGE in LDS, from
+//     which the split's lanes take their 48 bytes; the packed output of a step (32 rows x 96 bytes) goes through the same
+//     stage the other way and leaves as 192 pieces; and the A operands are a lane-linear image per step (host table, 4 KB a
+//     step, L2 resident), not rows gathered per lane.
+//   * THE SPLIT: lane (row = lane / 2, half = lane % 2) transposes the 48 bytes of its row's 8 frames into six plane dword
+//     pairs with a two-level v_perm_b32 network (2 permutes per plane dword, compile-time selectors), flips the offset digits'
+//     top bits and writes three ds_write2_b64.
+//   * ONE WAIT PER STEP.  vmcnt counts loads and stores together, in issue order: the next step's operands and the next chunk
+//     are requested at the top of a step and waited for once, behind the step's arithmetic.
 //   * RECOMBINATION in 32-bit integers: T0 = S0 + (S1 << 8), T1 = S2 + (S3 << 8), T2 = S4 + (S5 << 8) (each below 2^30),
 //     U = T1 + (T0 >> 16), W = T2 + (U >> 16), y = (W << 4) | bits 12..15 of U = floor(acc / 2^28) exactly (the low 16 bits of
 //     T0 and the low 12 of U cannot carry into bit 28), then one v_med3_i32.  Ten instructions per output.
 //   * PACK: the two channel lanes of a row hold four frames each; they exchange two values (DPP quad_perm), three v_perm_b32
-//     make the lane's 12 bytes, ONE global_store_dwordx3 per lane and tile writes them: a row's 16 frames are 96 contiguous
-//     bytes, consecutive steps complete the lines in the L2.
+//     make the lane's 12 bytes of the row's 96.
 // Bit-exact against the integer model (oracle/ohp_pipeline.c) like the kernels before it: same sum, same rounding.
 #include <hip/hip_runtime.h>
 
@@ -49,27 +53,47 @@
 #include "pcm_device.h"
 #include "src_block_common.h"
 
+#ifdef MF_DIAG_NO_MFMA
+#define MF_MFMA(a, b, c) ((c) + (a) + (b))
+#else
+#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_16x16x64_i8((a), (b), (c), 0, 0, 0)
+#endif
+
 namespace ohgpu {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef v4i v4i_u __attribute__((aligned(1)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-typedef u32x3 u32x3_u __attribute__((aligned(1)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 #ifndef OHGPU_MFMA_WAVES
-#define OHGPU_MFMA_WAVES 8                         // waves per workgroup = per CU (LDS: 12 KB each)
+#define OHGPU_MFMA_WAVES 10                        // waves per workgroup = per CU (LDS: 15 KB each)
 #endif
 constexpr uint32_t kMfPlaneBytes = 3 * 4 * 4 * 256; // [digit][column tile][chunk slot][column][16]
+constexpr uint32_t kMfStageBytes = 32 * 96;         // one chunk of every row as it lies in memory / one step of every row, packed
+constexpr uint32_t kMfWaveLds = kMfPlaneBytes + kMfStageBytes;
+constexpr uint32_t kMfStepImage = 4 * 1024;         // a step's A operands: [coefficient digit 4][lane 64][16 bytes]
 
 __device__ __forceinline__ uint32_t mf_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// Sixteen bytes from arena offset a, bytes outside the arena read as zero (they are frames before a stream's first or beyond the
+// last frame any output needs).  Only units at an end of the arena come here (kWorkChecked).
+__device__ __noinline__ u32x4 mf_load_piece_checked(const uint8_t* __restrict__ src, int64_t a, uint64_t arena_bytes)
+{
+    if (a >= 0 && (uint64_t)a + 16 <= arena_bytes) return *(const u32x4_u*)(src + a);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma nounroll
+    for (int bb = 0; bb < 16; bb++) {
+        const int64_t a1 = a + bb;
+        if (a1 >= 0 && (uint64_t)a1 < arena_bytes) w[bb >> 2] |= (uint32_t)src[a1] << (8 * (bb & 3));
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
 
 template <bool SRC_LE, bool DST_LE>
 __global__ __launch_bounds__(OHGPU_MFMA_WAVES * 64)
 void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
-                     const uint8_t* __restrict__ adig, const uint32_t adig_stride,
-                     const MfStep* __restrict__ steps,
+                     const uint8_t* __restrict__ amat, const MfStep* __restrict__ steps,
                      const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint64_t src_arena_bytes,
                      const uint32_t L_blk1, const uint32_t M_blk1, uint32_t* __restrict__ unit_counter)
@@ -79,15 +103,29 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     const uint32_t lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t n_waves = blockDim.x >> 6;
-    uint8_t* const wl = smem + wave * kMfPlaneBytes;
+    uint8_t* const wl = smem + wave * kMfWaveLds;
+    uint8_t* const stage = wl + kMfPlaneBytes;
 
-    // lane roles.  Matrix operands and results: g = K group / output quad, n = A row (output of the step) / column of the tile.
+    // ---- lane roles ----
+    // matrix operands and results: g = K group / output quad, n = A row (output of the step) / column of the tile
     const uint32_t g = lane >> 4, n = lane & 15;
     const uint32_t rr = n >> 1, ch = n & 1;                // the column's row within its tile, its channel
+    const uint8_t* const b_lds = wl + n * 16;              // + (digit * 4 + tile) * 1024 + slot * 256
     // the split: row and half chunk
     const uint32_t rs = lane >> 1, hs = lane & 1;
     uint8_t* const split_lds = wl + (rs >> 3) * 1024 + (rs & 7) * 32 + hs * 8;   // + digit * 4096 + slot * 256 + channel * 16
-    const uint8_t* const b_lds = wl + n * 16;                                     // + (digit * 4 + tile) * 1024 + slot * 256
+    const uint8_t* const split_stage = stage + rs * 96 + hs * 48;
+    // transfers: piece f = 64 k + lane of the stage (k = 0..2) is piece f % 6 of row f / 6
+    uint32_t tr_row[3], tr_piece[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t f = 64u * k + lane;
+        tr_row[k] = f / 6u;
+        tr_piece[k] = f - 6u * tr_row[k];
+    }
+    uint8_t* const tr_stage = stage + lane * 16;           // + 1024 k
+    // a tile's packed result: 12 bytes at 24 g + 12 ch of the row's 96 -- an aligned 8-byte and a 4-byte store
+    uint8_t* const out_stage = stage + rr * 96 + 24 * g + 12 * ch;    // + tile * 768
 
     // pack: {got, own} -> the lane's three dwords of two frames.  Channel 0 stores its own frames v = 0, 1 with its partner's,
     // channel 1 its own v = 2, 3 with its partner's: own = (L lane ? L : R), got = the other channel's value of the same frame.
@@ -112,43 +150,43 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         const bool first = (wk.flags & kWorkFirst) != 0;
         const uint32_t n_steps = L_blk >> 4;
         const uint32_t c_last = (M_blk + 31u) >> 4;                     // the last chunk any output of a row needs
-
-        // the split's source: frame 16 c + 8 hs of row rs (rows past the unit's last re-read row 0)
-        const int64_t split_off = wk.src_row0 + (int64_t)((rs < n_blocks ? rs : 0u) * M_blk) * 6 + 48 * (int64_t)hs;
-        const uint8_t* const split_src = src + split_off;
         const bool zero_history = first && rs == 0;                    // the stream's block 0: frames before it read as zeros
 
-        u32x4 raw[3];
-        auto load_chunk = [&](uint32_t c) __attribute__((always_inline)) {
+        // ---- the transfers' addresses: a wave-uniform base and a 32-bit lane offset (a unit spans far less than 4 GiB) ----
+        const uint8_t* const unit_src = src + wk.src_row0;
+        uint8_t* const unit_dst = dst + wk.dst_row0;
+        const uint32_t row_src_bytes = M_blk * 6u, row_dst_bytes = L_blk * 6u;
+        uint32_t tr_src[3], tr_dst[3];
+        bool tr_valid[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            tr_valid[k] = tr_row[k] < n_blocks;                        // (rows past the unit's last re-read row 0 and are not stored)
+            tr_src[k] = (tr_valid[k] ? tr_row[k] : 0u) * row_src_bytes + 16u * tr_piece[k];      // + 96 c
+            tr_dst[k] = tr_row[k] * row_dst_bytes + 16u * tr_piece[k];                           // + 96 t
+        }
+        auto load_chunk = [&](uint32_t c, u32x4 (&raw)[3]) __attribute__((always_inline)) {
             if (!checked) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) raw[k] = *(const u32x4_u*)(split_src + (uint64_t)c * 96 + 16 * k);
+                for (int k = 0; k < 3; k++) raw[k] = *(const u32x4_u*)(unit_src + (tr_src[k] + c * 96u));
             } else {
-                // a unit at an end of the arena: a 16-byte piece that is not wholly inside is fetched byte by byte, bytes outside
-                // read as zero (they are frames before a stream's first or beyond the last frame any output needs)
+                // a unit at an end of the arena: a 16-byte piece that is not wholly inside is fetched byte by byte (out of line)
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const int64_t a = split_off + (int64_t)c * 96 + 16 * k;
-                    if (a >= 0 && (uint64_t)a + 16 <= src_arena_bytes) raw[k] = *(const u32x4_u*)(src + a);
-                    else {
-                        uint32_t w[4] = {0, 0, 0, 0};
-                        for (int bb = 0; bb < 16; bb++) {
-                            const int64_t a1 = a + bb;
-                            if (a1 >= 0 && (uint64_t)a1 < src_arena_bytes) w[bb >> 2] |= (uint32_t)src[a1] << (8 * (bb & 3));
-                        }
-                        raw[k] = u32x4{w[0], w[1], w[2], w[3]};
-                    }
-                }
+                for (int k = 0; k < 3; k++) raw[k] = mf_load_piece_checked(src, wk.src_row0 + (int64_t)(tr_src[k] + c * 96u), src_arena_bytes);
             }
         };
-        // 48 bytes = 8 frames x {L, R} x 3 bytes -> six planes of 8 bytes; c0 = 3 * channel + byte position in the sample
-        auto split_chunk = [&](uint32_t c, bool prefetch) __attribute__((always_inline)) {
-            uint32_t w[12] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w, raw[2].x, raw[2].y, raw[2].z, raw[2].w};
-            if (first && c < 2) {
+        // the chunk's 32 x 96 bytes go through the stage; lane (row, half) takes its 48 bytes = 8 frames x {L, R} x 3 bytes and
+        // makes six planes of 8 bytes of them; c0 = 3 * channel + byte position in the sample
+        auto split_chunk = [&](uint32_t c, const u32x4 (&raw)[3], bool head) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) *(u32x4*)(tr_stage + 1024 * k) = raw[k];
+            u32x4 mine[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) mine[k] = *(const u32x4*)(split_stage + 16 * k);
+            uint32_t w[12] = {mine[0].x, mine[0].y, mine[0].z, mine[0].w, mine[1].x, mine[1].y, mine[1].z, mine[1].w, mine[2].x, mine[2].y, mine[2].z, mine[2].w};
+            if (head && first && c < 2) {
 #pragma unroll
                 for (int k = 0; k < 12; k++) w[k] = zero_history ? 0u : w[k];
             }
-            if (prefetch) load_chunk(c + 1);
             uint32_t pl[6][2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -170,62 +208,82 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
             }
         };
 
-        // the epilogue's addresses
-        const uint64_t dst_lane = (uint64_t)wk.dst_row0 + 24u * g + 12u * ch;                 // + row * L_blk * 6 + 96 t
         const uint8_t* const mbase = (const uint8_t*)planes + (uint64_t)wk.plane * plane_stride;
 
-        uint32_t cn = 0;                                   // next chunk to split
-        load_chunk(0);
-        // step 0's operands
+        // ---- the unit's head: the first window's four chunks and step 0's operands, one round trip ----
         MfStep const* st = steps;
         uint32_t kc = st->kc;
-        uint32_t aoff = st->aoff[n] + 16u * g;
-        v4i bias0 = *(const v4i*)(st->b0 + 4 * g), bias1 = *(const v4i*)(st->b1 + 4 * g), bias2 = *(const v4i*)(st->b2 + 4 * g);
+        v4i a[4];
+        v4i bias0, bias1, bias2;
+        {
+            u32x4 r4[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; c++) load_chunk((uint32_t)c, r4[c]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = *(const v4i*)(amat + (j * 1024u + lane * 16u));
+            bias0 = *(const v4i*)(st->b0 + 4 * g); bias1 = *(const v4i*)(st->b1 + 4 * g); bias2 = *(const v4i*)(st->b2 + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; c++) split_chunk((uint32_t)c, r4[c], true);
+        }
+        uint32_t cn = 4;                                   // chunks [0, cn) are in the planes (a step's window is chunks kc .. kc + 3)
         uint32_t claim = 0;
         for (uint32_t t = 0; t < n_steps; t++) {
-            // every chunk of the step's window is in the planes
-            uint32_t c_need = kc + 3u;
-            if (c_need > c_last) c_need = c_last;
-            while (cn <= c_need) {
-                split_chunk(cn, cn < c_last);
-                cn++;
-            }
-            // the coefficient digits of the step's 16 outputs: lane (n, g) holds output n's taps against frames 16 (kc + g) ..
-            v4i a[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) a[j] = *(const v4i_u*)(adig + (uint64_t)j * adig_stride + aoff);
-            const v4i b0 = bias0, b1 = bias1, b2 = bias2;
-            const uint32_t slot_g = ((kc + g) & 3u) * 256u;
-            // the next step's table entries ride under this step's work
-            if (t + 1 < n_steps) {
+            // ---- the next step's operands and the chunk its window adds are requested now and waited for ONCE, behind the step's
+            // arithmetic and in front of its stores: vmcnt counts loads and stores in issue order, so a load waited for later than
+            // that would wait for this step's stores as well ----
+            const bool more = t + 1 < n_steps;
+            v4i an[4] = {a[0], a[1], a[2], a[3]};
+            v4i bn0 = bias0, bn1 = bias1, bn2 = bias2;
+            uint32_t kc_n = kc;
+            u32x4 raw[3] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+            bool add_chunk = false;
+            if (more) {
                 st = steps + (t + 1);
-                kc = st->kc;
-                aoff = st->aoff[n] + 16u * g;
-                bias0 = *(const v4i*)(st->b0 + 4 * g); bias1 = *(const v4i*)(st->b1 + 4 * g); bias2 = *(const v4i*)(st->b2 + 4 * g);
+#ifndef MF_DIAG_NO_A
+#pragma unroll
+                for (int j = 0; j < 4; j++) an[j] = *(const v4i*)(amat + ((uint64_t)(t + 1) * kMfStepImage + j * 1024u + lane * 16u));
+#endif
+#ifndef MF_DIAG_NO_BIAS
+                bn0 = *(const v4i*)(st->b0 + 4 * g); bn1 = *(const v4i*)(st->b1 + 4 * g); bn2 = *(const v4i*)(st->b2 + 4 * g);
+#endif
+                kc_n = st->kc;
+                add_chunk = kc_n + 3u >= cn && cn <= c_last;           // (wave-uniform)
+#ifdef MF_DIAG_NO_RAW
+                add_chunk = false;
+#endif
+                if (add_chunk) load_chunk(cn, raw);
             } else if (lane == 0) {
                 claim = atomicAdd(unit_counter, 1u);       // the next unit, claimed at this one's last step
             }
+            u32x2 mm[4];
+            if (ramped) {
+                // RampApplicator's multipliers of the lane's four frames in every column tile (0xffff: the frame's message has no ramp)
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) {
+                    const uint32_t row = (uint32_t)ct * 8u + rr;
+                    mm[ct] = *(const u32x2*)(mbase + ((uint64_t)(row < n_blocks ? row * L_blk : 0u) + 16u * t + 4u * g) * 2u);
+                }
+            }
+            const uint32_t slot_g = ((kc + g) & 3u) * 256u;
 #pragma unroll
             for (int ct = 0; ct < 4; ct++) {
                 v4i bd[3];
 #pragma unroll
                 for (int d = 0; d < 3; d++) bd[d] = *(const v4i*)(b_lds + (d * 4 + ct) * 1024 + slot_g);
-                v4i s0 = b0, s1 = v4i{0, 0, 0, 0}, s2 = b1, s3 = v4i{0, 0, 0, 0}, s4 = b2, s5 = v4i{0, 0, 0, 0};
-                s0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0], bd[0], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1], bd[0], s1, 0, 0, 0);
-                s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[2], bd[0], s2, 0, 0, 0);
-                s3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[3], bd[0], s3, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0], bd[1], s1, 0, 0, 0);
-                s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1], bd[1], s2, 0, 0, 0);
-                s3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[2], bd[1], s3, 0, 0, 0);
-                s4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[3], bd[1], s4, 0, 0, 0);
-                s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0], bd[2], s2, 0, 0, 0);
-                s3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1], bd[2], s3, 0, 0, 0);
-                s4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[2], bd[2], s4, 0, 0, 0);
-                s5 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[3], bd[2], s5, 0, 0, 0);
+                v4i s0 = bias0, s1 = v4i{0, 0, 0, 0}, s2 = bias1, s3 = v4i{0, 0, 0, 0}, s4 = bias2, s5 = v4i{0, 0, 0, 0};
+                s0 = MF_MFMA(a[0], bd[0], s0);
+                s1 = MF_MFMA(a[1], bd[0], s1);
+                s2 = MF_MFMA(a[2], bd[0], s2);
+                s3 = MF_MFMA(a[3], bd[0], s3);
+                s1 = MF_MFMA(a[0], bd[1], s1);
+                s2 = MF_MFMA(a[1], bd[1], s2);
+                s3 = MF_MFMA(a[2], bd[1], s3);
+                s4 = MF_MFMA(a[3], bd[1], s4);
+                s2 = MF_MFMA(a[0], bd[2], s2);
+                s3 = MF_MFMA(a[1], bd[2], s3);
+                s4 = MF_MFMA(a[2], bd[2], s4);
+                s5 = MF_MFMA(a[3], bd[2], s5);
                 // ---- recombine, round (the bias carries 2^27), clamp: the lane's four frames 16 t + 4 g + v of column n ----
-                const uint32_t row = (uint32_t)ct * 8u + rr;
-                const bool valid = row < n_blocks;
                 int y[4];
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
@@ -237,10 +295,9 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                     y[v] = yy;
                 }
                 if (ramped) {
-                    // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero;
-                    // the multipliers of the row's four frames come from the unit's plane (0xffff: the frame's message has no ramp)
-                    const u32x2 mm = *(const u32x2*)(mbase + ((uint64_t)(valid ? row * L_blk : 0u) + 16u * t + 4u * g) * 2u);
-                    const uint32_t mu[4] = {mm.x & 0xffffu, mm.x >> 16, mm.y & 0xffffu, mm.y >> 16};
+                    // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero
+                    if (ct == 0) asm volatile("" : "+v"(mm[0]), "+v"(mm[1]), "+v"(mm[2]), "+v"(mm[3]));
+                    const uint32_t mu[4] = {mm[ct].x & 0xffffu, mm[ct].x >> 16, mm[ct].y & 0xffffu, mm[ct].y >> 16};
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
                         const int top = (int)((uint32_t)y[v] << 8) >> 16;  // bits 8..23, signed
@@ -248,19 +305,43 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         y[v] = mu[v] != 0xffffu ? r : y[v];
                     }
                 }
-                // ---- pack: exchange two values with the other channel's lane, three permutes, one 12-byte store ----
+                // ---- pack: exchange two values with the other channel's lane, three permutes, 12 bytes into the stage ----
                 const int give_a = ch ? y[0] : y[2], give_b = ch ? y[1] : y[3];
                 const int own_a = ch ? y[2] : y[0], own_b = ch ? y[3] : y[1];
                 const uint32_t got_a = (uint32_t)__builtin_amdgcn_mov_dpp(give_a, 0xb1, 0xf, 0xf, true);    // quad_perm:[1,0,3,2]
                 const uint32_t got_b = (uint32_t)__builtin_amdgcn_mov_dpp(give_b, 0xb1, 0xf, 0xf, true);
                 const uint32_t r_first = ch ? (uint32_t)own_a : got_a;      // R of the lane's first frame
                 const uint32_t l_second = ch ? got_b : (uint32_t)own_b;     // L of its second
-                u32x3 o;
-                o.x = mf_perm(got_a, (uint32_t)own_a, sel_d0);
-                o.y = mf_perm(l_second, r_first, sel_d1);
-                o.z = mf_perm(got_b, (uint32_t)own_b, sel_d2);
-                if (valid) *(u32x3_u*)(dst + dst_lane + (uint64_t)row * L_blk * 6u + 96u * (uint64_t)t) = o;
+                const uint32_t o0 = mf_perm(got_a, (uint32_t)own_a, sel_d0);
+                const uint32_t o1 = mf_perm(l_second, r_first, sel_d1);
+                const uint32_t o2 = mf_perm(got_b, (uint32_t)own_b, sel_d2);
+                // (the 12 bytes start on an 8-byte boundary for channel 0 and 4 bytes past one for channel 1)
+                *(u32x2*)(out_stage + ct * 768 + (ch ? 4 : 0)) = ch ? u32x2{o1, o2} : u32x2{o0, o1};
+                *(uint32_t*)(out_stage + ct * 768 + (ch ? 0 : 8)) = ch ? o0 : o2;
             }
+            // ---- the step's output leaves as 192 lane-contiguous pieces; everything requested at the top of the step has to be
+            // here before the first store goes out ----
+            u32x4 op[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) op[k] = *(const u32x4*)(tr_stage + 1024 * k);
+            asm volatile("" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]), "+v"(bn0), "+v"(bn1), "+v"(bn2));
+            asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+#if defined(MF_DIAG_NO_STORE)
+                if (tr_valid[k] && n_blocks > 1000000u) *(u32x4_u*)(unit_dst + (tr_dst[k] + 96u * t)) = op[k];
+#else
+                if (tr_valid[k]) *(u32x4_u*)(unit_dst + (tr_dst[k] + 96u * t)) = op[k];
+#endif
+            }
+            if (add_chunk) {
+                // the step has read its window: the slot of the window's oldest chunk takes the chunk the next step adds
+                split_chunk(cn, raw, false);
+                cn++;
+            }
+            a[0] = an[0]; a[1] = an[1]; a[2] = an[2]; a[3] = an[3];
+            bias0 = bn0; bias1 = bn1; bias2 = bn2;
+            kc = kc_n;
         }
         unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     }
@@ -331,6 +412,19 @@ bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q
     return true;
 }
 
+// The kernel's A operands, lane-linear: [step][coefficient digit][lane = 16 g + m][16 bytes] = the 16 bytes of output m's padded
+// coefficient row that meet frames 16 (kc + g) .. + 15 of the step's window (MfStep::aoff).
+void build_mfma_images(const std::vector<uint8_t>& adig, const std::vector<MfStep>& steps, uint32_t L, std::vector<uint8_t>* amat)
+{
+    amat->assign(steps.size() * (size_t)kMfStepImage, 0);
+    for (size_t t = 0; t < steps.size(); t++)
+        for (uint32_t j = 0; j < 4; j++)
+            for (uint32_t gq = 0; gq < 4; gq++)
+                for (uint32_t m = 0; m < 16; m++)
+                    memcpy(amat->data() + t * kMfStepImage + j * 1024 + (gq * 16 + m) * 16,
+                           adig.data() + (size_t)j * L * 96 + steps[t].aoff[m] + 16 * gq, 16);
+}
+
 bool src_mfma_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db)
 {
     return T == 32 && ch == 2 && sb == 3 && db == 3;
@@ -339,7 +433,7 @@ bool src_mfma_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db)
 void src_mfma_geometry(uint32_t* rows, uint32_t* wave_lds_bytes, uint32_t* max_waves)
 {
     *rows = 32;
-    *wave_lds_bytes = kMfPlaneBytes;
+    *wave_lds_bytes = kMfWaveLds;
     *max_waves = OHGPU_MFMA_WAVES;
 }
 
@@ -354,11 +448,11 @@ static hipError_t launch_mfma_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
     if (w > OHGPU_MFMA_WAVES) w = OHGPU_MFMA_WAVES;
     uint32_t gsz = (f.n_lean + w - 1) / w;
     if (gsz > cus) gsz = cus;
-    const uint32_t lds = w * kMfPlaneBytes;
+    const uint32_t lds = w * kMfWaveLds;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(w * 64), lds, s,
-                       (const LeanUnit*)f.d_lean_units, f.n_lean, (const uint8_t*)f.d_mf_adig, f.mf_adig_stride, (const MfStep*)f.d_mf_steps,
+                       (const LeanUnit*)f.d_lean_units, f.n_lean, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
                        (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.src_arena_bytes, p.L_blk, p.M_blk, (uint32_t*)f.d_counter);
     return hipGetLastError();
 }
