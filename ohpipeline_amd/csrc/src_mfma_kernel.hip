@@ -67,10 +67,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 #ifndef OHGPU_MFMA_WAVES
-#define OHGPU_MFMA_WAVES 10                        // waves per workgroup = per CU (LDS: 15 KB each)
+#define OHGPU_MFMA_WAVES 8                         // waves per workgroup = per CU (LDS: 18.2 KB each)
 #endif
 constexpr uint32_t kMfPlaneBytes = 3 * 4 * 4 * 256; // [digit][column tile][chunk slot][column][16]
-constexpr uint32_t kMfStageBytes = 32 * 96;         // one chunk of every row as it lies in memory / one step of every row, packed
+constexpr uint32_t kMfStageHalf = 32 * 96 + 96;     // one step of every row, packed (+ 96: the two halves start in different banks)
+constexpr uint32_t kMfStageBytes = 2 * kMfStageHalf; // two steps' output; the second half also takes a chunk of every row as it lies in memory
 constexpr uint32_t kMfWaveLds = kMfPlaneBytes + kMfStageBytes;
 constexpr uint32_t kMfStepImage = 4 * 1024;         // a step's A operands: [coefficient digit 4][lane 64][16 bytes]
 
@@ -104,7 +105,8 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t n_waves = blockDim.x >> 6;
     uint8_t* const wl = smem + wave * kMfWaveLds;
-    uint8_t* const stage = wl + kMfPlaneBytes;
+    uint8_t* const stage0 = wl + kMfPlaneBytes;             // even steps' packed output
+    uint8_t* const stage = stage0 + kMfStageHalf;          // odd steps' packed output; chunks on their way to the planes
 
     // ---- lane roles ----
     // matrix operands and results: g = K group / output quad, n = A row (output of the step) / column of the tile
@@ -125,7 +127,20 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     }
     uint8_t* const tr_stage = stage + lane * 16;           // + 1024 k
     // a tile's packed result: 12 bytes at 24 g + 12 ch of the row's 96 -- an aligned 8-byte and a 4-byte store
-    uint8_t* const out_stage = stage + rr * 96 + 24 * g + 12 * ch;    // + tile * 768
+    uint8_t* const out_stage = stage0 + rr * 96 + 24 * g + 12 * ch;   // + tile * 768 + (step & 1) * kMfStageHalf
+    // the write-back, every second step: piece f = 64 k + lane (k = 0..5) is piece f % 12 of row f / 12's 192 bytes = three whole
+    // 64-byte sectors when the stream's output starts on one (a block is a whole number of them)
+    uint32_t wb_row[6];
+    const uint8_t* wb_stage[6];
+    uint32_t wb_piece16[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t f = 64u * k + lane;
+        wb_row[k] = f / 12u;
+        const uint32_t pc = f - 12u * wb_row[k];
+        wb_piece16[k] = 16u * pc;
+        wb_stage[k] = stage0 + (pc >= 6u ? kMfStageHalf + 16u * (pc - 6u) : 16u * pc) + wb_row[k] * 96u;
+    }
 
     // pack: {got, own} -> the lane's three dwords of two frames.  Channel 0 stores its own frames v = 0, 1 with its partner's,
     // channel 1 its own v = 2, 3 with its partner's: own = (L lane ? L : R), got = the other channel's value of the same frame.
@@ -156,18 +171,21 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         const uint8_t* const unit_src = src + wk.src_row0;
         uint8_t* const unit_dst = dst + wk.dst_row0;
         const uint32_t row_src_bytes = M_blk * 6u, row_dst_bytes = L_blk * 6u;
-        uint32_t tr_src[3], tr_dst[3];
-        bool tr_valid[3];
+        uint32_t tr_src[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            tr_valid[k] = tr_row[k] < n_blocks;                        // (rows past the unit's last re-read row 0 and are not stored)
-            tr_src[k] = (tr_valid[k] ? tr_row[k] : 0u) * row_src_bytes + 16u * tr_piece[k];      // + 96 c
-            tr_dst[k] = tr_row[k] * row_dst_bytes + 16u * tr_piece[k];                           // + 96 t
-        }
+        for (int k = 0; k < 3; k++)                                     // (rows past the unit's last re-read row 0 and are not stored)
+            tr_src[k] = (tr_row[k] < n_blocks ? tr_row[k] : 0u) * row_src_bytes + 16u * tr_piece[k];      // + 96 c
+        uint32_t wb_dst[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) wb_dst[k] = wb_row[k] * row_dst_bytes + wb_piece16[k];                // + 96 (t - 1)
         auto load_chunk = [&](uint32_t c, u32x4 (&raw)[3]) __attribute__((always_inline)) {
             if (!checked) {
 #pragma unroll
+#ifdef MF_LOAD_NT
+                for (int k = 0; k < 3; k++) raw[k] = __builtin_nontemporal_load((const u32x4_u*)(unit_src + (tr_src[k] + c * 96u)));
+#else
                 for (int k = 0; k < 3; k++) raw[k] = *(const u32x4_u*)(unit_src + (tr_src[k] + c * 96u));
+#endif
             } else {
                 // a unit at an end of the arena: a 16-byte piece that is not wholly inside is fetched byte by byte (out of line)
 #pragma unroll
@@ -316,23 +334,29 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 const uint32_t o1 = mf_perm(l_second, r_first, sel_d1);
                 const uint32_t o2 = mf_perm(got_b, (uint32_t)own_b, sel_d2);
                 // (the 12 bytes start on an 8-byte boundary for channel 0 and 4 bytes past one for channel 1)
-                *(u32x2*)(out_stage + ct * 768 + (ch ? 4 : 0)) = ch ? u32x2{o1, o2} : u32x2{o0, o1};
-                *(uint32_t*)(out_stage + ct * 768 + (ch ? 0 : 8)) = ch ? o0 : o2;
+                uint8_t* const os = out_stage + ct * 768 + (t & 1u) * kMfStageHalf;
+                *(u32x2*)(os + (ch ? 4 : 0)) = ch ? u32x2{o1, o2} : u32x2{o0, o1};
+                *(uint32_t*)(os + (ch ? 0 : 8)) = ch ? o0 : o2;
             }
-            // ---- the step's output leaves as 192 lane-contiguous pieces; everything requested at the top of the step has to be
-            // here before the first store goes out ----
-            u32x4 op[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) op[k] = *(const u32x4*)(tr_stage + 1024 * k);
+            // ---- everything requested at the top of the step has to be here before a store goes out; every second step the
+            // two steps' output leaves as 384 lane-contiguous pieces, whole sectors, past the L2 (non-temporal: the lines are
+            // complete and nobody reads them again) ----
             asm volatile("" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]), "+v"(bn0), "+v"(bn1), "+v"(bn2));
             asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
+            if (t & 1u) {
+                u32x4 op[6];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+                for (int k = 0; k < 6; k++) op[k] = *(const u32x4*)(wb_stage[k]);
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
 #if defined(MF_DIAG_NO_STORE)
-                if (tr_valid[k] && n_blocks > 1000000u) *(u32x4_u*)(unit_dst + (tr_dst[k] + 96u * t)) = op[k];
+                    if (wb_row[k] < n_blocks && n_blocks > 1000000u) *(u32x4_u*)(unit_dst + (wb_dst[k] + 96u * (t - 1u))) = op[k];
+#elif defined(MF_STORE_PLAIN)
+                    if (wb_row[k] < n_blocks) *(u32x4_u*)(unit_dst + (wb_dst[k] + 96u * (t - 1u))) = op[k];
 #else
-                if (tr_valid[k]) *(u32x4_u*)(unit_dst + (tr_dst[k] + 96u * t)) = op[k];
+                    if (wb_row[k] < n_blocks) __builtin_nontemporal_store(op[k], (u32x4_u*)(unit_dst + (wb_dst[k] + 96u * (t - 1u))));
 #endif
+                }
             }
             if (add_chunk) {
                 // the step has read its window: the slot of the window's oldest chunk takes the chunk the next step adds

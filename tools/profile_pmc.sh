@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH_ARGS="--steps 5 --warmup 2 --no-cpu --no-extra-configs $*"
+BENCH_ARGS="--steps 5 --warmup 2 --no-cpu --no-extra-configs --sustain 0.05 $*"
 i=0
 while IFS= read -r SET; do
   [ -z "$SET" ] && continue
