@@ -74,6 +74,8 @@ constexpr uint32_t kMfStageHalf = 32 * 96 + 96;     // one step of every row, pa
 constexpr uint32_t kMfStageBytes = 2 * kMfStageHalf; // two steps' output; the second half also takes a chunk of every row as it lies in memory
 constexpr uint32_t kMfWaveLds = kMfPlaneBytes + kMfStageBytes;
 constexpr uint32_t kMfStepImage = 4 * 1024;         // a step's A operands: [coefficient digit 4][lane 64][16 bytes]
+constexpr uint32_t kMfBiasSteps = 16;               // steps per block the workgroup's table of accumulator biases holds (they repeat block by block)
+constexpr uint32_t kMfBiasBytes = kMfBiasSteps * 192; // [step][b0 16, b1 16, b2 16] dwords
 
 __device__ __forceinline__ uint32_t mf_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
@@ -104,7 +106,14 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     const uint32_t lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t n_waves = blockDim.x >> 6;
-    uint8_t* const wl = smem + wave * kMfWaveLds;
+    // the accumulators' initial values (MfStep::b0..b2): they depend on the outputs' phases only, so a block's steps hold them all
+    const uint32_t spb = L_blk1 >> 4;                       // steps per block (<= kMfBiasSteps: the launch checks)
+    for (uint32_t i = tid; i < spb * 48u; i += blockDim.x) {
+        const uint32_t t = i / 48u, r = i - 48u * t;
+        ((uint32_t*)smem)[i] = steps[t].b0[r];             // (b0, b1, b2 lie one after the other)
+    }
+    __syncthreads();
+    uint8_t* const wl = smem + kMfBiasBytes + wave * kMfWaveLds;
     uint8_t* const stage0 = wl + kMfPlaneBytes;             // even steps' packed output
     uint8_t* const stage = stage0 + kMfStageHalf;          // odd steps' packed output; chunks on their way to the planes
 
@@ -129,17 +138,17 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     // a tile's packed result: 12 bytes at 24 g + 12 ch of the row's 96 -- an aligned 8-byte and a 4-byte store
     uint8_t* const out_stage = stage0 + rr * 96 + 24 * g + 12 * ch;   // + tile * 768 + (step & 1) * kMfStageHalf
     // the write-back, every second step: piece f = 64 k + lane (k = 0..5) is piece f % 12 of row f / 12's 192 bytes = three whole
-    // 64-byte sectors when the stream's output starts on one (a block is a whole number of them)
-    uint32_t wb_row[6];
-    const uint8_t* wb_stage[6];
-    uint32_t wb_piece16[6];
+    // 64-byte sectors when the stream's output starts on one (a block is a whole number of them).  64 k = 12 (5 k) + 4 k and
+    // 4 (k + 3) = 12 + 4 k: instructions k and k + 3 differ by 16 rows, so three (row, piece) pairs serve the six.
+    uint32_t wb_row[3], wb_piece16[3];
+    const uint8_t* wb_stage[3];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const uint32_t f = 64u * k + lane;
-        wb_row[k] = f / 12u;
-        const uint32_t pc = f - 12u * wb_row[k];
+    for (int k = 0; k < 3; k++) {
+        const uint32_t q = 4u * k + lane;
+        wb_row[k] = 5u * k + q / 12u;                      // (instruction k + 3: + 16)
+        const uint32_t pc = q % 12u;
         wb_piece16[k] = 16u * pc;
-        wb_stage[k] = stage0 + (pc >= 6u ? kMfStageHalf + 16u * (pc - 6u) : 16u * pc) + wb_row[k] * 96u;
+        wb_stage[k] = stage0 + (pc >= 6u ? kMfStageHalf + 16u * (pc - 6u) : 16u * pc) + wb_row[k] * 96u;   // (+ 1536)
     }
 
     // pack: {got, own} -> the lane's three dwords of two frames.  Channel 0 stores its own frames v = 0, 1 with its partner's,
@@ -161,12 +170,16 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
         const uint32_t kb = (wk.flags >> 8) & 0xffu;
         const uint32_t L_blk = L_blk1 * kb, M_blk = M_blk1 * kb;        // outputs / input frames per row
         const bool ramped = (wk.flags & kWorkRamped) != 0;             // wave-uniform
-        const bool checked = (wk.flags & kWorkChecked) != 0;
         const bool first = (wk.flags & kWorkFirst) != 0;
         const uint32_t n_steps = L_blk >> 4;
         const uint32_t c_last = (M_blk + 31u) >> 4;                     // the last chunk any output of a row needs
         const bool zero_history = first && rs == 0;                    // the stream's block 0: frames before it read as zeros
 
+        uint32_t claim = 0;
+        // (the unit's body, once for units whose every piece lies inside the arena and once, with out-of-line checked loads, for the few
+        // at its ends: a load that is a load on one path and a call on the other would be waited for at the join)
+        auto run_unit = [&](auto checked_c) __attribute__((always_inline)) {
+        constexpr bool CHECKED = decltype(checked_c)::value;
         // ---- the transfers' addresses: a wave-uniform base and a 32-bit lane offset (a unit spans far less than 4 GiB) ----
         const uint8_t* const unit_src = src + wk.src_row0;
         uint8_t* const unit_dst = dst + wk.dst_row0;
@@ -175,11 +188,11 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 #pragma unroll
         for (int k = 0; k < 3; k++)                                     // (rows past the unit's last re-read row 0 and are not stored)
             tr_src[k] = (tr_row[k] < n_blocks ? tr_row[k] : 0u) * row_src_bytes + 16u * tr_piece[k];      // + 96 c
-        uint32_t wb_dst[6];
+        uint32_t wb_dst[3];
 #pragma unroll
-        for (int k = 0; k < 6; k++) wb_dst[k] = wb_row[k] * row_dst_bytes + wb_piece16[k];                // + 96 (t - 1)
+        for (int k = 0; k < 3; k++) wb_dst[k] = wb_row[k] * row_dst_bytes + wb_piece16[k];                // + 96 t (+ 16 rows)
         auto load_chunk = [&](uint32_t c, u32x4 (&raw)[3]) __attribute__((always_inline)) {
-            if (!checked) {
+            if constexpr (!CHECKED) {
 #pragma unroll
 #ifdef MF_LOAD_NT
                 for (int k = 0; k < 3; k++) raw[k] = __builtin_nontemporal_load((const u32x4_u*)(unit_src + (tr_src[k] + c * 96u)));
@@ -228,51 +241,15 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 
         const uint8_t* const mbase = (const uint8_t*)planes + (uint64_t)wk.plane * plane_stride;
 
-        // ---- the unit's head: the first window's four chunks and step 0's operands, one round trip ----
-        MfStep const* st = steps;
-        uint32_t kc = st->kc;
-        v4i a[4];
-        v4i bias0, bias1, bias2;
-        {
-            u32x4 r4[4][3];
+        struct StepOps { v4i a[4]; uint32_t kc; };
+        auto load_ops = [&](uint32_t t, StepOps& o) __attribute__((always_inline)) {
+            const MfStep* const st = steps + t;
 #pragma unroll
-            for (int c = 0; c < 4; c++) load_chunk((uint32_t)c, r4[c]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) a[j] = *(const v4i*)(amat + (j * 1024u + lane * 16u));
-            bias0 = *(const v4i*)(st->b0 + 4 * g); bias1 = *(const v4i*)(st->b1 + 4 * g); bias2 = *(const v4i*)(st->b2 + 4 * g);
-#pragma unroll
-            for (int c = 0; c < 4; c++) split_chunk((uint32_t)c, r4[c], true);
-        }
-        uint32_t cn = 4;                                   // chunks [0, cn) are in the planes (a step's window is chunks kc .. kc + 3)
-        uint32_t claim = 0;
-        for (uint32_t t = 0; t < n_steps; t++) {
-            // ---- the next step's operands and the chunk its window adds are requested now and waited for ONCE, behind the step's
-            // arithmetic and in front of its stores: vmcnt counts loads and stores in issue order, so a load waited for later than
-            // that would wait for this step's stores as well ----
-            const bool more = t + 1 < n_steps;
-            v4i an[4] = {a[0], a[1], a[2], a[3]};
-            v4i bn0 = bias0, bn1 = bias1, bn2 = bias2;
-            uint32_t kc_n = kc;
-            u32x4 raw[3] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
-            bool add_chunk = false;
-            if (more) {
-                st = steps + (t + 1);
-#ifndef MF_DIAG_NO_A
-#pragma unroll
-                for (int j = 0; j < 4; j++) an[j] = *(const v4i*)(amat + ((uint64_t)(t + 1) * kMfStepImage + j * 1024u + lane * 16u));
-#endif
-#ifndef MF_DIAG_NO_BIAS
-                bn0 = *(const v4i*)(st->b0 + 4 * g); bn1 = *(const v4i*)(st->b1 + 4 * g); bn2 = *(const v4i*)(st->b2 + 4 * g);
-#endif
-                kc_n = st->kc;
-                add_chunk = kc_n + 3u >= cn && cn <= c_last;           // (wave-uniform)
-#ifdef MF_DIAG_NO_RAW
-                add_chunk = false;
-#endif
-                if (add_chunk) load_chunk(cn, raw);
-            } else if (lane == 0) {
-                claim = atomicAdd(unit_counter, 1u);       // the next unit, claimed at this one's last step
-            }
+            for (int j = 0; j < 4; j++) o.a[j] = *(const v4i*)(amat + ((uint64_t)t * kMfStepImage + j * 1024u + lane * 16u));
+            o.kc = st->kc;
+        };
+        // one step: the four column tiles' 16 output frames -> the stage (half `t & 1`)
+        auto do_step = [&](uint32_t t, const StepOps& o) __attribute__((always_inline)) {
             u32x2 mm[4];
             if (ramped) {
                 // RampApplicator's multipliers of the lane's four frames in every column tile (0xffff: the frame's message has no ramp)
@@ -282,25 +259,27 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                     mm[ct] = *(const u32x2*)(mbase + ((uint64_t)(row < n_blocks ? row * L_blk : 0u) + 16u * t + 4u * g) * 2u);
                 }
             }
-            const uint32_t slot_g = ((kc + g) & 3u) * 256u;
+            const uint32_t slot_g = ((o.kc + g) & 3u) * 256u;
+            const uint8_t* const bl = smem + (t % spb) * 192u + 16u * g;
+            const v4i bias0 = *(const v4i*)bl, bias1 = *(const v4i*)(bl + 64), bias2 = *(const v4i*)(bl + 128);
 #pragma unroll
             for (int ct = 0; ct < 4; ct++) {
                 v4i bd[3];
 #pragma unroll
                 for (int d = 0; d < 3; d++) bd[d] = *(const v4i*)(b_lds + (d * 4 + ct) * 1024 + slot_g);
                 v4i s0 = bias0, s1 = v4i{0, 0, 0, 0}, s2 = bias1, s3 = v4i{0, 0, 0, 0}, s4 = bias2, s5 = v4i{0, 0, 0, 0};
-                s0 = MF_MFMA(a[0], bd[0], s0);
-                s1 = MF_MFMA(a[1], bd[0], s1);
-                s2 = MF_MFMA(a[2], bd[0], s2);
-                s3 = MF_MFMA(a[3], bd[0], s3);
-                s1 = MF_MFMA(a[0], bd[1], s1);
-                s2 = MF_MFMA(a[1], bd[1], s2);
-                s3 = MF_MFMA(a[2], bd[1], s3);
-                s4 = MF_MFMA(a[3], bd[1], s4);
-                s2 = MF_MFMA(a[0], bd[2], s2);
-                s3 = MF_MFMA(a[1], bd[2], s3);
-                s4 = MF_MFMA(a[2], bd[2], s4);
-                s5 = MF_MFMA(a[3], bd[2], s5);
+                s0 = MF_MFMA(o.a[0], bd[0], s0);
+                s1 = MF_MFMA(o.a[1], bd[0], s1);
+                s2 = MF_MFMA(o.a[2], bd[0], s2);
+                s3 = MF_MFMA(o.a[3], bd[0], s3);
+                s1 = MF_MFMA(o.a[0], bd[1], s1);
+                s2 = MF_MFMA(o.a[1], bd[1], s2);
+                s3 = MF_MFMA(o.a[2], bd[1], s3);
+                s4 = MF_MFMA(o.a[3], bd[1], s4);
+                s2 = MF_MFMA(o.a[0], bd[2], s2);
+                s3 = MF_MFMA(o.a[1], bd[2], s3);
+                s4 = MF_MFMA(o.a[2], bd[2], s4);
+                s5 = MF_MFMA(o.a[3], bd[2], s5);
                 // ---- recombine, round (the bias carries 2^27), clamp: the lane's four frames 16 t + 4 g + v of column n ----
                 int y[4];
 #pragma unroll
@@ -314,7 +293,6 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 }
                 if (ramped) {
                     // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero
-                    if (ct == 0) asm volatile("" : "+v"(mm[0]), "+v"(mm[1]), "+v"(mm[2]), "+v"(mm[3]));
                     const uint32_t mu[4] = {mm[ct].x & 0xffffu, mm[ct].x >> 16, mm[ct].y & 0xffffu, mm[ct].y >> 16};
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
@@ -338,35 +316,117 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                 *(u32x2*)(os + (ch ? 4 : 0)) = ch ? u32x2{o1, o2} : u32x2{o0, o1};
                 *(uint32_t*)(os + (ch ? 0 : 8)) = ch ? o0 : o2;
             }
-            // ---- everything requested at the top of the step has to be here before a store goes out; every second step the
-            // two steps' output leaves as 384 lane-contiguous pieces, whole sectors, past the L2 (non-temporal: the lines are
-            // complete and nobody reads them again) ----
-            asm volatile("" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]), "+v"(bn0), "+v"(bn1), "+v"(bn2));
-            asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
-            if (t & 1u) {
+        };
+
+        // ---- the unit's head: the first window's four chunks, the chunk step 1 may add, the first pair's operands: one round trip ----
+        StepOps e, f;                                       // the pair's even and odd step
+        u32x4 raw_b[3];                                    // the chunk the pair's odd step adds to the planes, if it does
+        bool add_b;
+        uint32_t cn = 4;                                   // chunks [0, cn) are in the planes (a step's window is chunks kc .. kc + 3)
+        {
+            u32x4 r4[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; c++) load_chunk((uint32_t)c, r4[c]);
+            load_ops(0, e);
+            load_ops(1, f);                                 // (a row is a whole number of blocks = an even number of steps)
+            add_b = f.kc + 3u >= cn && cn <= c_last;
+            load_chunk(cn <= c_last ? cn : c_last, raw_b);
+#pragma unroll
+            for (int c = 0; c < 4; c++) split_chunk((uint32_t)c, r4[c], true);
+        }
+        for (uint32_t t = 0; t < n_steps; t += 2) {
+            // ---- PAIRS of steps.  vmcnt counts loads and stores together, in issue order, and the compiler waits for all of them at
+            // the first use of any: so the next pair's operands and the (at most two) chunks its windows add are requested HERE, a whole
+            // pair ahead -- a step's arithmetic alone is shorter than a trip to memory -- and waited for once, at the pair's end, in
+            // front of its stores ----
+            // (No load sits in a conditional: a value that is loaded on one path and copied on the other meets it in a register COPY
+            // behind the join, and the copy is a use -- the wait would land here, in front of the pair's arithmetic.  A pair that needs
+            // no chunk, and the unit's last pair, fetch the unit's last chunk again instead: a hit in the L2.)
+            const bool more = t + 2 < n_steps;
+            const uint32_t t2 = more ? t + 2u : t;
+            StepOps e2, f2;
+            load_ops(t2, e2);
+            load_ops(t2 + 1u, f2);
+            const uint32_t c_a2 = cn + (add_b ? 1u : 0u);              // the chunks in the planes once this pair is through
+            const bool add_a2 = more && e2.kc + 3u >= c_a2 && c_a2 <= c_last;       // (wave-uniform)
+            const uint32_t c_b2 = c_a2 + (add_a2 ? 1u : 0u);
+            const bool add_b2 = more && f2.kc + 3u >= c_b2 && c_b2 <= c_last;
+            u32x4 raw_a2[3], raw_b2[3];
+#if defined(MF_DIAG_IO_CONTIG)
+            // (timing only: the pair's two chunks as ONE contiguous 6 KB run near the unit's input span, clamped into the arena)
+            {
+                int64_t a0 = (wk.src_row0 > 0 ? wk.src_row0 : 0) + (int64_t)((t >> 1) * 5616u);
+                if (a0 + 6144 > (int64_t)src_arena_bytes) a0 = (int64_t)src_arena_bytes - 6144;
+                if (a0 < 0) a0 = 0;
+                // (the bench's arena is far larger than 6 KB: this build is for it alone)
+#pragma unroll
+                for (int k = 0; k < 3; k++) raw_a2[k] = *(const u32x4_u*)(src + (a0 + 1024 * k + 16 * (int)lane));
+#pragma unroll
+                for (int k = 0; k < 3; k++) raw_b2[k] = *(const u32x4_u*)(src + (a0 + 3072 + 1024 * k + 16 * (int)lane));
+            }
+#elif !defined(MF_DIAG_NO_RAW)
+            load_chunk(add_a2 ? c_a2 : c_last, raw_a2);
+            load_chunk(add_b2 ? c_b2 : c_last, raw_b2);
+#else
+#pragma unroll
+            for (int k = 0; k < 3; k++) raw_a2[k] = raw_b2[k] = raw_b[k];
+#endif
+#ifndef MF_DIAG_IO_ONLY
+            do_step(t, e);
+#endif
+            if (add_b) {
+                // the even step has read its window: the slot of the window's oldest chunk takes the chunk the odd step adds
+#ifndef MF_DIAG_NO_RAW
+                split_chunk(cn, raw_b, false);
+#endif
+                cn++;
+            }
+#ifndef MF_DIAG_IO_ONLY
+            do_step(t + 1, f);
+#endif
+            // ---- everything requested at the top of the pair has to be here before a store goes out; then the two steps' output
+            // leaves as 384 lane-contiguous pieces, whole sectors, past the L2 (non-temporal: the lines are complete and nobody
+            // reads them again) ----
+            asm volatile("" : "+v"(e2.a[0]), "+v"(e2.a[1]), "+v"(e2.a[2]), "+v"(e2.a[3]), "+v"(f2.a[0]), "+v"(f2.a[1]), "+v"(f2.a[2]), "+v"(f2.a[3]));
+            asm volatile("" : "+v"(raw_a2[0]), "+v"(raw_a2[1]), "+v"(raw_a2[2]), "+v"(raw_b2[0]), "+v"(raw_b2[1]), "+v"(raw_b2[2]));
+            if (!more && lane == 0) claim = atomicAdd(unit_counter, 1u);            // the next unit, claimed in this one's last pair (behind the wait: its result is a use)
+            {
                 u32x4 op[6];
 #pragma unroll
-                for (int k = 0; k < 6; k++) op[k] = *(const u32x4*)(wb_stage[k]);
+                for (int k = 0; k < 6; k++) op[k] = *(const u32x4*)(wb_stage[k % 3] + (k / 3) * 1536);
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
-#if defined(MF_DIAG_NO_STORE)
-                    if (wb_row[k] < n_blocks && n_blocks > 1000000u) *(u32x4_u*)(unit_dst + (wb_dst[k] + 96u * (t - 1u))) = op[k];
-#elif defined(MF_STORE_PLAIN)
-                    if (wb_row[k] < n_blocks) *(u32x4_u*)(unit_dst + (wb_dst[k] + 96u * (t - 1u))) = op[k];
+#ifdef MF_DIAG_IO_CONTIG
+                    // (timing only: the pair's output as ONE contiguous 6 KB run of the unit's own output span; a pair that would
+                    // leave a partly filled unit's span is not stored)
+                    const bool valid = ((t >> 1) + 1u) * 6144u <= n_blocks * row_dst_bytes;
+                    u32x4_u* const at = (u32x4_u*)(unit_dst + ((t >> 1) * 6144u + 1024u * k + 16u * lane));
 #else
-                    if (wb_row[k] < n_blocks) __builtin_nontemporal_store(op[k], (u32x4_u*)(unit_dst + (wb_dst[k] + 96u * (t - 1u))));
+                    const bool valid = wb_row[k % 3] + 16u * (k / 3) < n_blocks;
+                    u32x4_u* const at = (u32x4_u*)(unit_dst + (wb_dst[k % 3] + (k / 3) * 16u * row_dst_bytes + 96u * t));
+#endif
+#if defined(MF_DIAG_NO_STORE)
+                    if (valid && n_blocks > 1000000u) *at = op[k];
+#elif defined(MF_STORE_PLAIN)
+                    if (valid) *at = op[k];
+#else
+                    if (valid) __builtin_nontemporal_store(op[k], at);
 #endif
                 }
             }
-            if (add_chunk) {
-                // the step has read its window: the slot of the window's oldest chunk takes the chunk the next step adds
-                split_chunk(cn, raw, false);
+            if (add_a2) {
+#ifndef MF_DIAG_NO_RAW
+                split_chunk(cn, raw_a2, false);             // (cn == c_a2 by now)
+#endif
                 cn++;
             }
-            a[0] = an[0]; a[1] = an[1]; a[2] = an[2]; a[3] = an[3];
-            bias0 = bn0; bias1 = bn1; bias2 = bn2;
-            kc = kc_n;
+            e = e2; f = f2;
+            raw_b[0] = raw_b2[0]; raw_b[1] = raw_b2[1]; raw_b[2] = raw_b2[2];
+            add_b = add_b2;
         }
+        };
+        if (wk.flags & kWorkChecked) run_unit(std::true_type{});
+        else run_unit(std::false_type{});
         unit = first_claimed + (uint32_t)__builtin_amdgcn_readfirstlane((int)claim);
     }
     // The counters reset themselves: a wave reports in after its last claim, and the last wave of the grid zeroes both.
@@ -472,7 +532,8 @@ static hipError_t launch_mfma_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, co
     if (w > OHGPU_MFMA_WAVES) w = OHGPU_MFMA_WAVES;
     uint32_t gsz = (f.n_lean + w - 1) / w;
     if (gsz > cus) gsz = cus;
-    const uint32_t lds = w * kMfWaveLds;
+    if ((p.L_blk >> 4) > kMfBiasSteps) return hipErrorInvalidValue;            // (src_mfma_supported keeps such a filter off this kernel)
+    const uint32_t lds = kMfBiasBytes + w * kMfWaveLds;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(w * 64), lds, s,

@@ -269,7 +269,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // block length and rows of up to mf_kb_cap blocks -- with its own number of waves per CU
     uint32_t mf_rows = 0, mf_wave_lds = 0, mf_max_waves = 0;
     src_mfma_geometry(&mf_rows, &mf_wave_lds, &mf_max_waves);
-    const bool mfma = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk &&
+    const bool mfma = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (L_blk >> 4) <= 16u &&      // (the kernel's bias table: one block's steps)
                       mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
     std::vector<LeanUnit> lean_units;
     if (lean) {

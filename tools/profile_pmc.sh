@@ -12,6 +12,7 @@ i=0
 while IFS= read -r SET; do
   [ -z "$SET" ] && continue
   i=$((i+1))
+  if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi
   echo "== pmc$i: $SET" >> "$OUT/log.txt"
   timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- python3 "$R/bench.py" $BENCH_ARGS >> "$OUT/log.txt" 2>&1 || echo "pmc$i failed" | tee -a "$OUT/log.txt"
 done <<'SETS'
