@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libohgpu.so")
 
-HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "ohm_frame_kernel.hip", "ramp_plane_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip", "src_lean_kernel.hip", "src_mfma_kernel.hip"]
+HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "ohm_frame_kernel.hip", "ramp_plane_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip", "src_lean_kernel.hip", "src_mfma_kernel.hip", "src_mfma_wg_kernel.hip"]
 PARTED = ("src_block_kernel.hip", "src_lean_kernel.hip")     # compiled once per part of the instantiation list (csrc/src_block_common.h)
 HEADERS = ["ohgpu_internal.h", "pcm_device.h", os.path.join(ROOT, "include", "ohgpu.h")]
 # Per-source flags.  The lean kernel's per-frame control flow is wave-uniform (scalar compares); LLVM's structurizer

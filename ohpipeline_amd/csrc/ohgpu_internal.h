@@ -124,6 +124,8 @@ struct SrcFastPlan {
     bool     lean_only = false;   // ... and round 1's kernel has no instantiation for its layout (variant 2 then runs the lean kernel too)
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
     bool     mfma = false;        // ... and its layout is one src_mfma_kernel (round 4) serves: same units and planes, the filter's digit tables
+    uint32_t n_wg = 0;            // mfma_wg: lean units [0, n_wg) are src_mfma_wg_kernel's, [n_wg, n_lean) the edge units src_mfma_kernel runs
+    bool     mfma_wg = false;     // ... as src_mfma_wg_kernel cuts them: one unit per workgroup (rows of ONE block; units that leave the arena are the generic kernel's)
     const void* d_mf_amat = nullptr;   // (owned by the ohgpu_src)
     const void* d_mf_steps = nullptr;
     void*    d_planes = nullptr;  // uint16: RampApplicator's multiplier per output frame of every ramped unit, [blocks of the unit][L_blk]
@@ -341,7 +343,10 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
-hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_kernel.hip
+hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit = 0);   // csrc/src_mfma_kernel.hip (units [first_unit, n_lean))
+hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_wg_kernel.hip
+bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db);
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes);
 bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, uint32_t L_blk, uint32_t kb_cap,
                        std::vector<uint8_t>* adig, std::vector<MfStep>* steps);
 void build_mfma_images(const std::vector<uint8_t>& adig, const std::vector<MfStep>& steps, uint32_t L, std::vector<uint8_t>* amat);

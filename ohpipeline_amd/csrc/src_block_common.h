@@ -63,7 +63,8 @@ static constexpr int lean_in_blocks_planar(int ch) { return ((lean_stage_frames(
 // SrcWork::flags
 enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output range
        kWorkChecked = 2u,     // some staging piece of the unit lies outside the source arena (ends of the arena)
-       kWorkFirst = 4u };     // LeanUnit only: row 0 is its stream's block 0 (the frames before it read as zeros)
+       kWorkFirst = 4u,       // LeanUnit only: row 0 is its stream's block 0 (the frames before it read as zeros)
+       kWorkEdge = 8u };      // LeanUnit of a src_mfma_wg_kernel plan: the unit's 32-row input image leaves the arena -- src_mfma_kernel runs it
 
 }  // namespace ohgpu
 

@@ -1,0 +1,60 @@
+// src_mfma_common.h -- what the two matrix-pipe resampler kernels (src_mfma_kernel.hip: one unit per wave; src_mfma_wg_kernel.hip:
+// one unit per workgroup, one output step per wave) share: vector types, the byte permute, the size of a step's A image.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "src_block_common.h"
+
+#ifdef MF_DIAG_NO_MFMA
+#define MF_MFMA(a, b, c) ((c) + (a) + (b))
+#else
+#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_16x16x64_i8((a), (b), (c), 0, 0, 0)
+#endif
+
+namespace ohgpu {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+constexpr uint32_t kMfStepImage = 4 * 1024;         // a step's A operands: [coefficient digit 4][lane 64][16 bytes]
+
+// A value the compiler has to take as it stands, here: keeps a lane offset's widening to 64 bits next to the access that uses it
+// (instruction selection works block by block and finds the scalar-base form only when it sees the widening).
+__device__ __forceinline__ uint32_t mf_here(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+
+__device__ __forceinline__ uint32_t mf_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 48 bytes = 8 frames x {L, R} x 3 bytes (twelve dwords as they lie in memory) -> six planes of 8 bytes: pl[3 * channel + byte
+// position in the sample][two dwords of four frames each].  A two-level v_perm_b32 network, two permutes per plane dword.
+__device__ __forceinline__ void mf_split48(const uint32_t (&w)[12], uint32_t (&pl)[6][2])
+{
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t* v = w + 6 * q;
+        // level 1: two frames of two planes per permute ({hi, lo} = bytes 7..0)
+        const uint32_t x01 = mf_perm(v[1], v[0], 0x07010600u), x23 = mf_perm(v[2], v[0], 0x05030402u), x45 = mf_perm(v[2], v[1], 0x07010600u);
+        const uint32_t y01 = mf_perm(v[4], v[3], 0x07010600u), y23 = mf_perm(v[5], v[3], 0x05030402u), y45 = mf_perm(v[5], v[4], 0x07010600u);
+        // level 2: four frames of one plane
+        pl[0][q] = mf_perm(y01, x01, 0x05040100u); pl[1][q] = mf_perm(y01, x01, 0x07060302u);
+        pl[2][q] = mf_perm(y23, x23, 0x05040100u); pl[3][q] = mf_perm(y23, x23, 0x07060302u);
+        pl[4][q] = mf_perm(y45, x45, 0x05040100u); pl[5][q] = mf_perm(y45, x45, 0x07060302u);
+    }
+}
+
+// The six accumulators of an output -> floor(acc / 2^28), clamped to 24 bits.  T0 = S0 + (S1 << 8), T1 = S2 + (S3 << 8),
+// T2 = S4 + (S5 << 8) (each below 2^30), U = T1 + (T0 >> 16), W = T2 + (U >> 16), y = (W << 4) | bits 12..15 of U: the low 16 bits of
+// T0 and the low 12 of U cannot carry into bit 28.  The rounding 2^27 rides in the accumulators' initial values.
+__device__ __forceinline__ int mf_recombine(int s0, int s1, int s2, int s3, int s4, int s5)
+{
+    const int t0 = (int)(((uint32_t)s1 << 8) + (uint32_t)s0);
+    const int u = (int)(((uint32_t)s3 << 8) + (uint32_t)s2) + (t0 >> 16);
+    const int w = (int)(((uint32_t)s5 << 8) + (uint32_t)s4) + (u >> 16);
+    const int yy = (int)(((uint32_t)w << 4) | (((uint32_t)u >> 12) & 15u));
+    return yy < -8388608 ? -8388608 : (yy > 8388607 ? 8388607 : yy);
+}
+
+}  // namespace ohgpu

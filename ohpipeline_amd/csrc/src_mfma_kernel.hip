@@ -51,20 +51,9 @@
 
 #include "ohgpu_internal.h"
 #include "pcm_device.h"
-#include "src_block_common.h"
-
-#ifdef MF_DIAG_NO_MFMA
-#define MF_MFMA(a, b, c) ((c) + (a) + (b))
-#else
-#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_16x16x64_i8((a), (b), (c), 0, 0, 0)
-#endif
+#include "src_mfma_common.h"
 
 namespace ohgpu {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef u32x4 u32x4_u __attribute__((aligned(1)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 #ifndef OHGPU_MFMA_WAVES
 #define OHGPU_MFMA_WAVES 8                         // waves per workgroup = per CU (LDS: 18.2 KB each)
@@ -73,11 +62,8 @@ constexpr uint32_t kMfPlaneBytes = 3 * 4 * 4 * 256; // [digit][column tile][chun
 constexpr uint32_t kMfStageHalf = 32 * 96 + 96;     // one step of every row, packed (+ 96: the two halves start in different banks)
 constexpr uint32_t kMfStageBytes = 2 * kMfStageHalf; // two steps' output; the second half also takes a chunk of every row as it lies in memory
 constexpr uint32_t kMfWaveLds = kMfPlaneBytes + kMfStageBytes;
-constexpr uint32_t kMfStepImage = 4 * 1024;         // a step's A operands: [coefficient digit 4][lane 64][16 bytes]
 constexpr uint32_t kMfBiasSteps = 16;               // steps per block the workgroup's table of accumulator biases holds (they repeat block by block)
 constexpr uint32_t kMfBiasBytes = kMfBiasSteps * 192; // [step][b0 16, b1 16, b2 16] dwords
-
-__device__ __forceinline__ uint32_t mf_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 // Sixteen bytes from arena offset a, bytes outside the arena read as zero (they are frames before a stream's first or beyond the
 // last frame any output needs).  Only units at an end of the arena come here (kWorkChecked).
@@ -522,33 +508,35 @@ void src_mfma_geometry(uint32_t* rows, uint32_t* wave_lds_bytes, uint32_t* max_w
 }
 
 template <bool SRC_LE, bool DST_LE>
-static hipError_t launch_mfma_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
+static hipError_t launch_mfma_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s, uint32_t first_unit)
 {
     auto kernel = src_mfma_kernel<SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
-    uint32_t w = (f.n_lean + cus - 1) / cus;
+    if (first_unit >= f.n_lean) return hipSuccess;
+    const uint32_t n_units = f.n_lean - first_unit;
+    uint32_t w = (n_units + cus - 1) / cus;
     if (w < 1) w = 1;
     if (w > OHGPU_MFMA_WAVES) w = OHGPU_MFMA_WAVES;
-    uint32_t gsz = (f.n_lean + w - 1) / w;
+    uint32_t gsz = (n_units + w - 1) / w;
     if (gsz > cus) gsz = cus;
     if ((p.L_blk >> 4) > kMfBiasSteps) return hipErrorInvalidValue;            // (src_mfma_supported keeps such a filter off this kernel)
     const uint32_t lds = kMfBiasBytes + w * kMfWaveLds;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(w * 64), lds, s,
-                       (const LeanUnit*)f.d_lean_units, f.n_lean, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
+                       (const LeanUnit*)f.d_lean_units + first_unit, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
                        (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.src_arena_bytes, p.L_blk, p.M_blk, (uint32_t*)f.d_counter);
     return hipGetLastError();
 }
 
-hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit)
 {
     SrcFastParams prm = b->fast.params;
     prm.src = src;
     prm.dst = dst;
-    if (prm.src_le) return prm.dst_le ? launch_mfma_one<true, true>(ctx, b, prm, s) : launch_mfma_one<true, false>(ctx, b, prm, s);
-    return prm.dst_le ? launch_mfma_one<false, true>(ctx, b, prm, s) : launch_mfma_one<false, false>(ctx, b, prm, s);
+    if (prm.src_le) return prm.dst_le ? launch_mfma_one<true, true>(ctx, b, prm, s, first_unit) : launch_mfma_one<true, false>(ctx, b, prm, s, first_unit);
+    return prm.dst_le ? launch_mfma_one<false, true>(ctx, b, prm, s, first_unit) : launch_mfma_one<false, false>(ctx, b, prm, s, first_unit);
 }
 
 }  // namespace ohgpu

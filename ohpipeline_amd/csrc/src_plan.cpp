@@ -131,6 +131,16 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if (M_blk64 + T > 32000 || M_blk64 < T) return OHGPU_OK;    // a block is at least one filter length of input
     const uint32_t M_blk = (uint32_t)M_blk64;
 
+    // src_mfma_kernel (round 4) runs the same units for the layouts it serves, from the filter's digit tables -- made for this
+    // block length and rows of up to mf_kb_cap blocks -- with its own number of waves per CU.  src_mfma_wg_kernel (the default where
+    // it applies; ohgpu_set_kernel_variant(5) keeps the unit-per-wave kernel) takes a unit per WORKGROUP: rows of one block, so that
+    // a unit's input and output are each one contiguous run, and no unit whose 32-row input image leaves the arena.
+    uint32_t mf_rows = 0, mf_wave_lds = 0, mf_max_waves = 0;
+    src_mfma_geometry(&mf_rows, &mf_wave_lds, &mf_max_waves);
+    const bool mfma = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (L_blk >> 4) <= 16u &&      // (the kernel's bias table: one block's steps)
+                      mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
+    const bool mfma_wg = mfma && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db) && !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
+
     // order messages by (stream, output position); a stream is identified by where its absolute frame 0 lives
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
@@ -265,12 +275,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // work allows (claimed first: every wave starts on one), everything else -- what does not divide, and the ramped units,
     // which stay one block long because a long unit would run the ramp path for all its outputs -- as one-block units for
     // the waves to level out on.
-    // src_mfma_kernel (round 4) runs the same units for the layouts it serves, from the filter's digit tables -- made for this
-    // block length and rows of up to mf_kb_cap blocks -- with its own number of waves per CU
-    uint32_t mf_rows = 0, mf_wave_lds = 0, mf_max_waves = 0;
-    src_mfma_geometry(&mf_rows, &mf_wave_lds, &mf_max_waves);
-    const bool mfma = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (L_blk >> 4) <= 16u &&      // (the kernel's bias table: one block's steps)
-                      mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
     std::vector<LeanUnit> lean_units;
     if (lean) {
         const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * (mfma ? mf_max_waves : lean_max_waves);
@@ -290,13 +294,14 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         if (const char* e = getenv("OHGPU_DIAG_LONG_ROUNDS")) long_rounds = (uint32_t)atoi(e);
 #endif
         if (mfma && kb_max > flt->mf_kb_cap) kb_max = flt->mf_kb_cap;      // (the step table's length)
+        if (mfma_wg) kb_max = 1;                                           // (a unit = consecutive blocks)
         // the plain, full one-block units (the only ones that merge), in runs between ramped or partly filled ones
         uint64_t plain_total = 0;
         for (const SrcWork& w : work) plain_total += (!(w.flags & kWorkRamped) && w.n_blocks == rows) ? 1u : 0u;
         const double plain_avail = (double)plain_total - tail_rounds * waves;
         uint32_t kb_long = 1;
         uint64_t long_target = 0;                            // long units to cut, over all segments
-        if (ctx && ctx->variant == 3) {                    // ohgpu_set_kernel_variant(3): the long rows forced, for tests with small batches
+        if (ctx && ctx->variant == 3 && !mfma_wg) {        // ohgpu_set_kernel_variant(3): the long rows forced, for tests with small batches
             kb_long = 3;
             long_target = ~(uint64_t)0;
         } else if (plain_avail >= 2.0 * waves && kb_max >= 2) {
@@ -319,6 +324,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             u.src_plane_stride = planar ? seg_plane_stride[r.seg] : 0u;
             if (w1) u.flags |= w1->flags & (kWorkRamped | kWorkChecked);
             else if (unit_leaves_arena(segs[r.seg].src_base, u.src_plane_stride, bk, n_rows, kb)) u.flags |= kWorkChecked;
+            // the workgroup kernel reads 32 rows' worth of input per unit whatever the unit holds and checks nothing: the (at most two)
+            // units of a batch for which that leaves the arena stay with the unit-per-wave kernel
+            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes)) u.flags |= kWorkEdge;
             if (u.flags & kWorkRamped) {
                 // one plane of multipliers per ramped unit -- n_rows * L_blk entries (uint16, 0xffff = no ramp on that frame), in
                 // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16
@@ -374,6 +382,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             auto cost = [](const LeanUnit& u) { return ((u.flags & kWorkRamped) ? 6u : 5u) * ((u.flags >> 8) & 0xffu) * u.n_blocks; };
             return cost(x) > cost(y);
         });
+        // (the workgroup kernel's units in front, the edge units behind them: two launches over one array)
+        if (mfma_wg) std::stable_partition(lean_units.begin(), lean_units.end(), [](const LeanUnit& u) { return !(u.flags & kWorkEdge); });
     }
     // (round 1's kernel, variant 2, keeps one-block units; ramped first, partly filled units last)
     std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {
@@ -415,6 +425,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.plane_stride = 16;                                              // SrcWork::plane counts 16-byte pieces
     f.lean_max_waves = lean_max_waves;
     f.mfma = mfma;
+    f.mfma_wg = mfma_wg;
+    f.n_wg = 0;
+    if (mfma_wg) for (const LeanUnit& u : lean_units) f.n_wg += (u.flags & kWorkEdge) ? 0u : 1u;
     f.d_mf_amat = mfma ? flt->d_mf_amat : nullptr;
     f.d_mf_steps = mfma ? flt->d_mf_steps : nullptr;
     f.fast_out_frames = fast_frames;
