@@ -45,8 +45,9 @@ constexpr uint32_t kWgRowInPitch = kWgRowIn + 16;   // ... and its pitch in LDS 
 constexpr uint32_t kWgRowOut = 160 * 6;             // bytes of a row's output
 constexpr uint32_t kWgPlaneBytes = 3 * kWgChunks * 1024;   // [digit][chunk][column tile 4][column 16][16 frames]
 constexpr uint32_t kWgStageBytes = kWgRows * kWgRowInPitch;  // the input image; the output image (32 x 960) lies over it
-constexpr uint32_t kWgBiasBytes = kWgSteps * 192;   // [step][b0 16, b1 16, b2 16] dwords
-constexpr uint32_t kWgLdsBytes = kWgPlaneBytes + kWgStageBytes + kWgBiasBytes + 64;
+constexpr uint32_t kWgBiasBytes = kWgSteps * 768;   // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
+constexpr uint32_t kWgLdsBytes = kWgPlaneBytes + kWgStageBytes + kWgBiasBytes;
+static_assert(2 * kWgLdsBytes <= 160 * 1024, "two workgroups per CU");
 constexpr uint32_t kWgOutPieces = kWgRows * (kWgRowOut / 16);    // 1920
 static_assert(kWgTilesPerWave * kWgWaves == kWgSteps * 4 && kWgTilesPerWave == 5, "five tiles per wave: at most two steps");
 static_assert(kWgThreads == 16 * kWgRows && kWgRowIn == 72 * 16, "sixteen lanes per row of the input image, 4.5 pieces each");
@@ -95,7 +96,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     // the accumulators' initial values (MfStep::b0..b2) of the block's steps
     for (uint32_t i = tid; i < kWgSteps * 48u; i += kWgThreads) {
         const uint32_t t = i / 48u, r = i - 48u * t;
-        ((uint32_t*)bias_lds)[i] = steps[t].b0[r];         // (b0, b1, b2 lie one after the other)
+        const uint32_t v = steps[t].b0[r];                 // (b0, b1, b2 lie one after the other)
+        ((u32x4*)bias_lds)[i] = u32x4{v, v, v, v};
     }
     // this wave's A operands, for good: its two steps'
     v4i a_a[4], a_b[4];
@@ -107,12 +109,13 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t kc_a = steps[step_a].kc, kc_b = steps[step_b_c].kc;
 
     // ---- lane roles ----
-    // matrix operands and results: g = K group / output quad, n = A row (output of the step) / column of the tile
+    // matrix operands: the SAMPLES are the A operand (lane = column n of the tile, K group g), the coefficients the B operand (lane =
+    // output n of the step, K group g); the result's lane (g, n) then holds output frame n of the four columns 4 g .. 4 g + 3 =
+    // rows 2 g and 2 g + 1 of the tile, both channels: a whole frame of each in one lane, nothing to exchange
     const uint32_t g = lane >> 4, n = lane & 15;
-    const uint32_t rr = n >> 1, ch = n & 1;                // the column's row within its tile, its channel
     const uint8_t* const b_lds = pl_lds + g * 1024u + n * 16u;                    // + kc * 1024 + digit * 12288 + tile * 256
-    const uint8_t* const my_bias = bias_lds + 16u * g;                            // + step * 192: b0; b1 at + 64, b2 at + 128
-    uint8_t* const out_lds = stage + rr * kWgRowOut + 24u * g + 12u * ch;         // + 96 * step + tile * 8 rows
+    const uint8_t* const my_bias = bias_lds + 16u * n;                            // + step * 768: b0; b1 at + 256, b2 at + 512
+    uint8_t* const out_lds = stage + 2u * g * kWgRowOut + 6u * n;                  // + 96 * step + tile * 8 rows (+ a row for the second frame)
     // the input image: sixteen lanes per row; lane `sub` of a row moves its pieces sub, sub + 16, .. sub + 48 and (sub < 8) sub + 64 of
     // the row's 72 -- an instruction reads 256 contiguous bytes of every row, and a lane's addresses differ by constants
     const uint32_t in_row = tid >> 4, in_sub = tid & 15u;
@@ -123,12 +126,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     // bytes are 32 contiguous bytes each)
     const uint32_t sp_row = tid & 31u, sp_hc0 = tid >> 5;                          // (second round: half chunk + 16)
 
-    // pack: {got, own} -> the lane's three dwords of two frames (src_mfma_kernel.hip)
-    constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;
-    const uint32_t own_l = ch == 0 ? 0u : 4u, own_r = ch == 0 ? 4u : 0u;
-    const uint32_t sel_d0 = (own_l + kB0) | (own_l + kB1) << 8 | (own_l + kB2) << 16 | (own_r + kB0) << 24;
-    const uint32_t sel_d2 = (own_l + kB2) | (own_r + kB0) << 8 | (own_r + kB1) << 16 | (own_r + kB2) << 24;
-    constexpr uint32_t sel_d1 = kB1 | kB2 << 8 | (4 + kB0) << 16 | (4 + kB1) << 24;
+    // pack: a frame's six bytes from its two 24-bit values, L then R, each most significant byte first (big endian) or last
+    constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;       // byte of the 24-bit value that is memory byte 0, 1, 2
+    constexpr uint32_t sel_lo = kB0 | kB1 << 8 | kB2 << 16 | (4 + kB0) << 24;     // {R, L} -> L's three bytes, R's first
+    constexpr uint32_t sel_hi = (4 + kB1) | (4 + kB2) << 8 | 0x0c0c0000u;          // {R, L} -> R's other two
 
     auto issue_input = [&](const LeanUnit& w, u32x4 (&raw)[5]) __attribute__((always_inline)) {
         // (scalar base + 32-bit lane offset is the load's scalar-base form, but only if the offset is widened in THIS block: hoisted out
@@ -215,25 +216,25 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             const uint32_t step = first_step ? step_a : step_b;
             const uint32_t ct = (tile0 + (uint32_t)i) & 3u;
             const uint8_t* const bl = b_lds + (first_step ? kc_a : kc_b) * 1024u + ct * 256u;
-            const uint8_t* const bi = my_bias + step * 192u;
+            const uint8_t* const bi = my_bias + step * 768u;
             v4i bd[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) bd[d] = *(const v4i*)(bl + d * 12288);
-            v4i s0 = *(const v4i*)bi, s1 = v4i{0, 0, 0, 0}, s2 = *(const v4i*)(bi + 64), s3 = v4i{0, 0, 0, 0},
-                s4 = *(const v4i*)(bi + 128), s5 = v4i{0, 0, 0, 0};
+            v4i s0 = *(const v4i*)bi, s1 = v4i{0, 0, 0, 0}, s2 = *(const v4i*)(bi + 256), s3 = v4i{0, 0, 0, 0},
+                s4 = *(const v4i*)(bi + 512), s5 = v4i{0, 0, 0, 0};
             auto taps = [&](const v4i (&a)[4]) __attribute__((always_inline)) {
-                s0 = MF_MFMA(a[0], bd[0], s0);
-                s1 = MF_MFMA(a[1], bd[0], s1);
-                s2 = MF_MFMA(a[2], bd[0], s2);
-                s3 = MF_MFMA(a[3], bd[0], s3);
-                s1 = MF_MFMA(a[0], bd[1], s1);
-                s2 = MF_MFMA(a[1], bd[1], s2);
-                s3 = MF_MFMA(a[2], bd[1], s3);
-                s4 = MF_MFMA(a[3], bd[1], s4);
-                s2 = MF_MFMA(a[0], bd[2], s2);
-                s3 = MF_MFMA(a[1], bd[2], s3);
-                s4 = MF_MFMA(a[2], bd[2], s4);
-                s5 = MF_MFMA(a[3], bd[2], s5);
+                s0 = MF_MFMA(bd[0], a[0], s0);
+                s1 = MF_MFMA(bd[0], a[1], s1);
+                s2 = MF_MFMA(bd[0], a[2], s2);
+                s3 = MF_MFMA(bd[0], a[3], s3);
+                s1 = MF_MFMA(bd[1], a[0], s1);
+                s2 = MF_MFMA(bd[1], a[1], s2);
+                s3 = MF_MFMA(bd[1], a[2], s3);
+                s4 = MF_MFMA(bd[1], a[3], s4);
+                s2 = MF_MFMA(bd[2], a[0], s2);
+                s3 = MF_MFMA(bd[2], a[1], s3);
+                s4 = MF_MFMA(bd[2], a[2], s4);
+                s5 = MF_MFMA(bd[2], a[3], s5);
             };
             if (first_step) taps(a_a); else taps(a_b);
             int y[4];
@@ -241,31 +242,30 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             for (int v = 0; v < 4; v++) y[v] = mf_recombine(s0[v], s1[v], s2[v], s3[v], s4[v], s5[v]);
             if (ramped) {
                 // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero; the
-                // multipliers of the lane's four frames come from the unit's plane (0xffff: the frame's message has no ramp)
-                const uint32_t row = ct * 8u + rr;
-                const u32x2 mm = *(const u32x2*)(mbase + mf_here(((row < n_blocks ? row * 160u : 0u) + 16u * step + 4u * g) * 2u));
-                const uint32_t mu[4] = {mm.x & 0xffffu, mm.x >> 16, mm.y & 0xffffu, mm.y >> 16};
+                // multiplier of the lane's frame in each of its two rows comes from the unit's plane (0xffff: the frame's message has no ramp)
+                const uint32_t row = ct * 8u + 2u * g;
+                const uint32_t e0 = (row < n_blocks ? row * 160u : 0u) + 16u * step + n;
+                const uint32_t e1 = (row + 1u < n_blocks ? (row + 1u) * 160u : 0u) + 16u * step + n;
+                const uint32_t mu[2] = {*(const uint16_t*)(mbase + mf_here(2u * e0)), *(const uint16_t*)(mbase + mf_here(2u * e1))};
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     const int top = (int)((uint32_t)y[v] << 8) >> 16;  // bits 8..23, signed
-                    const int r = (int)((uint32_t)((top * (int)mu[v]) >> 15) << 8);
-                    y[v] = mu[v] != 0xffffu ? r : y[v];
+                    const int r = (int)((uint32_t)((top * (int)mu[v >> 1]) >> 15) << 8);
+                    y[v] = mu[v >> 1] != 0xffffu ? r : y[v];
                 }
             }
-            // pack: exchange two values with the other channel's lane, three permutes, 12 bytes of the row's 96 into the output image
-            const int give_a = ch ? y[0] : y[2], give_b = ch ? y[1] : y[3];
-            const int own_a = ch ? y[2] : y[0], own_b = ch ? y[3] : y[1];
-            const uint32_t got_a = (uint32_t)__builtin_amdgcn_mov_dpp(give_a, 0xb1, 0xf, 0xf, true);    // quad_perm:[1,0,3,2]
-            const uint32_t got_b = (uint32_t)__builtin_amdgcn_mov_dpp(give_b, 0xb1, 0xf, 0xf, true);
-            const uint32_t r_first = ch ? (uint32_t)own_a : got_a;      // R of the lane's first frame
-            const uint32_t l_second = ch ? got_b : (uint32_t)own_b;     // L of its second
-            const uint32_t o0 = mf_perm(got_a, (uint32_t)own_a, sel_d0);
-            const uint32_t o1 = mf_perm(l_second, r_first, sel_d1);
-            const uint32_t o2 = mf_perm(got_b, (uint32_t)own_b, sel_d2);
-            // (the 12 bytes start on an 8-byte boundary for channel 0 and 4 bytes past one for channel 1)
+            // pack: two permutes and three 16-bit stores per frame into the output image (a frame starts on an even byte)
             uint8_t* const os = out_lds + ct * (8u * kWgRowOut) + 96u * step;
-            *(u32x2*)(os + (ch ? 4 : 0)) = ch ? u32x2{o1, o2} : u32x2{o0, o1};
-            *(uint32_t*)(os + (ch ? 0 : 8)) = ch ? o0 : o2;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t lo = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_lo);
+                const uint32_t hi = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_hi);
+                // (written out: left to the compiler the first two become one 4-byte store, misaligned for odd frames.  LDS operations
+                // complete in order and every barrier here waits for lgkmcnt(0), so the compiler's own counts stay safe)
+                const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(os + q * kWgRowOut);
+                asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:2\n\tds_write_b16 %0, %2 offset:4"
+                             : : "v"(at), "v"(lo), "v"(hi) : "memory");
+            }
         }
         wg_barrier<0>();                                    // the output image is whole; the planes are free
 
