@@ -18,7 +18,7 @@
 //   (C) runs the 40 tiles, packed results into an LDS image of the unit's output,
 //   (D) writes that image out: 30 KB contiguous, whole lines, non-temporal,
 // with a workgroup barrier between the phases; the input image and the output image share their LDS (72.5 KB a workgroup, two
-// workgroups per CU), the next unit's input is in flight in registers during (C) and (D).
+// workgroups per CU for 32-row units, 44 KB and three for 16-row ones), the next unit's input is in flight in registers during (C) and (D).
 // Units whose 32-row input image does not lie wholly inside the source arena (kWorkEdge: the first of the first stream, the last of
 // the last) stay with the unit-per-wave kernel, so nothing is checked here.
 #include <hip/hip_runtime.h>
@@ -32,25 +32,45 @@
 #include "pcm_device.h"
 #include "src_mfma_common.h"
 
+#ifndef OHGPU_WG_ROWS
+#define OHGPU_WG_ROWS 16                            // rows (blocks) a workgroup takes at a time: 16 (three workgroups per CU) or 32 (two)
+#endif
+
 namespace ohgpu {
 
 constexpr uint32_t kWgSteps = 10;                   // steps per block (a 160-output block)
-constexpr uint32_t kWgWaves = 8;                    // waves per workgroup: two per SIMD, and two workgroups per CU
-constexpr uint32_t kWgThreads = kWgWaves * 64;
-constexpr uint32_t kWgTilesPerWave = kWgSteps * 4 / kWgWaves;      // a unit is 10 steps x 4 column tiles; a wave takes 5 in step-major order
-constexpr uint32_t kWgRows = 32;
+constexpr uint32_t kWgUnitRows = 32;                // rows of a planner unit (LeanUnit)
 constexpr uint32_t kWgChunks = 12;                  // chunks (16 frames) a row's outputs touch: frames -32 .. 159 of the row
 constexpr uint32_t kWgRowIn = kWgChunks * 96;       // bytes of a row's input image
 constexpr uint32_t kWgRowInPitch = kWgRowIn + 16;   // ... and its pitch in LDS (16 rows, 16 bytes each, then meet all 64 banks once)
 constexpr uint32_t kWgRowOut = 160 * 6;             // bytes of a row's output
-constexpr uint32_t kWgPlaneBytes = 3 * kWgChunks * 1024;   // [digit][chunk][column tile 4][column 16][16 frames]
-constexpr uint32_t kWgStageBytes = kWgRows * kWgRowInPitch;  // the input image; the output image (32 x 960) lies over it
 constexpr uint32_t kWgBiasBytes = kWgSteps * 768;   // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
-constexpr uint32_t kWgLdsBytes = kWgPlaneBytes + kWgStageBytes + kWgBiasBytes;
-static_assert(2 * kWgLdsBytes <= 160 * 1024, "two workgroups per CU");
-constexpr uint32_t kWgOutPieces = kWgRows * (kWgRowOut / 16);    // 1920
-static_assert(kWgTilesPerWave * kWgWaves == kWgSteps * 4 && kWgTilesPerWave == 5, "five tiles per wave: at most two steps");
-static_assert(kWgThreads == 16 * kWgRows && kWgRowIn == 72 * 16, "sixteen lanes per row of the input image, 4.5 pieces each");
+
+// A workgroup's share of a unit is ROWS rows = CT = ROWS / 8 column tiles per step, 10 CT tiles in all; a wave takes FIVE of them
+// in step-major order (2 CT waves: two per SIMD for 32 rows, one for 16 -- whole numbers per SIMD whatever SIMD the first wave lands
+// on; ten waves, one per step, would be 3, 3, 2, 2, and the phase between two barriers lasts as long as its slowest wave).
+template <int ROWS>
+struct WgGeom {
+    static_assert(ROWS == 16 || ROWS == 32, "rows per workgroup");
+    static constexpr uint32_t kCt = ROWS / 8;
+    static constexpr uint32_t kWaves = 2 * kCt;
+    static constexpr uint32_t kThreads = 64 * kWaves;                 // = 16 * ROWS: sixteen lanes per row of the input image
+    static constexpr uint32_t kTilesPerWave = 5;
+    static constexpr uint32_t kASets = kCt == 4 ? 2 : 3;              // steps a wave's five tiles touch
+    static constexpr uint32_t kHalf = kCt * 128;                      // a digit plane's chunk: [half of its frames 2][column tile][column 16][8 frames]
+    static constexpr uint32_t kChunk = 2 * kHalf;
+    static constexpr uint32_t kDigit = kWgChunks * kChunk;
+    static constexpr uint32_t kPlaneBytes = 3 * kDigit;
+    static constexpr uint32_t kStageBytes = ROWS * kWgRowInPitch;     // the input image; the output image (ROWS x 960) lies over it
+    static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kWgBiasBytes;
+    static constexpr uint32_t kGroupsPerCu = ROWS == 32 ? 2 : 3;
+    static constexpr uint32_t kSubUnits = kWgUnitRows / ROWS;         // workgroup units per planner unit
+    static constexpr uint32_t kOutPieces = ROWS * (kWgRowOut / 16);
+    static constexpr uint32_t kStoreRounds = (kOutPieces + kThreads - 1) / kThreads;
+    static_assert(kGroupsPerCu * kLdsBytes <= 160 * 1024, "workgroups per CU");
+    static_assert(kTilesPerWave * kWaves == kWgSteps * kCt, "five tiles per wave");
+    static_assert(kThreads == 16 * ROWS && kWgRowIn == 72 * 16, "sixteen lanes per row of the input image, 4.5 pieces each");
+};
 
 #ifndef MF_DIAG_BARRIER_MASK
 #define MF_DIAG_BARRIER_MASK 0xf
@@ -63,57 +83,52 @@ __device__ __forceinline__ void wg_barrier()
         return;
     }
     // every LDS access of this wave has completed; nothing moves across (global loads in flight stay in flight)
-#ifdef MF_DIAG_NO_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
-template <bool SRC_LE, bool DST_LE>
-__global__ __launch_bounds__(kWgThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))       // (two workgroups of eight waves per CU: 128 registers)
+template <int ROWS, bool SRC_LE, bool DST_LE>
+__global__ __launch_bounds__(WgGeom<ROWS>::kThreads) __attribute__((amdgpu_waves_per_eu(ROWS == 32 ? 4 : 3, ROWS == 32 ? 4 : 3)))
 void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         const uint8_t* __restrict__ amat, const MfStep* __restrict__ steps,
                         const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                         const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                         const uint32_t row_src_bytes)
 {
+    using G = WgGeom<ROWS>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const pl_lds = smem;
-    uint8_t* const stage = smem + kWgPlaneBytes;
-    uint8_t* const bias_lds = stage + kWgStageBytes;
+    uint8_t* const stage = smem + G::kPlaneBytes;
+    uint8_t* const bias_lds = stage + G::kStageBytes;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    // A unit is 40 tiles: (step 0..9) x (column tile 0..3).  Wave w takes tiles 5 w .. 5 w + 4 in step-major order: the last
-    // n_a = 4 - w % 4 column tiles of step s_a = 5 (w / 4) + w % 4 ... no: its first n_a tiles are step s_a's, the rest step s_a + 1's.
-    // Eight waves are two per SIMD whatever SIMD the first one lands on; ten (one per step) are 3, 3, 2, 2, and the phase between
-    // two barriers lasts as long as its slowest wave.
-    const uint32_t tile0 = kWgTilesPerWave * wave;
-    const uint32_t step_a = tile0 >> 2, n_a = 4u - (tile0 & 3u);                         // tiles [0, n_a) of the wave are step_a's (column tiles 4 - n_a ..)
-    const uint32_t step_b = step_a + 1u;                                               // (n_a = 4 and w = 7: step 10 is never used: 5 * 7 = 35 -> step 8, n_a = 1; fine)
+    // this wave's tiles: tile0 .. tile0 + 4 of the unit's (step, column tile) pairs; its first step, and the A operands of the steps it touches
+    const uint32_t tile0 = G::kTilesPerWave * wave;
+    const uint32_t step0 = tile0 / G::kCt;
 
     // the accumulators' initial values (MfStep::b0..b2) of the block's steps
-    for (uint32_t i = tid; i < kWgSteps * 48u; i += kWgThreads) {
+    for (uint32_t i = tid; i < kWgSteps * 48u; i += G::kThreads) {
         const uint32_t t = i / 48u, r = i - 48u * t;
         const uint32_t v = steps[t].b0[r];                 // (b0, b1, b2 lie one after the other)
         ((u32x4*)bias_lds)[i] = u32x4{v, v, v, v};
     }
-    // this wave's A operands, for good: its two steps'
-    v4i a_a[4], a_b[4];
-    const uint32_t step_b_c = step_b < kWgSteps ? step_b : step_a;
+    // this wave's A operands, for good
+    v4i a[G::kASets][4];
+    uint32_t kc[G::kASets];
 #pragma unroll
-    for (int j = 0; j < 4; j++) a_a[j] = *(const v4i*)(amat + ((uint64_t)step_a * kMfStepImage + j * 1024u + lane * 16u));
+    for (int q = 0; q < (int)G::kASets; q++) {
+        const uint32_t st = step0 + q < kWgSteps ? step0 + q : kWgSteps - 1u;     // (a set past the last step is never used)
 #pragma unroll
-    for (int j = 0; j < 4; j++) a_b[j] = *(const v4i*)(amat + ((uint64_t)step_b_c * kMfStepImage + j * 1024u + lane * 16u));
-    const uint32_t kc_a = steps[step_a].kc, kc_b = steps[step_b_c].kc;
+        for (int j = 0; j < 4; j++) a[q][j] = *(const v4i*)(amat + ((uint64_t)st * kMfStepImage + j * 1024u + lane * 16u));
+        kc[q] = steps[st].kc;
+    }
 
     // ---- lane roles ----
     // matrix operands: the SAMPLES are the A operand (lane = column n of the tile, K group g), the coefficients the B operand (lane =
     // output n of the step, K group g); the result's lane (g, n) then holds output frame n of the four columns 4 g .. 4 g + 3 =
     // rows 2 g and 2 g + 1 of the tile, both channels: a whole frame of each in one lane, nothing to exchange
     const uint32_t g = lane >> 4, n = lane & 15;
-    const uint8_t* const b_lds = pl_lds + g * 1024u + n * 16u;                    // + kc * 1024 + digit * 12288 + tile * 256
+    const uint8_t* const b_lds = pl_lds + g * G::kChunk + n * 8u;                 // + kc * chunk + digit * kDigit + ((half * kHalf + tile * 128) ^ parity of the chunk * 128)
     const uint8_t* const my_bias = bias_lds + 16u * n;                            // + step * 768: b0; b1 at + 256, b2 at + 512
     uint8_t* const out_lds = stage + 2u * g * kWgRowOut + 6u * n;                  // + 96 * step + tile * 8 rows (+ a row for the second frame)
     // the input image: sixteen lanes per row; lane `sub` of a row moves its pieces sub, sub + 16, .. sub + 48 and (sub < 8) sub + 64 of
@@ -122,19 +137,32 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t in_src = in_row * row_src_bytes + 16u * in_sub;                 // + 256 k
     const uint32_t in_lds = in_row * kWgRowInPitch + 16u * in_sub;
     const uint32_t in_last = in_sub < 8u ? 1024u : 0u;                             // (the fifth round's spare lanes repeat their first piece)
-    // the split: task q = 512 k + tid (k = 0, 1; q < 768) is half chunk q / 32 of row q % 32 (32 rows side by side: their plane
-    // bytes are 32 contiguous bytes each)
-    const uint32_t sp_row = tid & 31u, sp_hc0 = tid >> 5;                          // (second round: half chunk + 16)
+    // the split: task q = threads * k + tid (k = 0, 1; q < 24 ROWS) is half chunk q / ROWS of row q % ROWS (the rows side by side)
+    const uint32_t sp_row = tid % (uint32_t)ROWS, sp_hc0 = tid / (uint32_t)ROWS;   // (0..15; second round: half chunk + 16 while < 24)
 
     // pack: a frame's six bytes from its two 24-bit values, L then R, each most significant byte first (big endian) or last
     constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;       // byte of the 24-bit value that is memory byte 0, 1, 2
     constexpr uint32_t sel_lo = kB0 | kB1 << 8 | kB2 << 16 | (4 + kB0) << 24;     // {R, L} -> L's three bytes, R's first
     constexpr uint32_t sel_hi = (4 + kB1) | (4 + kB2) << 8 | 0x0c0c0000u;          // {R, L} -> R's other two
 
-    auto issue_input = [&](const LeanUnit& w, u32x4 (&raw)[5]) __attribute__((always_inline)) {
+    // a workgroup unit = sub-unit `u % kSubUnits` of planner unit `u / kSubUnits`
+    struct Unit { int64_t src0, dst0; uint32_t n_blocks, plane; bool ramped, first; };
+    auto fetch_unit = [&](uint32_t u) __attribute__((always_inline)) {
+        const LeanUnit w = units[u / G::kSubUnits];
+        const uint32_t sub = u % G::kSubUnits, r0 = sub * (uint32_t)ROWS;
+        Unit o;
+        o.src0 = w.src_row0 + (int64_t)(r0 * row_src_bytes);
+        o.dst0 = w.dst_row0 + (int64_t)(r0 * kWgRowOut);
+        o.n_blocks = w.n_blocks > r0 ? (w.n_blocks - r0 < (uint32_t)ROWS ? w.n_blocks - r0 : (uint32_t)ROWS) : 0u;
+        o.plane = w.plane + r0 * 20u;                       // (a plane row is 160 entries of 2 bytes = 20 of the plane stride's 16)
+        o.ramped = (w.flags & kWorkRamped) != 0;
+        o.first = (w.flags & kWorkFirst) != 0 && sub == 0;
+        return o;
+    };
+    auto issue_input = [&](const Unit& w, u32x4 (&raw)[5]) __attribute__((always_inline)) {
         // (scalar base + 32-bit lane offset is the load's scalar-base form, but only if the offset is widened in THIS block: hoisted out
         // of the loop as a 64-bit pair it costs eight registers for the whole launch and a 64-bit add per load -- mf_here pins it)
-        const uint8_t* const base = src + w.src_row0;
+        const uint8_t* const base = src + w.src0;
 #ifdef MF_DIAG_NO_LOAD
         (void)base;
 #pragma unroll
@@ -166,12 +194,17 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         for (int k = 0; k < 12; k++) w[k] = zero ? 0u : w[k];
         uint32_t pl[6][2];
         mf_split48(w, pl);
-        uint8_t* const to = pl_lds + (hc >> 1) * 1024u + sp_row * 32u + (hc & 1u) * 8u;     // + digit * 12288 + channel * 16
+        // A plane's chunk is [half][row][channel 2][8 frames]: a lane's two channels are 16 contiguous bytes, the rows of a task a
+        // contiguous run, a wave's tasks whole halves -- one conflict-free 16-byte store per digit (the 8-byte stores of a
+        // [row][channel][16 frames] layout met the banks four deep).  Odd chunks are stored with bit 7 of the offset flipped, so that the
+        // 8-byte reads of chunks kc + g and kc + g + 1, which share a 32-lane half of the A operand's load, fall into different banks.
+        const uint32_t c = hc >> 1;
+        uint8_t* const to = pl_lds + c * G::kChunk + (((hc & 1u) * G::kHalf + sp_row * 16u) ^ ((c & 1u) * 128u));     // + digit * kDigit
 #pragma unroll
-        for (int c0 = 0; c0 < 6; c0++) {
-            const int chn = c0 / 3, bpos = c0 % 3, digit = SRC_LE ? bpos : 2 - bpos;
+        for (int bpos = 0; bpos < 3; bpos++) {
+            const int digit = SRC_LE ? bpos : 2 - bpos;
             const uint32_t flip = digit < 2 ? 0x80808080u : 0u;
-            *(u32x2*)(to + digit * 12288 + chn * 16) = u32x2{pl[c0][0] ^ flip, pl[c0][1] ^ flip};
+            *(u32x4*)(to + digit * G::kDigit) = u32x4{pl[bpos][0] ^ flip, pl[bpos][1] ^ flip, pl[3 + bpos][0] ^ flip, pl[3 + bpos][1] ^ flip};
         }
     };
     auto split_all = [&](bool first) __attribute__((always_inline)) {
@@ -179,7 +212,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         return;
 #endif
         split_task(sp_hc0, first);
-        if (tid < 256u) split_task(sp_hc0 + 16u, first);
+        if (sp_hc0 < 8u) split_task(sp_hc0 + 16u, first);
     };
 
     // Units are dealt round robin: they cost the same (a ramped one a few instructions per tile more), so a workgroup's share
@@ -189,54 +222,74 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     uint32_t u_cur = blockIdx.x;                           // the unit in the planes
     if (u_cur >= n_work) return;                            // (uniform; the launch keeps the grid within the units)
     uint32_t u_nxt = u_cur + n_groups;                     // the unit whose input is in flight
-    LeanUnit wk = units[u_cur];
+    Unit wk = fetch_unit(u_cur);
     u32x4 raw[5];
     issue_input(wk, raw);
     __syncthreads();                                        // (the bias table)
     stage_input(raw);
     wg_barrier();
-    split_all((wk.flags & kWorkFirst) != 0);
-    LeanUnit wk_nxt = units[u_nxt < n_work ? u_nxt : u_cur];
+    split_all(wk.first);
+    Unit wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
     issue_input(wk_nxt, raw);                               // (past the last unit: the current one again, never used)
     wg_barrier();
 
     while (true) {
-        // ---- (C) this wave's step of the unit: four column tiles ----
+        // ---- (C) this wave's five tiles of the unit ----
         const uint32_t n_blocks = wk.n_blocks;
-        const bool ramped = (wk.flags & kWorkRamped) != 0;
+        const bool ramped = wk.ramped;
         const uint8_t* const mbase = (const uint8_t*)planes + (uint64_t)wk.plane * plane_stride;
 #ifdef MF_DIAG_IO_ONLY
 #pragma unroll
         for (int i = 0; i < 0; i++) {
-#else
+#elif defined(MF_WG_ROLLED)
 #pragma nounroll
-        for (int i = 0; i < (int)kWgTilesPerWave; i++) {
+        for (int i = 0; i < (int)G::kTilesPerWave; i++) {
+#else
+        // (unrolled where the registers allow it -- 168 at three waves per SIMD --, so that a tile's operands are fetched under its
+        // predecessor's arithmetic; at 128 registers the unrolled loop spills)
+#pragma unroll ROWS == 16 ? 5 : 1
+        for (int i = 0; i < (int)G::kTilesPerWave; i++) {
 #endif
-            const bool first_step = (uint32_t)i < n_a;                 // (wave-uniform)
-            const uint32_t step = first_step ? step_a : step_b;
-            const uint32_t ct = (tile0 + (uint32_t)i) & 3u;
-            const uint8_t* const bl = b_lds + (first_step ? kc_a : kc_b) * 1024u + ct * 256u;
+            const uint32_t idx = tile0 + (uint32_t)i;
+            const uint32_t step = idx / G::kCt, ct = idx % G::kCt, set = step - step0;      // (wave-uniform)
+            const uint32_t kcs = set == 0 ? kc[0] : (set == 1 || G::kASets == 2 ? kc[1] : kc[G::kASets - 1]);
             const uint8_t* const bi = my_bias + step * 768u;
             v4i bd[3];
+            {
+                // six 8-byte reads, written out (the compiler pairs the halves into ds_read2st64_b64, which the LDS serves at half the
+                // rate), with their wait in the same statement: what leaves it is data, whatever the compiler copies afterwards
+                const uint32_t in_chunk = (ct * 128u) ^ (((kcs + g) & 1u) * 128u);
+                const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(b_lds + kcs * G::kChunk + in_chunk);
+                u32x2 h[6];
+                asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:%7\n\t"
+                             "ds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %6 offset:%9\n\t"
+                             "ds_read_b64 %4, %6 offset:%10\n\tds_read_b64 %5, %6 offset:%11\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5])
+                             : "v"(at), "n"(G::kHalf), "n"(G::kDigit), "n"(G::kDigit + G::kHalf), "n"(2 * G::kDigit), "n"(2 * G::kDigit + G::kHalf)
+                             : "memory");
 #pragma unroll
-            for (int d = 0; d < 3; d++) bd[d] = *(const v4i*)(bl + d * 12288);
+                for (int d = 0; d < 3; d++) bd[d] = v4i{(int)h[2 * d].x, (int)h[2 * d].y, (int)h[2 * d + 1].x, (int)h[2 * d + 1].y};
+            }
             v4i s0 = *(const v4i*)bi, s1 = v4i{0, 0, 0, 0}, s2 = *(const v4i*)(bi + 256), s3 = v4i{0, 0, 0, 0},
                 s4 = *(const v4i*)(bi + 512), s5 = v4i{0, 0, 0, 0};
-            auto taps = [&](const v4i (&a)[4]) __attribute__((always_inline)) {
-                s0 = MF_MFMA(bd[0], a[0], s0);
-                s1 = MF_MFMA(bd[0], a[1], s1);
-                s2 = MF_MFMA(bd[0], a[2], s2);
-                s3 = MF_MFMA(bd[0], a[3], s3);
-                s1 = MF_MFMA(bd[1], a[0], s1);
-                s2 = MF_MFMA(bd[1], a[1], s2);
-                s3 = MF_MFMA(bd[1], a[2], s3);
-                s4 = MF_MFMA(bd[1], a[3], s4);
-                s2 = MF_MFMA(bd[2], a[0], s2);
-                s3 = MF_MFMA(bd[2], a[1], s3);
-                s4 = MF_MFMA(bd[2], a[2], s4);
-                s5 = MF_MFMA(bd[2], a[3], s5);
+            auto taps = [&](const v4i (&c)[4]) __attribute__((always_inline)) {
+                s0 = MF_MFMA(bd[0], c[0], s0);
+                s1 = MF_MFMA(bd[0], c[1], s1);
+                s2 = MF_MFMA(bd[0], c[2], s2);
+                s3 = MF_MFMA(bd[0], c[3], s3);
+                s1 = MF_MFMA(bd[1], c[0], s1);
+                s2 = MF_MFMA(bd[1], c[1], s2);
+                s3 = MF_MFMA(bd[1], c[2], s3);
+                s4 = MF_MFMA(bd[1], c[3], s4);
+                s2 = MF_MFMA(bd[2], c[0], s2);
+                s3 = MF_MFMA(bd[2], c[1], s3);
+                s4 = MF_MFMA(bd[2], c[2], s4);
+                s5 = MF_MFMA(bd[2], c[3], s5);
             };
-            if (first_step) taps(a_a); else taps(a_b);
+            if (set == 0) taps(a[0]);
+            else if (set == 1 || G::kASets == 2) taps(a[1]);
+            else taps(a[G::kASets - 1]);
             int y[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) y[v] = mf_recombine(s0[v], s1[v], s2[v], s3[v], s4[v], s5[v]);
@@ -269,23 +322,22 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         }
         wg_barrier<0>();                                    // the output image is whole; the planes are free
 
-        // ---- (D) the unit leaves: 1920 lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
+        // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
         // unit's input -- requested a whole phase (C) ago -- is waited for HERE, in front of the stores, not behind them ----
         asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]));
         {
-            uint8_t* const unit_dst = dst + wk.dst_row0;
+            uint8_t* const unit_dst = dst + wk.dst0;
             const uint32_t out_bytes = n_blocks * kWgRowOut;
-            constexpr int kRounds = (kWgOutPieces + kWgThreads - 1) / kWgThreads;      // 4: the last one three quarters full
-            u32x4 op[kRounds];
+            u32x4 op[G::kStoreRounds];
 #pragma unroll
-            for (int k = 0; k < kRounds; k++) {
-                uint32_t f = kWgThreads * k + tid;
-                if (f >= kWgOutPieces) f = kWgOutPieces - 1;
+            for (int k = 0; k < (int)G::kStoreRounds; k++) {
+                uint32_t f = G::kThreads * k + tid;
+                if (f >= G::kOutPieces) f = G::kOutPieces - 1;
                 op[k] = *(const u32x4*)(stage + 16u * f);
             }
 #pragma unroll
-            for (int k = 0; k < kRounds; k++) {
-                const uint32_t o = mf_here(16u * (kWgThreads * k + tid));
+            for (int k = 0; k < (int)G::kStoreRounds; k++) {
+                const uint32_t o = mf_here(16u * (G::kThreads * k + tid));
 #if defined(MF_DIAG_NO_STORE)
                 if (o < out_bytes && n_blocks > 1000000u) *(u32x4_u*)(unit_dst + o) = op[k];
 #else
@@ -299,11 +351,11 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         // ---- (A) + (S) the next unit: registers -> input image -> planes; then its successor's input is requested ----
         stage_input(raw);
         wg_barrier<2>();
-        split_all((wk_nxt.flags & kWorkFirst) != 0);
+        split_all(wk_nxt.first);
         wk = wk_nxt;
         u_cur = u_nxt;
         u_nxt += n_groups;
-        wk_nxt = units[u_nxt < n_work ? u_nxt : u_cur];
+        wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
         issue_input(wk_nxt, raw);
         wg_barrier<3>();
     }
@@ -317,23 +369,25 @@ bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t
 // does a unit's input image -- 32 rows of kWgRowIn bytes, whatever the number of blocks the unit holds -- lie inside the arena?
 bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes)
 {
-    return src_row0 >= 0 && (uint64_t)src_row0 + (uint64_t)(kWgRows - 1) * row_src_bytes + kWgRowIn <= src_arena_bytes;
+    return src_row0 >= 0 && (uint64_t)src_row0 + (uint64_t)(kWgUnitRows - 1) * row_src_bytes + kWgRowIn <= src_arena_bytes;
 }
 
 template <bool SRC_LE, bool DST_LE>
 static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
 {
-    auto kernel = src_mfma_wg_kernel<SRC_LE, DST_LE>;
+    using G = WgGeom<OHGPU_WG_ROWS>;
+    auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
     if (f.n_wg == 0) return hipSuccess;
     if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db)) return hipErrorInvalidValue;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
-    uint32_t gsz = 2u * cus;                                 // two workgroups per CU (LDS), eight waves each
-    if (gsz > f.n_wg) gsz = f.n_wg;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLdsBytes);
+    const uint32_t n_units = f.n_wg * G::kSubUnits;
+    uint32_t gsz = G::kGroupsPerCu * cus;                     // as many workgroups as the LDS holds
+    if (gsz > n_units) gsz = n_units;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLdsBytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(gsz), dim3(kWgThreads), kWgLdsBytes, s,
-                       (const LeanUnit*)f.d_lean_units, f.n_wg, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
+    hipLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s,
+                       (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
                        (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * 6u);
     return hipGetLastError();
 }
