@@ -238,42 +238,40 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         const uint32_t n_blocks = wk.n_blocks;
         const bool ramped = wk.ramped;
         const uint8_t* const mbase = (const uint8_t*)planes + (uint64_t)wk.plane * plane_stride;
-#ifdef MF_DIAG_IO_ONLY
+        // The five tiles as straight-line code, one copy per (pattern of the wave's tiles, ramped or not): which of the wave's A sets a
+        // tile takes and which column tile it is are constants of the wave's position among the kCt waves that share five steps, so
+        // nothing branches between two tiles and a tile's operands are fetched under its predecessor's matrix instructions.
+        auto read_planes = [&](uint32_t kcs, uint32_t ct, v4i (&bd)[3]) __attribute__((always_inline)) {
+            // six 8-byte reads, written out (the compiler pairs the halves into ds_read2st64_b64, which the LDS serves at half the
+            // rate), with their wait in the same statement: what leaves it is data, whatever the compiler copies afterwards
+            const uint32_t in_chunk = (ct * 128u) ^ (((kcs + g) & 1u) * 128u);
+            const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(b_lds + kcs * G::kChunk + in_chunk);
+            u32x2 h[6];
+            asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:%7\n\t"
+                         "ds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %6 offset:%9\n\t"
+                         "ds_read_b64 %4, %6 offset:%10\n\tds_read_b64 %5, %6 offset:%11\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5])
+                         : "v"(at), "n"(G::kHalf), "n"(G::kDigit), "n"(G::kDigit + G::kHalf), "n"(2 * G::kDigit), "n"(2 * G::kDigit + G::kHalf)
+                         : "memory");
 #pragma unroll
-        for (int i = 0; i < 0; i++) {
-#elif defined(MF_WG_ROLLED)
-#pragma nounroll
-        for (int i = 0; i < (int)G::kTilesPerWave; i++) {
-#else
-        // (unrolled where the registers allow it -- 168 at three waves per SIMD --, so that a tile's operands are fetched under its
-        // predecessor's arithmetic; at 128 registers the unrolled loop spills)
-#pragma unroll ROWS == 16 ? 5 : 1
-        for (int i = 0; i < (int)G::kTilesPerWave; i++) {
-#endif
-            const uint32_t idx = tile0 + (uint32_t)i;
-            const uint32_t step = idx / G::kCt, ct = idx % G::kCt, set = step - step0;      // (wave-uniform)
-            const uint32_t kcs = set == 0 ? kc[0] : (set == 1 || G::kASets == 2 ? kc[1] : kc[G::kASets - 1]);
-            const uint8_t* const bi = my_bias + step * 768u;
+            for (int d = 0; d < 3; d++) bd[d] = v4i{(int)h[2 * d].x, (int)h[2 * d].y, (int)h[2 * d + 1].x, (int)h[2 * d + 1].y};
+        };
+        auto run_tiles = [&](auto pattern_c, auto ramped_c) __attribute__((always_inline)) {
+            constexpr uint32_t P = decltype(pattern_c)::value;
+            constexpr bool RAMPED = decltype(ramped_c)::value;
+            constexpr uint32_t kFirst = 5u * P;                          // the pattern's first tile, counted from a multiple of five steps
             v4i bd[3];
-            {
-                // six 8-byte reads, written out (the compiler pairs the halves into ds_read2st64_b64, which the LDS serves at half the
-                // rate), with their wait in the same statement: what leaves it is data, whatever the compiler copies afterwards
-                const uint32_t in_chunk = (ct * 128u) ^ (((kcs + g) & 1u) * 128u);
-                const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(b_lds + kcs * G::kChunk + in_chunk);
-                u32x2 h[6];
-                asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:%7\n\t"
-                             "ds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %6 offset:%9\n\t"
-                             "ds_read_b64 %4, %6 offset:%10\n\tds_read_b64 %5, %6 offset:%11\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5])
-                             : "v"(at), "n"(G::kHalf), "n"(G::kDigit), "n"(G::kDigit + G::kHalf), "n"(2 * G::kDigit), "n"(2 * G::kDigit + G::kHalf)
-                             : "memory");
-#pragma unroll
-                for (int d = 0; d < 3; d++) bd[d] = v4i{(int)h[2 * d].x, (int)h[2 * d].y, (int)h[2 * d + 1].x, (int)h[2 * d + 1].y};
-            }
-            v4i s0 = *(const v4i*)bi, s1 = v4i{0, 0, 0, 0}, s2 = *(const v4i*)(bi + 256), s3 = v4i{0, 0, 0, 0},
-                s4 = *(const v4i*)(bi + 512), s5 = v4i{0, 0, 0, 0};
-            auto taps = [&](const v4i (&c)[4]) __attribute__((always_inline)) {
+            read_planes(kc[0], kFirst % G::kCt, bd);
+            static_for([&](auto ic) __attribute__((always_inline)) {
+                constexpr uint32_t i = decltype(ic)::value;
+                constexpr uint32_t set = (kFirst + i) / G::kCt - kFirst / G::kCt, ct = (kFirst + i) % G::kCt;
+                static_assert(set < G::kASets, "a wave's tiles touch kASets steps");
+                const uint32_t step = step0 + set;
+                const uint8_t* const bi = my_bias + step * 768u;
+                v4i s0 = *(const v4i*)bi, s1 = v4i{0, 0, 0, 0}, s2 = *(const v4i*)(bi + 256), s3 = v4i{0, 0, 0, 0},
+                    s4 = *(const v4i*)(bi + 512), s5 = v4i{0, 0, 0, 0};
+                const v4i (&c)[4] = a[set];
                 s0 = MF_MFMA(bd[0], c[0], s0);
                 s1 = MF_MFMA(bd[0], c[1], s1);
                 s2 = MF_MFMA(bd[0], c[2], s2);
@@ -286,40 +284,53 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                 s3 = MF_MFMA(bd[2], c[1], s3);
                 s4 = MF_MFMA(bd[2], c[2], s4);
                 s5 = MF_MFMA(bd[2], c[3], s5);
-            };
-            if (set == 0) taps(a[0]);
-            else if (set == 1 || G::kASets == 2) taps(a[1]);
-            else taps(a[G::kASets - 1]);
-            int y[4];
-#pragma unroll
-            for (int v = 0; v < 4; v++) y[v] = mf_recombine(s0[v], s1[v], s2[v], s3[v], s4[v], s5[v]);
-            if (ramped) {
-                // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero; the
-                // multiplier of the lane's frame in each of its two rows comes from the unit's plane (0xffff: the frame's message has no ramp)
-                const uint32_t row = ct * 8u + 2u * g;
-                const uint32_t e0 = (row < n_blocks ? row * 160u : 0u) + 16u * step + n;
-                const uint32_t e1 = (row + 1u < n_blocks ? (row + 1u) * 160u : 0u) + 16u * step + n;
-                const uint32_t mu[2] = {*(const uint16_t*)(mbase + mf_here(2u * e0)), *(const uint16_t*)(mbase + mf_here(2u * e1))};
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int top = (int)((uint32_t)y[v] << 8) >> 16;  // bits 8..23, signed
-                    const int r = (int)((uint32_t)((top * (int)mu[v >> 1]) >> 15) << 8);
-                    y[v] = mu[v >> 1] != 0xffffu ? r : y[v];
+                if constexpr (i + 1 < G::kTilesPerWave) {
+                    // the next tile's planes, while this one's matrix instructions run
+                    constexpr uint32_t set_n = (kFirst + i + 1) / G::kCt - kFirst / G::kCt, ct_n = (kFirst + i + 1) % G::kCt;
+                    read_planes(kc[set_n], ct_n, bd);
                 }
-            }
-            // pack: two permutes and three 16-bit stores per frame into the output image (a frame starts on an even byte)
-            uint8_t* const os = out_lds + ct * (8u * kWgRowOut) + 96u * step;
+                int y[4];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const uint32_t lo = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_lo);
-                const uint32_t hi = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_hi);
-                // (written out: left to the compiler the first two become one 4-byte store, misaligned for odd frames.  LDS operations
-                // complete in order and every barrier here waits for lgkmcnt(0), so the compiler's own counts stay safe)
-                const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(os + q * kWgRowOut);
-                asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:2\n\tds_write_b16 %0, %2 offset:4"
-                             : : "v"(at), "v"(lo), "v"(hi) : "memory");
+                for (int v = 0; v < 4; v++) y[v] = mf_recombine(s0[v], s1[v], s2[v], s3[v], s4[v], s5[v]);
+                if constexpr (RAMPED) {
+                    // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero; the
+                    // multiplier of the lane's frame in each of its two rows comes from the unit's plane (0xffff: the frame's message has no ramp)
+                    const uint32_t row = ct * 8u + 2u * g;
+                    const uint32_t e0 = (row < n_blocks ? row * 160u : 0u) + 16u * step + n;
+                    const uint32_t e1 = (row + 1u < n_blocks ? (row + 1u) * 160u : 0u) + 16u * step + n;
+                    const uint32_t mu[2] = {*(const uint16_t*)(mbase + mf_here(2u * e0)), *(const uint16_t*)(mbase + mf_here(2u * e1))};
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int top = (int)((uint32_t)y[v] << 8) >> 16;  // bits 8..23, signed
+                        const int r = (int)((uint32_t)((top * (int)mu[v >> 1]) >> 15) << 8);
+                        y[v] = mu[v >> 1] != 0xffffu ? r : y[v];
+                    }
+                }
+                // pack: two permutes and three 16-bit stores per frame into the output image (a frame starts on an even byte)
+                uint8_t* const os = out_lds + ct * (8u * kWgRowOut) + 96u * step;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const uint32_t lo = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_lo);
+                    const uint32_t hi = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_hi);
+                    // (written out: left to the compiler the first two become one 4-byte store, misaligned for odd frames.  LDS operations
+                    // complete in order and every barrier here waits for lgkmcnt(0), so the compiler's own counts stay safe)
+                    const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(os + q * kWgRowOut);
+                    asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:2\n\tds_write_b16 %0, %2 offset:4"
+                                 : : "v"(at), "v"(lo), "v"(hi) : "memory");
+                }
+            }, std::make_integer_sequence<int, (int)G::kTilesPerWave>{});
+        };
+#ifndef MF_DIAG_IO_ONLY
+        static_for([&](auto pc) __attribute__((always_inline)) {
+            if (wave % G::kCt == (uint32_t)decltype(pc)::value) {         // (wave-uniform)
+                if (ramped) run_tiles(pc, std::true_type{});
+                else run_tiles(pc, std::false_type{});
             }
-        }
+        }, std::make_integer_sequence<int, (int)G::kCt>{});
+#endif
+#ifndef MF_WG_NO_PRIO
+        __builtin_amdgcn_s_setprio(0);                       // (the tiles run at priority 3: -2 % on the headline, same box, alternating)
+#endif
         wg_barrier<0>();                                    // the output image is whole; the planes are free
 
         // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
@@ -357,6 +368,9 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         u_nxt += n_groups;
         wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
         issue_input(wk_nxt, raw);
+#ifndef MF_WG_NO_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         wg_barrier<3>();
     }
 }
