@@ -442,7 +442,7 @@ def source_fingerprint():
     """sha256 over the sources of the kernel the headline times (what a stored profile must have been taken from)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("src_lean_kernel.hip", "src_block_common.h", "src_plan.cpp", "ohgpu_internal.h"):
+    for f in ("src_mfma_wg_kernel.hip", "src_mfma_kernel.hip", "src_mfma_common.h", "src_lean_kernel.hip", "src_block_common.h", "src_plan.cpp", "ohgpu_internal.h"):
         with open(os.path.join(ROOT, "ohpipeline_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -538,8 +538,16 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             checks_ok = bool(okt.item() > 0.5)
 
-    # per-launch kernel time (HIP events on the launch stream), this rank
-    grp_ms = [float(np.mean([ctx.elapsed_ms(ev[k][i][0], ev[k][i][1]) for k in range(args.steps)])) for i in range(n_ev)]
+    # per-launch kernel time (HIP events on the launch stream), this rank; and the shader clock the chip holds right behind the
+    # timed launches (a 0.2 ms probe kernel, queued before anything lets the chip idle): a slow box shows in the clock or, the clock
+    # being the same, in the memory system -- either way not in the build
+    try:
+        clock_mhz = round(ctx.shader_clock_mhz(), 1)
+    except Exception:
+        clock_mhz = None
+    per_step = np.array([[ctx.elapsed_ms(ev[k][i][0], ev[k][i][1]) for i in range(n_ev)] for k in range(args.steps)], dtype=np.float64)
+    grp_ms = [float(per_step[:, i].mean()) for i in range(n_ev)]
+    step_kernel_ms = per_step[:, :len(groups)].sum(axis=1)             # per timed step: its launches' kernel time
     for row in ev:
         for pair in row:
             for e in pair:
@@ -579,7 +587,9 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64",
+            # exact integer sums either way: 24-bit samples x Q28 coefficients as int8 digits accumulated in int32 (matrix-pipe
+            # kernels), or as integer-valued doubles (lean kernel)
+            "dtype": "int32" if all("mfma" in ctx.src_kernel_name(g.batch) for g in groups) else "f64",
             "data": "synthetic",
             "config": {"workload": f"{names[args.config]}: {what}, {args.seconds:g} s each, 5 ms output messages, ramp up 50 ms / down 500 ms, S24 BE out",
                        "kernel_variant": args.variant, "sustain_s": args.sustain,
@@ -593,12 +603,16 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
                        "sharding": f"streams over {world} rank(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": ("fused resample+ramp+pack (src_lean_kernel), every launch of the step" if args.variant == 0 else f"variant {args.variant}"),
+                         "kernel": "fused resample+ramp+pack: " + ", ".join(sorted(set(ctx.src_kernel_name(g.batch) for g in groups)))
+                                   + f" (kernel variant {args.variant}), every launch of the step",
                          "kernel_avg_ms": round(kernel_ms, 4),
+                         "kernel_min_ms": round(float(step_kernel_ms.min()), 4), "kernel_median_ms": round(float(np.median(step_kernel_ms)), 4),
+                         "shader_clock_mhz": clock_mhz,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "bytes_per_input_frame": round(head.fb_src + head.fb_dst * head.L / head.M, 4),
-                         # the pipe the taps run on: 2*T*channels fp64 flop per output frame on the vector fp64
-                         # pipe, 78.6 TFLOP/s dense on MI355X
+                         # the taps as arithmetic: 2*T*channels multiply-adds' worth of flop per output frame -- on the
+                         # fp64 vector pipe (78.6 TFLOP/s dense on MI355X) in the lean kernel; the matrix-pipe kernels do the same sums
+                         # exactly in int8 digits (twelve 16x16x64 int8 MFMAs per 256 output subsamples, half of each band matrix zeros)
                          "fp64_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 2), "fp64_peak_tflops": 78.6,
                          "fp64_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / 78.6, 4)},
         }
@@ -653,7 +667,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json configs[config-1]: 3 = the headline")
     ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: 10 s)")
     ap.add_argument("--streams", type=int, default=None, help="config 3/5: streams per GPU (256); config 4: streams in all (2048)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 2 round 1's block kernel)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 2 round 1's block kernel, 4 round 2's lean kernel, 5 round 4's unit-per-wave matrix kernel)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / check, end_to_end and cadence legs (profiling runs)")
     ap.add_argument("--no-extra-configs", action="store_true", help="the default line without its `configs` object (configs[3] and configs[4] at full size)")
     ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the warm-up and the timed steps, so that they see the clock the chip holds under this load")

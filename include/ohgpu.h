@@ -331,11 +331,25 @@ int ohgpu_src_batch_plan(const ohgpu_batch* batch, uint64_t* block_kernel_out_fr
  * batch runs on the generic kernel alone. */
 int ohgpu_src_batch_units(const ohgpu_batch* batch, uint64_t* units, uint64_t* long_units);
 
+/* Which kernel ohgpu_src_batch_run launches for the batch's whole phase-aligned blocks under the context's current kernel
+ * variant: "src_mfma_wg_kernel", "src_mfma_kernel", "src_lean_kernel", "src_block_kernel" or "src_kernel_v1" (the generic one
+ * alone); a batch of several layouts names its parts' kernels, comma separated.  A measurement's label (bench.py), nothing the
+ * data path depends on.  The name is written to out[0, cap) NUL-terminated (truncated if it does not fit). */
+int ohgpu_src_batch_kernel_name(ohgpu_ctx* ctx, const ohgpu_batch* batch, char* out, size_t cap);
+
+/* The shader clock the device holds right now, in MHz: a short kernel on every CU (about 0.2 ms of dependent vector work,
+ * queued on `stream` like any launch) compares the shader cycle counter (s_memtime) with the constant 100 MHz reference counter
+ * (s_memrealtime) and the call waits for it.  For a benchmark to report next to a kernel time, so that a slow box can be told
+ * from a slow build; it touches no audio buffer. */
+int ohgpu_measure_shader_clock(ohgpu_ctx* ctx, void* stream, double* mhz);
+
 /* Kernel selection for A/B measurement and tests: 0 = default/best; 1 = baseline "v1" kernels; 2 = round 1's block resampler
  * kernel where it has the layout; 3 = the default kernels with the resampler's long-row unit schedule forced onto batches of
  * any size (a resampled batch created while 3 is set cuts every run of plain units into rows of three blocks -- what only a
  * batch of thousands of units gets otherwise -- so that tests reach that path with small inputs; results are identical);
- * 4 = round 2's fp64 "lean" block kernel where round 4's matrix-pipe kernel (24-bit stereo) would run, for A/B. */
+ * 4 = round 2's fp64 "lean" block kernel where round 4's matrix-pipe kernels (24-bit stereo) would run, for A/B;
+ * 5 = round 4's matrix-pipe kernel with a unit per wave (src_mfma_kernel) where the unit-per-workgroup one (src_mfma_wg_kernel,
+ * the default) would run.  Variants 2..5 take effect for batches created while they are set (they shape the plan). */
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant);
 
 #ifdef __cplusplus

@@ -107,6 +107,8 @@ SYMBOLS = {
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_src_batch_units": (C.c_int, [_vp, _u64p, _u64p]),
+    "ohgpu_src_batch_kernel_name": (C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t]),
+    "ohgpu_measure_shader_clock": (C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
     "ohgpu_src_process_host": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
     "ohgpu_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }
@@ -386,6 +388,16 @@ class Context:
         a, b = C.c_uint64(0), C.c_uint64(0)
         check(lib().ohgpu_src_batch_units(batch, C.byref(a), C.byref(b)))
         return {"units": int(a.value), "long_units": int(b.value)}
+
+    def src_kernel_name(self, batch):
+        buf = C.create_string_buffer(256)
+        check(lib().ohgpu_src_batch_kernel_name(self._h, batch, buf, 256))
+        return buf.value.decode()
+
+    def shader_clock_mhz(self, stream=None):
+        mhz = C.c_double(0)
+        check(lib().ohgpu_measure_shader_clock(self._h, stream, C.byref(mhz)))
+        return float(mhz.value)
 
     def src_run(self, batch, d_src, d_dst, stream=None):
         check(lib().ohgpu_src_batch_run(self._h, batch, d_src, d_dst, stream))
