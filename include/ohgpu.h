@@ -331,6 +331,20 @@ int ohgpu_src_batch_plan(const ohgpu_batch* batch, uint64_t* block_kernel_out_fr
  * batch runs on the generic kernel alone. */
 int ohgpu_src_batch_units(const ohgpu_batch* batch, uint64_t* units, uint64_t* long_units);
 
+/* Planning is host work, done per batch: the descriptors are independent per message and per stream, so the library checks them
+ * and cuts the streams into work units on several threads (up to 16, by the size of the batch).  `threads` caps that number for
+ * every later ohgpu_*_batch_create of the process (1: the calling thread alone; 0: no cap, the default).  The plan does not depend
+ * on it. */
+int ohgpu_set_plan_threads(int threads);
+
+/* The plan ohgpu_src_batch_create would make for these messages, as a 64-bit hash of its unit list, ramp jobs and generic-kernel
+ * pieces -- computed on the host alone (no context, no device): what tests/test_plan_threads.py compares across thread counts.
+ * `kernel` is set to the newest kernel the plan serves: 3 / 2 / 1 / 0 for src_mfma_wg_kernel / src_mfma_kernel / src_lean_kernel / round 1's or none
+ * (which one runs is the run-time variant's choice among those). */
+int ohgpu_src_plan_digest(uint32_t L, uint32_t M, uint32_t taps_per_phase, const ohgpu_src_msg_desc* descs, size_t n,
+                          uint64_t src_arena_bytes, uint64_t dst_arena_bytes, int kernel_variant,
+                          uint64_t* digest, uint64_t* units, uint64_t* generic_pieces, int* kernel);
+
 /* Which kernel ohgpu_src_batch_run launches for the batch's whole phase-aligned blocks under the context's current kernel
  * variant: "src_mfma_wg_kernel", "src_mfma_kernel", "src_lean_kernel", "src_block_kernel" or "src_kernel_v1" (the generic one
  * alone); a batch of several layouts names its parts' kernels, comma separated.  A measurement's label (bench.py), nothing the

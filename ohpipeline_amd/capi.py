@@ -107,6 +107,9 @@ SYMBOLS = {
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_src_batch_units": (C.c_int, [_vp, _u64p, _u64p]),
+    "ohgpu_set_plan_threads": (C.c_int, [C.c_int]),
+    "ohgpu_src_plan_digest": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int,
+                                        _u64p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "ohgpu_src_batch_kernel_name": (C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t]),
     "ohgpu_measure_shader_clock": (C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
     "ohgpu_src_process_host": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
@@ -164,6 +167,19 @@ def device_count():
 
 MF_STEP = np.dtype([("aoff", "<u4", (16,)), ("b0", "<u4", (16,)), ("b1", "<u4", (16,)), ("b2", "<i4", (16,)), ("kc", "<u4"), ("pad", "<u4", (7,))])
 assert MF_STEP.itemsize == 288
+
+
+def set_plan_threads(threads):
+    check(lib().ohgpu_set_plan_threads(int(threads)))
+
+
+def src_plan_digest(L, M, T, descs, src_arena_bytes, dst_arena_bytes, kernel_variant=0):
+    """The plan ohgpu_src_batch_create would make, hashed on the host (no device): {digest, units, generic_pieces, kernel}."""
+    d = np.ascontiguousarray(descs)
+    h, u, p, k = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+    check(lib().ohgpu_src_plan_digest(L, M, T, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes, dst_arena_bytes, kernel_variant,
+                                      C.byref(h), C.byref(u), C.byref(p), C.byref(k)))
+    return {"digest": int(h.value), "units": int(u.value), "generic_pieces": int(p.value), "kernel": int(k.value)}
 
 
 def src_mfma_tables(L, M, T, coef_q28, max_blocks_per_row=8):

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <chrono>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -17,6 +19,8 @@
 namespace ohgpu {
 
 static thread_local char g_err[512] = "";
+static int g_plan_threads = 0;
+int plan_thread_cap() { return g_plan_threads; }
 
 int set_error(int code, const char* fmt, ...)
 {
@@ -713,24 +717,27 @@ int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src)
     return OHGPU_OK;
 }
 
-int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
-                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
+}  // extern "C"
+
+namespace {
+
+struct SrcRangeResult {
+    int err = OHGPU_OK;
+    char msg[512] = "";
+    uint64_t in_frames = 0, out_frames = 0, src_bytes_touched = 0, dst_bytes_written = 0;
+    uint32_t max_frames = 0;
+    bool uniform = true;
+    void fail(int code) { err = code; snprintf(msg, sizeof(msg), "%s", ohgpu_last_error()); }
+};
+
+// messages [lo, hi) of a resampled batch: validation (ohgpu.h: ohgpu_src_msg_desc) and the device form of each
+void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t lo_i, size_t hi_i, uint64_t src_arena_bytes,
+                     uint64_t dst_arena_bytes, DevSrcDesc* dev, SrcRangeResult* out)
 {
-    CTX_GUARD("ohgpu_src_batch_create");
-    if (!out || !src || (n && !descs)) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_create: null argument");
-    *out = nullptr;
-    if (n > 0xffffffffull) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_create: too many descriptors");
-    ohgpu_batch* b = new (std::nothrow) ohgpu_batch();
-    if (!b) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory");
-    b->kind = kBatchSrc;
-    b->n = n;
-    b->src = src;
-    b->src_arena_bytes = src_arena_bytes;
-    b->dst_arena_bytes = dst_arena_bytes;
-    b->uniform = true;
-    std::vector<DevSrcDesc> dev(n);
+    SrcRangeResult& r = *out;
     const uint64_t L = src->L, M = src->M, T = src->T;
-    for (size_t i = 0; i < n; i++) {
+    const ohgpu_src_msg_desc& d0 = descs[0];
+    for (size_t i = lo_i; i < hi_i; i++) {
         const ohgpu_src_msg_desc& d = descs[i];
         int err = OHGPU_OK;
         if (d.channels < 1 || d.channels > OHGPU_MAX_CHANNELS) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: channels %u outside 1..8", i, d.channels);
@@ -744,7 +751,7 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         else if ((d.flags & OHGPU_FLAG_RAMP) && d.n_frames > 131071u) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: ramped message of %u frames", i, d.n_frames);
         else if (d.attenuation != OHGPU_UNITY_ATTENUATION) err = set_error(OHGPU_ERR_UNSUPPORTED, "src desc %zu: attenuation %u (resampled audio is 24-bit; Msg.cpp:2741 allows 16-bit only)", i, d.attenuation);
         else if (d.out_frame0 > (1ull << 48) || d.src_frame0 > (1ull << 48) || d.src_frames > (1ull << 40)) err = set_error(OHGPU_ERR_INVALID, "src desc %zu: frame index out of range", i);
-        if (err != OHGPU_OK) { delete b; return err; }
+        if (err != OHGPU_OK) { r.fail(err); return; }
         const uint64_t fb_src = (uint64_t)d.channels * (d.src_bits / 8);
         const uint64_t fb_dst = (uint64_t)d.channels * (d.dst_bits / 8);
         const bool planar = (d.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
@@ -755,20 +762,20 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         uint64_t planes_end = 0;
         if (planar && (!span_end(d.src_offset, d.src_plane_stride, d.channels - 1u, src_bytes, &planes_end) || planes_end > src_arena_bytes ||
                        (d.channels > 1 && d.src_plane_stride < src_bytes))) {
-            delete b;
-            return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: %u planes of %llu bytes, %llu apart from %llu, beyond the %llu-byte source arena (or overlapping)", i,
+            r.fail(set_error(OHGPU_ERR_BOUNDS, "src desc %zu: %u planes of %llu bytes, %llu apart from %llu, beyond the %llu-byte source arena (or overlapping)", i,
                              d.channels, (unsigned long long)src_bytes, (unsigned long long)d.src_plane_stride, (unsigned long long)d.src_offset,
-                             (unsigned long long)src_arena_bytes);
+                             (unsigned long long)src_arena_bytes));
+            return;
         }
         if (d.src_offset > src_arena_bytes || src_bytes > src_arena_bytes - d.src_offset) {
-            delete b;
-            return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: input window [%llu, +%llu) beyond the %llu-byte source arena", i,
-                             (unsigned long long)d.src_offset, (unsigned long long)src_bytes, (unsigned long long)src_arena_bytes);
+            r.fail(set_error(OHGPU_ERR_BOUNDS, "src desc %zu: input window [%llu, +%llu) beyond the %llu-byte source arena", i,
+                             (unsigned long long)d.src_offset, (unsigned long long)src_bytes, (unsigned long long)src_arena_bytes));
+            return;
         }
         if (d.dst_offset > dst_arena_bytes || dst_bytes > dst_arena_bytes - d.dst_offset) {
-            delete b;
-            return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: writes [%llu, +%llu) beyond the %llu-byte destination arena", i,
-                             (unsigned long long)d.dst_offset, (unsigned long long)dst_bytes, (unsigned long long)dst_arena_bytes);
+            r.fail(set_error(OHGPU_ERR_BOUNDS, "src desc %zu: writes [%llu, +%llu) beyond the %llu-byte destination arena", i,
+                             (unsigned long long)d.dst_offset, (unsigned long long)dst_bytes, (unsigned long long)dst_arena_bytes));
+            return;
         }
         DevSrcDesc& o = dev[i];
         memset(&o, 0, sizeof(o));
@@ -777,20 +784,20 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
             const int64_t n0_first = (int64_t)(t_first / L), n0_last = (int64_t)(t_last / L);
             const int64_t n_lo = n0_first - (int64_t)(T - 1);
             if (n_lo >= 0 ? (uint64_t)n_lo < d.src_frame0 : d.src_frame0 != 0) {
-                delete b;
-                return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: filter history starts at input frame %lld but the buffer starts at %llu", i,
-                                 (long long)(n_lo < 0 ? 0 : n_lo), (unsigned long long)d.src_frame0);
+                r.fail(set_error(OHGPU_ERR_BOUNDS, "src desc %zu: filter history starts at input frame %lld but the buffer starts at %llu", i,
+                                 (long long)(n_lo < 0 ? 0 : n_lo), (unsigned long long)d.src_frame0));
+                return;
             }
             if ((uint64_t)n0_last >= d.src_frame0 + d.src_frames) {
-                delete b;
-                return set_error(OHGPU_ERR_BOUNDS, "src desc %zu: needs input frame %lld but the buffer ends at %llu", i,
-                                 (long long)n0_last, (unsigned long long)(d.src_frame0 + d.src_frames));
+                r.fail(set_error(OHGPU_ERR_BOUNDS, "src desc %zu: needs input frame %lld but the buffer ends at %llu", i,
+                                 (long long)n0_last, (unsigned long long)(d.src_frame0 + d.src_frames)));
+                return;
             }
             o.in_rel0 = n0_first - (int64_t)d.src_frame0;
             o.phase0 = (uint32_t)(t_first % L);
             const int64_t lo = n_lo < 0 ? 0 : n_lo;
-            b->in_frames += (uint64_t)(n0_last - n0_first + 1);   // new input frames this message advances over
-            b->src_bytes_touched += (uint64_t)(n0_last - lo + 1) * (planar ? 4ull * d.channels : fb_src);
+            r.in_frames += (uint64_t)(n0_last - n0_first + 1);   // new input frames this message advances over
+            r.src_bytes_touched += (uint64_t)(n0_last - lo + 1) * (planar ? 4ull * d.channels : fb_src);
         }
         o.src_offset = d.src_offset;
         o.dst_offset = d.dst_offset;
@@ -806,20 +813,75 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
         o.dst_endian = d.dst_endian;
         o.flags = d.flags;
         o.plane_frames = (uint32_t)(d.src_plane_stride >> 2);
-        b->out_frames += d.n_frames;
-        b->dst_bytes_written += dst_bytes;
-        if (d.n_frames > b->max_frames) b->max_frames = d.n_frames;
-        if (i == 0) {
-            b->channels = d.channels; b->src_bits = d.src_bits; b->src_endian = d.src_endian;
-            b->dst_bits = d.dst_bits; b->dst_endian = d.dst_endian;
-            b->src_planar = planar;
-        } else if (d.channels != b->channels || d.src_bits != b->src_bits || d.src_endian != b->src_endian ||
-                   d.dst_bits != b->dst_bits || d.dst_endian != b->dst_endian || planar != b->src_planar) {
-            b->uniform = false;
+        r.out_frames += d.n_frames;
+        r.dst_bytes_written += dst_bytes;
+        if (d.n_frames > r.max_frames) r.max_frames = d.n_frames;
+        if (d.channels != d0.channels || d.src_bits != d0.src_bits || d.src_endian != d0.src_endian || d.dst_bits != d0.dst_bits ||
+            d.dst_endian != d0.dst_endian || planar != ((d0.flags & OHGPU_FLAG_SRC_PLANAR32) != 0)) r.uniform = false;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
+                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** out)
+{
+    CTX_GUARD("ohgpu_src_batch_create");
+    if (!out || !src || (n && !descs)) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_create: null argument");
+    *out = nullptr;
+    if (n > 0xffffffffull) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_create: too many descriptors");
+    ohgpu_batch* b = new (std::nothrow) ohgpu_batch();
+    if (!b) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory");
+    b->kind = kBatchSrc;
+    b->n = n;
+    b->src = src;
+    b->src_arena_bytes = src_arena_bytes;
+    b->dst_arena_bytes = dst_arena_bytes;
+    b->uniform = true;
+#ifdef OHGPU_PLAN_TIMING
+    const auto tp0 = std::chrono::steady_clock::now();
+#endif
+    // every message is checked and converted on its own: in ranges, on as many threads as the batch is worth (the first error in
+    // message order is the one reported)
+    b->host_descs.reset(new (std::nothrow) DevSrcDesc[n ? n : 1]);     // (not zeroed here: the ranges' threads touch their own pages)
+    if (!b->host_descs) { delete b; return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory"); }
+    DevSrcDesc* const dev = b->host_descs.get();
+    {
+        const unsigned n_thr = plan_threads(n, 16384);
+        std::vector<SrcRangeResult> res(n_thr);
+        parallel_ranges(n, n_thr, [&](unsigned t, size_t lo, size_t hi) { src_check_range(src, descs, lo, hi, src_arena_bytes, dst_arena_bytes, dev, &res[t]); });
+        for (const SrcRangeResult& r : res) {
+            if (r.err != OHGPU_OK) { const int err = set_error(r.err, "%s", r.msg); delete b; return err; }
+            b->in_frames += r.in_frames; b->out_frames += r.out_frames;
+            b->src_bytes_touched += r.src_bytes_touched; b->dst_bytes_written += r.dst_bytes_written;
+            if (r.max_frames > b->max_frames) b->max_frames = r.max_frames;
+            b->uniform = b->uniform && r.uniform;
+        }
+        if (n > 0) {
+            const ohgpu_src_msg_desc& d0 = descs[0];
+            b->channels = d0.channels; b->src_bits = d0.src_bits; b->src_endian = d0.src_endian;
+            b->dst_bits = d0.dst_bits; b->dst_endian = d0.dst_endian;
+            b->src_planar = (d0.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
         }
     }
-    int err = upload_batch(ctx, b, dev.data(), n * sizeof(DevSrcDesc));
-    if (err == OHGPU_OK && b->uniform) err = plan_src_fast(ctx, b, descs, n, dev);
+#ifdef OHGPU_PLAN_TIMING
+    const auto tp1 = std::chrono::steady_clock::now();
+#endif
+    // (the device copy of the per-message descriptors is the generic kernel's: it is made when that kernel first runs the whole batch)
+    int err = OHGPU_OK;
+#ifdef OHGPU_PLAN_TIMING
+    const auto tp2 = std::chrono::steady_clock::now();
+#endif
+    if (b->uniform) err = plan_src_fast(ctx, b, descs, n, dev);
+#ifdef OHGPU_PLAN_TIMING
+    {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        fprintf(stderr, "[plan timing] validate+convert %.2f ms, descriptor upload %.2f ms, plan_src_fast %.2f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
+    }
+#endif
     if (err == OHGPU_OK && !b->uniform) {
         // Mixed layouts (channel counts, depths, byte orders, planar or packed sources): the block kernels are instantiated per
         // layout, so the batch becomes one uniform batch per layout, messages in their given order.  (More than 32 layouts: the
@@ -874,6 +936,55 @@ int ohgpu_src_batch_plan(const ohgpu_batch* b, uint64_t* block_kernel_out_frames
     return OHGPU_OK;
 }
 
+int ohgpu_set_plan_threads(int threads)
+{
+    if (threads < 0 || threads > 256) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_plan_threads: %d", threads);
+    g_plan_threads = threads;
+    return OHGPU_OK;
+}
+
+int ohgpu_src_plan_digest(uint32_t L, uint32_t M, uint32_t taps_per_phase, const ohgpu_src_msg_desc* descs, size_t n,
+                          uint64_t src_arena_bytes, uint64_t dst_arena_bytes, int kernel_variant,
+                          uint64_t* digest, uint64_t* units, uint64_t* generic_pieces, int* kernel)
+{
+    if (!descs || n == 0 || L == 0 || M == 0 || taps_per_phase == 0) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_plan_digest: bad argument");
+    // a filter and a context as far as the planner looks at them: no device behind either
+    ohgpu_src flt{};
+    flt.L = L; flt.M = M; flt.T = taps_per_phase;
+    flt.max_sum_abs = (int64_t)1 << 28;
+    flt.halfband = false;
+    flt.mf_L_blk = taps_per_phase == 32 ? src_block_outputs(L, 6) : 0;
+    flt.mf_kb_cap = 8;
+    flt.d_mf_amat = flt.mf_L_blk ? (uint8_t*)&flt : nullptr;         // (only its being there is looked at)
+    ohgpu_ctx ctx{};
+    ctx.variant = kernel_variant;
+    ctx.num_cus = 256;
+    ohgpu_batch b;
+    b.kind = kBatchSrc; b.n = n; b.src = &flt; b.src_arena_bytes = src_arena_bytes; b.dst_arena_bytes = dst_arena_bytes; b.uniform = true;
+    std::unique_ptr<DevSrcDesc[]> dev(new (std::nothrow) DevSrcDesc[n]);
+    if (!dev) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_plan_digest: out of host memory");
+    const unsigned n_thr = plan_threads(n, 16384);
+    std::vector<SrcRangeResult> res(n_thr);
+    parallel_ranges(n, n_thr, [&](unsigned t, size_t lo, size_t hi) { src_check_range(&flt, descs, lo, hi, src_arena_bytes, dst_arena_bytes, dev.get(), &res[t]); });
+    for (const SrcRangeResult& r : res) {
+        if (r.err != OHGPU_OK) return set_error(r.err, "%s", r.msg);
+        b.uniform = b.uniform && r.uniform;
+    }
+    const ohgpu_src_msg_desc& d0 = descs[0];
+    b.channels = d0.channels; b.src_bits = d0.src_bits; b.src_endian = d0.src_endian; b.dst_bits = d0.dst_bits; b.dst_endian = d0.dst_endian;
+    b.src_planar = (d0.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
+    PlanDigest pd{};
+    if (b.uniform) {
+        const int err = plan_src_fast(&ctx, &b, descs, n, dev.get(), &pd);
+        if (err != OHGPU_OK) return err;
+    }
+    if (digest) *digest = pd.hash;
+    if (units) *units = pd.units;
+    if (generic_pieces) *generic_pieces = pd.pieces;
+    if (kernel) *kernel = pd.kernel;
+    return OHGPU_OK;
+}
+
 int ohgpu_src_batch_units(const ohgpu_batch* b, uint64_t* units, uint64_t* long_units)
 {
     if (!b || b->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_units: not a src batch");
@@ -898,7 +1009,7 @@ static const char* src_kernel_of(const ohgpu_ctx* ctx, const ohgpu_batch* b)
     if (ctx->variant == 1 || !b->fast.enabled) return "src_kernel_v1";
     if (b->fast.mfma_wg && ctx->variant == 0) return "src_mfma_wg_kernel";
     if (b->fast.mfma && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 5)) return "src_mfma_kernel";
-    if (b->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 5 || b->fast.lean_only)) return "src_lean_kernel";
+    if (b->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 5 || b->fast.lean_only || !b->fast.d_work)) return "src_lean_kernel";
     return "src_block_kernel";
 }
 
@@ -992,11 +1103,20 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
             OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         else if (batch->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts; variant 4: the lean kernel where round 4's would run)
             OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
-        else
+        else if (batch->fast.d_work)
             OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+        else                                                                                           // (round 1's kernel asked for a batch planned without its tables)
+            OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         launched(batch, s);
     } else {
+        {   // (the whole batch on the generic kernel: its per-message descriptors go to the device the first time this happens)
+            std::lock_guard<std::mutex> hold(batch->lazy);
+            if (!batch->d_descs && batch->n) {
+                const int err = upload_batch(ctx, const_cast<ohgpu_batch*>(batch), batch->host_descs.get(), batch->n * sizeof(DevSrcDesc));
+                if (err != OHGPU_OK) return err;
+            }
+        }
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->d_descs, batch->n, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
     }
     return OHGPU_OK;

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ohgpu.h"
@@ -141,6 +144,30 @@ struct SrcFastPlan {
     size_t   n_rem = 0;
     uint64_t fast_out_frames = 0;
 };
+
+int plan_thread_cap();     // ohgpu_set_plan_threads (0: no cap)
+// How many threads a host loop over n independent items is worth (at least `per_thread` items each, at most 16 and what the host has)
+inline unsigned plan_threads(size_t n, size_t per_thread)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t t = n / (per_thread ? per_thread : 1);
+    if (t < 1) t = 1;
+    if (t > 16) t = 16;
+    if (hw && t > hw) t = hw;
+    if (ohgpu::plan_thread_cap() > 0 && t > (size_t)ohgpu::plan_thread_cap()) t = (size_t)ohgpu::plan_thread_cap();
+    return (unsigned)t;
+}
+// f(thread, lo, hi) over [0, n) cut into n_thr contiguous ranges, range t on its own thread (range 0 on the caller's)
+template <typename F>
+inline void parallel_ranges(size_t n, unsigned n_thr, F&& f)
+{
+    if (n_thr <= 1) { f(0u, (size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(n_thr - 1);
+    for (unsigned t = 1; t < n_thr; t++) pool.emplace_back([&f, t, n, n_thr] { f(t, n * t / n_thr, n * (t + 1) / n_thr); });
+    f(0u, (size_t)0, n / n_thr);
+    for (std::thread& th : pool) th.join();
+}
 
 // x / d == umulhi(x, m) >> s for every x < 2^31 (d >= 2; m == 0 stands for d == 1): with 2^(l-1) < d <= 2^l and
 // m = floor(2^(31+l) / d) + 1 the error term x * (m * d - 2^(31+l)) stays below 2^(31+l).  Host side of the line kernels.
@@ -286,6 +313,8 @@ struct ohgpu_batch {
     int      kind;
     size_t   n;
     void*    d_descs;             // ohgpu_msg_desc[] or DevSrcDesc[] (every message, generic kernels)
+    std::unique_ptr<ohgpu::DevSrcDesc[]> host_descs;   // kBatchSrc: the same on the host (n of them); d_descs is made from it when the generic kernel first runs the whole batch
+    mutable std::mutex lazy;      // ... under this
     const ohgpu_src* src;         // kBatchSrc only
     uint64_t src_arena_bytes, dst_arena_bytes;
     uint64_t in_frames, out_frames, src_bytes_touched, dst_bytes_written;
@@ -366,8 +395,9 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
 void build_ramp_table(uint16_t out[512]);
 int  design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, double f_pass,
                 std::vector<int32_t>* coef_q28, uint32_t* L, uint32_t* M);
-int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n,
-                   const std::vector<DevSrcDesc>& dev);
+struct PlanDigest { uint64_t hash, units, pieces, ramp_jobs; int kernel; };   // ohgpu_src_plan_digest: a plan without a device
+int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, const DevSrcDesc* dev, PlanDigest* digest = nullptr);
+
 void free_src_fast(ohgpu_batch* b);
 void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b);
 

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -88,8 +90,7 @@ static uint32_t src_block_outputs_for(uint32_t L, uint32_t fb_dst, uint32_t min_
 }
 uint32_t src_block_outputs(uint32_t L, uint32_t fb_dst) { return src_block_outputs_for(L, fb_dst, 128); }
 
-int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n,
-                  const std::vector<DevSrcDesc>& dev)
+int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, const DevSrcDesc* dev, PlanDigest* digest)
 {
     SrcFastPlan& f = b->fast;
     f = SrcFastPlan();
@@ -141,6 +142,13 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                       mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
     const bool mfma_wg = mfma && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db) && !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
 
+#ifdef OHGPU_PLAN_TIMING
+    std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> tps;
+    auto mark = [&](const char* what) { tps.emplace_back(what, std::chrono::steady_clock::now()); };
+    mark("start");
+#else
+    auto mark = [](const char*) {};
+#endif
     // order messages by (stream, output position); a stream is identified by where its absolute frame 0 lives
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
@@ -161,16 +169,28 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     };
     // (a caller that lists its streams one after the other, each in time order -- the usual case -- is in order already: one
     // linear pass instead of a sort of half a million messages)
-    if (!std::is_sorted(order.begin(), order.end(), before)) std::sort(order.begin(), order.end(), before);
+    {
+        const unsigned n_thr = plan_threads(n, 32768);
+        std::vector<char> sorted(n_thr, 1);
+        parallel_ranges(n, n_thr, [&](unsigned t, size_t lo, size_t hi) {
+            for (size_t k = lo > 0 ? lo : 1; k < hi && sorted[t]; k++)               // (k against k - 1: the ranges' seams are the next range's first test)
+                if (before(order[k], order[k - 1])) sorted[t] = 0;
+        });
+        if (std::find(sorted.begin(), sorted.end(), 0) != sorted.end()) std::sort(order.begin(), order.end(), before);
+    }
 
-    std::vector<SrcSeg> segs;
+    mark("order");
     struct SegRun { uint32_t seg; uint64_t blk_lo, blk_hi; uint32_t work_begin; };   // a segment's whole blocks and where its units start in `work`
-    std::vector<SegRun> seg_runs;
-    std::vector<uint32_t> seg_plane_stride;             // planar batches: bytes between a segment's planes
-    std::vector<SegMsg> msgs;
-    std::vector<SrcWork> work;
-    std::vector<DevSrcDesc> rem;
-    uint64_t fast_frames = 0;
+    // what a stretch of messages contributes (indices local to the stretch until the stretches are put together)
+    struct Stretch {
+        std::vector<SrcSeg> segs;
+        std::vector<SegRun> seg_runs;
+        std::vector<uint32_t> seg_plane_stride;         // planar batches: bytes between a segment's planes
+        std::vector<SegMsg> msgs;
+        std::vector<SrcWork> work;
+        std::vector<DevSrcDesc> rem;
+        uint64_t fast_frames = 0;
+    };
     // lean kernel: one plane of multipliers per ramped unit -- rows * L_blk entries (uint16, 0xffff = no ramp on that frame)
     // (the kernel loads eight entries at a time; a row is a whole number of loads when L_blk is a multiple of 8, else the slack covers the last one)
     // (the multipliers themselves are computed on the device, csrc/ramp_plane_kernel.hip: the planner only says which message
@@ -193,81 +213,139 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         return false;
     };
 
-    size_t i = 0;
-    while (i < n) {
-        // grow a run of messages that tile a contiguous output range of one stream
-        size_t e = i + 1;
-        const ohgpu_src_msg_desc& d0 = descs[order[i]];
-        const int64_t sbase = src_base_of(d0), dbase = dst_base_of(d0);
-        uint64_t next_out = d0.out_frame0 + d0.n_frames;
-        bool zero_len = d0.n_frames == 0;
-        while (!zero_len && e < n) {
-            const ohgpu_src_msg_desc& d = descs[order[e]];
-            if (d.n_frames == 0 || src_base_of(d) != sbase || dst_base_of(d) != dbase || d.out_frame0 != next_out ||
-                d.src_plane_stride != d0.src_plane_stride) break;
-            next_out += d.n_frames;
-            e++;
-        }
-        const uint64_t m_begin = d0.out_frame0, m_end = next_out;
-        uint64_t blk_lo = (m_begin + L_blk - 1) / L_blk, blk_hi = m_end / L_blk;
-        // (a stream whose output does not start on a 64-byte boundary is written with unaligned 16-byte stores: they run at
-        // the aligned rate -- tools/micro/unaligned_store.hip -- only the lines are then no longer whole)
-        bool fast_ok = !zero_len && blk_hi > blk_lo;
-        if (fast_ok) {
-            // every whole block's history must be present in the windows the caller declared (they were validated
-            // per message; the block reads nothing a message of the block does not itself need)
-            const uint32_t msg_begin = (uint32_t)msgs.size();
+    // Message k continues message k - 1 -- same stream, the next output frame -- or starts a segment: a test on the pair alone, so
+    // the messages can be cut into stretches of whole segments and the stretches planned side by side; put together in order they
+    // are the arrays one thread walking all the messages makes.
+    auto continues = [&](size_t k) {
+        const ohgpu_src_msg_desc& p = descs[order[k - 1]];
+        const ohgpu_src_msg_desc& d = descs[order[k]];
+        return p.n_frames != 0 && d.n_frames != 0 && src_base_of(d) == src_base_of(p) && dst_base_of(d) == dst_base_of(p) &&
+               d.out_frame0 == p.out_frame0 + p.n_frames && d.src_plane_stride == p.src_plane_stride;
+    };
+    auto plan_stretch = [&](size_t i_begin, size_t i_end, Stretch& o) {
+            size_t i = i_begin;
+            while (i < i_end) {
+            // grow a run of messages that tile a contiguous output range of one stream
+            size_t e = i + 1;
+            const ohgpu_src_msg_desc& d0 = descs[order[i]];
+            const int64_t sbase = src_base_of(d0), dbase = dst_base_of(d0);
+            uint64_t next_out = d0.out_frame0 + d0.n_frames;
+            bool zero_len = d0.n_frames == 0;
+            while (!zero_len && e < i_end) {
+                const ohgpu_src_msg_desc& d = descs[order[e]];
+                if (d.n_frames == 0 || src_base_of(d) != sbase || dst_base_of(d) != dbase || d.out_frame0 != next_out ||
+                    d.src_plane_stride != d0.src_plane_stride) break;
+                next_out += d.n_frames;
+                e++;
+            }
+            const uint64_t m_begin = d0.out_frame0, m_end = next_out;
+            uint64_t blk_lo = (m_begin + L_blk - 1) / L_blk, blk_hi = m_end / L_blk;
+            // (a stream whose output does not start on a 64-byte boundary is written with unaligned 16-byte stores: they run at
+            // the aligned rate -- tools/micro/unaligned_store.hip -- only the lines are then no longer whole)
+            bool fast_ok = !zero_len && blk_hi > blk_lo;
+            if (fast_ok) {
+                // every whole block's history must be present in the windows the caller declared (they were validated
+                // per message; the block reads nothing a message of the block does not itself need)
+                const uint32_t msg_begin = (uint32_t)o.msgs.size();
+                for (size_t k = i; k < e; k++) {
+                    const ohgpu_src_msg_desc& d = descs[order[k]];
+                    SegMsg sm;
+                    memset(&sm, 0, sizeof(sm));
+                    sm.out0 = d.out_frame0; sm.n = d.n_frames; sm.ramp_start = d.ramp_start; sm.ramp_end = d.ramp_end; sm.flags = d.flags;
+                    if (d.flags & OHGPU_FLAG_RAMP) {            // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
+                        uint32_t sh = 0;
+                        magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &sm.m_n1, &sh);
+                        sm.s_n1 = (uint8_t)sh;
+                    }
+                    o.msgs.push_back(sm);
+                }
+                SrcSeg sg;
+                sg.src_base = sbase; sg.dst_base = dbase; sg.msg_begin = msg_begin; sg.msg_end = (uint32_t)o.msgs.size();
+                const uint32_t seg_index = (uint32_t)o.segs.size();
+                o.segs.push_back(sg);
+                o.seg_plane_stride.push_back((uint32_t)d0.src_plane_stride);
+                o.seg_runs.push_back(SegRun{seg_index, blk_lo, blk_hi, (uint32_t)o.work.size()});
+                uint32_t mi = msg_begin;                      // message that holds the unit's first output frame
+                for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
+                    SrcWork w;
+                    w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
+                    while (mi + 1 < sg.msg_end && o.msgs[mi + 1].out0 <= bk * L_blk) mi++;
+                    w.msg_first = mi;
+                    // cost class, for the order below: a wave that meets a ramped message goes through the per-output ramp path
+                    // for all of its lanes, which makes such a unit two to three times as long as a plain one
+                    const uint64_t u_lo = bk * L_blk, u_hi = (bk + w.n_blocks) * L_blk;
+                    bool ramped = false;
+                    for (uint32_t m = mi; m < sg.msg_end && o.msgs[m].out0 < u_hi && !ramped; m++)
+                        ramped = (o.msgs[m].flags & OHGPU_FLAG_RAMP) && o.msgs[m].out0 + o.msgs[m].n > u_lo;
+                    w.flags = ramped ? kWorkRamped : 0u;
+                    w.plane = 0; w.pad = 0;
+                    if (unit_leaves_arena(sbase, d0.src_plane_stride, bk, w.n_blocks, 1)) w.flags |= kWorkChecked;
+                    o.work.push_back(w);
+                }
+                o.fast_frames += (blk_hi - blk_lo) * L_blk;
+            } else {
+                blk_lo = blk_hi = 0;   // everything goes to the generic kernel
+            }
+            const uint64_t fast_lo = fast_ok ? blk_lo * L_blk : m_end, fast_hi = fast_ok ? blk_hi * L_blk : m_end;
             for (size_t k = i; k < e; k++) {
                 const ohgpu_src_msg_desc& d = descs[order[k]];
-                SegMsg sm;
-                memset(&sm, 0, sizeof(sm));
-                sm.out0 = d.out_frame0; sm.n = d.n_frames; sm.ramp_start = d.ramp_start; sm.ramp_end = d.ramp_end; sm.flags = d.flags;
-                if (d.flags & OHGPU_FLAG_RAMP) {            // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
-                    uint32_t sh = 0;
-                    magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &sm.m_n1, &sh);
-                    sm.s_n1 = (uint8_t)sh;
-                }
-                msgs.push_back(sm);
+                if (d.n_frames == 0) continue;
+                const uint64_t lo = d.out_frame0, hi = d.out_frame0 + d.n_frames;
+                if (!fast_ok) { o.rem.push_back(make_piece(d, dev[order[k]], lo, hi, L, M)); continue; }
+                if (lo < fast_lo) o.rem.push_back(make_piece(d, dev[order[k]], lo, std::min(hi, fast_lo), L, M));
+                if (hi > fast_hi) o.rem.push_back(make_piece(d, dev[order[k]], std::max(lo, fast_hi), hi, L, M));
             }
-            SrcSeg sg;
-            sg.src_base = sbase; sg.dst_base = dbase; sg.msg_begin = msg_begin; sg.msg_end = (uint32_t)msgs.size();
-            const uint32_t seg_index = (uint32_t)segs.size();
-            segs.push_back(sg);
-            seg_plane_stride.push_back((uint32_t)d0.src_plane_stride);
-            seg_runs.push_back(SegRun{seg_index, blk_lo, blk_hi, (uint32_t)work.size()});
-            uint32_t mi = msg_begin;                      // message that holds the unit's first output frame
-            for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
-                SrcWork w;
-                w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
-                while (mi + 1 < sg.msg_end && msgs[mi + 1].out0 <= bk * L_blk) mi++;
-                w.msg_first = mi;
-                // cost class, for the order below: a wave that meets a ramped message goes through the per-output ramp path
-                // for all of its lanes, which makes such a unit two to three times as long as a plain one
-                const uint64_t u_lo = bk * L_blk, u_hi = (bk + w.n_blocks) * L_blk;
-                bool ramped = false;
-                for (uint32_t m = mi; m < sg.msg_end && msgs[m].out0 < u_hi && !ramped; m++)
-                    ramped = (msgs[m].flags & OHGPU_FLAG_RAMP) && msgs[m].out0 + msgs[m].n > u_lo;
-                w.flags = ramped ? kWorkRamped : 0u;
-                w.plane = 0; w.pad = 0;
-                if (unit_leaves_arena(sbase, d0.src_plane_stride, bk, w.n_blocks, 1)) w.flags |= kWorkChecked;
-                work.push_back(w);
-            }
-            fast_frames += (blk_hi - blk_lo) * L_blk;
-        } else {
-            blk_lo = blk_hi = 0;   // everything goes to the generic kernel
+            i = e;
         }
-        const uint64_t fast_lo = fast_ok ? blk_lo * L_blk : m_end, fast_hi = fast_ok ? blk_hi * L_blk : m_end;
-        for (size_t k = i; k < e; k++) {
-            const ohgpu_src_msg_desc& d = descs[order[k]];
-            if (d.n_frames == 0) continue;
-            const uint64_t lo = d.out_frame0, hi = d.out_frame0 + d.n_frames;
-            if (!fast_ok) { rem.push_back(make_piece(d, dev[order[k]], lo, hi, L, M)); continue; }
-            if (lo < fast_lo) rem.push_back(make_piece(d, dev[order[k]], lo, std::min(hi, fast_lo), L, M));
-            if (hi > fast_hi) rem.push_back(make_piece(d, dev[order[k]], std::max(lo, fast_hi), hi, L, M));
+    };
+    const unsigned n_stretch = plan_threads(n, 32768);
+    std::vector<Stretch> parts(n_stretch);
+    {
+        std::vector<size_t> cut(n_stretch + 1, n);
+        cut[0] = 0;
+        for (unsigned t = 1; t < n_stretch; t++) {
+            size_t k = n * t / n_stretch;
+            while (k < n && k > 0 && continues(k)) k++;                  // (forward to the next segment's first message)
+            cut[t] = k;
         }
-        i = e;
+        for (unsigned t = 1; t <= n_stretch; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+        parallel_ranges(n_stretch, n_stretch, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t t = lo; t < hi; t++) if (cut[t] < cut[t + 1]) plan_stretch(cut[t], cut[t + 1], parts[t]);
+        });
+    }
+    std::vector<SrcSeg> segs;
+    std::vector<SegRun> seg_runs;
+    std::vector<uint32_t> seg_plane_stride;
+    std::vector<SegMsg> msgs;
+    std::vector<SrcWork> work;
+    std::vector<DevSrcDesc> rem;
+    uint64_t fast_frames = 0;
+    {
+        size_t n_segs = 0, n_msgs = 0, n_work0 = 0, n_rem = 0;
+        for (const Stretch& o : parts) { n_segs += o.segs.size(); n_msgs += o.msgs.size(); n_work0 += o.work.size(); n_rem += o.rem.size(); }
+        segs.reserve(n_segs); seg_runs.reserve(n_segs); seg_plane_stride.reserve(n_segs); msgs.resize(n_msgs); work.reserve(n_work0); rem.reserve(n_rem);
+        size_t msg_at = 0;
+        std::vector<size_t> msg_base(parts.size());
+        for (size_t t = 0; t < parts.size(); t++) {
+            Stretch& o = parts[t];
+            const uint32_t seg_base = (uint32_t)segs.size(), work_base = (uint32_t)work.size();
+            msg_base[t] = msg_at;
+            for (SrcSeg sg : o.segs) { sg.msg_begin += (uint32_t)msg_at; sg.msg_end += (uint32_t)msg_at; segs.push_back(sg); }
+            for (SegRun r : o.seg_runs) { r.seg += seg_base; r.work_begin += work_base; seg_runs.push_back(r); }
+            seg_plane_stride.insert(seg_plane_stride.end(), o.seg_plane_stride.begin(), o.seg_plane_stride.end());
+            for (SrcWork w : o.work) { w.seg += seg_base; w.msg_first += (uint32_t)msg_at; work.push_back(w); }
+            rem.insert(rem.end(), o.rem.begin(), o.rem.end());
+            fast_frames += o.fast_frames;
+            msg_at += o.msgs.size();
+        }
+        // (the messages are the bulk: copied side by side)
+        parallel_ranges(parts.size(), (unsigned)parts.size(), [&](unsigned, size_t lo, size_t hi) {
+            for (size_t t = lo; t < hi; t++) if (!parts[t].msgs.empty()) memcpy(msgs.data() + msg_base[t], parts[t].msgs.data(), parts[t].msgs.size() * sizeof(SegMsg));
+        });
+        parts.clear();
     }
     if (work.empty()) return OHGPU_OK;
+    mark("segments");
     // ---- the lean kernel's units.  A unit is `rows` rows; a row is `kb` CONSECUTIVE blocks of its stream.  With kb = 1 (round
     // 2) every block pays a filter length of warm-up advances and re-reads that much history (32 frames per 147), and every
     // 160 outputs a unit set-up; a row of kb blocks pays them once.  But long units make the end of the launch coarse -- round
@@ -390,17 +468,47 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         return ((x.flags & kWorkRamped) ? 3u : 1u) * x.n_blocks > ((y.flags & kWorkRamped) ? 3u : 1u) * y.n_blocks;
     });
 
+    mark("units");
+    if (digest) {
+        // (ohgpu_src_plan_digest: what the plan consists of, hashed; nothing goes to a device)
+        auto fnv = [](uint64_t h, const void* p, size_t bytes) {
+            const uint8_t* q = (const uint8_t*)p;
+            for (size_t k = 0; k < bytes; k++) h = (h ^ q[k]) * 1099511628211ull;
+            return h;
+        };
+        uint64_t h = 1469598103934665603ull;
+        h = fnv(h, lean_units.data(), lean_units.size() * sizeof(LeanUnit));
+        h = fnv(h, work.data(), work.size() * sizeof(SrcWork));
+        h = fnv(h, segs.data(), segs.size() * sizeof(SrcSeg));
+        h = fnv(h, msgs.data(), msgs.size() * sizeof(SegMsg));
+        h = fnv(h, rem.data(), rem.size() * sizeof(DevSrcDesc));
+        h = fnv(h, ramp_jobs.data(), ramp_jobs.size() * sizeof(RampJob));
+        h = fnv(h, &plane_entries, sizeof(plane_entries));
+        digest->hash = h;
+        digest->units = lean ? lean_units.size() : work.size();
+        digest->pieces = rem.size();
+        digest->ramp_jobs = ramp_jobs.size();
+        digest->kernel = mfma_wg ? 3 : (mfma ? 2 : (lean ? 1 : 0));
+        return OHGPU_OK;
+    }
+    // (segments, messages and one-block work units are round 1's kernel's: they go to the device only for a batch planned while
+    // ohgpu_set_kernel_variant(2) is in force, or one the lean kernel cannot run -- 12 MB of the headline's plan, and most of the time its upload took)
+    const bool round1 = block_ok && ((ctx && ctx->variant == 2) || !lean);      // (a filter the lean kernel's rounding does not hold runs on round 1's whatever the variant)
     Slab slab;
-    slab.add(segs, &f.d_segs);
-    slab.add(msgs, &f.d_msgs);
-    slab.add(work, &f.d_work);
+    if (round1) {
+        slab.add(segs, &f.d_segs);
+        slab.add(msgs, &f.d_msgs);
+        slab.add(work, &f.d_work);
+    }
     if (lean) slab.add(lean_units, &f.d_lean_units);
     slab.add(rem, &f.d_rem);
     slab.add(std::vector<uint32_t>(2, 0u), &f.d_counter);            // {units claimed, waves finished}: zero between launches
     slab.add(ramp_jobs, &f.d_ramp_jobs);
     slab.reserve((plane_entries ? plane_entries : 8) * sizeof(uint16_t), &f.d_planes);
+    mark("slab");
     int err = slab.upload(&f.d_slab);
     if (err != OHGPU_OK) { free_src_fast(b); return err; }
+    mark("upload");
     {   // the planes: preset to "no ramp", then RampApplicator's multiplier for every frame of a ramped message (device)
         hipStream_t s0 = ctx ? ctx->stream : nullptr;
         hipError_t e = hipMemsetAsync(f.d_planes, 0xff, (plane_entries ? plane_entries : 8) * sizeof(uint16_t), s0);
@@ -408,6 +516,12 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         if (e == hipSuccess) e = hipStreamSynchronize(s0);
         if (e != hipSuccess) { free_src_fast(b); return set_error(OHGPU_ERR_DEVICE, "ramp planes: %s", hipGetErrorString(e)); }
     }
+    mark("planes");
+#ifdef OHGPU_PLAN_TIMING
+    for (size_t k = 1; k < tps.size(); k++)
+        fprintf(stderr, "[plan timing]   %s %.2f ms\n", tps[k].first, std::chrono::duration<double, std::milli>(tps[k].second - tps[k - 1].second).count());
+    fprintf(stderr, "[plan timing]   slab %zu bytes, %zu units, %zu ramp jobs, %zu plane entries\n", slab.host.size(), lean_units.size(), ramp_jobs.size(), plane_entries);
+#endif
     f.enabled = true;
     f.T = T;
     f.n_work = (uint32_t)work.size();

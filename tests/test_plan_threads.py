@@ -1,0 +1,91 @@
+"""The resampler's host planner cuts a batch's streams into work units on several threads (ohpipeline_amd/csrc/src_plan.cpp,
+ohgpu_api.hip: the per-message checks, the ordering test, the segments).  The plan must not depend on how many: this compares
+`ohgpu_src_plan_digest` -- the unit list, ramp jobs and generic-kernel pieces hashed on the host, no device -- across thread
+counts, message orders and kernel variants.  CPU only."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import workloads as W
+from ohpipeline_amd import capi
+
+
+def headline_like(n_streams, seconds, channels=2, rate_in=44100):
+    ref = O.Src(rate_in, 48000)
+    in_frames = int(seconds * rate_in)
+    out_total = (in_frames * ref.L + ref.M - 1) // ref.M
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 50 * 56448, 500 * 56448)
+    d, sb, db, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, channels, 24, O.ENDIAN_LITTLE, 24, O.ENDIAN_BIG,
+                                         schedule=sched, dtype=capi.SRC_MSG_DESC)
+    return ref, d, sb, db
+
+
+@pytest.fixture(autouse=True)
+def _no_cap():
+    yield
+    capi.set_plan_threads(0)
+
+
+def test_the_plan_does_not_depend_on_the_thread_count():
+    ref, d, sb, db = headline_like(96, 4.0)                 # ~77 000 messages: enough for several ranges of every parallel pass
+    assert d.size > 70000
+    capi.set_plan_threads(1)
+    one = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
+    assert one["units"] > 0 and one["kernel"] == 3 and one["generic_pieces"] == 0
+    for threads in (2, 3, 5, 16, 0):
+        capi.set_plan_threads(threads)
+        assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db) == one, threads
+
+
+def test_messages_in_any_order_make_the_same_plan():
+    ref, d, sb, db = headline_like(40, 3.0)
+    capi.set_plan_threads(1)
+    want = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
+    rng = np.random.default_rng(11)
+    shuffled = d[rng.permutation(d.size)]
+    for threads in (1, 4, 0):
+        capi.set_plan_threads(threads)
+        assert capi.src_plan_digest(ref.L, ref.M, ref.T, shuffled, sb, db) == want, threads
+
+
+@pytest.mark.parametrize("variant,kernel", [(0, 3), (5, 2), (4, 2), (3, 2), (2, 2)])
+def test_every_variants_plan_is_thread_independent(variant, kernel):
+    ref, d, sb, db = headline_like(64, 3.0)
+    capi.set_plan_threads(1)
+    one = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, variant)
+    assert one["kernel"] == kernel
+    capi.set_plan_threads(7)
+    assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, variant) == one
+
+
+def test_gaps_and_empty_messages_cut_the_segments_where_one_thread_cuts_them():
+    ref, d, sb, db = headline_like(48, 3.0)
+    d = d.copy()
+    # a hole in every third stream (a message dropped) and an empty message in every fifth
+    n_msgs = d.size // 48
+    keep = np.ones(d.size, dtype=bool)
+    for s in range(0, 48, 3):
+        keep[s * n_msgs + n_msgs // 2] = False
+    for s in range(1, 48, 5):
+        d["n_frames"][s * n_msgs + n_msgs // 3] = 0
+    d = d[keep]
+    capi.set_plan_threads(1)
+    one = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
+    assert one["generic_pieces"] > 0
+    for threads in (2, 6, 16):
+        capi.set_plan_threads(threads)
+        assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db) == one, threads
+
+
+def test_a_bad_descriptor_is_reported_by_its_index_whatever_thread_finds_it():
+    ref, d, sb, db = headline_like(64, 3.0)
+    d = d.copy()
+    bad = d.size * 3 // 4 + 5
+    d["channels"][bad] = 9
+    d["channels"][bad + 1000] = 0
+    for threads in (1, 8):
+        capi.set_plan_threads(threads)
+        with pytest.raises(capi.OhGpuError) as e:
+            capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
+        assert f"src desc {bad}:" in str(e.value)
