@@ -9,8 +9,12 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <unistd.h>
+
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -21,6 +25,69 @@ namespace ohgpu {
 static thread_local char g_err[512] = "";
 static int g_plan_threads = 0;
 int plan_thread_cap() { return g_plan_threads; }
+
+// ---- the planning pool: up to 15 helper threads, started on first use, one job at a time (callers queue on a mutex) ----
+namespace {
+struct PlanPool {
+    std::mutex one_job;                       // a job owns the pool from start to finish
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::vector<std::thread*> threads;          // (pointers: a forked child has the objects but not the threads, and abandons them)
+    long owner_pid = 0;
+    void (*job)(void*, unsigned) = nullptr;
+    void* arg = nullptr;
+    unsigned n_thr = 0;                       // ranges of the current job (helpers run ranges 1 .. n_thr - 1)
+    uint64_t generation = 0;
+    unsigned pending = 0;
+    bool quit = false;
+    void helper(unsigned id)                  // id = 1 .. 15
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            wake.wait(lk, [&] { return quit || generation != seen; });
+            if (quit) return;
+            seen = generation;
+            if (id < n_thr) {
+                void (*j)(void*, unsigned) = job;
+                void* a = arg;
+                lk.unlock();
+                j(a, id);
+                lk.lock();
+                if (--pending == 0) done.notify_one();
+            }
+        }
+    }
+    void run(unsigned n, void (*j)(void*, unsigned), void* a)
+    {
+        std::lock_guard<std::mutex> hold(one_job);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (owner_pid != (long)getpid()) { threads.clear(); owner_pid = (long)getpid(); pending = 0; }
+            while (threads.size() + 1 < n) { const unsigned id = (unsigned)threads.size() + 1; threads.push_back(new std::thread([this, id] { helper(id); })); }
+            job = j; arg = a; n_thr = n; pending = n - 1;
+            generation++;
+        }
+        wake.notify_all();
+        j(a, 0);
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return pending == 0; });
+    }
+    ~PlanPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        wake.notify_all();
+        if (owner_pid == (long)getpid()) for (std::thread* t : threads) { t->join(); delete t; }
+    }
+};
+PlanPool g_pool;
+}  // namespace
+
+void run_on_pool(unsigned n_thr, void (*job)(void* arg, unsigned t), void* arg)
+{
+    if (n_thr <= 1) { job(arg, 0); return; }
+    g_pool.run(n_thr > 16 ? 16 : n_thr, job, arg);
+}
 
 int set_error(int code, const char* fmt, ...)
 {
@@ -1093,6 +1160,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
     if (ctx->variant != 1 && batch->fast.enabled && aligned) {
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
         if (claim != OHGPU_OK) return claim;
+        if (batch->fast.planes_ready) OHGPU_HIP_TRY(hipStreamWaitEvent(s, batch->fast.planes_ready, 0));     // (the ramp planes are filled on the context's stream)
         // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
         if (batch->fast.mfma_wg && ctx->variant == 0)                                                                  // 24-bit stereo: the taps on the matrix pipe (round 4), a unit per workgroup
         {

@@ -132,6 +132,7 @@ struct SrcFastPlan {
     const void* d_mf_amat = nullptr;   // (owned by the ohgpu_src)
     const void* d_mf_steps = nullptr;
     void*    d_planes = nullptr;  // uint16: RampApplicator's multiplier per output frame of every ramped unit, [blocks of the unit][L_blk]
+    hipEvent_t planes_ready = nullptr;   // recorded on the context's stream behind the kernel that fills them: a run on any stream waits for it (on the device)
     uint32_t plane_stride = 0;    // the unit of SrcWork::plane / LeanUnit::plane in bytes (16: planes are as long as their units)
     void*    d_slab = nullptr;    // the one allocation the arrays below live in
     void*    d_segs = nullptr;
@@ -157,16 +158,20 @@ inline unsigned plan_threads(size_t n, size_t per_thread)
     if (ohgpu::plan_thread_cap() > 0 && t > (size_t)ohgpu::plan_thread_cap()) t = (size_t)ohgpu::plan_thread_cap();
     return (unsigned)t;
 }
-// f(thread, lo, hi) over [0, n) cut into n_thr contiguous ranges, range t on its own thread (range 0 on the caller's)
+// f(thread, lo, hi) over [0, n) cut into n_thr contiguous ranges, range t on thread t of the library's planning pool (range 0 on
+// the caller's).  The pool's threads are started on first use and sleep between jobs: starting sixteen threads per pass cost more
+// than the passes of a half-million-message plan.
+void run_on_pool(unsigned n_thr, void (*job)(void* arg, unsigned t), void* arg);     // csrc/ohgpu_api.hip
 template <typename F>
 inline void parallel_ranges(size_t n, unsigned n_thr, F&& f)
 {
     if (n_thr <= 1) { f(0u, (size_t)0, n); return; }
-    std::vector<std::thread> pool;
-    pool.reserve(n_thr - 1);
-    for (unsigned t = 1; t < n_thr; t++) pool.emplace_back([&f, t, n, n_thr] { f(t, n * t / n_thr, n * (t + 1) / n_thr); });
-    f(0u, (size_t)0, n / n_thr);
-    for (std::thread& th : pool) th.join();
+    if (n_thr > 16) n_thr = 16;                            // (the pool's size)
+    struct Ctx { F* f; size_t n; unsigned n_thr; } c{&f, n, n_thr};
+    run_on_pool(n_thr, [](void* a, unsigned t) {
+        Ctx* c = (Ctx*)a;
+        (*c->f)(t, c->n * t / c->n_thr, c->n * (t + 1) / c->n_thr);
+    }, &c);
 }
 
 // x / d == umulhi(x, m) >> s for every x < 2^31 (d >= 2; m == 0 stands for d == 1): with 2^(l-1) < d <= 2^l and
@@ -174,8 +179,7 @@ inline void parallel_ranges(size_t n, unsigned n_thr, F&& f)
 inline void magic_u31(uint32_t d, uint32_t* m, uint32_t* s)
 {
     if (d <= 1) { *m = 0; *s = 0; return; }
-    uint32_t l = 0;
-    while ((1ull << l) < d) l++;
+    const uint32_t l = 32u - (uint32_t)__builtin_clz(d - 1u);          // 2^(l-1) < d <= 2^l
     *m = (uint32_t)(((1ull << (31 + l)) / d) + 1);
     *s = l - 1;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -21,7 +22,8 @@ namespace ohgpu {
 void free_src_fast(ohgpu_batch* b)
 {
     SrcFastPlan& f = b->fast;
-    if (f.d_slab) (void)hipFree(f.d_slab);                            // (every d_* below points into it)
+    if (f.planes_ready) (void)hipEventDestroy(f.planes_ready);
+    if (f.d_slab) (void)hipFree(f.d_slab);                            // (every d_* below points into it; hipFree waits for the device)
     f = SrcFastPlan();
 }
 
@@ -186,7 +188,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         std::vector<SrcSeg> segs;
         std::vector<SegRun> seg_runs;
         std::vector<uint32_t> seg_plane_stride;         // planar batches: bytes between a segment's planes
-        std::vector<SegMsg> msgs;
         std::vector<SrcWork> work;
         std::vector<DevSrcDesc> rem;
         uint64_t fast_frames = 0;
@@ -246,37 +247,26 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             if (fast_ok) {
                 // every whole block's history must be present in the windows the caller declared (they were validated
                 // per message; the block reads nothing a message of the block does not itself need)
-                const uint32_t msg_begin = (uint32_t)o.msgs.size();
-                for (size_t k = i; k < e; k++) {
-                    const ohgpu_src_msg_desc& d = descs[order[k]];
-                    SegMsg sm;
-                    memset(&sm, 0, sizeof(sm));
-                    sm.out0 = d.out_frame0; sm.n = d.n_frames; sm.ramp_start = d.ramp_start; sm.ramp_end = d.ramp_end; sm.flags = d.flags;
-                    if (d.flags & OHGPU_FLAG_RAMP) {            // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
-                        uint32_t sh = 0;
-                        magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &sm.m_n1, &sh);
-                        sm.s_n1 = (uint8_t)sh;
-                    }
-                    o.msgs.push_back(sm);
-                }
+                // (a message is known by its position in `order`: the segment's are [i, e).  Their ramp parameters are read from the
+                // descriptors where a unit needs them; round 1's kernel gets them as an array, made when that kernel is planned for)
                 SrcSeg sg;
-                sg.src_base = sbase; sg.dst_base = dbase; sg.msg_begin = msg_begin; sg.msg_end = (uint32_t)o.msgs.size();
+                sg.src_base = sbase; sg.dst_base = dbase; sg.msg_begin = (uint32_t)i; sg.msg_end = (uint32_t)e;
                 const uint32_t seg_index = (uint32_t)o.segs.size();
                 o.segs.push_back(sg);
                 o.seg_plane_stride.push_back((uint32_t)d0.src_plane_stride);
                 o.seg_runs.push_back(SegRun{seg_index, blk_lo, blk_hi, (uint32_t)o.work.size()});
-                uint32_t mi = msg_begin;                      // message that holds the unit's first output frame
+                uint32_t mi = (uint32_t)i;                    // message that holds the unit's first output frame
                 for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
                     SrcWork w;
                     w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
-                    while (mi + 1 < sg.msg_end && o.msgs[mi + 1].out0 <= bk * L_blk) mi++;
+                    while (mi + 1 < sg.msg_end && descs[order[mi + 1]].out_frame0 <= bk * L_blk) mi++;
                     w.msg_first = mi;
                     // cost class, for the order below: a wave that meets a ramped message goes through the per-output ramp path
                     // for all of its lanes, which makes such a unit two to three times as long as a plain one
                     const uint64_t u_lo = bk * L_blk, u_hi = (bk + w.n_blocks) * L_blk;
                     bool ramped = false;
-                    for (uint32_t m = mi; m < sg.msg_end && o.msgs[m].out0 < u_hi && !ramped; m++)
-                        ramped = (o.msgs[m].flags & OHGPU_FLAG_RAMP) && o.msgs[m].out0 + o.msgs[m].n > u_lo;
+                    for (uint32_t m = mi; m < sg.msg_end && descs[order[m]].out_frame0 < u_hi && !ramped; m++)
+                        ramped = (descs[order[m]].flags & OHGPU_FLAG_RAMP) && descs[order[m]].out_frame0 + descs[order[m]].n_frames > u_lo;
                     w.flags = ramped ? kWorkRamped : 0u;
                     w.plane = 0; w.pad = 0;
                     if (unit_leaves_arena(sbase, d0.src_plane_stride, bk, w.n_blocks, 1)) w.flags |= kWorkChecked;
@@ -316,32 +306,23 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     std::vector<SrcSeg> segs;
     std::vector<SegRun> seg_runs;
     std::vector<uint32_t> seg_plane_stride;
-    std::vector<SegMsg> msgs;
     std::vector<SrcWork> work;
     std::vector<DevSrcDesc> rem;
     uint64_t fast_frames = 0;
     {
-        size_t n_segs = 0, n_msgs = 0, n_work0 = 0, n_rem = 0;
-        for (const Stretch& o : parts) { n_segs += o.segs.size(); n_msgs += o.msgs.size(); n_work0 += o.work.size(); n_rem += o.rem.size(); }
-        segs.reserve(n_segs); seg_runs.reserve(n_segs); seg_plane_stride.reserve(n_segs); msgs.resize(n_msgs); work.reserve(n_work0); rem.reserve(n_rem);
-        size_t msg_at = 0;
-        std::vector<size_t> msg_base(parts.size());
+        size_t n_segs = 0, n_work0 = 0, n_rem = 0;
+        for (const Stretch& o : parts) { n_segs += o.segs.size(); n_work0 += o.work.size(); n_rem += o.rem.size(); }
+        segs.reserve(n_segs); seg_runs.reserve(n_segs); seg_plane_stride.reserve(n_segs); work.reserve(n_work0); rem.reserve(n_rem);
         for (size_t t = 0; t < parts.size(); t++) {
             Stretch& o = parts[t];
             const uint32_t seg_base = (uint32_t)segs.size(), work_base = (uint32_t)work.size();
-            msg_base[t] = msg_at;
-            for (SrcSeg sg : o.segs) { sg.msg_begin += (uint32_t)msg_at; sg.msg_end += (uint32_t)msg_at; segs.push_back(sg); }
+            segs.insert(segs.end(), o.segs.begin(), o.segs.end());
             for (SegRun r : o.seg_runs) { r.seg += seg_base; r.work_begin += work_base; seg_runs.push_back(r); }
             seg_plane_stride.insert(seg_plane_stride.end(), o.seg_plane_stride.begin(), o.seg_plane_stride.end());
-            for (SrcWork w : o.work) { w.seg += seg_base; w.msg_first += (uint32_t)msg_at; work.push_back(w); }
+            for (SrcWork w : o.work) { w.seg += seg_base; work.push_back(w); }
             rem.insert(rem.end(), o.rem.begin(), o.rem.end());
             fast_frames += o.fast_frames;
-            msg_at += o.msgs.size();
         }
-        // (the messages are the bulk: copied side by side)
-        parallel_ranges(parts.size(), (unsigned)parts.size(), [&](unsigned, size_t lo, size_t hi) {
-            for (size_t t = lo; t < hi; t++) if (!parts[t].msgs.empty()) memcpy(msgs.data() + msg_base[t], parts[t].msgs.data(), parts[t].msgs.size() * sizeof(SegMsg));
-        });
         parts.clear();
     }
     if (work.empty()) return OHGPU_OK;
@@ -413,16 +394,18 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 const size_t per = (((size_t)n_rows * L_blk + 8) + 7) & ~(size_t)7;
                 if (plane_entries / 8 + per / 8 > 0xffffffffull) return false;
                 u.plane = (uint32_t)(plane_entries / 8);
-                for (uint32_t m = w1->msg_first; m < sg.msg_end && msgs[m].out0 < u_hi; m++) {
-                    const SegMsg& sm = msgs[m];
-                    if (!(sm.flags & OHGPU_FLAG_RAMP)) continue;
-                    const uint64_t lo = std::max<uint64_t>(sm.out0, u_lo), hi = std::min<uint64_t>(sm.out0 + sm.n, u_hi);
+                for (uint32_t m = w1->msg_first; m < sg.msg_end && descs[order[m]].out_frame0 < u_hi; m++) {
+                    const ohgpu_src_msg_desc& d = descs[order[m]];
+                    if (!(d.flags & OHGPU_FLAG_RAMP)) continue;
+                    const uint64_t lo = std::max<uint64_t>(d.out_frame0, u_lo), hi = std::min<uint64_t>(d.out_frame0 + d.n_frames, u_hi);
                     if (hi <= lo) continue;
                     RampJob j;
                     memset(&j, 0, sizeof(j));
                     j.plane_entry = plane_entries + (lo - u_lo);
-                    j.i0 = (uint32_t)(lo - sm.out0); j.count = (uint32_t)(hi - lo); j.n = sm.n;
-                    j.m_n1 = sm.m_n1; j.s_n1 = sm.s_n1; j.ramp_start = sm.ramp_start; j.ramp_end = sm.ramp_end;
+                    j.i0 = (uint32_t)(lo - d.out_frame0); j.count = (uint32_t)(hi - lo); j.n = d.n_frames;
+                    uint32_t sh = 0;                        // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
+                    magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &j.m_n1, &sh);
+                    j.s_n1 = (uint8_t)sh; j.ramp_start = d.ramp_start; j.ramp_end = d.ramp_end;
                     ramp_jobs.push_back(j);
                 }
                 plane_entries += per;
@@ -456,10 +439,20 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         }
         if (plane_entries) plane_entries += (size_t)rows * L_blk + 8;                             // (lanes without a block read their row's place too)
         // Longest first: the waves claim units in this order, and the kernel ends when the last unit does.
-        std::stable_sort(lean_units.begin(), lean_units.end(), [](const LeanUnit& x, const LeanUnit& y) {
+        {   // (a stable sort by descending cost; the costs are a handful of values, so: one bucket per value, in order)
             auto cost = [](const LeanUnit& u) { return ((u.flags & kWorkRamped) ? 6u : 5u) * ((u.flags >> 8) & 0xffu) * u.n_blocks; };
-            return cost(x) > cost(y);
-        });
+            std::vector<uint32_t> costs;
+            for (const LeanUnit& u : lean_units) { const uint32_t c = cost(u); if (std::find(costs.begin(), costs.end(), c) == costs.end()) costs.push_back(c); }
+            if (costs.size() <= 64) {
+                std::sort(costs.begin(), costs.end(), std::greater<uint32_t>());
+                std::vector<LeanUnit> sorted;
+                sorted.reserve(lean_units.size());
+                for (uint32_t c : costs) for (const LeanUnit& u : lean_units) if (cost(u) == c) sorted.push_back(u);
+                lean_units.swap(sorted);
+            } else {
+                std::stable_sort(lean_units.begin(), lean_units.end(), [&](const LeanUnit& x, const LeanUnit& y) { return cost(x) > cost(y); });
+            }
+        }
         // (the workgroup kernel's units in front, the edge units behind them: two launches over one array)
         if (mfma_wg) std::stable_partition(lean_units.begin(), lean_units.end(), [](const LeanUnit& u) { return !(u.flags & kWorkEdge); });
     }
@@ -480,7 +473,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         h = fnv(h, lean_units.data(), lean_units.size() * sizeof(LeanUnit));
         h = fnv(h, work.data(), work.size() * sizeof(SrcWork));
         h = fnv(h, segs.data(), segs.size() * sizeof(SrcSeg));
-        h = fnv(h, msgs.data(), msgs.size() * sizeof(SegMsg));
         h = fnv(h, rem.data(), rem.size() * sizeof(DevSrcDesc));
         h = fnv(h, ramp_jobs.data(), ramp_jobs.size() * sizeof(RampJob));
         h = fnv(h, &plane_entries, sizeof(plane_entries));
@@ -496,6 +488,21 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const bool round1 = block_ok && ((ctx && ctx->variant == 2) || !lean);      // (a filter the lean kernel's rounding does not hold runs on round 1's whatever the variant)
     Slab slab;
     if (round1) {
+        // the messages' ramp parameters as an array, by position in `order` (SrcSeg::msg_begin .. msg_end, SrcWork::msg_first)
+        std::vector<SegMsg> msgs(n);
+        parallel_ranges(n, plan_threads(n, 32768), [&](unsigned, size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; k++) {
+                const ohgpu_src_msg_desc& d = descs[order[k]];
+                SegMsg& sm = msgs[k];
+                memset(&sm, 0, sizeof(sm));
+                sm.out0 = d.out_frame0; sm.n = d.n_frames; sm.ramp_start = d.ramp_start; sm.ramp_end = d.ramp_end; sm.flags = d.flags;
+                if (d.flags & OHGPU_FLAG_RAMP) {            // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
+                    uint32_t sh = 0;
+                    magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &sm.m_n1, &sh);
+                    sm.s_n1 = (uint8_t)sh;
+                }
+            }
+        });
         slab.add(segs, &f.d_segs);
         slab.add(msgs, &f.d_msgs);
         slab.add(work, &f.d_work);
@@ -513,7 +520,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         hipStream_t s0 = ctx ? ctx->stream : nullptr;
         hipError_t e = hipMemsetAsync(f.d_planes, 0xff, (plane_entries ? plane_entries : 8) * sizeof(uint16_t), s0);
         if (e == hipSuccess && ctx) e = launch_ramp_planes(ctx, f.d_ramp_jobs, (uint32_t)ramp_jobs.size(), f.d_planes, s0);
-        if (e == hipSuccess) e = hipStreamSynchronize(s0);
+        // (not waited for here: a run of the batch waits for this event on its own stream, on the device)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f.planes_ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(f.planes_ready, s0);
         if (e != hipSuccess) { free_src_fast(b); return set_error(OHGPU_ERR_DEVICE, "ramp planes: %s", hipGetErrorString(e)); }
     }
     mark("planes");
