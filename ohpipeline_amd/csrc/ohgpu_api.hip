@@ -1163,10 +1163,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         if (batch->fast.planes_ready) OHGPU_HIP_TRY(hipStreamWaitEvent(s, batch->fast.planes_ready, 0));     // (the ramp planes are filled on the context's stream)
         // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
         if (batch->fast.mfma_wg && ctx->variant == 0)                                                                  // 24-bit stereo: the taps on the matrix pipe (round 4), a unit per workgroup
-        {
             OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
-            OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s, batch->fast.n_wg));     // (the edge units)
-        }
         else if (batch->fast.mfma && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 5))   // ... a unit per wave (variant 5, and where the workgroup kernel's block geometry does not hold)
             OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         else if (batch->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts; variant 4: the lean kernel where round 4's would run)

@@ -20,7 +20,7 @@
 // with a workgroup barrier between the phases; the input image and the output image share their LDS (72.5 KB a workgroup, two
 // workgroups per CU for 32-row units, 44 KB and three for 16-row ones), the next unit's input is in flight in registers during (C) and (D).
 // Units whose 32-row input image does not lie wholly inside the source arena (kWorkEdge: the first of the first stream, the last of
-// the last) stay with the unit-per-wave kernel, so nothing is checked here.
+// the last) fetch their pieces through a checked, out-of-line load.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -86,13 +86,26 @@ __device__ __forceinline__ void wg_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Sixteen bytes from arena offset a, bytes outside the arena read as zero.  Only units at an end of the arena come here (kWorkEdge).
+__device__ __noinline__ u32x4 wg_load_piece_checked(const uint8_t* __restrict__ src, int64_t a, uint64_t arena_bytes)
+{
+    if (a >= 0 && (uint64_t)a + 16 <= arena_bytes) return *(const u32x4_u*)(src + a);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma nounroll
+    for (int bb = 0; bb < 16; bb++) {
+        const int64_t a1 = a + bb;
+        if (a1 >= 0 && (uint64_t)a1 < arena_bytes) w[bb >> 2] |= (uint32_t)src[a1] << (8 * (bb & 3));
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
+
 template <int ROWS, bool SRC_LE, bool DST_LE>
 __global__ __launch_bounds__(WgGeom<ROWS>::kThreads) __attribute__((amdgpu_waves_per_eu(ROWS == 32 ? 4 : 3, ROWS == 32 ? 4 : 3)))
 void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         const uint8_t* __restrict__ amat, const MfStep* __restrict__ steps,
                         const uint16_t* __restrict__ planes, const uint32_t plane_stride,
                         const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                        const uint32_t row_src_bytes)
+                        const uint32_t row_src_bytes, const uint64_t src_arena_bytes)
 {
     using G = WgGeom<ROWS>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -146,7 +159,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     constexpr uint32_t sel_hi = (4 + kB1) | (4 + kB2) << 8 | 0x0c0c0000u;          // {R, L} -> R's other two
 
     // a workgroup unit = sub-unit `u % kSubUnits` of planner unit `u / kSubUnits`
-    struct Unit { int64_t src0, dst0; uint32_t n_blocks, plane; bool ramped, first; };
+    struct Unit { int64_t src0, dst0; uint32_t n_blocks, plane; bool ramped, first, edge; };
     auto fetch_unit = [&](uint32_t u) __attribute__((always_inline)) {
         const LeanUnit w = units[u / G::kSubUnits];
         const uint32_t sub = u % G::kSubUnits, r0 = sub * (uint32_t)ROWS;
@@ -157,6 +170,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         o.plane = w.plane + r0 * 20u;                       // (a plane row is 160 entries of 2 bytes = 20 of the plane stride's 16)
         o.ramped = (w.flags & kWorkRamped) != 0;
         o.first = (w.flags & kWorkFirst) != 0 && sub == 0;
+        o.edge = (w.flags & kWorkEdge) != 0;
         return o;
     };
     auto issue_input = [&](const Unit& w, u32x4 (&raw)[5]) __attribute__((always_inline)) {
@@ -168,10 +182,19 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #pragma unroll
         for (int k = 0; k < 5; k++) raw[k] = u32x4{tid, in_src, (uint32_t)w.n_blocks, (uint32_t)k};
 #else
-        const uint32_t o = mf_here(in_src);
+        if (w.edge) {
+            // a unit at an end of the arena (the first of the first stream, the last of the last): its pieces one by one, out of line,
+            // bytes outside the arena read as zero -- they are history before a stream's first frame, rows the unit does not hold, or
+            // the slack behind a row's last frame
 #pragma unroll
-        for (int k = 0; k < 4; k++) raw[k] = *(const u32x4_u*)(base + o + 256 * k);
-        raw[4] = *(const u32x4_u*)(base + mf_here(in_src + in_last));
+            for (int k = 0; k < 5; k++)
+                raw[k] = wg_load_piece_checked(src, w.src0 + (int64_t)(k < 4 ? in_src + 256u * (uint32_t)k : in_src + in_last), src_arena_bytes);
+        } else {
+            const uint32_t o = mf_here(in_src);
+#pragma unroll
+            for (int k = 0; k < 4; k++) raw[k] = *(const u32x4_u*)(base + o + 256 * k);
+            raw[4] = *(const u32x4_u*)(base + mf_here(in_src + in_last));
+        }
 #endif
     };
     auto stage_input = [&](const u32x4 (&raw)[5]) __attribute__((always_inline)) {
@@ -392,17 +415,17 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     using G = WgGeom<OHGPU_WG_ROWS>;
     auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
-    if (f.n_wg == 0) return hipSuccess;
+    if (f.n_lean == 0) return hipSuccess;
     if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db)) return hipErrorInvalidValue;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
-    const uint32_t n_units = f.n_wg * G::kSubUnits;
+    const uint32_t n_units = f.n_lean * G::kSubUnits;                // (edge units included: their loads are checked)
     uint32_t gsz = G::kGroupsPerCu * cus;                     // as many workgroups as the LDS holds
     if (gsz > n_units) gsz = n_units;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLdsBytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s,
                        (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
-                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * 6u);
+                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * 6u, p.src_arena_bytes);
     return hipGetLastError();
 }
 

@@ -453,8 +453,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 std::stable_sort(lean_units.begin(), lean_units.end(), [&](const LeanUnit& x, const LeanUnit& y) { return cost(x) > cost(y); });
             }
         }
-        // (the workgroup kernel's units in front, the edge units behind them: two launches over one array)
-        if (mfma_wg) std::stable_partition(lean_units.begin(), lean_units.end(), [](const LeanUnit& u) { return !(u.flags & kWorkEdge); });
+        // (the edge units in front: their checked loads are slow, and the launch should not end on them)
+        if (mfma_wg) std::stable_partition(lean_units.begin(), lean_units.end(), [](const LeanUnit& u) { return (u.flags & kWorkEdge) != 0; });
     }
     // (round 1's kernel, variant 2, keeps one-block units; ramped first, partly filled units last)
     std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {

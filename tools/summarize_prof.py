@@ -13,8 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = name.split("(")[0]
-    if "src_lean_kernel" in name:                                      # keep the instantiation: <T, channels, src bytes, src LE, dst bytes, dst LE>
-        return "src_lean_kernel" + name[name.index("src_lean_kernel") + len("src_lean_kernel"):].replace(" ", "")
+    for k in ("src_mfma_wg_kernel", "src_mfma_kernel", "src_lean_kernel"):      # keep the instantiation (lean: <T, channels, src bytes, src LE, dst bytes, dst LE>)
+        if k in name:
+            return k + name[name.index(k) + len(k):].replace(" ", "")
     for k in ("src_block_kernel", "src_msg_kernel_v1", "pcm_line_kernel", "pcm_msg_kernel_v1", "fmt_line_kernel", "fmt_kernel_v1", "flywheel_kernel", "ohm_header_kernel", "ohm_wide_kernel", "ohm_select_ramp_kernel",
               "unpack_stereo_kernel", "flac_stereo_kernel"):
         if k in name:
@@ -64,9 +65,19 @@ def main():
             md.write(f"| {k} | {v['calls']} | {v['avg_us']:.1f} | {v['median_us']:.1f} | {v['min_us']:.1f} | {v['max_us']:.1f} |\n")
         if stats:
             md.write("\n## rocprofv3 --stats (verbatim)\n\n```\n" + open(stats[0]).read() + "```\n")
-        notes = os.path.join(ROOT, "profiles", f"{tag}_notes.md")      # hand-written reading of the numbers, kept next to them
-        if os.path.exists(notes):
-            md.write("\n" + open(notes).read().rstrip() + "\n")
+        # A hand-written reading of the numbers, kept next to them -- and only next to the run it reads: the notes name the trace
+        # average they were written from (`<!-- trace-avg-us: 438.8 -->`), and notes of another run are left out, loudly.
+        notes = os.path.join(ROOT, "profiles", f"{tag}_notes.md")
+        if os.path.exists(notes) and out["kernels"]:
+            import re
+            text = open(notes).read()
+            m = re.search(r"<!--\s*trace-avg-us:\s*([0-9.]+)\s*-->", text)
+            dom_avg = max(out["kernels"].values(), key=lambda v: v["avg_us"] * v["calls"])["avg_us"]
+            if m and abs(float(m.group(1)) - dom_avg) <= 0.005 * dom_avg:
+                md.write("\n" + text.rstrip() + "\n")
+            else:
+                sys.stderr.write(f"summarize_prof: profiles/{tag}_notes.md was written for a trace average of {m.group(1) if m else '?'} us, this run's is "
+                                 f"{dom_avg:.1f} us: notes NOT included (re-read the numbers, then update the marker)\n")
         md.write("\n## PMC counters (mean per dispatch)\n\n")
         for k, cs in out["counters"].items():
             md.write(f"### {k}\n\n| counter | value |\n|---|---|\n")
