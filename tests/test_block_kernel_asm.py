@@ -227,3 +227,80 @@ def test_no_instruction_touches_a_load_destination_before_its_wait(which, reques
                 for tok in re.findall(r"v\[\d+:\d+\]|v\d+", code):
                     used |= _regs(tok)
                 assert not (used & dst), (name, line.strip(), code)
+
+
+# ---- round 4: what the round-3 diagnostic build's memory access fault came down to ----
+# A build with the coefficient reloads compiled out (and the taps: nothing consumed the coefficient registers any more) faulted on
+# the device.  Its ISA shows why it was an ADDRESS and not a sample that went wrong: the unit's first coefficient reads,
+# `ds_read_b64 v[0:1]`, are issued from inline asm and nothing names v[0:1] afterwards -- so the compiler took the pair for dead
+# and put a 64-bit global address into it three instructions later (`v_lshl_add_u64 v[0:1], ...`, then `global_load_ubyte`),
+# while the LDS read was still on its way: the late write landed in the address.  The product build is safe because every
+# asm-issued load's destination is an operand of a later statement that sits behind a wait covering the load; the check below
+# holds the generated code to exactly that, by walking the LGKM queue instead of accepting "some wait" as the older test does:
+# LDS operations complete in issue order, so `s_waitcnt lgkmcnt(N)` covers a read iff at least N younger LDS operations were issued
+# behind it -- and covers nothing counted if a scalar load (out of order on the same counter) is in flight, unless N is 0.
+LGKM_OP = re.compile(r"^\s*(ds_\w+|s_load\w*|s_buffer_load\w*)\b")
+LGKM_WAIT = re.compile(r"s_waitcnt.*lgkmcnt\((\d+)\)")
+
+
+def _uncovered_touches(body):
+    """(load line, touching line) for every LDS read whose destination is named by an instruction of the straight-line code behind
+    it before a wait that covers it."""
+    bad = []
+    for i, line in enumerate(body):
+        m = LOAD.match(line)
+        if not m or not m.group(1).startswith("ds_read"):
+            continue
+        dst = _regs(m.group(2))
+        younger, scalar_in_flight = 0, False
+        for follow in body[i + 1:i + 600]:
+            code = follow.split(";")[0].strip()
+            if not code or code.startswith("."):
+                if re.match(r"^\.?LBB|^\d+:", code):
+                    break
+                continue
+            if re.match(r"^(\d+|\.LBB\w+):", code) or re.match(r"^(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc)", code):
+                break
+            w = LGKM_WAIT.search(code)
+            if w:
+                n = int(w.group(1))
+                if n == 0 or (n <= younger and not scalar_in_flight):
+                    break                                   # covered
+                continue
+            if re.match(r"^s_waitcnt", code) and "lgkmcnt" not in code:
+                continue
+            if LGKM_OP.match(code):
+                if code.startswith("s_"):
+                    scalar_in_flight = True
+                younger += 1
+            used = set()
+            for tok in re.findall(r"v\[\d+:\d+\]|v\d+", code):
+                used |= _regs(tok)
+            # (a later LDS READ into the same registers is the next load's business; a store or ALU instruction naming them is not)
+            if used & dst and not (LOAD.match(follow) and _regs(LOAD.match(follow).group(2)) == dst and not (used - dst) & dst):
+                bad.append((line.strip(), code))
+                break
+    return bad
+
+
+@pytest.mark.parametrize("which", ["lean", "block"])
+def test_no_lds_read_lands_in_a_register_the_code_has_moved_on_from(which, request):
+    for name, body in request.getfixturevalue(which).items():
+        assert not _uncovered_touches(body), (name, _uncovered_touches(body)[:3])
+
+
+def test_the_check_sees_the_diagnostic_builds_fault():
+    """The shape of the round-3 fault, reduced: an asm-issued read nobody names again, its register pair recycled for an address."""
+    body = ["\tv_mov_b64_e32 v[0:1], 0", "\tds_read_b64 v[0:1], v28 offset:0x80", "\ts_and_b32 s14, s12, -16",
+            "\tv_lshl_add_u64 v[0:1], s[14:15], 0, v[10:11]", "\tglobal_load_ubyte v3, v[0:1], off", "\ts_endpgm"]
+    assert _uncovered_touches(body) == [("ds_read_b64 v[0:1], v28 offset:0x80", "v_lshl_add_u64 v[0:1], s[14:15], 0, v[10:11]")]
+    # a counted wait with enough younger LDS operations behind the read covers it ...
+    ok = ["\tds_read_b64 v[0:1], v28", "\tds_read_b64 v[2:3], v28 offset:8", "\ts_waitcnt lgkmcnt(1)", "\tv_add_f64 v[4:5], v[0:1], v[0:1]", "\ts_endpgm"]
+    assert _uncovered_touches(ok) == []
+    # ... one that leaves the read itself among the operations still allowed in flight does not, nor does any count above zero
+    # while a scalar load shares the counter
+    short = ["\tds_read_b64 v[0:1], v28", "\ts_waitcnt lgkmcnt(1)", "\tv_add_f64 v[4:5], v[0:1], v[0:1]", "\ts_endpgm"]
+    assert _uncovered_touches(short)
+    scalar = ["\tds_read_b64 v[0:1], v28", "\ts_load_dwordx2 s[4:5], s[0:1], 0x0", "\tds_read_b64 v[2:3], v28 offset:8", "\ts_waitcnt lgkmcnt(1)",
+              "\tv_add_f64 v[4:5], v[0:1], v[0:1]", "\ts_endpgm"]
+    assert _uncovered_touches(scalar)
