@@ -41,17 +41,21 @@ namespace ohgpu {
 constexpr uint32_t kWgSteps = 10;                   // steps per block (a 160-output block)
 constexpr uint32_t kWgUnitRows = 32;                // rows of a planner unit (LeanUnit)
 constexpr uint32_t kWgChunks = 12;                  // chunks (16 frames) a row's outputs touch: frames -32 .. 159 of the row
-constexpr uint32_t kWgRowIn = kWgChunks * 96;       // bytes of a row's input image
+constexpr uint32_t kWgRowIn = kWgChunks * 96;       // bytes of a row's input image, packed 24-bit stereo
 constexpr uint32_t kWgRowInPitch = kWgRowIn + 16;   // ... and its pitch in LDS (16 rows, 16 bytes each, then meet all 64 banks once)
+constexpr uint32_t kWgPlaneIn = kWgChunks * 64;     // planar TInt32 source: bytes of one channel's frames of a row's image (two of them side by side)
+constexpr uint32_t kWgRowInPitchPl = 2 * kWgPlaneIn + 16;
 constexpr uint32_t kWgRowOut = 160 * 6;             // bytes of a row's output
 constexpr uint32_t kWgBiasBytes = kWgSteps * 768;   // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
 
 // A workgroup's share of a unit is ROWS rows = CT = ROWS / 8 column tiles per step, 10 CT tiles in all; a wave takes FIVE of them
 // in step-major order (2 CT waves: two per SIMD for 32 rows, one for 16 -- whole numbers per SIMD whatever SIMD the first wave lands
 // on; ten waves, one per step, would be 3, 3, 2, 2, and the phase between two barriers lasts as long as its slowest wave).
-template <int ROWS>
+template <int ROWS, int PLANAR = 0>
 struct WgGeom {
     static_assert(ROWS == 16 || ROWS == 32, "rows per workgroup");
+    static constexpr uint32_t kRowInPitch = PLANAR ? kWgRowInPitchPl : kWgRowInPitch;
+    static constexpr uint32_t kInRounds = PLANAR ? 6 : 5;              // 16-byte pieces per lane of the input image (sixteen lanes per row)
     static constexpr uint32_t kCt = ROWS / 8;
     static constexpr uint32_t kWaves = 2 * kCt;
     static constexpr uint32_t kThreads = 64 * kWaves;                 // = 16 * ROWS: sixteen lanes per row of the input image
@@ -61,7 +65,7 @@ struct WgGeom {
     static constexpr uint32_t kChunk = 2 * kHalf;
     static constexpr uint32_t kDigit = kWgChunks * kChunk;
     static constexpr uint32_t kPlaneBytes = 3 * kDigit;
-    static constexpr uint32_t kStageBytes = ROWS * kWgRowInPitch;     // the input image; the output image (ROWS x 960) lies over it
+    static constexpr uint32_t kStageBytes = ROWS * kRowInPitch;       // the input image; the output image (ROWS x 960) lies over it
     static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kWgBiasBytes;
     static constexpr uint32_t kGroupsPerCu = ROWS == 32 ? 2 : 3;
     static constexpr uint32_t kSubUnits = kWgUnitRows / ROWS;         // workgroup units per planner unit
@@ -99,7 +103,10 @@ __device__ __noinline__ u32x4 wg_load_piece_checked(const uint8_t* __restrict__ 
     return u32x4{w[0], w[1], w[2], w[3]};
 }
 
-template <int ROWS, bool SRC_LE, bool DST_LE>
+// PLANAR: 0 = packed 24-bit stereo frames (SRC_LE: their byte order); 1 + k = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32 (one per
+// channel, `src_plane_stride` apart, host byte order), the sample being the low 24 - 8 k bits of a plane's value shifted up k bytes
+// (k = 0, 1, 2 for 24-, 16- and 8-bit streams: CodecFlac::CallbackWrite's pack, Flac.cpp:379-417, folded into the load).
+template <int ROWS, int PLANAR, bool SRC_LE, bool DST_LE>
 __global__ __launch_bounds__(WgGeom<ROWS>::kThreads) __attribute__((amdgpu_waves_per_eu(ROWS == 32 ? 4 : 3, ROWS == 32 ? 4 : 3)))
 void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         const uint8_t* __restrict__ amat, const MfStep* __restrict__ steps,
@@ -107,7 +114,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                         const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                         const uint32_t row_src_bytes, const uint64_t src_arena_bytes)
 {
-    using G = WgGeom<ROWS>;
+    using G = WgGeom<ROWS, PLANAR>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const pl_lds = smem;
     uint8_t* const stage = smem + G::kPlaneBytes;
@@ -146,10 +153,11 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     uint8_t* const out_lds = stage + 2u * g * kWgRowOut + 6u * n;                  // + 96 * step + tile * 8 rows (+ a row for the second frame)
     // the input image: sixteen lanes per row; lane `sub` of a row moves its pieces sub, sub + 16, .. sub + 48 and (sub < 8) sub + 64 of
     // the row's 72 -- an instruction reads 256 contiguous bytes of every row, and a lane's addresses differ by constants
+    // (planar: a channel's 768 bytes are three rounds exactly; the second channel's come from `src_plane_stride` further on)
     const uint32_t in_row = tid >> 4, in_sub = tid & 15u;
     const uint32_t in_src = in_row * row_src_bytes + 16u * in_sub;                 // + 256 k
-    const uint32_t in_lds = in_row * kWgRowInPitch + 16u * in_sub;
-    const uint32_t in_last = in_sub < 8u ? 1024u : 0u;                             // (the fifth round's spare lanes repeat their first piece)
+    const uint32_t in_lds = in_row * G::kRowInPitch + 16u * in_sub;
+    const uint32_t in_last = in_sub < 8u ? 1024u : 0u;                             // (packed: the fifth round's spare lanes repeat their first piece)
     // the split: task q = threads * k + tid (k = 0, 1; q < 24 ROWS) is half chunk q / ROWS of row q % ROWS (the rows side by side)
     const uint32_t sp_row = tid % (uint32_t)ROWS, sp_hc0 = tid / (uint32_t)ROWS;   // (0..15; second round: half chunk + 16 while < 24)
 
@@ -159,7 +167,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     constexpr uint32_t sel_hi = (4 + kB1) | (4 + kB2) << 8 | 0x0c0c0000u;          // {R, L} -> R's other two
 
     // a workgroup unit = sub-unit `u % kSubUnits` of planner unit `u / kSubUnits`
-    struct Unit { int64_t src0, dst0; uint32_t n_blocks, plane; bool ramped, first, edge; };
+    struct Unit { int64_t src0, dst0; uint32_t n_blocks, plane, plane_stride; bool ramped, first, edge; };
     auto fetch_unit = [&](uint32_t u) __attribute__((always_inline)) {
         const LeanUnit w = units[u / G::kSubUnits];
         const uint32_t sub = u % G::kSubUnits, r0 = sub * (uint32_t)ROWS;
@@ -168,27 +176,38 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         o.dst0 = w.dst_row0 + (int64_t)(r0 * kWgRowOut);
         o.n_blocks = w.n_blocks > r0 ? (w.n_blocks - r0 < (uint32_t)ROWS ? w.n_blocks - r0 : (uint32_t)ROWS) : 0u;
         o.plane = w.plane + r0 * 20u;                       // (a plane row is 160 entries of 2 bytes = 20 of the plane stride's 16)
+        o.plane_stride = w.src_plane_stride;
         o.ramped = (w.flags & kWorkRamped) != 0;
         o.first = (w.flags & kWorkFirst) != 0 && sub == 0;
         o.edge = (w.flags & kWorkEdge) != 0;
         return o;
     };
-    auto issue_input = [&](const Unit& w, u32x4 (&raw)[5]) __attribute__((always_inline)) {
+    auto issue_input = [&](const Unit& w, u32x4 (&raw)[G::kInRounds]) __attribute__((always_inline)) {
         // (scalar base + 32-bit lane offset is the load's scalar-base form, but only if the offset is widened in THIS block: hoisted out
         // of the loop as a 64-bit pair it costs eight registers for the whole launch and a 64-bit add per load -- mf_here pins it)
         const uint8_t* const base = src + w.src0;
 #ifdef MF_DIAG_NO_LOAD
         (void)base;
 #pragma unroll
-        for (int k = 0; k < 5; k++) raw[k] = u32x4{tid, in_src, (uint32_t)w.n_blocks, (uint32_t)k};
+        for (int k = 0; k < (int)G::kInRounds; k++) raw[k] = u32x4{tid, in_src, (uint32_t)w.n_blocks, (uint32_t)k};
 #else
         if (w.edge) {
             // a unit at an end of the arena (the first of the first stream, the last of the last): its pieces one by one, out of line,
             // bytes outside the arena read as zero -- they are history before a stream's first frame, rows the unit does not hold, or
             // the slack behind a row's last frame
 #pragma unroll
-            for (int k = 0; k < 5; k++)
-                raw[k] = wg_load_piece_checked(src, w.src0 + (int64_t)(k < 4 ? in_src + 256u * (uint32_t)k : in_src + in_last), src_arena_bytes);
+            for (int k = 0; k < (int)G::kInRounds; k++) {
+                const int64_t at = PLANAR ? (int64_t)(in_src + 256u * (uint32_t)(k % 3)) + (int64_t)(k / 3) * w.plane_stride
+                                          : (int64_t)(k < 4 ? in_src + 256u * (uint32_t)k : in_src + in_last);
+                raw[k] = wg_load_piece_checked(src, w.src0 + at, src_arena_bytes);
+            }
+        } else if constexpr (PLANAR != 0) {
+            const uint32_t o = mf_here(in_src);
+            const uint8_t* const base1 = base + w.plane_stride;
+#pragma unroll
+            for (int k = 0; k < 3; k++) raw[k] = *(const u32x4_u*)(base + o + 256 * k);
+#pragma unroll
+            for (int k = 0; k < 3; k++) raw[3 + k] = *(const u32x4_u*)(base1 + o + 256 * k);
         } else {
             const uint32_t o = mf_here(in_src);
 #pragma unroll
@@ -197,26 +216,54 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         }
 #endif
     };
-    auto stage_input = [&](const u32x4 (&raw)[5]) __attribute__((always_inline)) {
+    auto stage_input = [&](const u32x4 (&raw)[G::kInRounds]) __attribute__((always_inline)) {
 #ifdef MF_DIAG_NO_STAGE
         return;
 #endif
+        if constexpr (PLANAR != 0) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) *(u32x4*)(stage + in_lds + 256 * k) = raw[k];
-        *(u32x4*)(stage + in_lds + in_last) = raw[4];
+            for (int k = 0; k < 6; k++) *(u32x4*)(stage + in_lds + (k / 3) * kWgPlaneIn + 256 * (k % 3)) = raw[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) *(u32x4*)(stage + in_lds + 256 * k) = raw[k];
+            *(u32x4*)(stage + in_lds + in_last) = raw[4];
+        }
     };
     auto split_task = [&](uint32_t hc, bool first) __attribute__((always_inline)) {
-        const uint8_t* const from = stage + sp_row * kWgRowInPitch + 48u * hc;
-        u32x4 mine[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) mine[k] = *(const u32x4*)(from + 16 * k);
-        uint32_t w[12] = {mine[0].x, mine[0].y, mine[0].z, mine[0].w, mine[1].x, mine[1].y, mine[1].z, mine[1].w, mine[2].x, mine[2].y, mine[2].z, mine[2].w};
         // the stream's block 0: the frames before it (chunks 0 and 1 of row 0) read as zeros
         const bool zero = first && sp_row == 0 && hc < 4u;
+        uint32_t pl[6][2];                                  // [3 * channel + byte of the 24-bit sample, least significant first... in memory order for packed][frames 0-3, 4-7]
+        if constexpr (PLANAR != 0) {
+            // eight frames of each channel, 4 bytes apiece: a 4 x 4 byte transpose per four frames (two permute levels) of which the
+            // sample's bytes are kept -- byte b of the plane value is byte b + k of the 24-bit sample
+            constexpr int kShift = PLANAR - 1;
 #pragma unroll
-        for (int k = 0; k < 12; k++) w[k] = zero ? 0u : w[k];
-        uint32_t pl[6][2];
-        mf_split48(w, pl);
+            for (int c = 0; c < 2; c++) {
+                const uint8_t* const from = stage + sp_row * G::kRowInPitch + c * kWgPlaneIn + 32u * hc;
+                const u32x4 lo4 = *(const u32x4*)from, hi4 = *(const u32x4*)(from + 16);
+                const uint32_t f[8] = {zero ? 0u : lo4.x, zero ? 0u : lo4.y, zero ? 0u : lo4.z, zero ? 0u : lo4.w,
+                                       zero ? 0u : hi4.x, zero ? 0u : hi4.y, zero ? 0u : hi4.z, zero ? 0u : hi4.w};
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const uint32_t p01 = mf_perm(f[4 * q + 1], f[4 * q], 0x05010400u), q01 = mf_perm(f[4 * q + 1], f[4 * q], 0x07030602u);   // {A0 B0 A1 B1}, {A2 B2 A3 B3}
+                    const uint32_t p23 = mf_perm(f[4 * q + 3], f[4 * q + 2], 0x05010400u), q23 = mf_perm(f[4 * q + 3], f[4 * q + 2], 0x07030602u);
+                    const uint32_t b0 = mf_perm(p23, p01, 0x05040100u), b1 = mf_perm(p23, p01, 0x07060302u), b2 = mf_perm(q23, q01, 0x05040100u);
+                    // sample byte j (least significant first) = plane byte j - kShift, zero below
+                    const uint32_t sb[3] = {kShift == 0 ? b0 : 0u, kShift == 0 ? b1 : (kShift == 1 ? b0 : 0u), kShift == 0 ? b2 : (kShift == 1 ? b1 : b0)};
+#pragma unroll
+                    for (int j = 0; j < 3; j++) pl[3 * c + j][q] = sb[j];
+                }
+            }
+        } else {
+            const uint8_t* const from = stage + sp_row * G::kRowInPitch + 48u * hc;
+            u32x4 mine[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) mine[k] = *(const u32x4*)(from + 16 * k);
+            uint32_t w[12] = {mine[0].x, mine[0].y, mine[0].z, mine[0].w, mine[1].x, mine[1].y, mine[1].z, mine[1].w, mine[2].x, mine[2].y, mine[2].z, mine[2].w};
+#pragma unroll
+            for (int k = 0; k < 12; k++) w[k] = zero ? 0u : w[k];
+            mf_split48(w, pl);
+        }
         // A plane's chunk is [half][row][channel 2][8 frames]: a lane's two channels are 16 contiguous bytes, the rows of a task a
         // contiguous run, a wave's tasks whole halves -- one conflict-free 16-byte store per digit (the 8-byte stores of a
         // [row][channel][16 frames] layout met the banks four deep).  Odd chunks are stored with bit 7 of the offset flipped, so that the
@@ -225,7 +272,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         uint8_t* const to = pl_lds + c * G::kChunk + (((hc & 1u) * G::kHalf + sp_row * 16u) ^ ((c & 1u) * 128u));     // + digit * kDigit
 #pragma unroll
         for (int bpos = 0; bpos < 3; bpos++) {
-            const int digit = SRC_LE ? bpos : 2 - bpos;
+            const int digit = (SRC_LE || PLANAR) ? bpos : 2 - bpos;
             const uint32_t flip = digit < 2 ? 0x80808080u : 0u;
             *(u32x4*)(to + digit * G::kDigit) = u32x4{pl[bpos][0] ^ flip, pl[bpos][1] ^ flip, pl[3 + bpos][0] ^ flip, pl[3 + bpos][1] ^ flip};
         }
@@ -246,7 +293,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     if (u_cur >= n_work) return;                            // (uniform; the launch keeps the grid within the units)
     uint32_t u_nxt = u_cur + n_groups;                     // the unit whose input is in flight
     Unit wk = fetch_unit(u_cur);
-    u32x4 raw[5];
+    u32x4 raw[G::kInRounds];
     issue_input(wk, raw);
     __syncthreads();                                        // (the bias table)
     stage_input(raw);
@@ -359,6 +406,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
         // unit's input -- requested a whole phase (C) ago -- is waited for HERE, in front of the stores, not behind them ----
         asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]));
+        if constexpr (PLANAR != 0) asm volatile("" : "+v"(raw[5]));
         {
             uint8_t* const unit_dst = dst + wk.dst0;
             const uint32_t out_bytes = n_blocks * kWgRowOut;
@@ -398,25 +446,27 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     }
 }
 
-bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db)
+bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar)
 {
-    return ch == 2 && sb == 3 && db == 3 && L_blk == 16u * kWgSteps && (M_blk + 31u) / 16u + 1u == kWgChunks;
+    // (planar: sb is the stream's sample size, 1..3 bytes, whatever the planes hold above it)
+    return ch == 2 && (planar ? (sb >= 1 && sb <= 3) : sb == 3) && db == 3 && L_blk == 16u * kWgSteps && (M_blk + 31u) / 16u + 1u == kWgChunks;
 }
 
 // does a unit's input image -- 32 rows of kWgRowIn bytes, whatever the number of blocks the unit holds -- lie inside the arena?
-bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes)
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, bool planar, uint64_t plane_stride)
 {
-    return src_row0 >= 0 && (uint64_t)src_row0 + (uint64_t)(kWgUnitRows - 1) * row_src_bytes + kWgRowIn <= src_arena_bytes;
+    const uint64_t row_in = planar ? kWgPlaneIn : kWgRowIn, last_plane = planar ? plane_stride : 0;
+    return src_row0 >= 0 && (uint64_t)src_row0 + last_plane + (uint64_t)(kWgUnitRows - 1) * row_src_bytes + row_in <= src_arena_bytes;
 }
 
-template <bool SRC_LE, bool DST_LE>
+template <int PLANAR, bool SRC_LE, bool DST_LE>
 static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
 {
-    using G = WgGeom<OHGPU_WG_ROWS>;
-    auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, SRC_LE, DST_LE>;
+    using G = WgGeom<OHGPU_WG_ROWS, PLANAR>;
+    auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
     if (f.n_lean == 0) return hipSuccess;
-    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db)) return hipErrorInvalidValue;
+    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0)) return hipErrorInvalidValue;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     const uint32_t n_units = f.n_lean * G::kSubUnits;                // (edge units included: their loads are checked)
     uint32_t gsz = G::kGroupsPerCu * cus;                     // as many workgroups as the LDS holds
@@ -425,7 +475,7 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s,
                        (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
-                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * 6u, p.src_arena_bytes);
+                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * (PLANAR ? 4u : 6u), p.src_arena_bytes);
     return hipGetLastError();
 }
 
@@ -434,8 +484,16 @@ hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const 
     SrcFastParams prm = b->fast.params;
     prm.src = src;
     prm.dst = dst;
-    if (prm.src_le) return prm.dst_le ? launch_wg_one<true, true>(ctx, b, prm, s) : launch_wg_one<true, false>(ctx, b, prm, s);
-    return prm.dst_le ? launch_wg_one<false, true>(ctx, b, prm, s) : launch_wg_one<false, false>(ctx, b, prm, s);
+    if (b->src_planar) {
+        switch (prm.sb) {                                    // (the stream's bytes per sample)
+        case 3: return prm.dst_le ? launch_wg_one<1, true, true>(ctx, b, prm, s) : launch_wg_one<1, true, false>(ctx, b, prm, s);
+        case 2: return prm.dst_le ? launch_wg_one<2, true, true>(ctx, b, prm, s) : launch_wg_one<2, true, false>(ctx, b, prm, s);
+        case 1: return prm.dst_le ? launch_wg_one<3, true, true>(ctx, b, prm, s) : launch_wg_one<3, true, false>(ctx, b, prm, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (prm.src_le) return prm.dst_le ? launch_wg_one<0, true, true>(ctx, b, prm, s) : launch_wg_one<0, true, false>(ctx, b, prm, s);
+    return prm.dst_le ? launch_wg_one<0, false, true>(ctx, b, prm, s) : launch_wg_one<0, false, false>(ctx, b, prm, s);
 }
 
 }  // namespace ohgpu

@@ -142,7 +142,11 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     src_mfma_geometry(&mf_rows, &mf_wave_lds, &mf_max_waves);
     const bool mfma = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (L_blk >> 4) <= 16u &&      // (the kernel's bias table: one block's steps)
                       mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
-    const bool mfma_wg = mfma && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db) && !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
+    // (a planar source -- the FLAC decoder's planes -- is the workgroup kernel's too: its split reads the planes; the unit-per-wave
+    // kernel has no such form, so with variants 3..5 a planar batch stays on the lean kernel)
+    const bool wg_tables = lean && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && T == 32 && mf_rows == rows;
+    const bool mfma_wg = wg_tables && (planar || mfma) && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db, planar) &&
+                         !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
 
 #ifdef OHGPU_PLAN_TIMING
     std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> tps;
@@ -385,7 +389,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             else if (unit_leaves_arena(segs[r.seg].src_base, u.src_plane_stride, bk, n_rows, kb)) u.flags |= kWorkChecked;
             // the workgroup kernel reads 32 rows' worth of input per unit whatever the unit holds and checks nothing: the (at most two)
             // units of a batch for which that leaves the arena stay with the unit-per-wave kernel
-            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes)) u.flags |= kWorkEdge;
+            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, planar, (uint64_t)(ch - 1) * u.src_plane_stride)) u.flags |= kWorkEdge;
             if (u.flags & kWorkRamped) {
                 // one plane of multipliers per ramped unit -- n_rows * L_blk entries (uint16, 0xffff = no ramp on that frame), in
                 // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16
@@ -551,8 +555,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.mfma_wg = mfma_wg;
     f.n_wg = 0;
     if (mfma_wg) for (const LeanUnit& u : lean_units) f.n_wg += (u.flags & kWorkEdge) ? 0u : 1u;
-    f.d_mf_amat = mfma ? flt->d_mf_amat : nullptr;
-    f.d_mf_steps = mfma ? flt->d_mf_steps : nullptr;
+    f.d_mf_amat = (mfma || mfma_wg) ? flt->d_mf_amat : nullptr;
+    f.d_mf_steps = (mfma || mfma_wg) ? flt->d_mf_steps : nullptr;
     f.fast_out_frames = fast_frames;
     SrcFastParams& p = f.params;
     memset(&p, 0, sizeof(p));
