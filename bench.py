@@ -271,30 +271,65 @@ def cpu_baseline(groups, got_by_group, light=False):
                                  (bounds[t + 1] - bounds[t]) * g.in_frames * g.channels * g.taps))
         jobs.sort(key=lambda j: -j[4])                                   # longest first over the pinned threads
 
-        def run(kj):
-            k, (ref, part, src, dst, _) = kj
-            return pin_and_call(cpus[k % threads], lib.ohp_src_msg_process_batch_steady, ref.h, part.ctypes.data_as(C.c_void_p), part.size,
-                                src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
-        times = []
-        with ThreadPoolExecutor(threads) as ex:
+        def run(job):
+            ref, part, src, dst, _ = job
+            return lib.ohp_src_msg_process_batch_steady(ref.h, part.ctypes.data_as(C.c_void_p), part.size,
+                                                        src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p))
+        # every worker thread gets a CPU of its own, once, when it starts (pinning per job let two live jobs share a core while
+        # others idled); the pool is started -- all threads pinned -- before the first timed pass
+        import threading
+        slot = iter(range(threads))
+        slot_lock = threading.Lock()
+        started = threading.Barrier(threads + 1)
+
+        def pin_worker():
+            with slot_lock:
+                k = next(slot)
+            try:
+                os.sched_setaffinity(0, {cpus[k]})         # (the calling thread only)
+            except OSError:
+                pass
+
+        times, cpu_user, cpu_sys = [], [], []
+        with ThreadPoolExecutor(threads, initializer=pin_worker) as ex:
+            warm = [ex.submit(started.wait) for _ in range(threads)]        # (every worker exists and is pinned once these return)
+            started.wait()
+            for w in warm:
+                w.result()
             for _ in range(passes):
+                c0 = os.times()
                 t0 = time.perf_counter()
-                rcs = list(ex.map(run, enumerate(jobs)))
+                rcs = list(ex.map(run, jobs))
                 times.append(time.perf_counter() - t0)
+                c1 = os.times()
+                cpu_user.append(c1.user - c0.user)
+                cpu_sys.append(c1.system - c0.system)
                 assert all(r == 0 for r in rcs)
-        return sorted(times)[len(times) // 2], len(jobs), sum(times) * threads
+        mid = sorted(range(len(times)), key=lambda i: times[i])[len(times) // 2]
+        return times[mid], len(jobs), cpu_user[mid], cpu_sys[mid]
 
     passes = 1 if light else 3
-    dt, n_jobs, core_s = timed(phys, passes)
+    dt, n_jobs, cpu_u, cpu_s = timed(phys, passes)
     ok = all(np.array_equal(a, b) for a, b in zip(got_by_group, outs))
+    cpu_max = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # the container's CPU quota, if it has one ("max 100000" = none)
+            cpu_max = f.read().strip()
+    except OSError:
+        pass
     base = dict(value=round(frames / dt / 1e6, 3), unit="Msamples/s", cores=len(phys), kind="port",
                 host_cores_online=os.cpu_count(), host_cores_allowed=len(allowed), host_physical_cores_allowed=len(physical_cpus(allowed)),
-                sample=f"the whole step, median of {passes} pass(es): {frames} input frames in {n_jobs} jobs, one pinned thread per physical core "
-                       f"({len(phys)}; gcc -O2 oracle, scratch allocated once per job; {dt:.2f} s per pass, {core_s:.0f} core-seconds in all)")
+                # what the pass consumed, by the kernel's accounting for the whole process (os.times): user time is the oracle's
+                # arithmetic, system time the page faults of its per-job scratch and of the output's first touch
+                cpu_seconds=round(cpu_u + cpu_s, 3), cpu_seconds_user=round(cpu_u, 3), cpu_seconds_system=round(cpu_s, 3),
+                wall_seconds=round(dt, 4), cgroup_cpu_max=cpu_max,
+                sample=f"the whole step, median of {passes} pass(es): {frames} input frames in {n_jobs} jobs, one thread per physical core, each "
+                       f"pinned to its core when it starts ({len(phys)}; gcc -O2 oracle, scratch allocated once per job)")
     if not light:
         if len(phys) > 16:
-            dt16, _, _ = timed(phys[:16], 3)
+            dt16, _, u16, s16 = timed(phys[:16], 3)
             base["threads_16"] = round(frames / dt16 / 1e6, 3)
+            base["threads_16_cpu_seconds"] = round(u16 + s16, 3)
         # one thread alone: the first streams of the first group, about a second of work
         g0 = groups[0]
         n_one = max(1, min(len(g0.stream_ids), 8))
@@ -312,6 +347,10 @@ def cpu_baseline(groups, got_by_group, light=False):
         except OSError:
             pass
         base["single_thread"] = round(n_one * g0.in_frames / sorted(one)[1] / 1e6, 3)
+        # the threads' arithmetic is independent: what the many-thread figure falls short of threads x one thread is time not spent in
+        # it (the CPU seconds say how much of the wall time the cores were busy at all)
+        base["parallel_efficiency"] = round(base["value"] / (base["single_thread"] * len(phys)), 4)
+        base["cores_busy"] = round((cpu_u + cpu_s) / (dt * len(phys)), 4)
     return base, ("bit-exact vs oracle" if ok else "MISMATCH")
 
 
