@@ -249,6 +249,22 @@ def cpu_baseline(groups, got_by_group, light=False):
     phys = physical_cpus(allowed)
     if os.environ.get("OHGPU_BENCH_CPU_THREADS"):
         phys = phys[:max(1, int(os.environ["OHGPU_BENCH_CPU_THREADS"]))]
+    # The container's CPU quota (cgroup v2 cpu.max = "<quota us> <period us>", or "max ..."): more runnable threads than that get no
+    # more CPU time -- on the pool's boxes 128 physical cores are visible and 16 CPUs' worth of time is granted, and 128 pinned
+    # threads measured 15 cores busy (cpu_seconds / wall_seconds), 1.2x the 16-thread figure.  The baseline therefore runs one thread
+    # per physical core UP TO the quota, and says so.
+    cpu_max, quota_cpus = None, None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            cpu_max = f.read().strip()
+        q, per = cpu_max.split()
+        if q != "max":
+            quota_cpus = max(1, int(-(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    phys_all = len(phys)
+    if quota_cpus is not None and quota_cpus < len(phys):
+        phys = phys[:quota_cpus]
     lib = O.lib()
     outs = [np.zeros(g.dst_bytes, dtype=np.uint8) for g in groups]
     frames = sum(len(g.stream_ids) * g.in_frames for g in groups)
@@ -311,22 +327,18 @@ def cpu_baseline(groups, got_by_group, light=False):
     passes = 1 if light else 3
     dt, n_jobs, cpu_u, cpu_s = timed(phys, passes)
     ok = all(np.array_equal(a, b) for a, b in zip(got_by_group, outs))
-    cpu_max = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:          # the container's CPU quota, if it has one ("max 100000" = none)
-            cpu_max = f.read().strip()
-    except OSError:
-        pass
     base = dict(value=round(frames / dt / 1e6, 3), unit="Msamples/s", cores=len(phys), kind="port",
-                host_cores_online=os.cpu_count(), host_cores_allowed=len(allowed), host_physical_cores_allowed=len(physical_cpus(allowed)),
+                host_cores_online=os.cpu_count(), host_cores_allowed=len(allowed), host_physical_cores_allowed=phys_all,
+                cgroup_cpu_max=cpu_max, cgroup_quota_cpus=quota_cpus,
                 # what the pass consumed, by the kernel's accounting for the whole process (os.times): user time is the oracle's
                 # arithmetic, system time the page faults of its per-job scratch and of the output's first touch
                 cpu_seconds=round(cpu_u + cpu_s, 3), cpu_seconds_user=round(cpu_u, 3), cpu_seconds_system=round(cpu_s, 3),
-                wall_seconds=round(dt, 4), cgroup_cpu_max=cpu_max,
-                sample=f"the whole step, median of {passes} pass(es): {frames} input frames in {n_jobs} jobs, one thread per physical core, each "
-                       f"pinned to its core when it starts ({len(phys)}; gcc -O2 oracle, scratch allocated once per job)")
+                wall_seconds=round(dt, 4),
+                sample=f"the whole step, median of {passes} pass(es): {frames} input frames in {n_jobs} jobs, one thread per physical core up to the "
+                       f"container's CPU quota, each pinned to its core when it starts ({len(phys)} of {phys_all} physical cores; gcc -O2 oracle, "
+                       f"scratch allocated once per job)")
     if not light:
-        if len(phys) > 16:
+        if len(phys) > 16:                                  # (no quota: beside the all-cores figure, a one-GPU box's usual CPU share)
             dt16, _, u16, s16 = timed(phys[:16], 3)
             base["threads_16"] = round(frames / dt16 / 1e6, 3)
             base["threads_16_cpu_seconds"] = round(u16 + s16, 3)
