@@ -1073,7 +1073,7 @@ int ohgpu_src_batch_units(const ohgpu_batch* b, uint64_t* units, uint64_t* long_
 
 static const char* src_kernel_of(const ohgpu_ctx* ctx, const ohgpu_batch* b)
 {
-    if (ctx->variant == 1 || !b->fast.enabled) return "src_kernel_v1";
+    if (ctx->variant == 1 || !b->fast.enabled || (b->fast.wg_only && ctx->variant != 0)) return "src_kernel_v1";
     if (b->fast.mfma_wg && ctx->variant == 0) return "src_mfma_wg_kernel";
     if (b->fast.mfma && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 5)) return "src_mfma_kernel";
     if (b->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 5 || b->fast.lean_only || !b->fast.d_work)) return "src_lean_kernel";
@@ -1157,7 +1157,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         return OHGPU_OK;
     }
     const bool aligned = ((uintptr_t)src_base & 15u) == 0;          // the staging loads move aligned 16-byte pieces of the arena
-    if (ctx->variant != 1 && batch->fast.enabled && aligned) {
+    if (ctx->variant != 1 && batch->fast.enabled && aligned && !(batch->fast.wg_only && ctx->variant != 0)) {
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
         if (claim != OHGPU_OK) return claim;
         if (batch->fast.planes_ready) OHGPU_HIP_TRY(hipStreamWaitEvent(s, batch->fast.planes_ready, 0));     // (the ramp planes are filled on the context's stream)

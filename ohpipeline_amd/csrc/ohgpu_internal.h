@@ -125,6 +125,7 @@ struct SrcFastPlan {
     uint32_t ring_bytes = 0;      // bytes of packed output a block row's LDS ring holds
     bool     lean = false;        // the batch runs on src_lean_kernel (round 2) rather than src_block_kernel
     bool     lean_only = false;   // ... and round 1's kernel has no instantiation for its layout (variant 2 then runs the lean kernel too)
+    bool     wg_only = false;     // ... or no block kernel but src_mfma_wg_kernel has one: any variant that asks for another kernel gets the generic one
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
     bool     mfma = false;        // ... and its layout is one src_mfma_kernel (round 4) serves: same units and planes, the filter's digit tables
     uint32_t n_wg = 0;            // mfma_wg: lean units [0, n_wg) are src_mfma_wg_kernel's, [n_wg, n_lean) the edge units src_mfma_kernel runs
@@ -379,7 +380,7 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
 hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit = 0);   // csrc/src_mfma_kernel.hip (units [first_unit, n_lean))
 hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_wg_kernel.hip
 bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar);
-bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, bool planar, uint64_t plane_stride);
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, bool planar, uint64_t plane_stride);
 bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, uint32_t L_blk, uint32_t kb_cap,
                        std::vector<uint8_t>* adig, std::vector<MfStep>* steps);
 void build_mfma_images(const std::vector<uint8_t>& adig, const std::vector<MfStep>& steps, uint32_t L, std::vector<uint8_t>* amat);

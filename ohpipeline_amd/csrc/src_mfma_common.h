@@ -19,6 +19,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
 
 constexpr uint32_t kMfStepImage = 4 * 1024;         // a step's A operands: [coefficient digit 4][lane 64][16 bytes]
 
@@ -42,6 +43,25 @@ __device__ __forceinline__ void mf_split48(const uint32_t (&w)[12], uint32_t (&p
         pl[0][q] = mf_perm(y01, x01, 0x05040100u); pl[1][q] = mf_perm(y01, x01, 0x07060302u);
         pl[2][q] = mf_perm(y23, x23, 0x05040100u); pl[3][q] = mf_perm(y23, x23, 0x07060302u);
         pl[4][q] = mf_perm(y45, x45, 0x05040100u); pl[5][q] = mf_perm(y45, x45, 0x07060302u);
+    }
+}
+
+// The same planes from eight frames that do NOT lie side by side (a channel pair of a six- or eight-channel stream): frame n's six
+// bytes are the low 48 bits of {hi[n], lo[n]}.  Level 1 interleaves two frames' bytes, level 2 two such pairs: 24 permutes again.
+__device__ __forceinline__ void mf_split_frames(const uint32_t (&lo)[8], const uint32_t (&hi)[8], uint32_t (&pl)[6][2])
+{
+    uint32_t t01[4], t23[4], t45[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        t01[m] = mf_perm(lo[2 * m + 1], lo[2 * m], 0x05010400u);     // {x0 y0 x1 y1}: bytes 0 and 1 of frames 2 m (x) and 2 m + 1 (y)
+        t23[m] = mf_perm(lo[2 * m + 1], lo[2 * m], 0x07030602u);     // bytes 2 and 3
+        t45[m] = mf_perm(hi[2 * m + 1], hi[2 * m], 0x05010400u);     // bytes 4 and 5
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        pl[0][q] = mf_perm(t01[2 * q + 1], t01[2 * q], 0x05040100u); pl[1][q] = mf_perm(t01[2 * q + 1], t01[2 * q], 0x07060302u);
+        pl[2][q] = mf_perm(t23[2 * q + 1], t23[2 * q], 0x05040100u); pl[3][q] = mf_perm(t23[2 * q + 1], t23[2 * q], 0x07060302u);
+        pl[4][q] = mf_perm(t45[2 * q + 1], t45[2 * q], 0x05040100u); pl[5][q] = mf_perm(t45[2 * q + 1], t45[2 * q], 0x07060302u);
     }
 }
 

@@ -1,6 +1,6 @@
 // src_mfma_wg_kernel.hip -- the matrix-pipe resampler (src_mfma_kernel.hip has the arithmetic: int8 digit planes, twelve
 // v_mfma_i32_16x16x64_i8 per tile of 16 outputs x 16 columns, 32-bit recombination) with the work cut for the MEMORY system:
-// one unit per WORKGROUP, one output step per WAVE.
+// one unit per WORKGROUP, five tiles per WAVE.
 //
 // Why.  With a unit per wave (src_mfma_kernel.hip) a wave reads 96 bytes of each of its 32 rows per step and writes 192 bytes of
 // each per pair of steps.  Every byte is fetched once and every sector written whole (1.09 x the algorithmic traffic), and still
@@ -9,17 +9,20 @@
 // the same bytes as one contiguous 6 KB run per wave and pair of steps takes 0.30 ms (`tools/exp_mfma.sh`, MF_DIAG_IO_CONTIG).
 // So a unit has to arrive and leave in ONE piece.
 //
-// How.  A unit is up to 32 CONSECUTIVE blocks of a stream (src_plan.cpp: rows of one block): 28 KB of input and 30 KB of
-// output, each contiguous in memory.  A block is `spb` = 10 steps of 16 output frames, and a step's coefficient image is the same
-// for every block: wave w of the workgroup owns step w -- its A operands stay in 16 registers for the whole launch, no table is
-// read in the loop -- and computes that step's four column tiles (32 rows x 2 channels) of every unit.  Per unit the workgroup
-//   (A) copies the rows' input, 32 x 1152 bytes, from registers (loaded a unit ahead, lane-contiguous) into an LDS image,
-//   (S) splits it into the digit planes (lane = one row's eight frames: src_mfma_common.h),
-//   (C) runs the 40 tiles, packed results into an LDS image of the unit's output,
-//   (D) writes that image out: 30 KB contiguous, whole lines, non-temporal,
-// with a workgroup barrier between the phases; the input image and the output image share their LDS (72.5 KB a workgroup, two
-// workgroups per CU for 32-row units, 44 KB and three for 16-row ones), the next unit's input is in flight in registers during (C) and (D).
-// Units whose 32-row input image does not lie wholly inside the source arena (kWorkEdge: the first of the first stream, the last of
+// How.  A planner unit is 64 / channels CONSECUTIVE blocks of a stream (src_plan.cpp: rows of one block; 32 for stereo), its input
+// and its output each contiguous in memory; a workgroup takes half of one at a time (14 KB in, 15 KB out).  A block is 10 steps of
+// 16 output frames, a tile 16 outputs x 16 columns = 8 channel PAIRS; a step's coefficient image is the same for every block: a
+// wave owns five of the pass's 20 tiles in step-major order and keeps the A operands of the three steps they touch in registers for
+// the whole launch -- no table is read in the loop.  Per pass the workgroup
+//   (A) copies the rows' input from registers (loaded a pass ahead, lane-contiguous) into an LDS image,
+//   (S) splits it into the digit planes (lane = eight frames of one channel pair: src_mfma_common.h),
+//   (C) runs the 20 tiles, packed results into an LDS image of the pass's output,
+//   (D) writes that image out: 15 KB contiguous, whole 16-byte pieces, non-temporal,
+// with a workgroup barrier between the phases; the input image and the output image share their LDS (44 KB a workgroup, three
+// workgroups per CU), the next pass's input is in flight in registers during (C) and (D).
+// Six and eight channels (PAIRS = 3, 4) are the same sixteen pair-rows cut differently: 5 stream rows x 3 pairs (the sixteenth
+// column pair idles) or 4 x 4; only the addresses of the split's reads and of the tiles' stores know.
+// Units whose input image does not lie wholly inside the source arena (kWorkEdge: the first of the first stream, the last of
 // the last) fetch their pieces through a checked, out-of-line load.
 #include <hip/hip_runtime.h>
 
@@ -39,41 +42,47 @@
 namespace ohgpu {
 
 constexpr uint32_t kWgSteps = 10;                   // steps per block (a 160-output block)
-constexpr uint32_t kWgUnitRows = 32;                // rows of a planner unit (LeanUnit)
 constexpr uint32_t kWgChunks = 12;                  // chunks (16 frames) a row's outputs touch: frames -32 .. 159 of the row
-constexpr uint32_t kWgRowIn = kWgChunks * 96;       // bytes of a row's input image, packed 24-bit stereo
-constexpr uint32_t kWgRowInPitch = kWgRowIn + 16;   // ... and its pitch in LDS (16 rows, 16 bytes each, then meet all 64 banks once)
 constexpr uint32_t kWgPlaneIn = kWgChunks * 64;     // planar TInt32 source: bytes of one channel's frames of a row's image (two of them side by side)
-constexpr uint32_t kWgRowInPitchPl = 2 * kWgPlaneIn + 16;
-constexpr uint32_t kWgRowOut = 160 * 6;             // bytes of a row's output
 constexpr uint32_t kWgBiasBytes = kWgSteps * 768;   // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
 
-// A workgroup's share of a unit is ROWS rows = CT = ROWS / 8 column tiles per step, 10 CT tiles in all; a wave takes FIVE of them
-// in step-major order (2 CT waves: two per SIMD for 32 rows, one for 16 -- whole numbers per SIMD whatever SIMD the first wave lands
-// on; ten waves, one per step, would be 3, 3, 2, 2, and the phase between two barriers lasts as long as its slowest wave).
-template <int ROWS, int PLANAR = 0>
+// A workgroup's pass is ROWS pair-rows (a pair-row = one channel pair of one block of a stream) = CT = ROWS / 8 column tiles per
+// step, 10 CT tiles in all; a wave takes FIVE of them in step-major order (2 CT waves: two per SIMD for 32 rows, one for 16 -- whole
+// numbers per SIMD whatever SIMD the first wave lands on; ten waves, one per step, would be 3, 3, 2, 2, and the phase between two
+// barriers lasts as long as its slowest wave).  PAIRS = channels / 2: the pass holds ROWS / PAIRS whole stream rows.
+template <int ROWS, int PLANAR = 0, int PAIRS = 1>
 struct WgGeom {
-    static_assert(ROWS == 16 || ROWS == 32, "rows per workgroup");
-    static constexpr uint32_t kRowInPitch = PLANAR ? kWgRowInPitchPl : kWgRowInPitch;
-    static constexpr uint32_t kInRounds = PLANAR ? 6 : 5;              // 16-byte pieces per lane of the input image (sixteen lanes per row)
+    static_assert(ROWS == 16 || ROWS == 32, "pair-rows per workgroup");
+    static_assert(PAIRS == 1 || ((PAIRS == 3 || PAIRS == 4) && PLANAR == 0 && ROWS == 16), "six and eight channels: packed, sixteen pair-rows");
+    static constexpr uint32_t kFb = 6u * PAIRS;                       // bytes of a frame, in and out (24-bit samples)
+    static constexpr uint32_t kSR = ROWS / PAIRS;                     // stream rows of a pass: 16, 5 (fifteen of the sixteen pair-rows) or 4
+    static constexpr uint32_t kUnitRows = 32u / PAIRS;                // rows of a planner unit (LeanUnit): 64 / channels, src_block_geometry
+    static constexpr uint32_t kRowIn = kWgChunks * 16u * kFb;         // bytes of a row's input image, packed
+    static constexpr uint32_t kRowInPitch = PLANAR ? 2 * kWgPlaneIn + 16 : kRowIn + 16;   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
+    static constexpr uint32_t kRowLanes = 16u * PAIRS;                // lanes that move one row of the input image, 4.5 pieces each (planar: 6)
+    static constexpr uint32_t kRound = 16u * kRowLanes;               // ... and the bytes of it one round of them moves
+    static constexpr uint32_t kInRounds = PLANAR ? 6 : 5;
+    static constexpr uint32_t kRowOut = 160u * kFb;                   // bytes of a row's output
     static constexpr uint32_t kCt = ROWS / 8;
     static constexpr uint32_t kWaves = 2 * kCt;
-    static constexpr uint32_t kThreads = 64 * kWaves;                 // = 16 * ROWS: sixteen lanes per row of the input image
+    static constexpr uint32_t kThreads = 64 * kWaves;                 // = 16 * ROWS
     static constexpr uint32_t kTilesPerWave = 5;
     static constexpr uint32_t kASets = kCt == 4 ? 2 : 3;              // steps a wave's five tiles touch
     static constexpr uint32_t kHalf = kCt * 128;                      // a digit plane's chunk: [half of its frames 2][column tile][column 16][8 frames]
     static constexpr uint32_t kChunk = 2 * kHalf;
     static constexpr uint32_t kDigit = kWgChunks * kChunk;
     static constexpr uint32_t kPlaneBytes = 3 * kDigit;
-    static constexpr uint32_t kStageBytes = ROWS * kRowInPitch;       // the input image; the output image (ROWS x 960) lies over it
+    static constexpr uint32_t kInBytes = kSR * kRowInPitch;           // the input image ...
+    static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOut;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
+    static constexpr uint32_t kStageBytes = kInBytes > kOutBytes ? kInBytes : kOutBytes;
     static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kWgBiasBytes;
     static constexpr uint32_t kGroupsPerCu = ROWS == 32 ? 2 : 3;
-    static constexpr uint32_t kSubUnits = kWgUnitRows / ROWS;         // workgroup units per planner unit
-    static constexpr uint32_t kOutPieces = ROWS * (kWgRowOut / 16);
+    static constexpr uint32_t kSubUnits = kUnitRows / kSR;            // passes per planner unit
+    static constexpr uint32_t kOutPieces = kSR * (kRowOut / 16);
     static constexpr uint32_t kStoreRounds = (kOutPieces + kThreads - 1) / kThreads;
     static_assert(kGroupsPerCu * kLdsBytes <= 160 * 1024, "workgroups per CU");
     static_assert(kTilesPerWave * kWaves == kWgSteps * kCt, "five tiles per wave");
-    static_assert(kThreads == 16 * ROWS && kWgRowIn == 72 * 16, "sixteen lanes per row of the input image, 4.5 pieces each");
+    static_assert(kSR * kRowLanes <= kThreads && kRowIn == 72 * 16 * PAIRS && kSubUnits * kSR == kUnitRows, "lanes per row of the input image, 4.5 pieces each");
 };
 
 #ifndef MF_DIAG_BARRIER_MASK
@@ -106,7 +115,7 @@ __device__ __noinline__ u32x4 wg_load_piece_checked(const uint8_t* __restrict__ 
 // PLANAR: 0 = packed 24-bit stereo frames (SRC_LE: their byte order); 1 + k = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32 (one per
 // channel, `src_plane_stride` apart, host byte order), the sample being the low 24 - 8 k bits of a plane's value shifted up k bytes
 // (k = 0, 1, 2 for 24-, 16- and 8-bit streams: CodecFlac::CallbackWrite's pack, Flac.cpp:379-417, folded into the load).
-template <int ROWS, int PLANAR, bool SRC_LE, bool DST_LE>
+template <int ROWS, int PLANAR, int PAIRS, bool SRC_LE, bool DST_LE>
 __global__ __launch_bounds__(WgGeom<ROWS>::kThreads) __attribute__((amdgpu_waves_per_eu(ROWS == 32 ? 4 : 3, ROWS == 32 ? 4 : 3)))
 void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         const uint8_t* __restrict__ amat, const MfStep* __restrict__ steps,
@@ -114,7 +123,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                         const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                         const uint32_t row_src_bytes, const uint64_t src_arena_bytes)
 {
-    using G = WgGeom<ROWS, PLANAR>;
+    using G = WgGeom<ROWS, PLANAR, PAIRS>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const pl_lds = smem;
     uint8_t* const stage = smem + G::kPlaneBytes;
@@ -150,16 +159,24 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t g = lane >> 4, n = lane & 15;
     const uint8_t* const b_lds = pl_lds + g * G::kChunk + n * 8u;                 // + kc * chunk + digit * kDigit + ((half * kHalf + tile * 128) ^ parity of the chunk * 128)
     const uint8_t* const my_bias = bias_lds + 16u * n;                            // + step * 768: b0; b1 at + 256, b2 at + 512
-    uint8_t* const out_lds = stage + 2u * g * kWgRowOut + 6u * n;                  // + 96 * step + tile * 8 rows (+ a row for the second frame)
+    // where the lane's frame of pair-row 2 g lies in the output image (+ 16 frames per step; + 8 pair-rows per column tile; the pair-row
+    // 2 g + 1 is the next row (stereo) or the next pair of the same row (eight channels); six channels: out_at below)
+    uint8_t* const out_lds = stage + ((2u * g) / (uint32_t)PAIRS) * G::kRowOut + 6u * ((2u * g) % (uint32_t)PAIRS) + G::kFb * n;
+    auto pair_row_srow = [&](uint32_t ct, uint32_t q) __attribute__((always_inline)) { return (ct * 8u + 2u * g + q) / (uint32_t)PAIRS; };   // the stream row of a tile's pair-row
     // the input image: sixteen lanes per row; lane `sub` of a row moves its pieces sub, sub + 16, .. sub + 48 and (sub < 8) sub + 64 of
     // the row's 72 -- an instruction reads 256 contiguous bytes of every row, and a lane's addresses differ by constants
     // (planar: a channel's 768 bytes are three rounds exactly; the second channel's come from `src_plane_stride` further on)
-    const uint32_t in_row = tid >> 4, in_sub = tid & 15u;
-    const uint32_t in_src = in_row * row_src_bytes + 16u * in_sub;                 // + 256 k
+    // (16 PAIRS lanes per row and 256 PAIRS bytes per round for wider frames; six channels: 240 lanes move the five rows, the last
+    // sixteen repeat pieces of the fifth)
+    const uint32_t in_row_of = tid / G::kRowLanes, in_sub = tid - in_row_of * G::kRowLanes;
+    const uint32_t in_row = in_row_of < G::kSR ? in_row_of : G::kSR - 1u;
+    const uint32_t in_src = in_row * row_src_bytes + 16u * in_sub;                 // + kRound k
     const uint32_t in_lds = in_row * G::kRowInPitch + 16u * in_sub;
-    const uint32_t in_last = in_sub < 8u ? 1024u : 0u;                             // (packed: the fifth round's spare lanes repeat their first piece)
-    // the split: task q = threads * k + tid (k = 0, 1; q < 24 ROWS) is half chunk q / ROWS of row q % ROWS (the rows side by side)
+    const uint32_t in_last = in_sub < G::kRowLanes / 2u ? 4u * G::kRound : 0u;     // (packed: the fifth round's spare lanes repeat their first piece)
+    // the split: task q = threads * k + tid (k = 0, 1; q < 24 ROWS) is half chunk q / ROWS of pair-row q % ROWS (the pair-rows side by side)
     const uint32_t sp_row = tid % (uint32_t)ROWS, sp_hc0 = tid / (uint32_t)ROWS;   // (0..15; second round: half chunk + 16 while < 24)
+    const uint32_t sp_used = sp_row < G::kSR * (uint32_t)PAIRS ? sp_row : G::kSR * (uint32_t)PAIRS - 1u;    // (six channels: the idle pair-row repeats the fifteenth)
+    const uint32_t sp_srow = sp_used / (uint32_t)PAIRS, sp_pair = sp_used % (uint32_t)PAIRS;
 
     // pack: a frame's six bytes from its two 24-bit values, L then R, each most significant byte first (big endian) or last
     constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;       // byte of the 24-bit value that is memory byte 0, 1, 2
@@ -170,11 +187,11 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     struct Unit { int64_t src0, dst0; uint32_t n_blocks, plane, plane_stride; bool ramped, first, edge; };
     auto fetch_unit = [&](uint32_t u) __attribute__((always_inline)) {
         const LeanUnit w = units[u / G::kSubUnits];
-        const uint32_t sub = u % G::kSubUnits, r0 = sub * (uint32_t)ROWS;
+        const uint32_t sub = u % G::kSubUnits, r0 = sub * G::kSR;
         Unit o;
         o.src0 = w.src_row0 + (int64_t)(r0 * row_src_bytes);
-        o.dst0 = w.dst_row0 + (int64_t)(r0 * kWgRowOut);
-        o.n_blocks = w.n_blocks > r0 ? (w.n_blocks - r0 < (uint32_t)ROWS ? w.n_blocks - r0 : (uint32_t)ROWS) : 0u;
+        o.dst0 = w.dst_row0 + (int64_t)(r0 * G::kRowOut);
+        o.n_blocks = w.n_blocks > r0 ? (w.n_blocks - r0 < G::kSR ? w.n_blocks - r0 : G::kSR) : 0u;
         o.plane = w.plane + r0 * 20u;                       // (a plane row is 160 entries of 2 bytes = 20 of the plane stride's 16)
         o.plane_stride = w.src_plane_stride;
         o.ramped = (w.flags & kWorkRamped) != 0;
@@ -198,7 +215,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #pragma unroll
             for (int k = 0; k < (int)G::kInRounds; k++) {
                 const int64_t at = PLANAR ? (int64_t)(in_src + 256u * (uint32_t)(k % 3)) + (int64_t)(k / 3) * w.plane_stride
-                                          : (int64_t)(k < 4 ? in_src + 256u * (uint32_t)k : in_src + in_last);
+                                          : (int64_t)(k < 4 ? in_src + G::kRound * (uint32_t)k : in_src + in_last);
                 raw[k] = wg_load_piece_checked(src, w.src0 + at, src_arena_bytes);
             }
         } else if constexpr (PLANAR != 0) {
@@ -211,7 +228,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         } else {
             const uint32_t o = mf_here(in_src);
 #pragma unroll
-            for (int k = 0; k < 4; k++) raw[k] = *(const u32x4_u*)(base + o + 256 * k);
+            for (int k = 0; k < 4; k++) raw[k] = *(const u32x4_u*)(base + o + (int)G::kRound * k);
             raw[4] = *(const u32x4_u*)(base + mf_here(in_src + in_last));
         }
 #endif
@@ -225,13 +242,13 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             for (int k = 0; k < 6; k++) *(u32x4*)(stage + in_lds + (k / 3) * kWgPlaneIn + 256 * (k % 3)) = raw[k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) *(u32x4*)(stage + in_lds + 256 * k) = raw[k];
+            for (int k = 0; k < 4; k++) *(u32x4*)(stage + in_lds + (int)G::kRound * k) = raw[k];
             *(u32x4*)(stage + in_lds + in_last) = raw[4];
         }
     };
     auto split_task = [&](uint32_t hc, bool first) __attribute__((always_inline)) {
         // the stream's block 0: the frames before it (chunks 0 and 1 of row 0) read as zeros
-        const bool zero = first && sp_row == 0 && hc < 4u;
+        const bool zero = first && sp_srow == 0 && hc < 4u;
         uint32_t pl[6][2];                                  // [3 * channel + byte of the 24-bit sample, least significant first... in memory order for packed][frames 0-3, 4-7]
         if constexpr (PLANAR != 0) {
             // eight frames of each channel, 4 bytes apiece: a 4 x 4 byte transpose per four frames (two permute levels) of which the
@@ -254,6 +271,22 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     for (int j = 0; j < 3; j++) pl[3 * c + j][q] = sb[j];
                 }
             }
+        } else if constexpr (PAIRS != 1) {
+            // eight frames of the lane's channel pair, kFb bytes apart: six bytes each, wherever they start -- the 8 aligned bytes around
+            // them (two dwords in one LDS read), shifted down by the two bytes an odd start is off.  Frames at even and at odd distances
+            // differ in that only for six channels (18 n + 6 pair is a multiple of 4 or 2 off by turns).
+            const uint32_t byte0 = sp_srow * G::kRowInPitch + hc * (8u * G::kFb) + 6u * sp_pair;
+            const uint32_t at_e = byte0 & ~3u, sh_e = (byte0 & 2u) * 8u;
+            const uint32_t at_o = (byte0 + G::kFb) & ~3u, sh_o = ((byte0 + G::kFb) & 2u) * 8u;
+            uint32_t lo[8], hi[8];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const u32x2 e = *(const u32x2_a4*)(stage + at_e + 2 * (int)G::kFb * m), o = *(const u32x2_a4*)(stage + at_o + 2 * (int)G::kFb * m);
+                const uint64_t ve = (((uint64_t)e.y << 32) | e.x) >> sh_e, vo = (((uint64_t)o.y << 32) | o.x) >> sh_o;
+                lo[2 * m] = zero ? 0u : (uint32_t)ve; hi[2 * m] = zero ? 0u : (uint32_t)(ve >> 32);
+                lo[2 * m + 1] = zero ? 0u : (uint32_t)vo; hi[2 * m + 1] = zero ? 0u : (uint32_t)(vo >> 32);
+            }
+            mf_split_frames(lo, hi, pl);
         } else {
             const uint8_t* const from = stage + sp_row * G::kRowInPitch + 48u * hc;
             u32x4 mine[3];
@@ -365,10 +398,13 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                 if constexpr (RAMPED) {
                     // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero; the
                     // multiplier of the lane's frame in each of its two rows comes from the unit's plane (0xffff: the frame's message has no ramp)
-                    const uint32_t row = ct * 8u + 2u * g;
-                    const uint32_t e0 = (row < n_blocks ? row * 160u : 0u) + 16u * step + n;
-                    const uint32_t e1 = (row + 1u < n_blocks ? (row + 1u) * 160u : 0u) + 16u * step + n;
-                    const uint32_t mu[2] = {*(const uint16_t*)(mbase + mf_here(2u * e0)), *(const uint16_t*)(mbase + mf_here(2u * e1))};
+                    const uint32_t row0 = pair_row_srow(ct, 0), row1 = pair_row_srow(ct, 1);
+                    const uint32_t e0 = (row0 < n_blocks ? row0 * 160u : 0u) + 16u * step + n;
+                    const uint32_t e1 = (row1 < n_blocks ? row1 * 160u : 0u) + 16u * step + n;
+                    uint32_t mu[2];
+                    mu[0] = *(const uint16_t*)(mbase + mf_here(2u * e0));
+                    if constexpr (PAIRS == 4) mu[1] = mu[0];         // (pair-rows 2 g and 2 g + 1 are pairs of one row)
+                    else mu[1] = *(const uint16_t*)(mbase + mf_here(2u * e1));
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
                         const int top = (int)((uint32_t)y[v] << 8) >> 16;  // bits 8..23, signed
@@ -377,14 +413,20 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     }
                 }
                 // pack: two permutes and three 16-bit stores per frame into the output image (a frame starts on an even byte)
-                uint8_t* const os = out_lds + ct * (8u * kWgRowOut) + 96u * step;
+                uint8_t* const os = out_lds + ct * ((8u / (uint32_t)(PAIRS == 3 ? 1 : PAIRS)) * G::kRowOut) + 16u * G::kFb * step;
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const uint32_t lo = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_lo);
                     const uint32_t hi = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_hi);
                     // (written out: left to the compiler the first two become one 4-byte store, misaligned for odd frames.  LDS operations
                     // complete in order and every barrier here waits for lgkmcnt(0), so the compiler's own counts stay safe)
-                    const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(os + q * kWgRowOut);
+                    uint32_t at;
+                    if constexpr (PAIRS == 3) {                      // (a tile's eight pair-rows start anywhere in a row of three)
+                        const uint32_t pr = ct * 8u + 2u * g + (uint32_t)q, sr = pr / 3u;
+                        at = (uint32_t)(uintptr_t)(lds_u8_t)(stage + sr * G::kRowOut + 6u * (pr - 3u * sr) + G::kFb * n + 16u * G::kFb * step);
+                    } else {
+                        at = (uint32_t)(uintptr_t)(lds_u8_t)(os + q * (PAIRS == 1 ? G::kRowOut : 6u));
+                    }
                     asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:2\n\tds_write_b16 %0, %2 offset:4"
                                  : : "v"(at), "v"(lo), "v"(hi) : "memory");
                 }
@@ -409,7 +451,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         if constexpr (PLANAR != 0) asm volatile("" : "+v"(raw[5]));
         {
             uint8_t* const unit_dst = dst + wk.dst0;
-            const uint32_t out_bytes = n_blocks * kWgRowOut;
+            const uint32_t out_bytes = n_blocks * G::kRowOut;
             u32x4 op[G::kStoreRounds];
 #pragma unroll
             for (int k = 0; k < (int)G::kStoreRounds; k++) {
@@ -448,25 +490,26 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 
 bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar)
 {
-    // (planar: sb is the stream's sample size, 1..3 bytes, whatever the planes hold above it)
-    return ch == 2 && (planar ? (sb >= 1 && sb <= 3) : sb == 3) && db == 3 && L_blk == 16u * kWgSteps && (M_blk + 31u) / 16u + 1u == kWgChunks;
+    // (planar: sb is the stream's sample size, 1..3 bytes, whatever the planes hold above it; packed: stereo, six or eight channels of S24)
+    const bool layout = planar ? (ch == 2 && sb >= 1 && sb <= 3) : ((ch == 2 || ch == 6 || ch == 8) && sb == 3);
+    return layout && db == 3 && L_blk == 16u * kWgSteps && (M_blk + 31u) / 16u + 1u == kWgChunks;
 }
 
-// does a unit's input image -- 32 rows of kWgRowIn bytes, whatever the number of blocks the unit holds -- lie inside the arena?
-bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, bool planar, uint64_t plane_stride)
+// does a unit's input image -- 64 / channels rows of 192 frames, whatever the number of blocks the unit holds -- lie inside the arena?
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, bool planar, uint64_t plane_stride)
 {
-    const uint64_t row_in = planar ? kWgPlaneIn : kWgRowIn, last_plane = planar ? plane_stride : 0;
-    return src_row0 >= 0 && (uint64_t)src_row0 + last_plane + (uint64_t)(kWgUnitRows - 1) * row_src_bytes + row_in <= src_arena_bytes;
+    const uint64_t row_in = planar ? kWgPlaneIn : kWgChunks * 16u * 3u * ch, last_plane = planar ? plane_stride : 0;
+    return src_row0 >= 0 && (uint64_t)src_row0 + last_plane + (uint64_t)(64u / ch - 1u) * row_src_bytes + row_in <= src_arena_bytes;
 }
 
-template <int PLANAR, bool SRC_LE, bool DST_LE>
+template <int PLANAR, int PAIRS, bool SRC_LE, bool DST_LE>
 static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
 {
-    using G = WgGeom<OHGPU_WG_ROWS, PLANAR>;
-    auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, SRC_LE, DST_LE>;
+    using G = WgGeom<OHGPU_WG_ROWS, PLANAR, PAIRS>;
+    auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, PAIRS, SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
     if (f.n_lean == 0) return hipSuccess;
-    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0)) return hipErrorInvalidValue;
+    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0) || p.channels != 2u * PAIRS) return hipErrorInvalidValue;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     const uint32_t n_units = f.n_lean * G::kSubUnits;                // (edge units included: their loads are checked)
     uint32_t gsz = G::kGroupsPerCu * cus;                     // as many workgroups as the LDS holds
@@ -475,8 +518,15 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s,
                        (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
-                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * (PLANAR ? 4u : 6u), p.src_arena_bytes);
+                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * (PLANAR ? 4u : G::kFb), p.src_arena_bytes);
     return hipGetLastError();
+}
+
+template <int PAIRS>
+static hipError_t launch_wg_packed(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& prm, hipStream_t s)
+{
+    if (prm.src_le) return prm.dst_le ? launch_wg_one<0, PAIRS, true, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, true, false>(ctx, b, prm, s);
+    return prm.dst_le ? launch_wg_one<0, PAIRS, false, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, false, false>(ctx, b, prm, s);
 }
 
 hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
@@ -486,14 +536,18 @@ hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const 
     prm.dst = dst;
     if (b->src_planar) {
         switch (prm.sb) {                                    // (the stream's bytes per sample)
-        case 3: return prm.dst_le ? launch_wg_one<1, true, true>(ctx, b, prm, s) : launch_wg_one<1, true, false>(ctx, b, prm, s);
-        case 2: return prm.dst_le ? launch_wg_one<2, true, true>(ctx, b, prm, s) : launch_wg_one<2, true, false>(ctx, b, prm, s);
-        case 1: return prm.dst_le ? launch_wg_one<3, true, true>(ctx, b, prm, s) : launch_wg_one<3, true, false>(ctx, b, prm, s);
+        case 3: return prm.dst_le ? launch_wg_one<1, 1, true, true>(ctx, b, prm, s) : launch_wg_one<1, 1, true, false>(ctx, b, prm, s);
+        case 2: return prm.dst_le ? launch_wg_one<2, 1, true, true>(ctx, b, prm, s) : launch_wg_one<2, 1, true, false>(ctx, b, prm, s);
+        case 1: return prm.dst_le ? launch_wg_one<3, 1, true, true>(ctx, b, prm, s) : launch_wg_one<3, 1, true, false>(ctx, b, prm, s);
         default: return hipErrorInvalidValue;
         }
     }
-    if (prm.src_le) return prm.dst_le ? launch_wg_one<0, true, true>(ctx, b, prm, s) : launch_wg_one<0, true, false>(ctx, b, prm, s);
-    return prm.dst_le ? launch_wg_one<0, false, true>(ctx, b, prm, s) : launch_wg_one<0, false, false>(ctx, b, prm, s);
+    switch (prm.channels) {
+    case 2: return launch_wg_packed<1>(ctx, b, prm, s);
+    case 6: return launch_wg_packed<3>(ctx, b, prm, s);
+    case 8: return launch_wg_packed<4>(ctx, b, prm, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace ohgpu

@@ -108,7 +108,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const bool planar = b->src_planar;
     const bool block_ok = !planar && src_block_supported(T, ch, sb, src_le, db, dst_le);
     const bool lean_only = planar ? (T == 32 && ch == 2 && sb != 4 && db == 3) : (!block_ok && src_lean_only_supported(T, ch, sb, src_le, db, dst_le));
-    if (!block_ok && !lean_only) return OHGPU_OK;
+    // (a layout only the workgroup matrix kernel has -- big-endian S24 to little-endian S24: planned like a lean-only one, kept only if
+    // that kernel takes it, and run on the generic kernel under any variant that asks for another)
+    const bool wg_only = !block_ok && !lean_only && !planar && T == 32 && (ch == 2 || ch == 6 || ch == 8) && sb == 3 && db == 3;
+    if (!block_ok && !lean_only && !wg_only) return OHGPU_OK;
     const uint32_t sb_geo = planar ? 3u : sb;                           // (round 1's geometry: only its rows and ring are used)
     const uint32_t sb_lean = planar ? 0u : sb;                          // (LeanGeom: 0 = planar)
     const uint32_t fb_src = planar ? 4u : ch * sb, fb_dst = ch * db;    // (planar: a plane's frame)
@@ -122,7 +125,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 src_lean_geometry(L, T, flt->halfband, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves);
     if (lean && !block_ok && !planar) { rows = lean_rows; ring = lean_ring; }     // (no geometry of round 1's to agree with)
     lean = lean && lean_rows == rows && lean_ring == ring;
-    if (lean_only && !lean) return OHGPU_OK;
+    if ((lean_only || wg_only) && !lean) return OHGPU_OK;
     // a block: whole phase periods (multiple of L), at least 128 outputs, and a whole number of 64-byte output lines
     uint32_t min_blk = 128;
 #ifdef OHGPU_DIAG
@@ -144,9 +147,12 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                       mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
     // (a planar source -- the FLAC decoder's planes -- is the workgroup kernel's too: its split reads the planes; the unit-per-wave
     // kernel has no such form, so with variants 3..5 a planar batch stays on the lean kernel)
-    const bool wg_tables = lean && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && T == 32 && mf_rows == rows;
-    const bool mfma_wg = wg_tables && (planar || mfma) && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db, planar) &&
+    // (six and eight channels too: the same tiles over channel PAIRS, units of 64 / channels rows as the lean kernel's)
+    const bool wg_tables = lean && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && T == 32 && rows == 64u / ch;
+    const bool wg_wide = !planar && ch > 2 && (M_blk + T) * fb_src < (1u << 24);
+    const bool mfma_wg = wg_tables && (planar || mfma || wg_wide) && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db, planar) &&
                          !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
+    if (wg_only && !mfma_wg) return OHGPU_OK;
 
 #ifdef OHGPU_PLAN_TIMING
     std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> tps;
@@ -389,7 +395,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             else if (unit_leaves_arena(segs[r.seg].src_base, u.src_plane_stride, bk, n_rows, kb)) u.flags |= kWorkChecked;
             // the workgroup kernel reads 32 rows' worth of input per unit whatever the unit holds and checks nothing: the (at most two)
             // units of a batch for which that leaves the arena stay with the unit-per-wave kernel
-            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, planar, (uint64_t)(ch - 1) * u.src_plane_stride)) u.flags |= kWorkEdge;
+            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, ch, planar, (uint64_t)(ch - 1) * u.src_plane_stride)) u.flags |= kWorkEdge;
             if (u.flags & kWorkRamped) {
                 // one plane of multipliers per ramped unit -- n_rows * L_blk entries (uint16, 0xffff = no ramp on that frame), in
                 // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16
@@ -547,6 +553,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.ring_bytes = ring;
     f.lean = lean;
     f.lean_only = lean_only;
+    f.wg_only = wg_only;
     f.lean_coef_lds_bytes = lean_coef;
     f.lean_wave_lds_bytes = lean_wave_lds;
     f.plane_stride = 16;                                              // SrcWork::plane counts 16-byte pieces

@@ -27,10 +27,12 @@ def ctx():
     c.close()
 
 
-def run_groups(ctx, groups):
+def run_groups(ctx, groups, kernel=None):
     for g in groups:
         g.attach(ctx)
         try:
+            if kernel is not None:
+                assert ctx.src_kernel_name(g.batch) == kernel, (g.rate_in, g.channels, ctx.src_kernel_name(g.batch))
             ctx.src_run(g.batch, g.d_src, g.d_dst)
             ctx.sync()
             got = ctx.download(g.d_dst, g.dst_bytes)
@@ -45,7 +47,7 @@ def run_groups(ctx, groups):
         assert plan["block_kernel_out_frames"] > 0.9 * len(g.stream_ids) * g.out_total       # (and it ran on the block kernel)
 
 
-@pytest.mark.parametrize("variant", [0, 2], ids=["lean", "round1"])
+@pytest.mark.parametrize("variant", [0, 4, 2], ids=["tuned", "lean", "round1"])
 def test_config4_groups_are_bit_exact(ctx, variant):
     args = argparse.Namespace(config=4, streams=96, seconds=0.6, rate_in=44100, channels=2)
     groups, scaling = bench.build_groups(capi, args, 0, 1)
@@ -116,7 +118,8 @@ def test_every_block_kernel_instantiation_on_the_bench_workload(ctx, inst):
     else:
         le = [noise_le(sid, per, src_bits) for sid in g.stream_ids]
         g.src = np.concatenate([(x if src_le else x[:, ::-1]).reshape(-1) for x in le])
-    for variant in ((0, 2) if kind == "block" else (0,)):
+    # (variant 0 is the matrix-pipe kernel for the layouts it serves: variant 4 keeps the lean kernel covered there)
+    for variant in ((0, 2, 4) if kind == "block" else (0,)):
         ctx.set_kernel_variant(variant)
         try:
             run_groups(ctx, [g])
@@ -154,3 +157,20 @@ def test_plain_64_tap_kernels_still_run(ctx):
     ctx.src_destroy(h)
     ctx.free(d_src)
     ctx.free(d_dst)
+
+
+@pytest.mark.parametrize("channels", [2, 6, 8])
+@pytest.mark.parametrize("src_le", [True, False], ids=["sle", "sbe"])
+@pytest.mark.parametrize("dst_le", [True, False], ids=["dle", "dbe"])
+@pytest.mark.parametrize("n_streams, seconds", [(3, 0.31), (14, 0.83)])
+def test_workgroup_matrix_kernel_takes_packed_s24_of_two_six_and_eight_channels(ctx, channels, src_le, dst_le, n_streams, seconds):
+    """44.1 -> 48 kHz S24 in either byte order, ramped heads and tails, stream lengths that leave the last unit of a stream partly
+    filled (a pass of 16 / 5 / 4 rows with fewer blocks than rows, and one with none) and put units at both ends of the arena (the
+    checked loads): src_mfma_wg_kernel runs them all and the audio is the integer model's, byte for byte."""
+    g = bench.Group(capi, 44100, channels, range(300, 300 + n_streams), int(round(seconds * 44100)), src_bits=24,
+                    src_endian=capi.ENDIAN_LITTLE if src_le else capi.ENDIAN_BIG, dst_bits=24,
+                    dst_endian=capi.ENDIAN_LITTLE if dst_le else capi.ENDIAN_BIG)
+    per = g.in_frames * channels
+    le = [noise_le(sid, per, 24) for sid in g.stream_ids]
+    g.src = np.concatenate([(x if src_le else x[:, ::-1]).reshape(-1) for x in le])
+    run_groups(ctx, [g], kernel="src_mfma_wg_kernel")

@@ -525,10 +525,10 @@ def test_src_one_batch_of_mixed_layouts_runs_on_the_block_kernels(ctx):
     ctx.memset(d_dst, 0xA5, dp)
     b = ctx.src_batch(h, descs, src.size, dp)
     plan = ctx.src_plan(b)
-    # (the block kernels are instantiated for the layouts the configs need -- src_block_common.h: the eight-channel stream with
-    # little-endian output and the packed 32-bit one go to the generic kernel message by message, the other four streams, two of
-    # them sharing a layout, to their block kernels)
-    assert plan["block_kernel_out_frames"] == 4 * out_frames and plan["generic_pieces"] == 2 * n_msgs, plan
+    # (the block kernels are instantiated for the layouts the configs need -- src_block_common.h: the packed 32-bit stream with a
+    # 32-bit output goes to the generic kernel message by message, the other five streams, two of them sharing a layout, to their
+    # block kernels -- the eight-channel big-endian stream with little-endian output to the workgroup matrix kernel, which alone has it)
+    assert plan["block_kernel_out_frames"] == 5 * out_frames and plan["generic_pieces"] == n_msgs, plan
     ctx.src_run(b, d_src, d_dst)
     got = ctx.download(d_dst, dp)
     want = oracle_src(ref, descs, src, dp)

@@ -14,12 +14,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ohpipeline_amd", "csrc")
 OUTDIR = os.path.join(ROOT, "ohpipeline_amd", "build")
-NAME = re.compile(r"_ZN5ohgpu18src_mfma_wg_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)EE\w+")
+NAME = re.compile(r"_ZN5ohgpu18src_mfma_wg_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)EE\w+")     # <pair-rows, planar, channel pairs, src LE, dst LE>
 
 
 @pytest.fixture(scope="module")
 def wg():
-    """{mangled name: (rows, planar, body lines, metadata text)} for every instantiation the library carries."""
+    """{mangled name: (rows, planar + 10 * (channel pairs - 1), body lines, metadata text)} for every instantiation the library carries."""
     os.makedirs(OUTDIR, exist_ok=True)
     src = os.path.join(CSRC, "src_mfma_wg_kernel.hip")
     out = os.path.join(OUTDIR, "src_mfma_wg_kernel.test.s")
@@ -44,8 +44,8 @@ def wg():
         m = re.search(r"\.name:\s+(" + NAME.pattern + r")\n", entry)
         if m:
             meta[m.group(1)] = entry
-    assert len(found) >= 10 and set(found) == set(meta), (len(found), len(meta))
-    return {n: (int(NAME.match(n).group(1)), int(NAME.match(n).group(2)), found[n], meta[n]) for n in found}
+    assert len(found) >= 18 and set(found) == set(meta), (len(found), len(meta))
+    return {n: (int(NAME.match(n).group(1)), int(NAME.match(n).group(2)) + 10 * (int(NAME.match(n).group(3)) - 1), found[n], meta[n]) for n in found}
 
 
 def _field(meta, key):
@@ -61,16 +61,16 @@ def test_three_workgroups_per_cu_fit(wg):
 
 
 def test_no_scratch_but_where_design_says(wg):
-    """Packed sources and 24- and 8-bit planes: no spills at all.  The 16-bit planes spill four dwords in the split (outside the
-    tiles): tolerated, bounded here."""
+    """Packed stereo and eight-channel sources and 24- and 8-bit planes: no spills at all.  The 16-bit planes spill four dwords in the
+    split, the six-channel kernels (planar code 20) eight around the edge units' out-of-line loads -- outside the tiles: tolerated, bounded here."""
     for name, (rows, planar, body, meta) in wg.items():
         if rows != 16:
             continue
-        if planar == 2:
-            assert _field(meta, "private_segment_fixed_size") <= 16, name
+        if planar in (2, 20):
+            assert _field(meta, "private_segment_fixed_size") <= (16 if planar == 2 else 32), name
             tiles = [i for i, l in enumerate(body) if "v_mfma_i32_16x16x64_i8" in l]
             between = [l for l in body[tiles[0]:tiles[-1]] if re.match(r"^\s*scratch_", l)]
-            assert len(between) <= 8, (name, between[:4])
+            assert not between, (name, between[:4])
         else:
             assert _field(meta, "private_segment_fixed_size") == 0, name
             assert not any(re.match(r"^\s*scratch_", l) for l in body), name
