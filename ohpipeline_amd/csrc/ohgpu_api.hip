@@ -155,6 +155,8 @@ int ohgpu_init(int device, ohgpu_ctx** out)
         delete ctx;
         return set_error(OHGPU_ERR_DEVICE, "ramp table upload: %s", hipGetErrorString(e));
     }
+    // (the planner's own device pass -- the ramp planes' kernel -- is loaded here, not inside the first batch's creation)
+    (void)load_ramp_plane_kernel();
     *out = ctx;
     return OHGPU_OK;
 }

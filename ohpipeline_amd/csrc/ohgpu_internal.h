@@ -388,6 +388,7 @@ bool src_mfma_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t db);
 void src_mfma_geometry(uint32_t* rows, uint32_t* wave_lds_bytes, uint32_t* max_waves);
 uint32_t src_block_outputs(uint32_t L, uint32_t fb_dst);      // outputs per block (0: no block length fits): whole phase periods, >= 128, whole 64-byte lines
 hipError_t launch_ramp_planes(const ohgpu_ctx* ctx, const void* d_jobs, uint32_t n_jobs, void* d_planes, hipStream_t s);   // csrc/ramp_plane_kernel.hip
+hipError_t load_ramp_plane_kernel();
 bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves);

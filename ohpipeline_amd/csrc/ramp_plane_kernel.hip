@@ -35,4 +35,11 @@ hipError_t launch_ramp_planes(const ohgpu_ctx* ctx, const void* d_jobs, uint32_t
     return hipGetLastError();
 }
 
+// The code object is loaded when a kernel of it is first asked for: ask at context creation, so that no batch's creation pays for it.
+hipError_t load_ramp_plane_kernel()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, (const void*)ramp_plane_kernel);
+}
+
 }  // namespace ohgpu

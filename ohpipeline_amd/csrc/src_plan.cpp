@@ -383,7 +383,13 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         }
         uint64_t long_cut = 0;
         lean_units.reserve(work.size());
-        auto emit = [&](const SegRun& r, uint64_t bk, uint32_t n_rows, uint32_t kb, const SrcWork* w1) -> bool {
+        // (a unit goes to `units_out`, its ramp jobs to `jobs_out`, its plane behind `planes_out` entries: the batch's own arrays, or a
+        // thread's share of them that is put behind the others' afterwards)
+        auto emit_to = [&](std::vector<LeanUnit>& units_out, std::vector<RampJob>& jobs_out, size_t& planes_out,
+                           const SegRun& r, uint64_t bk, uint32_t n_rows, uint32_t kb, const SrcWork* w1) -> bool {
+            std::vector<LeanUnit>& lean_units = units_out;
+            std::vector<RampJob>& ramp_jobs = jobs_out;
+            size_t& plane_entries = planes_out;
             LeanUnit u;
             u.src_row0 = segs[r.seg].src_base + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
             u.dst_row0 = segs[r.seg].dst_base + (int64_t)(bk * L_blk) * fb_dst;
@@ -423,7 +429,34 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             lean_units.push_back(u);
             return true;
         };
-        for (const SegRun& r : seg_runs) {
+        auto emit = [&](const SegRun& r, uint64_t bk, uint32_t n_rows, uint32_t kb, const SrcWork* w1) -> bool {
+            return emit_to(lean_units, ramp_jobs, plane_entries, r, bk, n_rows, kb, w1);
+        };
+        if (kb_long == 1 && seg_runs.size() >= 64) {
+            // every unit is one of `work`'s: the segments' runs in ranges, side by side; a range's planes and jobs count from zero and
+            // are moved behind its predecessors' when the ranges are put together, in order -- the arrays one thread makes
+            struct Share { std::vector<LeanUnit> units; std::vector<RampJob> jobs; size_t planes = 0; bool ok = true; };
+            const unsigned n_thr = plan_threads(work.size(), 2048);
+            std::vector<Share> shares(n_thr);
+            parallel_ranges(seg_runs.size(), n_thr, [&](unsigned t, size_t lo, size_t hi) {
+                Share& sh = shares[t];
+                for (size_t ri = lo; ri < hi && sh.ok; ri++) {
+                    const SegRun& r = seg_runs[ri];
+                    const uint32_t n_units = (uint32_t)((r.blk_hi - r.blk_lo + rows - 1) / rows);
+                    for (uint32_t k = 0; k < n_units && sh.ok; k++) {
+                        const SrcWork& w1 = work[r.work_begin + k];
+                        sh.ok = emit_to(sh.units, sh.jobs, sh.planes, r, w1.first_block, w1.n_blocks, 1, &w1);
+                    }
+                }
+            });
+            for (Share& sh : shares) {
+                if (!sh.ok || (plane_entries + sh.planes) / 8 > 0xffffffffull) return OHGPU_OK;
+                const uint32_t plane_base = (uint32_t)(plane_entries / 8);
+                for (LeanUnit& u : sh.units) { if (u.flags & kWorkRamped) u.plane += plane_base; lean_units.push_back(u); }
+                for (RampJob& j : sh.jobs) { j.plane_entry += plane_entries; ramp_jobs.push_back(j); }
+                plane_entries += sh.planes;
+            }
+        } else for (const SegRun& r : seg_runs) {
             const uint32_t n_units = (uint32_t)((r.blk_hi - r.blk_lo + rows - 1) / rows);
             uint32_t k = 0;
             while (k < n_units) {
@@ -466,10 +499,14 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         // (the edge units in front: their checked loads are slow, and the launch should not end on them)
         if (mfma_wg) std::stable_partition(lean_units.begin(), lean_units.end(), [](const LeanUnit& u) { return (u.flags & kWorkEdge) != 0; });
     }
+    // (segments, messages and one-block work units are round 1's kernel's: they go to the device only for a batch planned while
+    // ohgpu_set_kernel_variant(2) is in force, or one the lean kernel cannot run -- 12 MB of the headline's plan, and most of the time its upload took)
+    const bool round1 = block_ok && ((ctx && ctx->variant == 2) || !lean);      // (a filter the lean kernel's rounding does not hold runs on round 1's whatever the variant)
     // (round 1's kernel, variant 2, keeps one-block units; ramped first, partly filled units last)
-    std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {
-        return ((x.flags & kWorkRamped) ? 3u : 1u) * x.n_blocks > ((y.flags & kWorkRamped) ? 3u : 1u) * y.n_blocks;
-    });
+    if (round1)
+        std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {
+            return ((x.flags & kWorkRamped) ? 3u : 1u) * x.n_blocks > ((y.flags & kWorkRamped) ? 3u : 1u) * y.n_blocks;
+        });
 
     mark("units");
     if (digest) {
@@ -491,11 +528,12 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         digest->pieces = rem.size();
         digest->ramp_jobs = ramp_jobs.size();
         digest->kernel = mfma_wg ? 3 : (mfma ? 2 : (lean ? 1 : 0));
+#ifdef OHGPU_PLAN_TIMING
+        for (size_t k = 1; k < tps.size(); k++)
+            fprintf(stderr, "[plan timing]   %s %.2f ms\n", tps[k].first, std::chrono::duration<double, std::milli>(tps[k].second - tps[k - 1].second).count());
+#endif
         return OHGPU_OK;
     }
-    // (segments, messages and one-block work units are round 1's kernel's: they go to the device only for a batch planned while
-    // ohgpu_set_kernel_variant(2) is in force, or one the lean kernel cannot run -- 12 MB of the headline's plan, and most of the time its upload took)
-    const bool round1 = block_ok && ((ctx && ctx->variant == 2) || !lean);      // (a filter the lean kernel's rounding does not hold runs on round 1's whatever the variant)
     Slab slab;
     if (round1) {
         // the messages' ramp parameters as an array, by position in `order` (SrcSeg::msg_begin .. msg_end, SrcWork::msg_first)
@@ -517,6 +555,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         slab.add(msgs, &f.d_msgs);
         slab.add(work, &f.d_work);
     }
+    slab.host.reserve((round1 ? segs.size() * sizeof(SrcSeg) + n * sizeof(SegMsg) + work.size() * sizeof(SrcWork) : 0) + lean_units.size() * sizeof(LeanUnit) +
+                      rem.size() * sizeof(DevSrcDesc) + ramp_jobs.size() * sizeof(RampJob) + 8 * 256);     // (one allocation, nothing copied twice)
     if (lean) slab.add(lean_units, &f.d_lean_units);
     slab.add(rem, &f.d_rem);
     slab.add(std::vector<uint32_t>(2, 0u), &f.d_counter);            // {units claimed, waves finished}: zero between launches
