@@ -914,7 +914,7 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
 #endif
     // every message is checked and converted on its own: in ranges, on as many threads as the batch is worth (the first error in
     // message order is the one reported)
-    b->host_descs.reset(new (std::nothrow) DevSrcDesc[n ? n : 1]);     // (not zeroed here: the ranges' threads touch their own pages)
+    b->host_descs.reset((DevSrcDesc*)host_alloc_huge((n ? n : 1) * sizeof(DevSrcDesc)));     // (not zeroed here: the ranges' threads touch their own pages)
     if (!b->host_descs) { delete b; return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory"); }
     DevSrcDesc* const dev = b->host_descs.get();
     {
