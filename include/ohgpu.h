@@ -357,6 +357,12 @@ int ohgpu_src_batch_kernel_name(ohgpu_ctx* ctx, const ohgpu_batch* batch, char* 
  * from a slow build; it touches no audio buffer. */
 int ohgpu_measure_shader_clock(ohgpu_ctx* ctx, void* stream, double* mhz);
 
+/* How many device allocations (hipMalloc) the context has made for batches' descriptors and plan arrays since ohgpu_init.  A
+ * destroyed batch's blocks stay with the context and serve the next batch of that size, so a caller in a steady state -- the
+ * StarvationRamper's rescue creates three batches per starving period (reference: StarvationRamper.cpp:560-620 does that work on
+ * the CPU, inside the period) -- sees this number stop growing; a test's handle on "nothing is allocated in the period". */
+int ohgpu_device_allocations(ohgpu_ctx* ctx, uint64_t* count);
+
 /* Kernel selection for A/B measurement and tests: 0 = default/best; 1 = baseline "v1" kernels; 2 = round 1's block resampler
  * kernel where it has the layout; 3 = the default kernels with the resampler's long-row unit schedule forced onto batches of
  * any size (a resampled batch created while 3 is set cuts every run of plain units into rows of three blocks -- what only a

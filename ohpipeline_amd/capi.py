@@ -112,6 +112,7 @@ SYMBOLS = {
                                         _u64p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "ohgpu_src_batch_kernel_name": (C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t]),
     "ohgpu_measure_shader_clock": (C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
+    "ohgpu_device_allocations": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ohgpu_src_process_host": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
     "ohgpu_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }
@@ -409,6 +410,11 @@ class Context:
         buf = C.create_string_buffer(256)
         check(lib().ohgpu_src_batch_kernel_name(self._h, batch, buf, 256))
         return buf.value.decode()
+
+    def device_allocations(self):
+        n = C.c_uint64(0)
+        check(lib().ohgpu_device_allocations(self._h, C.byref(n)))
+        return int(n.value)
 
     def shader_clock_mhz(self, stream=None):
         mhz = C.c_double(0)

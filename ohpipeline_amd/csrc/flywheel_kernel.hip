@@ -131,10 +131,10 @@ __global__ __launch_bounds__(64) void flywheel_kernel(const ohgpu_flywheel_desc*
     }
 }
 
-void free_flywheel(ohgpu_batch* b)
+void free_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b)
 {
-    if (b->fly.d_lanes) hipFree(b->fly.d_lanes);
-    if (b->fly.d_work) hipFree(b->fly.d_work);
+    if (b->fly.d_lanes) ctx_dev_free(ctx, b->fly.d_lanes);
+    if (b->fly.d_work) ctx_dev_free(ctx, b->fly.d_work);
     b->fly = FlywheelPlan();
 }
 
@@ -152,11 +152,11 @@ int plan_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_flywheel_desc* des
     }
     if (lanes.empty()) return OHGPU_OK;
     const uint32_t padded = (uint32_t)((lanes.size() + 63) / 64 * 64);
-    hipError_t e = hipMalloc(&b->fly.d_lanes, lanes.size() * sizeof(FlywheelLane));
+    hipError_t e = ctx_dev_alloc(ctx, &b->fly.d_lanes, lanes.size() * sizeof(FlywheelLane));
     if (e == hipSuccess) e = hipMemcpy(b->fly.d_lanes, lanes.data(), lanes.size() * sizeof(FlywheelLane), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&b->fly.d_work, (size_t)3 * max_count * padded * sizeof(int16_t));
+    if (e == hipSuccess) e = ctx_dev_alloc(ctx, &b->fly.d_work, (size_t)3 * max_count * padded * sizeof(int16_t));
     if (e != hipSuccess) {
-        free_flywheel(b);
+        free_flywheel(ctx, b);
         return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "flywheel plan: %s", hipGetErrorString(e));
     }
     b->fly.n_lanes = (uint32_t)lanes.size();

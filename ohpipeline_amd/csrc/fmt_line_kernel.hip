@@ -192,10 +192,10 @@ __global__ __launch_bounds__(256) void flac_stereo_kernel(const FmtChunk* __rest
 }
 
 // ---- host side ----
-void free_fmt_line(ohgpu_batch* b)
+void free_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b)
 {
-    if (b->fmtline.d_chunks) (void)hipFree(b->fmtline.d_chunks);
-    if (b->fmtline.d_wide) (void)hipFree(b->fmtline.d_wide);
+    if (b->fmtline.d_chunks) ctx_dev_free(ctx, b->fmtline.d_chunks);
+    if (b->fmtline.d_wide) ctx_dev_free(ctx, b->fmtline.d_wide);
     b->fmtline = FmtLinePlan();
 }
 
@@ -240,10 +240,10 @@ int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, s
                     recs.push_back(wide_record(descs[i].src_offset, descs[i].dst_offset, descs[i].n_frames, descs[i].channels, descs[i].src_bits / 8,
                                                false, b->src_arena_bytes));
             if (!recs.empty()) {
-                hipError_t e = hipMalloc(&b->fmtline.d_wide, recs.size() * sizeof(OhmSelRec));
+                hipError_t e = ctx_dev_alloc(ctx, &b->fmtline.d_wide, recs.size() * sizeof(OhmSelRec));
                 if (e == hipSuccess) e = hipMemcpy(b->fmtline.d_wide, recs.data(), recs.size() * sizeof(OhmSelRec), hipMemcpyHostToDevice);
                 if (e != hipSuccess) {
-                    free_fmt_line(b);
+                    free_fmt_line(ctx, b);
                     return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "record upload: %s", hipGetErrorString(e));
                 }
                 b->fmtline.n_wide = (uint32_t)recs.size();
@@ -272,10 +272,10 @@ int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, s
                 recs.push_back(c);
             }
             if (recs.empty()) return OHGPU_OK;
-            hipError_t e = hipMalloc(&b->fmtline.d_chunks, recs.size() * sizeof(FmtChunk));
+            hipError_t e = ctx_dev_alloc(ctx, &b->fmtline.d_chunks, recs.size() * sizeof(FmtChunk));
             if (e == hipSuccess) e = hipMemcpy(b->fmtline.d_chunks, recs.data(), recs.size() * sizeof(FmtChunk), hipMemcpyHostToDevice);
             if (e != hipSuccess) {
-                free_fmt_line(b);
+                free_fmt_line(ctx, b);
                 return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "record upload: %s", hipGetErrorString(e));
             }
             b->fmtline.n_chunks = (uint32_t)recs.size();
@@ -346,10 +346,10 @@ int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, s
         }
     }
     if (chunks.empty() || chunks.size() > 0xffffffffull) return OHGPU_OK;
-    hipError_t e = hipMalloc(&b->fmtline.d_chunks, chunks.size() * sizeof(FmtChunk));
+    hipError_t e = ctx_dev_alloc(ctx, &b->fmtline.d_chunks, chunks.size() * sizeof(FmtChunk));
     if (e == hipSuccess) e = hipMemcpy(b->fmtline.d_chunks, chunks.data(), chunks.size() * sizeof(FmtChunk), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        free_fmt_line(b);
+        free_fmt_line(ctx, b);
         return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "chunk plan upload: %s", hipGetErrorString(e));
     }
     b->fmtline.n_chunks = (uint32_t)chunks.size();

@@ -167,6 +167,7 @@ int ohgpu_shutdown(ohgpu_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     hipFree(ctx->d_ramp_table);
+    for (auto& list : ctx->cache.idle) for (void* p : list) (void)hipFree(p);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return OHGPU_OK;
@@ -345,15 +346,65 @@ static int validate_msg(const ohgpu_msg_desc& d, size_t i, uint64_t src_arena, u
     return OHGPU_OK;
 }
 
+}  // extern "C"
+
+namespace ohgpu {
+
+hipError_t ctx_dev_alloc(ohgpu_ctx* ctx, void** p, size_t bytes)
+{
+    *p = nullptr;
+    int c = 0;
+    while (c < DevCache::kClasses && ((size_t)256 << c) < bytes) c++;
+    DevCache& k = ctx->cache;
+    std::lock_guard<std::mutex> hold(k.m);
+    if (c < DevCache::kClasses && !k.idle[c].empty()) {
+        *p = k.idle[c].back();
+        k.idle[c].pop_back();
+        return hipSuccess;
+    }
+    const hipError_t e = hipMalloc(p, c < DevCache::kClasses ? ((size_t)256 << c) : bytes);
+    if (e != hipSuccess) { *p = nullptr; return e; }
+    k.device_allocs++;
+    k.cls[*p] = c < DevCache::kClasses ? c : -1;
+    return hipSuccess;
+}
+
+void ctx_dev_free(ohgpu_ctx* ctx, void* p)
+{
+    if (!p) return;
+    DevCache& k = ctx->cache;
+    std::lock_guard<std::mutex> hold(k.m);
+    const auto it = k.cls.find(p);
+    if (it != k.cls.end() && it->second >= 0 && k.idle[it->second].size() < 64) {      // (at most 64 idle blocks per class)
+        k.idle[it->second].push_back(p);
+        return;
+    }
+    if (it != k.cls.end()) k.cls.erase(it);
+    (void)hipFree(p);
+}
+
+}  // namespace ohgpu
+
+extern "C" {
+
+int ohgpu_device_allocations(ohgpu_ctx* ctx, uint64_t* count)
+{
+    CTX_GUARD("ohgpu_device_allocations");
+    if (!count) return set_error(OHGPU_ERR_INVALID, "ohgpu_device_allocations: null result");
+    std::lock_guard<std::mutex> hold(ctx->cache.m);
+    *count = ctx->cache.device_allocs;
+    return OHGPU_OK;
+}
+
 static int upload_batch(ohgpu_ctx* ctx, ohgpu_batch* b, const void* host_descs, size_t bytes)
 {
     if (bytes == 0) return OHGPU_OK;
-    hipError_t e = hipMalloc(&b->d_descs, bytes);
+    hipError_t e = ctx_dev_alloc(ctx, &b->d_descs, bytes);
     if (e == hipErrorOutOfMemory) return set_error(OHGPU_ERR_NOMEM, "descriptor upload: out of device memory");
     OHGPU_HIP_TRY(e);
     e = hipMemcpy(b->d_descs, host_descs, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        hipFree(b->d_descs);
+        ctx_dev_free(ctx, b->d_descs);
         b->d_descs = nullptr;
         return set_error(OHGPU_ERR_DEVICE, "descriptor upload: %s", hipGetErrorString(e));
     }
@@ -401,7 +452,7 @@ int ohgpu::pcm_batch_create_prefixed(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs
     }
     int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_msg_desc));
     if (err == OHGPU_OK) err = plan_pcm_line(ctx, b, descs, n, prefixes, blob, blob_bytes);
-    if (err != OHGPU_OK) { if (b->d_descs) hipFree(b->d_descs); delete b; return err; }
+    if (err != OHGPU_OK) { if (b->d_descs) ctx_dev_free(ctx, b->d_descs); delete b; return err; }
     *out = b;
     return OHGPU_OK;
 }
@@ -442,12 +493,15 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     CTX_GUARD("ohgpu_batch_destroy");
     if (!batch) return OHGPU_OK;
     for (ohgpu_batch* part : batch->parts) ohgpu_batch_destroy(ctx, part);
+    // (its blocks go back to the context's cache, for the next batch to write into: nothing of this one may still be running --
+    // what hipFree used to see to by itself)
+    if (batch->d_descs || batch->kind == kBatchPcm || batch->kind == kBatchFlywheel || batch->kind == kBatchFmt) (void)hipDeviceSynchronize();
     if (batch->last_done) hipEventDestroy(batch->last_done);
-    if (batch->d_descs) hipFree(batch->d_descs);
+    if (batch->d_descs) ctx_dev_free(ctx, batch->d_descs);
     if (batch->kind == kBatchSrc) free_src_fast(batch);
-    if (batch->kind == kBatchPcm) free_pcm_line(batch);
-    if (batch->kind == kBatchFlywheel) free_flywheel(batch);
-    if (batch->kind == kBatchFmt) { free_fmt_line(batch); free_pcm_line(batch); }
+    if (batch->kind == kBatchPcm) free_pcm_line(ctx, batch);
+    if (batch->kind == kBatchFlywheel) free_flywheel(ctx, batch);
+    if (batch->kind == kBatchFmt) { free_fmt_line(ctx, batch); free_pcm_line(ctx, batch); }
     if (batch->kind == kBatchOhm) free_ohm(ctx, batch);
     delete batch;
     return OHGPU_OK;
@@ -567,7 +621,7 @@ int ohgpu_fmt_batch_create(ohgpu_ctx* ctx, const ohgpu_fmt_desc* descs, size_t n
     }
     int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_fmt_desc));
     if (err == OHGPU_OK) err = plan_fmt_line(ctx, b, descs, n);
-    if (err != OHGPU_OK) { if (b->d_descs) hipFree(b->d_descs); delete b; return err; }
+    if (err != OHGPU_OK) { if (b->d_descs) ctx_dev_free(ctx, b->d_descs); delete b; return err; }
     *out = b;
     return OHGPU_OK;
 }
@@ -628,7 +682,7 @@ int ohgpu_flywheel_batch_create(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs
     }
     int err = upload_batch(ctx, b, descs, n * sizeof(ohgpu_flywheel_desc));
     if (err == OHGPU_OK) err = plan_flywheel(ctx, b, descs, n);
-    if (err != OHGPU_OK) { if (b->d_descs) hipFree(b->d_descs); delete b; return err; }
+    if (err != OHGPU_OK) { if (b->d_descs) ctx_dev_free(ctx, b->d_descs); delete b; return err; }
     *out = b;
     return OHGPU_OK;
 }
@@ -978,7 +1032,7 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
     }
     if (err != OHGPU_OK) {
         for (ohgpu_batch* part : b->parts) ohgpu_batch_destroy(ctx, part);
-        if (b->d_descs) hipFree(b->d_descs);
+        if (b->d_descs) ctx_dev_free(ctx, b->d_descs);
         delete b;
         return err;
     }

@@ -8,6 +8,7 @@
 
 #include <memory>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <vector>
 
@@ -127,6 +128,7 @@ struct SrcFastPlan {
     uint32_t ring_bytes = 0;      // bytes of packed output a block row's LDS ring holds
     bool     lean = false;        // the batch runs on src_lean_kernel (round 2) rather than src_block_kernel
     bool     lean_only = false;   // ... and round 1's kernel has no instantiation for its layout (variant 2 then runs the lean kernel too)
+    bool     lean_halfband = false;   // ... in its half-band form (the filter is one AND the layout has that instantiation): LDS sizing and dispatch agree on this
     bool     wg_only = false;     // ... or no block kernel but src_mfma_wg_kernel has one: any variant that asks for another kernel gets the generic one
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
     bool     mfma = false;        // ... and its layout is one src_mfma_kernel (round 4) serves: same units and planes, the filter's digit tables
@@ -293,7 +295,22 @@ enum BatchKind { kBatchPcm = 1, kBatchSrc = 2, kBatchFmt = 3, kBatchFlywheel = 4
 
 }  // namespace ohgpu
 
+namespace ohgpu {
+// Device blocks of the batches' descriptors and plan arrays, kept by the context between batches: a batch that is destroyed gives
+// its blocks back (by size class, 256 B << c), the next one of that size takes them -- a steady caller (the StarvationRamper's
+// rescue: three batch objects per starving period) allocates on the device once.  Blocks above the largest class go straight to
+// hipMalloc / hipFree.  `device_allocs` counts the hipMalloc calls made through it (ohgpu_device_allocations).
+struct DevCache {
+    static constexpr int kClasses = 15;                // 256 B .. 4 MiB
+    std::mutex m;
+    std::vector<void*> idle[kClasses];
+    std::unordered_map<void*, int> cls;                // every block handed out or idle -> its class (-1: not cached)
+    uint64_t device_allocs = 0;
+};
+}  // namespace ohgpu
+
 struct ohgpu_ctx {
+    ohgpu::DevCache cache;
     int          device;
     hipStream_t  stream;          // the context's own stream (used when the caller passes NULL)
     uint16_t*    d_ramp_table;    // 512 x u16 (RampArray.h:7-74)
@@ -381,15 +398,17 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
 // (*out)->line.prefixed tells whether the line kernel took them; if not, nobody writes them.
 int pcm_batch_create_prefixed(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n, uint64_t src_arena_bytes, uint64_t dst_arena_bytes,
                               const MsgPrefix* prefixes, const uint8_t* blob, size_t blob_bytes, ohgpu_batch** out);
-void free_pcm_line(ohgpu_batch* b);
+void free_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b);
 int plan_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_fmt_desc* descs, size_t n);
-void free_fmt_line(ohgpu_batch* b);
+void free_fmt_line(ohgpu_ctx* ctx, ohgpu_batch* b);
 hipError_t launch_fmt_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 // csrc/ohm_frame_kernel.hip: the two wire channels of streams wider than stereo (Sender::DoProcessFragment), one record per fragment
 OhmSelRec wide_record(uint64_t src_off, uint64_t dst_off, uint32_t n_frames, uint32_t channels, uint32_t sb, bool little, uint64_t src_arena_bytes);
 hipError_t launch_ohm_wide(const ohgpu_ctx* ctx, const void* d_recs, uint32_t n_recs, const uint8_t* src, uint8_t* dst, const uint8_t* prefix, hipStream_t s);
 int plan_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_flywheel_desc* descs, size_t n);
-void free_flywheel(ohgpu_batch* b);
+void free_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b);
+hipError_t ctx_dev_alloc(ohgpu_ctx* ctx, void** p, size_t bytes);     // csrc/ohgpu_api.hip: DevCache
+void ctx_dev_free(ohgpu_ctx* ctx, void* p);
 hipError_t launch_flywheel(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* src_filter,
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
@@ -412,6 +431,7 @@ bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint3
                        uint32_t* wave_lds_bytes, uint32_t* max_waves);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_lean_only_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
+bool src_lean_halfband_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,
                         uint32_t* rows, uint32_t* ring_bytes, uint32_t* coef_lds_bytes, uint32_t* wave_lds_bytes, uint32_t* max_waves);
 

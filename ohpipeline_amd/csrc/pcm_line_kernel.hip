@@ -512,10 +512,10 @@ __global__ __launch_bounds__(kLineWaves * 64) __attribute__((amdgpu_waves_per_eu
 }
 
 // ---- host side: chunk list and per-message multipliers ----
-void free_pcm_line(ohgpu_batch* b)
+void free_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b)
 {
-    if (b->line.d_chunks) (void)hipFree(b->line.d_chunks);
-    if (b->line.d_prefix) (void)hipFree(b->line.d_prefix);
+    if (b->line.d_chunks) ctx_dev_free(ctx, b->line.d_chunks);
+    if (b->line.d_prefix) ctx_dev_free(ctx, b->line.d_prefix);
     b->line = PcmLinePlan();
 }
 
@@ -643,17 +643,17 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
         if (all.size() > 0xffffffffull) return OHGPU_OK;
     }
     if (all.empty()) return OHGPU_OK;
-    hipError_t e = hipMalloc(&b->line.d_chunks, all.size() * sizeof(PcmChunk));
+    hipError_t e = ctx_dev_alloc(ctx, &b->line.d_chunks, all.size() * sizeof(PcmChunk));
     if (e == hipSuccess) e = hipMemcpy(b->line.d_chunks, all.data(), all.size() * sizeof(PcmChunk), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        free_pcm_line(b);
+        free_pcm_line(ctx, b);
         return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "chunk plan upload: %s", hipGetErrorString(e));
     }
     if (prefixes && blob_bytes) {
-        e = hipMalloc(&b->line.d_prefix, blob_bytes);
+        e = ctx_dev_alloc(ctx, &b->line.d_prefix, blob_bytes);
         if (e == hipSuccess) e = hipMemcpy(b->line.d_prefix, blob, blob_bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            free_pcm_line(b);
+            free_pcm_line(ctx, b);
             return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "prefix blob upload: %s", hipGetErrorString(e));
         }
         b->line.prefixed = true;

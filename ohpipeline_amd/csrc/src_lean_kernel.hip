@@ -938,12 +938,13 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
         OHGPU_LEAN_PLANAR_KERNELS(X)
         return hipErrorInvalidValue;
     }
-    if (b->src->halfband) {                                // the 2:1 decimator: 33 products per output instead of 64
+    if (b->fast.lean_halfband) {                           // the 2:1 decimator: 33 products per output instead of 64 (decided where the plan's LDS was sized: src_plan.cpp)
 #define XHB(t, c, s_, sl, d, dl)                                                                                          \
     if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
         return launch_lean_one<t, c, s_, sl, d, dl, true>(ctx, b, prm, s);
         OHGPU_LEAN_HB_KERNELS(XHB)
 #undef XHB
+        return hipErrorInvalidValue;                       // (the plan's table and waves are the half-band kernel's: never the plain one's launch)
     }
     OHGPU_BLOCK_KERNELS(X)
     OHGPU_LEAN_ONLY_KERNELS(X)
@@ -958,6 +959,17 @@ bool src_lean_only_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_
 #define X(t, c, s_, sl, d, dl) \
     if (T == t && ch == c && sb == s_ && (src_le != 0) == sl && db == d && (dst_le != 0) == dl) return true;
     OHGPU_LEAN_ONLY_KERNELS(X)
+#undef X
+    return false;
+}
+
+// ... and the layouts its half-band form (T / 2 + 1 products per output, a table half as long, twelve waves) is instantiated for: the ONE
+// place that says so, for the planner's geometry and for the dispatch above.
+bool src_lean_halfband_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le)
+{
+#define X(t, c, s_, sl, d, dl) \
+    if (T == t && ch == c && sb == s_ && (src_le != 0) == sl && db == d && (dst_le != 0) == dl) return true;
+    OHGPU_LEAN_HB_KERNELS(X)
 #undef X
     return false;
 }

@@ -121,8 +121,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if ((block_ok || planar) && !src_block_geometry(L, T, ch, sb_geo, db, out_per_drain, &rows, &ring, &coef_lds, &wave_lds, &max_waves)) return OHGPU_OK;
     // the lean kernel (round 2): same blocks, rows and ring; its rounding bias needs sum|c| < 2^29 in every phase
     uint32_t lean_rows = 0, lean_inb = 0, lean_sf = 8, lean_ring = 0, lean_coef = 0, lean_wave_lds = 0, lean_max_waves = 0;
+    const bool lean_hb = flt->halfband && !planar && src_lean_halfband_supported(T, ch, sb, src_le, db, dst_le);
     bool lean = flt->max_sum_abs < ((int64_t)1 << 29) &&
-                src_lean_geometry(L, T, flt->halfband, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves);
+                src_lean_geometry(L, T, lean_hb, ch, sb_lean, db, out_per_drain, &lean_rows, &lean_inb, &lean_sf, &lean_ring, &lean_coef, &lean_wave_lds, &lean_max_waves);
     if (lean && !block_ok && !planar) { rows = lean_rows; ring = lean_ring; }     // (no geometry of round 1's to agree with)
     lean = lean && lean_rows == rows && lean_ring == ring;
     if ((lean_only || wg_only) && !lean) return OHGPU_OK;
@@ -476,8 +477,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                         if (!emit(r, work[r.work_begin + k].first_block, rows, 1, &work[r.work_begin + k])) return OHGPU_OK;
                     continue;
                 }
-                if (!emit(r, w1.first_block, w1.n_blocks, 1, &w1)) return OHGPU_OK;
-                k++;
+                // (nothing long comes out of this run -- the target is met, or the run is shorter than a long unit: all of it as
+                // one-block units in one pass, not one rescan of the run per unit)
+                for (uint32_t q = 0; q < std::max(run, 1u); q++, k++)
+                    if (!emit(r, work[r.work_begin + k].first_block, work[r.work_begin + k].n_blocks, 1, &work[r.work_begin + k])) return OHGPU_OK;
             }
         }
         if (plane_entries) plane_entries += (size_t)rows * L_blk + 8;                             // (lanes without a block read their row's place too)
@@ -593,6 +596,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.ring_bytes = ring;
     f.lean = lean;
     f.lean_only = lean_only;
+    f.lean_halfband = lean_hb;
     f.wg_only = wg_only;
     f.lean_coef_lds_bytes = lean_coef;
     f.lean_wave_lds_bytes = lean_wave_lds;

@@ -295,7 +295,29 @@ void StarvationManager::Lane::Feed()
 StarvationManager::StarvationManager(MsgFactory& aFactory)
     : iFactory(aFactory)
     , iRescueLaunches(0)
+    , iDriverKnown(false)
 {
+}
+
+void StarvationManager::ClaimDriverThread()
+{
+    std::lock_guard<std::mutex> lock(iDriverLock);
+    if (!iDriverKnown) {
+        iDriver = std::this_thread::get_id();
+        iDriverKnown = true;
+    }
+    ASSERT(iDriver == std::this_thread::get_id());       // one driver thread per manager: the rescues share their device buffers
+}
+
+TUint64 StarvationManager::DeviceAllocations() const
+{
+    uint64_t n = 0;
+    ohgpu_ctx* ctx = iFactory.Gpu();
+    if (ctx != nullptr) {
+        const int err = ohgpu_device_allocations(ctx, &n);
+        ASSERT(err == OHGPU_OK);
+    }
+    return n;
 }
 
 StarvationManager::~StarvationManager()
@@ -562,6 +584,20 @@ Msg* StarvationManager::Next(Lane& aLane, TBool aMayBlock)
         if (msg != nullptr) {
             return msg;
         }
+        if (!aMayBlock) {
+            // The message was one Handle() consumes (Track, MetaText, Wait, discarded flush content) and it may have been the inbox's
+            // last: Prepare saw a non-empty inbox and did not rescue, the reference would block in DoDequeue here, and a lane that IS
+            // playing must not sit a period out unramped -- rescue it now, the flywheel audio goes out this period.
+            TBool rescue;
+            {
+                std::lock_guard<std::mutex> lock(aLane.m);
+                rescue = aLane.inbox.empty() && aLane.CanStarve() && !aLane.quitSeen;
+            }
+            if (rescue) {
+                SetBuffering(aLane, true);
+                RescueNow(aLane);
+            }
+        }
     }
 }
 
@@ -702,6 +738,7 @@ void StarvationManager::Tick(std::vector<Msg*>& aOut)
     // Nothing in a tick waits for a feeder: the reference gives every pipeline a StarvationRamper and a driver thread of its
     // own, so an idle pipeline blocks nobody else; here the lanes share the tick, and one that has nothing to say this period
     // (halted or not yet started with an empty inbox, or held at its occupancy gate) just says nothing -- nullptr.
+    ClaimDriverThread();
     RescueBatch batch(iFactory, &iArena);
     std::vector<TBool> takesPart(iLanes.size());
     for (size_t i = 0; i < iLanes.size(); i++) {
@@ -719,6 +756,7 @@ void StarvationManager::Tick(std::vector<Msg*>& aOut)
 
 Msg* StarvationManager::Pull(TUint aLane)
 {
+    ClaimDriverThread();
     Lane& lane = *iLanes.at(aLane);
     RescueBatch batch(iFactory, &iArena);
     Prepare(lane, batch, true);                          // (one lane, its own caller: blocks as the reference's Pull does)

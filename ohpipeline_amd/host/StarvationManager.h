@@ -103,6 +103,11 @@ public:
     ~StarvationManager();
     TUint AddLane(const LaneConfig& aConfig);
     TUint LaneCount() const { return (TUint)iLanes.size(); }
+    /** THREADS: Tick(), Pull() and everything they call belong to ONE driver thread per StarvationManager (the reference has one
+     *  driver thread per pipeline; a manager is many pipelines' worth of lanes behind one driver).  The rescues of all lanes share
+     *  one set of device buffers (RescueArena) and one context: two threads pulling different lanes would hand each other's
+     *  buffers out.  The first call names the driver thread; a call from another one ASSERTs.  Feeders, Flush(), DrainAllAudio(),
+     *  WaitForOccupancy() and the inspection calls may come from anywhere. */
     /** One driver period for every lane: aOut[i] is lane i's next message, or nullptr when the lane has none this period --
      *  its inbox is empty and it is not playing (halted, starting, flushing: a lane that IS playing is rescued instead), it is
      *  held at its occupancy gate, or its MsgQuit has already gone out (Finished()).  Never waits for a feeder. */
@@ -121,6 +126,7 @@ public: // inspection (the reference's suite reads these as a friend)
     TBool DrainRequested(TUint aLane) const;             // DrainAllAudio() called, not yet seen by a tick
     TUint64 RescueLaunches() const { return iRescueLaunches.load(); }   // device rescues so far (one per tick that needed any)
     TUint64 RescueAllocations() const { return iArena.Allocations(); } // device allocations of the rescue buffers so far
+    TUint64 DeviceAllocations() const;                   // ... and of everything the context allocated for batches (descriptors, plans): ohgpu_device_allocations
 private:
     struct Lane;
     TBool Prepare(Lane& aLane, RescueBatch& aBatch, TBool aMayBlock);   // tick step 1; false: the lane sits this period out
@@ -136,6 +142,10 @@ private:
     std::vector<std::unique_ptr<Lane>> iLanes;
     RescueArena iArena;                                   // the rescues' device buffers (one tick, one thread)
     std::atomic<TUint64> iRescueLaunches;
+    void ClaimDriverThread();                            // the first caller of Tick / Pull is the driver; anyone else ASSERTs
+    std::mutex iDriverLock;
+    std::thread::id iDriver;
+    TBool iDriverKnown;
 };
 
 } // namespace Media

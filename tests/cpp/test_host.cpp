@@ -759,10 +759,76 @@ static void SuiteRescueBuffersPersistGpu(MsgFactory& aFactory)
     feed(3);
     play_until_halt(3);
     TEST(manager.RescueLaunches() == 1 && manager.RescueAllocations() == 4);
+    const TUint64 batchAllocs = manager.DeviceAllocations(); // what the first rescue's three batch objects took for descriptors and plans
+    TEST(batchAllocs > 0);
     feed(40);                                                // 80 ms: through the 50 ms ramp up and on
     play_until_halt(40);
     TEST(manager.RescueLaunches() == 2);
-    TEST(manager.RescueAllocations() == 4);                  // the second rescue allocated nothing
+    TEST(manager.RescueAllocations() == 4);                  // the second rescue allocated nothing: not its buffers,
+    TEST(manager.DeviceAllocations() == batchAllocs);        // ... and not its batches' descriptors or plan arrays (the context's cache)
+    source.Push(aFactory.CreateMsgQuit());
+    for (TUint t = 0; t < 20000 && !manager.Finished(0); t++) {
+        manager.Tick(out);
+        if (out[0] != nullptr) out[0]->RemoveRef();
+        else std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    TEST(manager.Finished(0));
+}
+
+// A playing lane whose inbox holds nothing but a message the StarvationRamper consumes (MsgMetaText: :718-724 keep it from
+// downstream) has run dry all the same: the non-blocking Tick pops it, finds nothing behind it, and must rescue the lane in THAT
+// period -- the reference blocks in DoDequeue here and ramps when the wait times out; a lane that sat the period out would drop to
+// silence unramped and get its flywheel ramp a tick late.
+static void SuiteLaneLeftWithMetaTextIsRescuedGpu(MsgFactory& aFactory)
+{
+    ScriptedSource source;
+    CountingObserver observer;
+    StarvationManager manager(aFactory);
+    StarvationManager::LaneConfig cfg;
+    cfg.upstream = &source; cfg.observer = &observer;
+    cfg.sizeJiffies = 200 * Jiffies::kPerMs; cfg.rampUpJiffies = 50 * Jiffies::kPerMs; cfg.maxStreamCount = 10;
+    TEST(manager.AddLane(cfg) == 0);
+    source.Push(aFactory.CreateMsgMode(ModeInfo()));
+    DecodedStreamInfo info;
+    info.iStreamId = 5; info.iBitDepth = 16; info.iSampleRate = 48000; info.iNumChannels = 2;
+    source.Push(aFactory.CreateMsgDecodedStream(info));
+    uint32_t x = 77;
+    std::vector<TByte> pcm(4 * 96);                          // 2 ms of 48 kHz stereo S16
+    TUint fed = 0;
+    for (TUint m = 0; m < 40; m++) {                         // 80 ms: through the 50 ms ramp up and on
+        for (auto& b : pcm) { x = x * 1664525u + 1013904223u; b = (TByte)(x >> 24); }
+        MsgAudioPcm* audio = aFactory.CreateMsgAudioPcm(Brn(pcm.data(), (TUint)pcm.size()), 2, 48000, 16, AudioDataEndian::Big, 0);
+        fed += audio->Jiffies();
+        source.Push(audio);
+    }
+    while (manager.SizeInJiffies(0) != fed) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    std::vector<Msg*> out;
+    TUint audio = 0;
+    for (TUint t = 0; t < 42; t++) {                         // mode, stream, 40 x audio
+        manager.Tick(out);
+        TEST(out.size() == 1 && out[0] != nullptr);
+        if (out[0] == nullptr) return;
+        audio += KindOf(out[0]) == MsgKind::AudioPcm ? 1 : 0;
+        out[0]->RemoveRef();
+    }
+    TEST(audio == 40 && manager.RescueLaunches() == 0 && manager.State(0) == LaneState::Running);
+    source.Push(aFactory.CreateMsgMetaText());
+    while (manager.IsEmpty(0)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    manager.Tick(out);                                       // pops the meta text, finds the inbox dry, rescues: extrapolated audio, this period
+    TEST(out.size() == 1 && out[0] != nullptr && KindOf(out[0]) == MsgKind::AudioPcm);
+    TEST(manager.RescueLaunches() == 1);
+    if (out[0] != nullptr) out[0]->RemoveRef();
+    TUint more = 1;
+    for (TUint t = 0; t < 100; t++) {
+        manager.Tick(out);
+        TEST(out[0] != nullptr);
+        if (out[0] == nullptr) break;
+        const MsgKind k = KindOf(out[0]);
+        out[0]->RemoveRef();
+        if (k == MsgKind::Halt) break;
+        more++;
+    }
+    TEST(more == 20);                                        // the flywheel's 20 ms, then the halt
     source.Push(aFactory.CreateMsgQuit());
     for (TUint t = 0; t < 20000 && !manager.Finished(0); t++) {
         manager.Tick(out);
@@ -1860,6 +1926,7 @@ int main(int argc, char** argv)
             SuiteStarvationRescueGpu(f);
             SuiteManyLanesStarveTogetherGpu(f);
             SuiteRescueBuffersPersistGpu(f);
+            SuiteLaneLeftWithMetaTextIsRescuedGpu(f);
             SuiteSongcastSenderGpu(f);
             SuiteStarvationRamper starvation(f);
             starvation.RunControl();

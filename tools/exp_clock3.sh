@@ -2,6 +2,7 @@
 # The shader clock the chip holds under the lean kernel, by waves per CU (stamped diagnostic builds: s_memtime against the
 # 100 MHz s_memrealtime over every wave's life).  The product build is restored at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 run() {
   label="$1"; flags="$2"; shift 2
   OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL -DOHGPU_DIAG_STAMP $flags" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "$label: build failed"; return; }

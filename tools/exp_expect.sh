@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B, alternating: the advance-without-output block out of line (the tree) against in line (round 2's layout).
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 for flags in "" "-DOHGPU_DIAG_NO_EXPECT" "" "-DOHGPU_DIAG_NO_EXPECT" "" "-DOHGPU_DIAG_NO_EXPECT"; do
   OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL $flags" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "[$flags]: build failed"; continue; }
   echo -n "[$flags]: "

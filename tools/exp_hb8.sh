@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B on config 4: the eight-channel half-band kernel at 16 waves per CU (the tree) against 12.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 for w in 16 12 16 12; do
   OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_HB8_WAVES=$w" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "w $w: build failed"; continue; }
   echo -n "hb8 waves $w: "

@@ -3,6 +3,7 @@
 # kernel and with one access class taken out at a time (diagnostic one-kernel builds; wrong audio in the ablated ones, counters
 # only).  Output: gpurun_out/r3/lds_conflicts.txt.  The product build is restored at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 R=$(pwd)
 OUT=$R/gpurun_out/r3/lds_conflicts.txt
 : > "$OUT"

@@ -3,6 +3,7 @@
 # Usage (inside gpurun): bash tools/exp_lean.sh "<label>|<extra -D flags>|<env assignments for the run>|<env assignments for the build>" ...
 # The product build is restored at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 for spec in "$@"; do
   IFS='|' read -r label flags envs benvs <<< "$spec"
   env $benvs OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL $flags" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "$label: build failed"; continue; }

@@ -3,6 +3,7 @@
 # the coefficient reads, the sample reads, the ring stores, the write-back and the staging DMA are taken out one after the other.
 # (Wrong audio from the second line on: timing only.)  The product build is restored at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 acc=""
 # (round 3 ran this with a coefficient-read switch between the taps and the sample reads: those builds faulted on the device --
 # the counted waits of the output body rely on the reloads being issued -- and the switch is gone)

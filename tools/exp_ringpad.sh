@@ -2,6 +2,7 @@
 # Same-box A/B: the pad between the rows of the lean kernel's output ring (LDS bank spreading of the ring stores): time and
 # SQ_LDS_BANK_CONFLICT per launch.  The product build is restored at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 R=$(pwd)
 for pad in 4 12 4 12 28; do
   OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL -DOHGPU_LEAN_RING_PAD=$pad" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "pad $pad: build failed"; continue; }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B, alternating: ring pad 0 (twelve waves per CU fit the LDS) against the product's 4 (eleven).
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 for pad in 4 0 4 0 4 0; do
   OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL -DOHGPU_LEAN_RING_PAD=$pad" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "pad $pad: build failed"; continue; }
   echo -n "pad $pad: "

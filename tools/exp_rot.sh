@@ -2,6 +2,7 @@
 # Twelve waves with the rotated rings (the tree's kernel) against eleven waves (ring pad 4), alternating on one box; then the
 # LDS counters of the tree's kernel.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 R=$(pwd)
 for pad in 0 4 0 4 0 4; do
   OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL -DOHGPU_LEAN_RING_PAD=$pad" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "pad $pad: build failed"; continue; }

@@ -2,6 +2,7 @@
 # Kernel time and L2<->fabric traffic (FETCH_SIZE / WRITE_SIZE, KiB; TCC request counters) of diagnostic builds of the lean kernel.
 # Usage (inside gpurun): bash tools/exp_traffic2.sh "<label>|<extra -D flags>" ...
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 R=$(pwd)
 for spec in "$@"; do
   IFS='|' read -r label flags <<< "$spec"

@@ -3,6 +3,7 @@
 # diagnostic build, one instantiation, the planner's OHGPU_DIAG_KB_MAX / OHGPU_DIAG_TAIL_ROUNDS hooks; then the per-phase stamps.
 # Usage (inside gpurun): bash tools/exp_units.sh    The product build is restored at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "build failed"; exit 1; }
 for envs in "OHGPU_DIAG_KB_MAX=1" "OHGPU_DIAG_KB_MAX=2" "OHGPU_DIAG_KB_MAX=3" "OHGPU_DIAG_KB_MAX=8 OHGPU_DIAG_TAIL_ROUNDS=1.5" "OHGPU_DIAG_KB_MAX=8 OHGPU_DIAG_TAIL_ROUNDS=0.6" "OHGPU_DIAG_KB_MAX=1" "OHGPU_DIAG_KB_MAX=3"; do
   echo -n "$envs: "

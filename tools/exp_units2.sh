@@ -1,6 +1,7 @@
 #!/bin/bash
 # More of tools/exp_units.sh: rounds of long units per wave.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "build failed"; exit 1; }
 for envs in "X=1" "OHGPU_DIAG_LONG_ROUNDS=1" "OHGPU_DIAG_LONG_ROUNDS=3" "OHGPU_DIAG_LONG_ROUNDS=1 OHGPU_DIAG_TAIL_ROUNDS=1.0" "OHGPU_DIAG_TAIL_ROUNDS=1.0" "OHGPU_DIAG_TAIL_ROUNDS=2.0" "OHGPU_DIAG_KB_MAX=1" "X=2"; do
   echo -n "$envs: "

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Unit schedules against each other on ONE box, alternating (box-to-box differences are larger than the effect).
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "build failed"; exit 1; }
 for rep in 1 2 3; do
 for envs in "OHGPU_DIAG_KB_MAX=1" "OHGPU_DIAG_TAIL_ROUNDS=1.5" "OHGPU_DIAG_LONG_ROUNDS=1 OHGPU_DIAG_TAIL_ROUNDS=1.0" "OHGPU_DIAG_LONG_ROUNDS=1 OHGPU_DIAG_TAIL_ROUNDS=2.0" "OHGPU_DIAG_KB_MAX=2 OHGPU_DIAG_LONG_ROUNDS=3 OHGPU_DIAG_TAIL_ROUNDS=2.0"; do

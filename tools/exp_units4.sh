@@ -1,6 +1,7 @@
 #!/bin/bash
 # Unit schedules at twelve waves per CU (ring pad 0), alternating on one box.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "build failed"; exit 1; }
 for rep in 1 2; do
 for envs in "X=1" "OHGPU_DIAG_KB_MAX=1" "OHGPU_DIAG_KB_MAX=6" "OHGPU_DIAG_TAIL_ROUNDS=0.5" "OHGPU_DIAG_TAIL_ROUNDS=1.5" "OHGPU_DIAG_MAX_WAVES=11"; do

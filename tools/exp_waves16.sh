@@ -2,6 +2,7 @@
 # Same-box A/B: the stereo lean kernel with 8-frame stages and up to 16 waves per CU (four per SIMD) against the product shape
 # (16-frame stages, 11 waves).  Diagnostic one-kernel builds; the product build is restored at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 run() {
   label="$1"; flags="$2"; shift 2
   OHGPU_EXTRA_FLAGS="-DOHGPU_DIAG -DOHGPU_DIAG_ONE_KERNEL $flags" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "$label: build failed"; return; }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B on config 4: 16 waves per CU for the six- and eight-channel lean kernels (they fit 128 registers) against 12.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
+trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT     # an interrupted experiment must not leave a diagnostic library behind
 for w in 12 16 12 16; do
   OHGPU_EXTRA_FLAGS="-DOHGPU_LEAN_MAX_WAVES_WIDE=$w" python3 ohpipeline_amd/build.py --force > /dev/null 2>&1 || { echo "w $w: build failed"; continue; }
   echo -n "wide waves $w: "
