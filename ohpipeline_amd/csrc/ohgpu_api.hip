@@ -805,16 +805,23 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
     // src_mfma_kernel's digit tables, for the block length the planner gives 24-bit stereo output (rows of up to 8 blocks)
     std::vector<uint8_t> adig;
     std::vector<MfStep> steps;
-    const uint32_t mf_L_blk = T == 32 ? src_block_outputs(L, 6) : 0;
-    if (e == hipSuccess && mf_L_blk != 0 && build_mfma_tables(L, M, T, coef_q28, mf_L_blk, 8, &adig, &steps)) {
-        std::vector<uint8_t> amat;
+    const uint32_t mf_L_blk = (T == 32 || s->halfband) ? src_block_outputs(L, 6) : 0;
+    std::vector<uint8_t> amat;
+    bool tables = false;
+    if (e == hipSuccess && mf_L_blk != 0 && s->halfband) {
+        tables = build_mfma_halfband(coef_q28, mf_L_blk, &steps, &amat);
+        s->mf_halfband = tables;
+    } else if (e == hipSuccess && mf_L_blk != 0 && build_mfma_tables(L, M, T, coef_q28, mf_L_blk, 8, &adig, &steps)) {
         build_mfma_images(adig, steps, L, &amat);
+        tables = true;
+    }
+    if (tables) {
         e = hipMalloc((void**)&s->d_mf_amat, amat.size());
         if (e == hipSuccess) e = hipMalloc((void**)&s->d_mf_steps, steps.size() * sizeof(MfStep));
         if (e == hipSuccess) e = hipMemcpy(s->d_mf_amat, amat.data(), amat.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(s->d_mf_steps, steps.data(), steps.size() * sizeof(MfStep), hipMemcpyHostToDevice);
         s->mf_L_blk = mf_L_blk;
-        s->mf_kb_cap = 8;
+        s->mf_kb_cap = s->mf_halfband ? 1 : 8;
     }
     if (e != hipSuccess) {
         if (s->d_coef) hipFree(s->d_coef);

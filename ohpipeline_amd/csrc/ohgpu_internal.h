@@ -134,6 +134,7 @@ struct SrcFastPlan {
     bool     mfma = false;        // ... and its layout is one src_mfma_kernel (round 4) serves: same units and planes, the filter's digit tables
     uint32_t n_wg = 0;            // mfma_wg: lean units [0, n_wg) are src_mfma_wg_kernel's, [n_wg, n_lean) the edge units src_mfma_kernel runs
     bool     mfma_wg = false;     // ... as src_mfma_wg_kernel cuts them: one unit per workgroup (rows of ONE block; units that leave the arena are the generic kernel's)
+    bool     mfma_wg_halfband = false;   // ... in its half-band form (the filter's tables are build_mfma_halfband's)
     const void* d_mf_amat = nullptr;   // (owned by the ohgpu_src)
     const void* d_mf_steps = nullptr;
     void*    d_planes = nullptr;  // uint16: RampApplicator's multiplier per output frame of every ramped unit, [blocks of the unit][L_blk]
@@ -331,6 +332,7 @@ struct ohgpu_src {
     uint8_t* d_mf_amat = nullptr; // the steps' A operands, lane-linear: [step][4 digits][64 lanes][16 bytes] (build_mfma_images)
     ohgpu::MfStep* d_mf_steps = nullptr;
     uint32_t mf_L_blk = 0, mf_kb_cap = 0;
+    bool     mf_halfband = false; // ... in the half-band form: one coefficient image for every step (build_mfma_halfband)
 };
 
 namespace ohgpu {
@@ -416,8 +418,9 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit = 0);   // csrc/src_mfma_kernel.hip (units [first_unit, n_lean))
 hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_wg_kernel.hip
-bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar);
-bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, bool planar, uint64_t plane_stride);
+bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar, bool halfband);
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, bool planar, uint64_t plane_stride, bool halfband);
+bool build_mfma_halfband(const int32_t* coef_q28, uint32_t L_blk, std::vector<MfStep>* steps, std::vector<uint8_t>* amat);   // csrc/src_mfma_kernel.hip
 bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, uint32_t L_blk, uint32_t kb_cap,
                        std::vector<uint8_t>* adig, std::vector<MfStep>* steps);
 void build_mfma_images(const std::vector<uint8_t>& adig, const std::vector<MfStep>& steps, uint32_t L, std::vector<uint8_t>* amat);

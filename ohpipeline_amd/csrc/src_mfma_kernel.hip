@@ -482,6 +482,53 @@ bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q
     return true;
 }
 
+// The half-band 2:1 decimator (L = 1, M = 2, T = 64 stored taps of which the even ones and the centre tap 31 are not zero) on the
+// same tiles.  y[j] = sum_m c[2 m] x[2 j - 2 m] + c[31] x[2 j - 31]: with the row's image starting 64 frames before the block
+// (image frame a = frame + 64), its EVEN frames e = a / 2 and its ODD frames o = (a - 1) / 2 as two sample streams, output j
+// meets e = 32 + j - m (m = 0..31) and o = j + 16.  A step of 16 outputs j = 16 s + n therefore reads even samples 16 s ..
+// 16 s + 47 -- three aligned chunks, K groups 0..2 -- and the ONE odd chunk s + 1, sample n for output n -- K group 3, a diagonal.
+// One coefficient image serves every step (the phase never changes): [digit 4][lane = 16 g + n][16 bytes], and one bias.
+bool build_mfma_halfband(const int32_t* coef_q28, uint32_t L_blk, std::vector<MfStep>* steps, std::vector<uint8_t>* amat)
+{
+    if (L_blk == 0 || (L_blk % 16) != 0) return false;
+    int64_t sum = 0;
+    for (uint32_t k = 0; k < 64; k++) {
+        const int32_t c = coef_q28[k];
+        if (c > (127 << 24) + 0x7fffff || c < -(127 << 24)) return false;                        // the top digit is an int8
+        if ((k & 1u) && k != 31 && c != 0) return false;                                          // not a half-band filter
+        sum += c;
+    }
+    const int64_t bias = 32896 * sum + ((int64_t)1 << 27);
+    if (bias < -((int64_t)1 << 46) || bias > ((int64_t)1 << 46)) return false;
+    amat->assign(kMfStepImage, 0);
+    for (uint32_t gq = 0; gq < 4; gq++)
+        for (uint32_t n = 0; n < 16; n++)
+            for (uint32_t i = 0; i < 16; i++) {
+                int32_t c = 0;
+                if (gq < 3) {
+                    const int m_tap = 32 + (int)n - 16 * (int)gq - (int)i;                          // even sample 16 (s + gq) + i against output 16 s + n
+                    if (m_tap >= 0 && m_tap <= 31) c = coef_q28[2 * m_tap];
+                } else if (i == n) {
+                    c = coef_q28[31];
+                }
+                int8_t e[4];
+                coef_digits(c, e);
+                for (int j = 0; j < 4; j++) (*amat)[(size_t)j * 1024 + (gq * 16 + n) * 16 + i] = (uint8_t)e[j];
+            }
+    steps->assign(L_blk / 16, MfStep());
+    for (uint32_t t = 0; t < L_blk / 16; t++) {
+        MfStep& st = (*steps)[t];
+        memset(&st, 0, sizeof(st));
+        st.kc = t;                                                                                // even chunks t .. t + 2, odd chunk t + 1
+        for (uint32_t m = 0; m < 16; m++) {
+            st.b0[m] = (uint32_t)(bias & 0xffff);
+            st.b1[m] = (uint32_t)((bias >> 16) & 0xffff);
+            st.b2[m] = (uint32_t)(int32_t)(bias >> 32);
+        }
+    }
+    return true;
+}
+
 // The kernel's A operands, lane-linear: [step][coefficient digit][lane = 16 g + m][16 bytes] = the 16 bytes of output m's padded
 // coefficient row that meet frames 16 (kc + g) .. + 15 of the step's window (MfStep::aoff).
 void build_mfma_images(const std::vector<uint8_t>& adig, const std::vector<MfStep>& steps, uint32_t L, std::vector<uint8_t>* amat)

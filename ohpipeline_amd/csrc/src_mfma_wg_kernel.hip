@@ -41,48 +41,62 @@
 
 namespace ohgpu {
 
-constexpr uint32_t kWgSteps = 10;                   // steps per block (a 160-output block)
-constexpr uint32_t kWgChunks = 12;                  // chunks (16 frames) a row's outputs touch: frames -32 .. 159 of the row
-constexpr uint32_t kWgPlaneIn = kWgChunks * 64;     // planar TInt32 source: bytes of one channel's frames of a row's image (two of them side by side)
-constexpr uint32_t kWgBiasBytes = kWgSteps * 768;   // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
+constexpr uint32_t kWgPlaneIn = 12 * 64;            // planar TInt32 source: bytes of one channel's frames of a row's image (two of them side by side)
 
 // A workgroup's pass is ROWS pair-rows (a pair-row = one channel pair of one block of a stream) = CT = ROWS / 8 column tiles per
-// step, 10 CT tiles in all; a wave takes FIVE of them in step-major order (2 CT waves: two per SIMD for 32 rows, one for 16 -- whole
-// numbers per SIMD whatever SIMD the first wave lands on; ten waves, one per step, would be 3, 3, 2, 2, and the phase between two
-// barriers lasts as long as its slowest wave).  PAIRS = channels / 2: the pass holds ROWS / PAIRS whole stream rows.
-template <int ROWS, int PLANAR = 0, int PAIRS = 1>
+// step, STEPS x CT tiles in all; a wave takes FIVE (four: half-band) of them in step-major order (2 CT waves: two per SIMD for 32
+// rows, one for 16 -- whole numbers per SIMD whatever SIMD the first wave lands on; ten waves, one per step, would be 3, 3, 2, 2,
+// and the phase between two barriers lasts as long as its slowest wave).  PAIRS = channels / 2: the pass holds ROWS / PAIRS whole
+// stream rows.
+// HB: the half-band 2:1 decimator (build_mfma_halfband): blocks of 128 outputs = 8 steps from 256 + 64 input frames, a row's image
+// is 20 input chunks and its planes 10 chunks of EVEN frames (ids 0..9) and 10 of ODD ones (ids 10..19); a step's K groups 0..2
+// read even chunks step .. step + 2, group 3 the odd chunk step + 1.  The image is staged in TWO sections (rounds 0..4 of the
+// lanes' pieces = input chunks 0..12, then rounds 4..7 = chunks 13..19), so that three workgroups still share a CU's LDS.
+template <int ROWS, int PLANAR = 0, int PAIRS = 1, bool HB = false>
 struct WgGeom {
     static_assert(ROWS == 16 || ROWS == 32, "pair-rows per workgroup");
     static_assert(PAIRS == 1 || ((PAIRS == 3 || PAIRS == 4) && PLANAR == 0 && ROWS == 16), "six and eight channels: packed, sixteen pair-rows");
+    static_assert(!HB || (PLANAR == 0 && ROWS == 16), "half-band: packed, sixteen pair-rows");
+    static constexpr uint32_t kSteps = HB ? 8 : 10;                   // steps (16 output frames) per block
+    static constexpr uint32_t kOutFrames = 16u * kSteps;              // a block's outputs: 160, or 128
+    static constexpr uint32_t kImgChunks = HB ? 20 : 12;              // chunks (16 frames) of a row's input image: frames -32 .. 159 of the row, or -64 .. 255
+    static constexpr uint32_t kPlaneChunks = kImgChunks;              // ... and of its digit planes (half-band: ten of even frames, then ten of odd ones)
     static constexpr uint32_t kFb = 6u * PAIRS;                       // bytes of a frame, in and out (24-bit samples)
     static constexpr uint32_t kSR = ROWS / PAIRS;                     // stream rows of a pass: 16, 5 (fifteen of the sixteen pair-rows) or 4
     static constexpr uint32_t kUnitRows = 32u / PAIRS;                // rows of a planner unit (LeanUnit): 64 / channels, src_block_geometry
-    static constexpr uint32_t kRowIn = kWgChunks * 16u * kFb;         // bytes of a row's input image, packed
-    static constexpr uint32_t kRowInPitch = PLANAR ? 2 * kWgPlaneIn + 16 : kRowIn + 16;   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
-    static constexpr uint32_t kRowLanes = 16u * PAIRS;                // lanes that move one row of the input image, 4.5 pieces each (planar: 6)
+    static constexpr uint32_t kRowIn = kImgChunks * 16u * kFb;        // bytes of a row's input image, packed
+    static constexpr uint32_t kRowLanes = 16u * PAIRS;                // lanes that move one row of the input image, 4.5 (7.5) pieces each (planar: 6)
     static constexpr uint32_t kRound = 16u * kRowLanes;               // ... and the bytes of it one round of them moves
-    static constexpr uint32_t kInRounds = PLANAR ? 6 : 5;
-    static constexpr uint32_t kRowOut = 160u * kFb;                   // bytes of a row's output
+    static constexpr uint32_t kFullRounds = HB ? 7 : 4;               // whole rounds; then half a round
+    static constexpr uint32_t kInRounds = PLANAR ? 6 : kFullRounds + 1;
+    static constexpr uint32_t kRoundsA = HB ? 5 : kInRounds;          // half-band: the rounds of the first staging (the second: kRoundsA - 1 ..)
+    static constexpr uint32_t kChunksA = HB ? 13 : kImgChunks;        // ... and the input chunks it holds whole
+    static constexpr uint32_t kRowInPitch = PLANAR ? 2 * kWgPlaneIn + 16 : (HB ? kRoundsA * kRound + 16 : kRowIn + 16);   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
+    static constexpr uint32_t kRowOut = kOutFrames * kFb;             // bytes of a row's output
     static constexpr uint32_t kCt = ROWS / 8;
     static constexpr uint32_t kWaves = 2 * kCt;
     static constexpr uint32_t kThreads = 64 * kWaves;                 // = 16 * ROWS
-    static constexpr uint32_t kTilesPerWave = 5;
-    static constexpr uint32_t kASets = kCt == 4 ? 2 : 3;              // steps a wave's five tiles touch
+    static constexpr uint32_t kTilesPerWave = kSteps * kCt / kWaves;  // 5, or 4
+    static constexpr uint32_t kKcSets = HB ? 2 : (kCt == 4 ? 2 : 3);  // steps a wave's tiles touch
+    static constexpr uint32_t kASets = HB ? 1 : kKcSets;              // ... and the coefficient images they need (half-band: the one there is)
     static constexpr uint32_t kHalf = kCt * 128;                      // a digit plane's chunk: [half of its frames 2][column tile][column 16][8 frames]
     static constexpr uint32_t kChunk = 2 * kHalf;
-    static constexpr uint32_t kDigit = kWgChunks * kChunk;
+    static constexpr uint32_t kDigit = kPlaneChunks * kChunk;
     static constexpr uint32_t kPlaneBytes = 3 * kDigit;
+    static constexpr uint32_t kBiasSteps = HB ? 1 : kSteps;           // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
+    static constexpr uint32_t kBiasBytes = kBiasSteps * 768;
     static constexpr uint32_t kInBytes = kSR * kRowInPitch;           // the input image ...
     static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOut;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
     static constexpr uint32_t kStageBytes = kInBytes > kOutBytes ? kInBytes : kOutBytes;
-    static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kWgBiasBytes;
+    static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kBiasBytes;
     static constexpr uint32_t kGroupsPerCu = ROWS == 32 ? 2 : 3;
     static constexpr uint32_t kSubUnits = kUnitRows / kSR;            // passes per planner unit
     static constexpr uint32_t kOutPieces = kSR * (kRowOut / 16);
     static constexpr uint32_t kStoreRounds = (kOutPieces + kThreads - 1) / kThreads;
     static_assert(kGroupsPerCu * kLdsBytes <= 160 * 1024, "workgroups per CU");
-    static_assert(kTilesPerWave * kWaves == kWgSteps * kCt, "five tiles per wave");
-    static_assert(kSR * kRowLanes <= kThreads && kRowIn == 72 * 16 * PAIRS && kSubUnits * kSR == kUnitRows, "lanes per row of the input image, 4.5 pieces each");
+    static_assert(kTilesPerWave * kWaves == kSteps * kCt, "whole tiles per wave");
+    static_assert(kSR * kRowLanes <= kThreads && kRowIn == (2 * kFullRounds + 1) * 8 * 16 * PAIRS && kSubUnits * kSR == kUnitRows, "lanes per row of the input image, 4.5 (7.5) pieces each");
+    static_assert(!HB || (kChunksA * 16 * kFb <= kRoundsA * kRound && (kChunksA * 16 * kFb) >= (kRoundsA - 1) * kRound), "the two stagings meet in chunk 13");
 };
 
 #ifndef MF_DIAG_BARRIER_MASK
@@ -115,7 +129,7 @@ __device__ __noinline__ u32x4 wg_load_piece_checked(const uint8_t* __restrict__ 
 // PLANAR: 0 = packed 24-bit stereo frames (SRC_LE: their byte order); 1 + k = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32 (one per
 // channel, `src_plane_stride` apart, host byte order), the sample being the low 24 - 8 k bits of a plane's value shifted up k bytes
 // (k = 0, 1, 2 for 24-, 16- and 8-bit streams: CodecFlac::CallbackWrite's pack, Flac.cpp:379-417, folded into the load).
-template <int ROWS, int PLANAR, int PAIRS, bool SRC_LE, bool DST_LE>
+template <int ROWS, int PLANAR, int PAIRS, bool HB, bool SRC_LE, bool DST_LE>
 __global__ __launch_bounds__(WgGeom<ROWS>::kThreads) __attribute__((amdgpu_waves_per_eu(ROWS == 32 ? 4 : 3, ROWS == 32 ? 4 : 3)))
 void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
                         const uint8_t* __restrict__ amat, const MfStep* __restrict__ steps,
@@ -123,7 +137,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                         const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                         const uint32_t row_src_bytes, const uint64_t src_arena_bytes)
 {
-    using G = WgGeom<ROWS, PLANAR, PAIRS>;
+    using G = WgGeom<ROWS, PLANAR, PAIRS, HB>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const pl_lds = smem;
     uint8_t* const stage = smem + G::kPlaneBytes;
@@ -136,19 +150,22 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t step0 = tile0 / G::kCt;
 
     // the accumulators' initial values (MfStep::b0..b2) of the block's steps
-    for (uint32_t i = tid; i < kWgSteps * 48u; i += G::kThreads) {
+    for (uint32_t i = tid; i < G::kBiasSteps * 48u; i += G::kThreads) {
         const uint32_t t = i / 48u, r = i - 48u * t;
         const uint32_t v = steps[t].b0[r];                 // (b0, b1, b2 lie one after the other)
         ((u32x4*)bias_lds)[i] = u32x4{v, v, v, v};
     }
     // this wave's A operands, for good
     v4i a[G::kASets][4];
-    uint32_t kc[G::kASets];
+    uint32_t kc[G::kKcSets];
 #pragma unroll
-    for (int q = 0; q < (int)G::kASets; q++) {
-        const uint32_t st = step0 + q < kWgSteps ? step0 + q : kWgSteps - 1u;     // (a set past the last step is never used)
+    for (int q = 0; q < (int)G::kKcSets; q++) {
+        const uint32_t st = step0 + q < G::kSteps ? step0 + q : G::kSteps - 1u;   // (a set past the last step is never used)
+        if (q < (int)G::kASets) {
+            const uint32_t image = HB ? 0u : st;                                   // (half-band: one image for every step)
 #pragma unroll
-        for (int j = 0; j < 4; j++) a[q][j] = *(const v4i*)(amat + ((uint64_t)st * kMfStepImage + j * 1024u + lane * 16u));
+            for (int j = 0; j < 4; j++) a[q < (int)G::kASets ? q : 0][j] = *(const v4i*)(amat + ((uint64_t)image * kMfStepImage + j * 1024u + lane * 16u));
+        }
         kc[q] = steps[st].kc;
     }
 
@@ -157,7 +174,9 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     // output n of the step, K group g); the result's lane (g, n) then holds output frame n of the four columns 4 g .. 4 g + 3 =
     // rows 2 g and 2 g + 1 of the tile, both channels: a whole frame of each in one lane, nothing to exchange
     const uint32_t g = lane >> 4, n = lane & 15;
-    const uint8_t* const b_lds = pl_lds + g * G::kChunk + n * 8u;                 // + kc * chunk + digit * kDigit + ((half * kHalf + tile * 128) ^ parity of the chunk * 128)
+    // (half-band: K groups 0..2 are the even-frame chunks kc .. kc + 2, group 3 the odd-frame chunk kc + 1 = plane chunk 10 + kc + 1)
+    const uint32_t g_chunk = HB ? (g < 3u ? g : 11u) : g;
+    const uint8_t* const b_lds = pl_lds + g_chunk * G::kChunk + n * 8u;           // + kc * chunk + digit * kDigit + ((half * kHalf + tile * 128) ^ parity of the chunk * 128)
     const uint8_t* const my_bias = bias_lds + 16u * n;                            // + step * 768: b0; b1 at + 256, b2 at + 512
     // where the lane's frame of pair-row 2 g lies in the output image (+ 16 frames per step; + 8 pair-rows per column tile; the pair-row
     // 2 g + 1 is the next row (stereo) or the next pair of the same row (eight channels); six channels: out_at below)
@@ -172,7 +191,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t in_row = in_row_of < G::kSR ? in_row_of : G::kSR - 1u;
     const uint32_t in_src = in_row * row_src_bytes + 16u * in_sub;                 // + kRound k
     const uint32_t in_lds = in_row * G::kRowInPitch + 16u * in_sub;
-    const uint32_t in_last = in_sub < G::kRowLanes / 2u ? 4u * G::kRound : 0u;     // (packed: the fifth round's spare lanes repeat their first piece)
+    // (packed: the half round's spare lanes repeat an earlier piece of theirs -- the first; half-band: the fifth, which is staged with it)
+    const uint32_t in_last = in_sub < G::kRowLanes / 2u ? G::kFullRounds * G::kRound : (HB ? (G::kRoundsA - 1u) * G::kRound : 0u);
     // the split: task q = threads * k + tid (k = 0, 1; q < 24 ROWS) is half chunk q / ROWS of pair-row q % ROWS (the pair-rows side by side)
     const uint32_t sp_row = tid % (uint32_t)ROWS, sp_hc0 = tid / (uint32_t)ROWS;   // (0..15; second round: half chunk + 16 while < 24)
     const uint32_t sp_used = sp_row < G::kSR * (uint32_t)PAIRS ? sp_row : G::kSR * (uint32_t)PAIRS - 1u;    // (six channels: the idle pair-row repeats the fifteenth)
@@ -192,7 +212,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         o.src0 = w.src_row0 + (int64_t)(r0 * row_src_bytes);
         o.dst0 = w.dst_row0 + (int64_t)(r0 * G::kRowOut);
         o.n_blocks = w.n_blocks > r0 ? (w.n_blocks - r0 < G::kSR ? w.n_blocks - r0 : G::kSR) : 0u;
-        o.plane = w.plane + r0 * 20u;                       // (a plane row is 160 entries of 2 bytes = 20 of the plane stride's 16)
+        o.plane = w.plane + r0 * (G::kOutFrames / 8u);     // (a plane row is 160 (128) entries of 2 bytes = 20 (16) of the plane stride's 16)
         o.plane_stride = w.src_plane_stride;
         o.ramped = (w.flags & kWorkRamped) != 0;
         o.first = (w.flags & kWorkFirst) != 0 && sub == 0;
@@ -215,7 +235,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #pragma unroll
             for (int k = 0; k < (int)G::kInRounds; k++) {
                 const int64_t at = PLANAR ? (int64_t)(in_src + 256u * (uint32_t)(k % 3)) + (int64_t)(k / 3) * w.plane_stride
-                                          : (int64_t)(k < 4 ? in_src + G::kRound * (uint32_t)k : in_src + in_last);
+                                          : (int64_t)(k < (int)G::kFullRounds ? in_src + G::kRound * (uint32_t)k : in_src + in_last);
                 raw[k] = wg_load_piece_checked(src, w.src0 + at, src_arena_bytes);
             }
         } else if constexpr (PLANAR != 0) {
@@ -228,8 +248,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         } else {
             const uint32_t o = mf_here(in_src);
 #pragma unroll
-            for (int k = 0; k < 4; k++) raw[k] = *(const u32x4_u*)(base + o + (int)G::kRound * k);
-            raw[4] = *(const u32x4_u*)(base + mf_here(in_src + in_last));
+            for (int k = 0; k < (int)G::kFullRounds; k++) raw[k] = *(const u32x4_u*)(base + o + (int)G::kRound * k);
+            raw[G::kFullRounds] = *(const u32x4_u*)(base + mf_here(in_src + in_last));
         }
 #endif
     };
@@ -245,6 +265,58 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             for (int k = 0; k < 4; k++) *(u32x4*)(stage + in_lds + (int)G::kRound * k) = raw[k];
             *(u32x4*)(stage + in_lds + in_last) = raw[4];
         }
+    };
+    // half-band: the image in two sections over the same LDS -- section 0 = the lanes' rounds 0..4 (bytes 0 .. 5 kRound of every row:
+    // input chunks 0..12 whole), section 1 = rounds 4..7 (bytes 4 kRound .. 7.5 kRound, stored from the row's start: chunks 13..19)
+    auto stage_section = [&](auto sec_c, const u32x4 (&raw)[G::kInRounds]) __attribute__((always_inline)) {
+#ifdef MF_DIAG_NO_STAGE
+        return;
+#endif
+        constexpr int SEC = decltype(sec_c)::value;
+        if constexpr (SEC == 0) {
+#pragma unroll
+            for (int k = 0; k < (int)G::kRoundsA; k++) *(u32x4*)(stage + in_lds + (int)G::kRound * k) = raw[k];
+        } else {
+#pragma unroll
+            for (int k = (int)G::kRoundsA - 1; k < (int)G::kFullRounds; k++) *(u32x4*)(stage + in_lds + (int)G::kRound * (k - ((int)G::kRoundsA - 1))) = raw[k];
+            *(u32x4*)(stage + in_lds + (in_last - (G::kRoundsA - 1u) * G::kRound)) = raw[G::kFullRounds];
+        }
+    };
+    // ... and its split: task t of a section = (pair-row t % ROWS, input chunk and parity t / ROWS): the chunk's eight EVEN frames (or its
+    // eight odd ones) of the lane's channel pair -> half `chunk & 1` of plane chunk `chunk / 2` (+ 10 for the odd frames)
+    auto split_hb_task = [&](uint32_t t, uint32_t first_chunk, uint32_t image_byte0, bool first) __attribute__((always_inline)) {
+        const uint32_t t2 = t / (uint32_t)ROWS, ic = first_chunk + (t2 >> 1), par = t2 & 1u;
+        const bool zero = first && sp_srow == 0 && ic < 4u;         // the stream's block 0: the 64 frames before it read as zeros
+        const uint32_t byte0 = sp_srow * G::kRowInPitch + (ic * (16u * G::kFb) - image_byte0) + par * G::kFb + 6u * sp_pair;
+        const uint32_t at = byte0 & ~3u, sh = (byte0 & 2u) * 8u;  // (frames 2 kFb apart: all of them as far off a dword as the first)
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const u32x2 e = *(const u32x2_a4*)(stage + at + 2 * (int)G::kFb * m);
+            const uint64_t v = (((uint64_t)e.y << 32) | e.x) >> sh;
+            lo[m] = zero ? 0u : (uint32_t)v; hi[m] = zero ? 0u : (uint32_t)(v >> 32);
+        }
+        uint32_t pl[6][2];
+        mf_split_frames(lo, hi, pl);
+        const uint32_t c = par * 10u + (ic >> 1);
+        uint8_t* const to = pl_lds + c * G::kChunk + (((ic & 1u) * G::kHalf + sp_row * 16u) ^ ((c & 1u) * 128u));     // + digit * kDigit
+#pragma unroll
+        for (int bpos = 0; bpos < 3; bpos++) {
+            const int digit = SRC_LE ? bpos : 2 - bpos;
+            const uint32_t flip = digit < 2 ? 0x80808080u : 0u;
+            *(u32x4*)(to + digit * G::kDigit) = u32x4{pl[bpos][0] ^ flip, pl[bpos][1] ^ flip, pl[3 + bpos][0] ^ flip, pl[3 + bpos][1] ^ flip};
+        }
+    };
+    auto split_section = [&](auto sec_c, bool first) __attribute__((always_inline)) {
+#ifdef MF_DIAG_NO_SPLIT
+        return;
+#endif
+        constexpr int SEC = decltype(sec_c)::value;
+        constexpr uint32_t kFirstChunk = SEC == 0 ? 0u : G::kChunksA, kChunks = SEC == 0 ? G::kChunksA : G::kImgChunks - G::kChunksA;
+        constexpr uint32_t kTasks = kChunks * 2u * (uint32_t)ROWS, kByte0 = SEC == 0 ? 0u : (G::kRoundsA - 1u) * G::kRound;
+#pragma unroll
+        for (uint32_t k = 0; k * G::kThreads < kTasks; k++)
+            if (k * G::kThreads + tid < kTasks) split_hb_task(k * G::kThreads + tid, kFirstChunk, kByte0, first);
     };
     auto split_task = [&](uint32_t hc, bool first) __attribute__((always_inline)) {
         // the stream's block 0: the frames before it (chunks 0 and 1 of row 0) read as zeros
@@ -317,6 +389,22 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         split_task(sp_hc0, first);
         if (sp_hc0 < 8u) split_task(sp_hc0 + 16u, first);
     };
+    // a pass's input, from the registers it arrived in to the planes
+    auto stage_and_split = [&](const u32x4 (&raw)[G::kInRounds], bool first) __attribute__((always_inline)) {
+        if constexpr (HB) {
+            stage_section(std::integral_constant<int, 0>{}, raw);
+            wg_barrier<2>();
+            split_section(std::integral_constant<int, 0>{}, first);
+            wg_barrier<2>();                                 // section 0 has been read
+            stage_section(std::integral_constant<int, 1>{}, raw);
+            wg_barrier<2>();
+            split_section(std::integral_constant<int, 1>{}, first);
+        } else {
+            stage_input(raw);
+            wg_barrier<2>();
+            split_all(first);
+        }
+    };
 
     // Units are dealt round robin: they cost the same (a ramped one a few instructions per tile more), so a workgroup's share
     // is even to within one unit in a hundred, and a unit index that is a launch constant plus a counter stays in scalar registers --
@@ -329,9 +417,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     u32x4 raw[G::kInRounds];
     issue_input(wk, raw);
     __syncthreads();                                        // (the bias table)
-    stage_input(raw);
-    wg_barrier();
-    split_all(wk.first);
+    stage_and_split(raw, wk.first);
     Unit wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
     issue_input(wk_nxt, raw);                               // (past the last unit: the current one again, never used)
     wg_barrier();
@@ -347,7 +433,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         auto read_planes = [&](uint32_t kcs, uint32_t ct, v4i (&bd)[3]) __attribute__((always_inline)) {
             // six 8-byte reads, written out (the compiler pairs the halves into ds_read2st64_b64, which the LDS serves at half the
             // rate), with their wait in the same statement: what leaves it is data, whatever the compiler copies afterwards
-            const uint32_t in_chunk = (ct * 128u) ^ (((kcs + g) & 1u) * 128u);
+            const uint32_t in_chunk = (ct * 128u) ^ (((kcs + g_chunk) & 1u) * 128u);
             const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(b_lds + kcs * G::kChunk + in_chunk);
             u32x2 h[6];
             asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:%7\n\t"
@@ -363,18 +449,18 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         auto run_tiles = [&](auto pattern_c, auto ramped_c) __attribute__((always_inline)) {
             constexpr uint32_t P = decltype(pattern_c)::value;
             constexpr bool RAMPED = decltype(ramped_c)::value;
-            constexpr uint32_t kFirst = 5u * P;                          // the pattern's first tile, counted from a multiple of five steps
+            constexpr uint32_t kFirst = G::kTilesPerWave * P;           // the pattern's first tile, counted from a multiple of kTilesPerWave steps
             v4i bd[3];
             read_planes(kc[0], kFirst % G::kCt, bd);
             static_for([&](auto ic) __attribute__((always_inline)) {
                 constexpr uint32_t i = decltype(ic)::value;
                 constexpr uint32_t set = (kFirst + i) / G::kCt - kFirst / G::kCt, ct = (kFirst + i) % G::kCt;
-                static_assert(set < G::kASets, "a wave's tiles touch kASets steps");
+                static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
                 const uint32_t step = step0 + set;
-                const uint8_t* const bi = my_bias + step * 768u;
+                const uint8_t* const bi = my_bias + (HB ? 0u : step * 768u);
                 v4i s0 = *(const v4i*)bi, s1 = v4i{0, 0, 0, 0}, s2 = *(const v4i*)(bi + 256), s3 = v4i{0, 0, 0, 0},
                     s4 = *(const v4i*)(bi + 512), s5 = v4i{0, 0, 0, 0};
-                const v4i (&c)[4] = a[set];
+                const v4i (&c)[4] = a[HB ? 0 : set];
                 s0 = MF_MFMA(bd[0], c[0], s0);
                 s1 = MF_MFMA(bd[0], c[1], s1);
                 s2 = MF_MFMA(bd[0], c[2], s2);
@@ -399,8 +485,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero; the
                     // multiplier of the lane's frame in each of its two rows comes from the unit's plane (0xffff: the frame's message has no ramp)
                     const uint32_t row0 = pair_row_srow(ct, 0), row1 = pair_row_srow(ct, 1);
-                    const uint32_t e0 = (row0 < n_blocks ? row0 * 160u : 0u) + 16u * step + n;
-                    const uint32_t e1 = (row1 < n_blocks ? row1 * 160u : 0u) + 16u * step + n;
+                    const uint32_t e0 = (row0 < n_blocks ? row0 * G::kOutFrames : 0u) + 16u * step + n;
+                    const uint32_t e1 = (row1 < n_blocks ? row1 * G::kOutFrames : 0u) + 16u * step + n;
                     uint32_t mu[2];
                     mu[0] = *(const uint16_t*)(mbase + mf_here(2u * e0));
                     if constexpr (PAIRS == 4) mu[1] = mu[0];         // (pair-rows 2 g and 2 g + 1 are pairs of one row)
@@ -448,7 +534,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
         // unit's input -- requested a whole phase (C) ago -- is waited for HERE, in front of the stores, not behind them ----
         asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]));
-        if constexpr (PLANAR != 0) asm volatile("" : "+v"(raw[5]));
+        if constexpr (G::kInRounds > 5) asm volatile("" : "+v"(raw[5]));
+        if constexpr (G::kInRounds > 6) asm volatile("" : "+v"(raw[6]), "+v"(raw[7]));
         {
             uint8_t* const unit_dst = dst + wk.dst0;
             const uint32_t out_bytes = n_blocks * G::kRowOut;
@@ -473,9 +560,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         if (u_nxt >= n_work) break;                         // (uniform)
 
         // ---- (A) + (S) the next unit: registers -> input image -> planes; then its successor's input is requested ----
-        stage_input(raw);
-        wg_barrier<2>();
-        split_all(wk_nxt.first);
+        stage_and_split(raw, wk_nxt.first);
         wk = wk_nxt;
         u_cur = u_nxt;
         u_nxt += n_groups;
@@ -488,28 +573,29 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     }
 }
 
-bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar)
+bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar, bool halfband)
 {
     // (planar: sb is the stream's sample size, 1..3 bytes, whatever the planes hold above it; packed: stereo, six or eight channels of S24)
-    const bool layout = planar ? (ch == 2 && sb >= 1 && sb <= 3) : ((ch == 2 || ch == 6 || ch == 8) && sb == 3);
-    return layout && db == 3 && L_blk == 16u * kWgSteps && (M_blk + 31u) / 16u + 1u == kWgChunks;
+    const bool layout = planar ? (ch == 2 && sb >= 1 && sb <= 3 && !halfband) : ((ch == 2 || ch == 6 || ch == 8) && sb == 3);
+    if (halfband) return layout && db == 3 && L_blk == 128u && M_blk == 256u;          // (2:1: WgGeom<.., HB>)
+    return layout && db == 3 && L_blk == 160u && (M_blk + 31u) / 16u + 1u == 12u;     // (160 outputs from at most 160 inputs + 32 of history: twelve chunks)
 }
 
-// does a unit's input image -- 64 / channels rows of 192 frames, whatever the number of blocks the unit holds -- lie inside the arena?
-bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, bool planar, uint64_t plane_stride)
+// does a unit's input image -- 64 / channels rows of 192 (half-band: 320) frames, whatever the number of blocks the unit holds -- lie inside the arena?
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, bool planar, uint64_t plane_stride, bool halfband)
 {
-    const uint64_t row_in = planar ? kWgPlaneIn : kWgChunks * 16u * 3u * ch, last_plane = planar ? plane_stride : 0;
+    const uint64_t row_in = planar ? kWgPlaneIn : (halfband ? 320u : 192u) * 3u * ch, last_plane = planar ? plane_stride : 0;
     return src_row0 >= 0 && (uint64_t)src_row0 + last_plane + (uint64_t)(64u / ch - 1u) * row_src_bytes + row_in <= src_arena_bytes;
 }
 
-template <int PLANAR, int PAIRS, bool SRC_LE, bool DST_LE>
+template <int PLANAR, int PAIRS, bool HB, bool SRC_LE, bool DST_LE>
 static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
 {
-    using G = WgGeom<OHGPU_WG_ROWS, PLANAR, PAIRS>;
-    auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, PAIRS, SRC_LE, DST_LE>;
+    using G = WgGeom<OHGPU_WG_ROWS, PLANAR, PAIRS, HB>;
+    auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, PAIRS, HB, SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
     if (f.n_lean == 0) return hipSuccess;
-    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0) || p.channels != 2u * PAIRS) return hipErrorInvalidValue;
+    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0, HB) || p.channels != 2u * PAIRS) return hipErrorInvalidValue;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     const uint32_t n_units = f.n_lean * G::kSubUnits;                // (edge units included: their loads are checked)
     uint32_t gsz = G::kGroupsPerCu * cus;                     // as many workgroups as the LDS holds
@@ -522,11 +608,11 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     return hipGetLastError();
 }
 
-template <int PAIRS>
+template <int PAIRS, bool HB>
 static hipError_t launch_wg_packed(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& prm, hipStream_t s)
 {
-    if (prm.src_le) return prm.dst_le ? launch_wg_one<0, PAIRS, true, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, true, false>(ctx, b, prm, s);
-    return prm.dst_le ? launch_wg_one<0, PAIRS, false, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, false, false>(ctx, b, prm, s);
+    if (prm.src_le) return prm.dst_le ? launch_wg_one<0, PAIRS, HB, true, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, HB, true, false>(ctx, b, prm, s);
+    return prm.dst_le ? launch_wg_one<0, PAIRS, HB, false, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, HB, false, false>(ctx, b, prm, s);
 }
 
 hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
@@ -536,16 +622,17 @@ hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const 
     prm.dst = dst;
     if (b->src_planar) {
         switch (prm.sb) {                                    // (the stream's bytes per sample)
-        case 3: return prm.dst_le ? launch_wg_one<1, 1, true, true>(ctx, b, prm, s) : launch_wg_one<1, 1, true, false>(ctx, b, prm, s);
-        case 2: return prm.dst_le ? launch_wg_one<2, 1, true, true>(ctx, b, prm, s) : launch_wg_one<2, 1, true, false>(ctx, b, prm, s);
-        case 1: return prm.dst_le ? launch_wg_one<3, 1, true, true>(ctx, b, prm, s) : launch_wg_one<3, 1, true, false>(ctx, b, prm, s);
+        case 3: return prm.dst_le ? launch_wg_one<1, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<1, 1, false, true, false>(ctx, b, prm, s);
+        case 2: return prm.dst_le ? launch_wg_one<2, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<2, 1, false, true, false>(ctx, b, prm, s);
+        case 1: return prm.dst_le ? launch_wg_one<3, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<3, 1, false, true, false>(ctx, b, prm, s);
         default: return hipErrorInvalidValue;
         }
     }
+    const bool hb = b->fast.mfma_wg_halfband;
     switch (prm.channels) {
-    case 2: return launch_wg_packed<1>(ctx, b, prm, s);
-    case 6: return launch_wg_packed<3>(ctx, b, prm, s);
-    case 8: return launch_wg_packed<4>(ctx, b, prm, s);
+    case 2: return hb ? launch_wg_packed<1, true>(ctx, b, prm, s) : launch_wg_packed<1, false>(ctx, b, prm, s);
+    case 6: return hb ? launch_wg_packed<3, true>(ctx, b, prm, s) : launch_wg_packed<3, false>(ctx, b, prm, s);
+    case 8: return hb ? launch_wg_packed<4, true>(ctx, b, prm, s) : launch_wg_packed<4, false>(ctx, b, prm, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -163,11 +163,13 @@ def test_plain_64_tap_kernels_still_run(ctx):
 @pytest.mark.parametrize("src_le", [True, False], ids=["sle", "sbe"])
 @pytest.mark.parametrize("dst_le", [True, False], ids=["dle", "dbe"])
 @pytest.mark.parametrize("n_streams, seconds", [(3, 0.31), (14, 0.83)])
-def test_workgroup_matrix_kernel_takes_packed_s24_of_two_six_and_eight_channels(ctx, channels, src_le, dst_le, n_streams, seconds):
-    """44.1 -> 48 kHz S24 in either byte order, ramped heads and tails, stream lengths that leave the last unit of a stream partly
-    filled (a pass of 16 / 5 / 4 rows with fewer blocks than rows, and one with none) and put units at both ends of the arena (the
-    checked loads): src_mfma_wg_kernel runs them all and the audio is the integer model's, byte for byte."""
-    g = bench.Group(capi, 44100, channels, range(300, 300 + n_streams), int(round(seconds * 44100)), src_bits=24,
+@pytest.mark.parametrize("rate", [44100, 96000])
+def test_workgroup_matrix_kernel_takes_packed_s24_of_two_six_and_eight_channels(ctx, channels, src_le, dst_le, n_streams, seconds, rate):
+    """44.1 -> 48 kHz (32 taps per phase) and 96 -> 48 kHz (the half-band decimator) S24 in either byte order, ramped heads and
+    tails, stream lengths that leave the last unit of a stream partly filled (a pass of 16 / 5 / 4 rows with fewer blocks than
+    rows, and one with none) and put units at both ends of the arena (the checked loads): src_mfma_wg_kernel runs them all and the
+    audio is the integer model's, byte for byte."""
+    g = bench.Group(capi, rate, channels, range(300, 300 + n_streams), int(round(seconds * rate)), src_bits=24,
                     src_endian=capi.ENDIAN_LITTLE if src_le else capi.ENDIAN_BIG, dst_bits=24,
                     dst_endian=capi.ENDIAN_LITTLE if dst_le else capi.ENDIAN_BIG)
     per = g.in_frames * channels

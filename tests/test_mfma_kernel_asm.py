@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ohpipeline_amd", "csrc")
 OUTDIR = os.path.join(ROOT, "ohpipeline_amd", "build")
-NAME = re.compile(r"_ZN5ohgpu18src_mfma_wg_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)EE\w+")     # <pair-rows, planar, channel pairs, src LE, dst LE>
+NAME = re.compile(r"_ZN5ohgpu18src_mfma_wg_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)EE\w+")     # <pair-rows, planar, channel pairs, half-band, src LE, dst LE>
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +44,7 @@ def wg():
         m = re.search(r"\.name:\s+(" + NAME.pattern + r")\n", entry)
         if m:
             meta[m.group(1)] = entry
-    assert len(found) >= 18 and set(found) == set(meta), (len(found), len(meta))
+    assert len(found) >= 30 and set(found) == set(meta), (len(found), len(meta))
     return {n: (int(NAME.match(n).group(1)), int(NAME.match(n).group(2)) + 10 * (int(NAME.match(n).group(3)) - 1), found[n], meta[n]) for n in found}
 
 
