@@ -63,7 +63,7 @@ struct WgGeom {
     static constexpr uint32_t kPlaneChunks = kImgChunks;              // ... and of its digit planes (half-band: ten of even frames, then ten of odd ones)
     static constexpr uint32_t kFb = 6u * PAIRS;                       // bytes of a frame, in and out (24-bit samples)
     static constexpr uint32_t kSR = ROWS / PAIRS;                     // stream rows of a pass: 16, 5 (fifteen of the sixteen pair-rows) or 4
-    static constexpr uint32_t kUnitRows = 32u / PAIRS;                // rows of a planner unit (LeanUnit): 64 / channels, src_block_geometry
+    static constexpr uint32_t kUnitRows = PAIRS == 3 ? 30u : 32u;     // rows of a planner unit (LeanUnit: src_plan.cpp cuts them this long for this kernel): a whole number of passes
     static constexpr uint32_t kRowIn = kImgChunks * 16u * kFb;        // bytes of a row's input image, packed
     static constexpr uint32_t kRowLanes = 16u * PAIRS;                // lanes that move one row of the input image, 4.5 (7.5) pieces each (planar: 6)
     static constexpr uint32_t kRound = 16u * kRowLanes;               // ... and the bytes of it one round of them moves
@@ -581,11 +581,11 @@ bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t
     return layout && db == 3 && L_blk == 160u && (M_blk + 31u) / 16u + 1u == 12u;     // (160 outputs from at most 160 inputs + 32 of history: twelve chunks)
 }
 
-// does a unit's input image -- 64 / channels rows of 192 (half-band: 320) frames, whatever the number of blocks the unit holds -- lie inside the arena?
-bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, bool planar, uint64_t plane_stride, bool halfband)
+// does a unit's input image -- `unit_rows` rows of 192 (half-band: 320) frames, whatever the number of blocks the unit holds -- lie inside the arena?
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, uint32_t unit_rows, bool planar, uint64_t plane_stride, bool halfband)
 {
     const uint64_t row_in = planar ? kWgPlaneIn : (halfband ? 320u : 192u) * 3u * ch, last_plane = planar ? plane_stride : 0;
-    return src_row0 >= 0 && (uint64_t)src_row0 + last_plane + (uint64_t)(64u / ch - 1u) * row_src_bytes + row_in <= src_arena_bytes;
+    return src_row0 >= 0 && unit_rows >= 1 && (uint64_t)src_row0 + last_plane + (uint64_t)(unit_rows - 1u) * row_src_bytes + row_in <= src_arena_bytes;
 }
 
 template <int PLANAR, int PAIRS, bool HB, bool SRC_LE, bool DST_LE>
@@ -595,7 +595,7 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, PAIRS, HB, SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
     if (f.n_lean == 0) return hipSuccess;
-    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0, HB) || p.channels != 2u * PAIRS) return hipErrorInvalidValue;
+    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0, HB) || p.channels != 2u * PAIRS || f.wg_unit_rows != G::kUnitRows) return hipErrorInvalidValue;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     const uint32_t n_units = f.n_lean * G::kSubUnits;                // (edge units included: their loads are checked)
     uint32_t gsz = G::kGroupsPerCu * cus;                     // as many workgroups as the LDS holds

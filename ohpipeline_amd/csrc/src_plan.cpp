@@ -156,6 +156,11 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const bool mfma_wg = wg_tables && (planar || mfma || wg_wide) && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db, planar, wg_hb) &&
                          !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
     if (wg_only && !mfma_wg) return OHGPU_OK;
+    // The workgroup kernel walks a unit in passes of 16, 5 or 4 rows (WgGeom::kSR) and does not care how many a unit holds: six- and
+    // eight-channel units are cut 30 and 32 rows long instead of the lean kernel's 10 and 8 -- a third to a quarter of the units to
+    // plan, upload and fetch.  Such a plan is the workgroup kernel's alone (any variant that asks for another gets the generic one).
+    const bool wg_long_units = mfma_wg && !planar && ch > 2;
+    if (wg_long_units) rows = ch == 6 ? 30u : 32u;
 
 #ifdef OHGPU_PLAN_TIMING
     std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> tps;
@@ -404,7 +409,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             else if (unit_leaves_arena(segs[r.seg].src_base, u.src_plane_stride, bk, n_rows, kb)) u.flags |= kWorkChecked;
             // the workgroup kernel reads 32 rows' worth of input per unit whatever the unit holds and checks nothing: the (at most two)
             // units of a batch for which that leaves the arena stay with the unit-per-wave kernel
-            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, ch, planar, (uint64_t)(ch - 1) * u.src_plane_stride, wg_hb)) u.flags |= kWorkEdge;
+            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, ch, rows, planar, (uint64_t)(ch - 1) * u.src_plane_stride, wg_hb)) u.flags |= kWorkEdge;
             if (u.flags & kWorkRamped) {
                 // one plane of multipliers per ramped unit -- n_rows * L_blk entries (uint16, 0xffff = no ramp on that frame), in
                 // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16
@@ -599,7 +604,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.lean = lean;
     f.lean_only = lean_only;
     f.lean_halfband = lean_hb;
-    f.wg_only = wg_only;
+    f.wg_only = wg_only || wg_long_units;
     f.lean_coef_lds_bytes = lean_coef;
     f.lean_wave_lds_bytes = lean_wave_lds;
     f.plane_stride = 16;                                              // SrcWork::plane counts 16-byte pieces
@@ -607,6 +612,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.mfma = mfma;
     f.mfma_wg = mfma_wg;
     f.mfma_wg_halfband = mfma_wg && wg_hb;
+    f.wg_unit_rows = mfma_wg ? rows : 0u;
     f.n_wg = 0;
     if (mfma_wg) for (const LeanUnit& u : lean_units) f.n_wg += (u.flags & kWorkEdge) ? 0u : 1u;
     f.d_mf_amat = (mfma || mfma_wg) ? flt->d_mf_amat : nullptr;
