@@ -68,7 +68,13 @@ struct WgGeom {
     static constexpr uint32_t kRowLanes = 16u * PAIRS;                // lanes that move one row of the input image, 4.5 (7.5) pieces each (planar: 6)
     static constexpr uint32_t kRound = 16u * kRowLanes;               // ... and the bytes of it one round of them moves
     static constexpr uint32_t kFullRounds = HB ? 7 : 4;               // whole rounds; then half a round
-    static constexpr uint32_t kInRounds = PLANAR ? 6 : kFullRounds + 1;
+    // Packed sources (but the half-band form): a pass's rows overlap -- row r + 1 starts M_blk frames after row r and an image is 192
+    // frames long -- so the pass fetches their UNION, one run of at most 1024 16-byte pieces from the first row's start (four rounds
+    // of the workgroup's lanes, every instruction 4 KB contiguous), and the split finds a row at r * row_src_bytes in it: a fifth
+    // fewer loads and stage writes than row by row, and 5 % off the headline launch (0.317 -> 0.300 ms, same box, before the split paid for it).
+    static constexpr bool kSpan = PLANAR == 0 && !HB;
+    static constexpr uint32_t kSpanBytes = 1024u * 16u;
+    static constexpr uint32_t kInRounds = PLANAR ? 6 : (kSpan ? 4 : kFullRounds + 1);
     static constexpr uint32_t kRoundsA = HB ? 5 : kInRounds;          // half-band: the rounds of the first staging (the second: kRoundsA - 1 ..)
     static constexpr uint32_t kChunksA = HB ? 13 : kImgChunks;        // ... and the input chunks it holds whole
     static constexpr uint32_t kRowInPitch = PLANAR ? 2 * kWgPlaneIn + 16 : (HB ? kRoundsA * kRound + 16 : kRowIn + 16);   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
@@ -85,7 +91,7 @@ struct WgGeom {
     static constexpr uint32_t kPlaneBytes = 3 * kDigit;
     static constexpr uint32_t kBiasSteps = HB ? 1 : kSteps;           // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
     static constexpr uint32_t kBiasBytes = kBiasSteps * 768;
-    static constexpr uint32_t kInBytes = kSR * kRowInPitch;           // the input image ...
+    static constexpr uint32_t kInBytes = kSpan ? kSpanBytes : kSR * kRowInPitch;   // the input image ...
     static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOut;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
     static constexpr uint32_t kStageBytes = kInBytes > kOutBytes ? kInBytes : kOutBytes;
     static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kBiasBytes;
@@ -96,6 +102,9 @@ struct WgGeom {
     static_assert(kGroupsPerCu * kLdsBytes <= 160 * 1024, "workgroups per CU");
     static_assert(kTilesPerWave * kWaves == kSteps * kCt, "whole tiles per wave");
     static_assert(kSR * kRowLanes <= kThreads && kRowIn == (2 * kFullRounds + 1) * 8 * 16 * PAIRS && kSubUnits * kSR == kUnitRows, "lanes per row of the input image, 4.5 (7.5) pieces each");
+    // (the union of a pass's rows: at most kOutFrames input frames from one row to the next -- the block geometry src_mfma_wg_supported
+    // admits -- and at least 145, so that only the fourth round has pieces past its end)
+    static_assert(!kSpan || ((kSR - 1) * kOutFrames * kFb + kRowIn <= kSpanBytes && (kSR - 1) * 145 * kFb + kRowIn > 768 * 16 && kThreads == 256), "a pass's rows in four rounds");
     static_assert(!HB || (kChunksA * 16 * kFb <= kRoundsA * kRound && (kChunksA * 16 * kFb) >= (kRoundsA - 1) * kRound), "the two stagings meet in chunk 13");
 };
 
@@ -197,6 +206,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t sp_row = tid % (uint32_t)ROWS, sp_hc0 = tid / (uint32_t)ROWS;   // (0..15; second round: half chunk + 16 while < 24)
     const uint32_t sp_used = sp_row < G::kSR * (uint32_t)PAIRS ? sp_row : G::kSR * (uint32_t)PAIRS - 1u;    // (six channels: the idle pair-row repeats the fifteenth)
     const uint32_t sp_srow = sp_used / (uint32_t)PAIRS, sp_pair = sp_used % (uint32_t)PAIRS;
+    const uint32_t sp_span0 = sp_srow * row_src_bytes + 6u * sp_pair;               // (kSpan: the pair-row's first frame in the pass's run)
+    // kSpan: the run's pieces -- the rows' union, rounded up to whole pieces (src_mfma_wg_unit_inside leaves the 15 bytes that can add)
+    const uint32_t span_pieces = ((G::kSR - 1u) * row_src_bytes + G::kRowIn + 15u) >> 4;
+    const uint32_t span_p3 = 768u + tid < span_pieces ? 768u + tid : tid;           // (the fourth round's lanes past the end repeat their first piece)
 
     // pack: a frame's six bytes from its two 24-bit values, L then R, each most significant byte first (big endian) or last
     constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;       // byte of the 24-bit value that is memory byte 0, 1, 2
@@ -235,6 +248,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #pragma unroll
             for (int k = 0; k < (int)G::kInRounds; k++) {
                 const int64_t at = PLANAR ? (int64_t)(in_src + 256u * (uint32_t)(k % 3)) + (int64_t)(k / 3) * w.plane_stride
+                                 : G::kSpan ? (int64_t)(16u * (k < 3 ? tid + 256u * (uint32_t)k : span_p3))
                                           : (int64_t)(k < (int)G::kFullRounds ? in_src + G::kRound * (uint32_t)k : in_src + in_last);
                 raw[k] = wg_load_piece_checked(src, w.src0 + at, src_arena_bytes);
             }
@@ -246,10 +260,17 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #pragma unroll
             for (int k = 0; k < 3; k++) raw[3 + k] = *(const u32x4_u*)(base1 + o + 256 * k);
         } else {
-            const uint32_t o = mf_here(in_src);
+            if constexpr (G::kSpan) {
+                const uint32_t o = mf_here(16u * tid);
 #pragma unroll
-            for (int k = 0; k < (int)G::kFullRounds; k++) raw[k] = *(const u32x4_u*)(base + o + (int)G::kRound * k);
-            raw[G::kFullRounds] = *(const u32x4_u*)(base + mf_here(in_src + in_last));
+                for (int k = 0; k < 3; k++) raw[k] = *(const u32x4_u*)(base + o + 4096 * k);
+                raw[3] = *(const u32x4_u*)(base + mf_here(16u * span_p3));
+            } else {
+                const uint32_t o = mf_here(in_src);
+#pragma unroll
+                for (int k = 0; k < (int)G::kFullRounds; k++) raw[k] = *(const u32x4_u*)(base + o + (int)G::kRound * k);
+                raw[G::kFullRounds] = *(const u32x4_u*)(base + mf_here(in_src + in_last));
+            }
         }
 #endif
     };
@@ -260,10 +281,9 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         if constexpr (PLANAR != 0) {
 #pragma unroll
             for (int k = 0; k < 6; k++) *(u32x4*)(stage + in_lds + (k / 3) * kWgPlaneIn + 256 * (k % 3)) = raw[k];
-        } else {
+        } else if constexpr (G::kSpan) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) *(u32x4*)(stage + in_lds + (int)G::kRound * k) = raw[k];
-            *(u32x4*)(stage + in_lds + in_last) = raw[4];
+            for (int k = 0; k < 4; k++) *(u32x4*)(stage + 16u * tid + 4096 * k) = raw[k];      // (piece for piece: a wave writes a contiguous KB)
         }
     };
     // half-band: the image in two sections over the same LDS -- section 0 = the lanes' rounds 0..4 (bytes 0 .. 5 kRound of every row:
@@ -343,11 +363,12 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     for (int j = 0; j < 3; j++) pl[3 * c + j][q] = sb[j];
                 }
             }
-        } else if constexpr (PAIRS != 1) {
-            // eight frames of the lane's channel pair, kFb bytes apart: six bytes each, wherever they start -- the 8 aligned bytes around
-            // them (two dwords in one LDS read), shifted down by the two bytes an odd start is off.  Frames at even and at odd distances
-            // differ in that only for six channels (18 n + 6 pair is a multiple of 4 or 2 off by turns).
-            const uint32_t byte0 = sp_srow * G::kRowInPitch + hc * (8u * G::kFb) + 6u * sp_pair;
+        } else {
+            // eight frames of the lane's channel pair, kFb bytes apart: six bytes each, wherever they start (a row starts anywhere even in
+            // the pass's run) -- the 8 aligned bytes around them (two dwords in one LDS read), shifted down by the two bytes an odd start
+            // is off.  Frames at even and at odd distances differ in that for two and six channels (6 n and 18 n are a multiple of 4 or 2
+            // off by turns), not for eight.
+            const uint32_t byte0 = sp_span0 + hc * (8u * G::kFb);
             const uint32_t at_e = byte0 & ~3u, sh_e = (byte0 & 2u) * 8u;
             const uint32_t at_o = (byte0 + G::kFb) & ~3u, sh_o = ((byte0 + G::kFb) & 2u) * 8u;
             uint32_t lo[8], hi[8];
@@ -359,15 +380,6 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                 lo[2 * m + 1] = zero ? 0u : (uint32_t)vo; hi[2 * m + 1] = zero ? 0u : (uint32_t)(vo >> 32);
             }
             mf_split_frames(lo, hi, pl);
-        } else {
-            const uint8_t* const from = stage + sp_row * G::kRowInPitch + 48u * hc;
-            u32x4 mine[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) mine[k] = *(const u32x4*)(from + 16 * k);
-            uint32_t w[12] = {mine[0].x, mine[0].y, mine[0].z, mine[0].w, mine[1].x, mine[1].y, mine[1].z, mine[1].w, mine[2].x, mine[2].y, mine[2].z, mine[2].w};
-#pragma unroll
-            for (int k = 0; k < 12; k++) w[k] = zero ? 0u : w[k];
-            mf_split48(w, pl);
         }
         // A plane's chunk is [half][row][channel 2][8 frames]: a lane's two channels are 16 contiguous bytes, the rows of a task a
         // contiguous run, a wave's tasks whole halves -- one conflict-free 16-byte store per digit (the 8-byte stores of a
@@ -533,7 +545,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 
         // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
         // unit's input -- requested a whole phase (C) ago -- is waited for HERE, in front of the stores, not behind them ----
-        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]));
+        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
+        if constexpr (G::kInRounds > 4) asm volatile("" : "+v"(raw[4]));
         if constexpr (G::kInRounds > 5) asm volatile("" : "+v"(raw[5]));
         if constexpr (G::kInRounds > 6) asm volatile("" : "+v"(raw[6]), "+v"(raw[7]));
         {
@@ -585,7 +598,8 @@ bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t
 bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, uint32_t unit_rows, bool planar, uint64_t plane_stride, bool halfband)
 {
     const uint64_t row_in = planar ? kWgPlaneIn : (halfband ? 320u : 192u) * 3u * ch, last_plane = planar ? plane_stride : 0;
-    return src_row0 >= 0 && unit_rows >= 1 && (uint64_t)src_row0 + last_plane + (uint64_t)(unit_rows - 1u) * row_src_bytes + row_in <= src_arena_bytes;
+    // (packed: a pass's rows are fetched as one run of 16-byte pieces from the first row's start: the last piece may reach 15 bytes further)
+    return src_row0 >= 0 && unit_rows >= 1 && (uint64_t)src_row0 + last_plane + (uint64_t)(unit_rows - 1u) * row_src_bytes + row_in + (planar ? 0u : 15u) <= src_arena_bytes;
 }
 
 template <int PLANAR, int PAIRS, bool HB, bool SRC_LE, bool DST_LE>
