@@ -20,6 +20,7 @@ typedef u32x4 u32x4_u __attribute__((aligned(1)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 
 constexpr uint32_t kMfStepImage = 4 * 1024;         // a step's A operands: [coefficient digit 4][lane 64][16 bytes]
 

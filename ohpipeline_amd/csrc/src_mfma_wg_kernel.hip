@@ -108,6 +108,11 @@ struct WgGeom {
     static_assert(!HB || (kChunksA * 16 * kFb <= kRoundsA * kRound && (kChunksA * 16 * kFb) >= (kRoundsA - 1) * kRound), "the two stagings meet in chunk 13");
 };
 
+#ifdef MF_WG_SPLIT_GENERIC
+constexpr bool kDiagSplitGeneric = true;            // (timing experiments: stereo through the any-stride split)
+#else
+constexpr bool kDiagSplitGeneric = false;
+#endif
 #ifndef MF_DIAG_BARRIER_MASK
 #define MF_DIAG_BARRIER_MASK 0xf
 #endif
@@ -363,6 +368,22 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     for (int j = 0; j < 3; j++) pl[3 * c + j][q] = sb[j];
                 }
             }
+        } else if constexpr (PAIRS == 1 && !kDiagSplitGeneric) {
+            // stereo: the eight frames are 48 contiguous bytes from an even address -- the thirteen dwords around them, moved down by the
+            // two bytes an odd start is off (one v_alignbyte_b32 per dword), then the same network as for twelve aligned dwords
+            const uint32_t byte0 = sp_span0 + hc * 48u;
+            const uint32_t at = byte0 & ~3u, sh = byte0 & 2u;
+            uint32_t d[13];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const u32x4 q = *(const u32x4_a4*)(stage + at + 16 * k);
+                d[4 * k] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
+            }
+            d[12] = *(const uint32_t*)(stage + at + 48);
+            uint32_t w[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) w[k] = zero ? 0u : __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+            mf_split48(w, pl);
         } else {
             // eight frames of the lane's channel pair, kFb bytes apart: six bytes each, wherever they start (a row starts anywhere even in
             // the pass's run) -- the 8 aligned bytes around them (two dwords in one LDS read), shifted down by the two bytes an odd start
