@@ -463,19 +463,26 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         // The five tiles as straight-line code, one copy per (pattern of the wave's tiles, ramped or not): which of the wave's A sets a
         // tile takes and which column tile it is are constants of the wave's position among the kCt waves that share five steps, so
         // nothing branches between two tiles and a tile's operands are fetched under its predecessor's matrix instructions.
-        auto read_planes = [&](uint32_t kcs, uint32_t ct, v4i (&bd)[3]) __attribute__((always_inline)) {
-            // six 8-byte reads, written out (the compiler pairs the halves into ds_read2st64_b64, which the LDS serves at half the
-            // rate), with their wait in the same statement: what leaves it is data, whatever the compiler copies afterwards
+        // A tile's sample operands: six 8-byte reads, written out (the compiler pairs the halves into ds_read2st64_b64, which the LDS
+        // serves at half the rate).  They are ISSUED under the previous tile's matrix instructions and WAITED FOR in front of this
+        // tile's, a whole epilogue later: in between the registers belong to the reads in flight -- they are outputs of the first
+        // statement and in/outs of the second and of nothing else, so the compiler keeps them allocated and has no reason to name
+        // them (tests/test_mfma_kernel_asm.py walks the LDS queue of every instantiation to see that it did not).
+        auto issue_planes = [&](uint32_t kcs, uint32_t ct, u32x2 (&h)[6]) __attribute__((always_inline)) {
             const uint32_t in_chunk = (ct * 128u) ^ (((kcs + g_chunk) & 1u) * 128u);
             const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(b_lds + kcs * G::kChunk + in_chunk);
-            u32x2 h[6];
             asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:%7\n\t"
                          "ds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %6 offset:%9\n\t"
-                         "ds_read_b64 %4, %6 offset:%10\n\tds_read_b64 %5, %6 offset:%11\n\t"
-                         "s_waitcnt lgkmcnt(0)"
+                         "ds_read_b64 %4, %6 offset:%10\n\tds_read_b64 %5, %6 offset:%11"
+#ifdef MF_WG_EARLY_WAIT
+                         "\n\ts_waitcnt lgkmcnt(0)"
+#endif
                          : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5])
                          : "v"(at), "n"(G::kHalf), "n"(G::kDigit), "n"(G::kDigit + G::kHalf), "n"(2 * G::kDigit), "n"(2 * G::kDigit + G::kHalf)
                          : "memory");
+        };
+        auto take_planes = [&](u32x2 (&h)[6], v4i (&bd)[3]) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]) : : "memory");
 #pragma unroll
             for (int d = 0; d < 3; d++) bd[d] = v4i{(int)h[2 * d].x, (int)h[2 * d].y, (int)h[2 * d + 1].x, (int)h[2 * d + 1].y};
         };
@@ -483,10 +490,12 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             constexpr uint32_t P = decltype(pattern_c)::value;
             constexpr bool RAMPED = decltype(ramped_c)::value;
             constexpr uint32_t kFirst = G::kTilesPerWave * P;           // the pattern's first tile, counted from a multiple of kTilesPerWave steps
-            v4i bd[3];
-            read_planes(kc[0], kFirst % G::kCt, bd);
+            u32x2 h[6];
+            issue_planes(kc[0], kFirst % G::kCt, h);
             static_for([&](auto ic) __attribute__((always_inline)) {
                 constexpr uint32_t i = decltype(ic)::value;
+                v4i bd[3];
+                take_planes(h, bd);
                 constexpr uint32_t set = (kFirst + i) / G::kCt - kFirst / G::kCt, ct = (kFirst + i) % G::kCt;
                 static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
                 const uint32_t step = step0 + set;
@@ -509,7 +518,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                 if constexpr (i + 1 < G::kTilesPerWave) {
                     // the next tile's planes, while this one's matrix instructions run
                     constexpr uint32_t set_n = (kFirst + i + 1) / G::kCt - kFirst / G::kCt, ct_n = (kFirst + i + 1) % G::kCt;
-                    read_planes(kc[set_n], ct_n, bd);
+                    issue_planes(kc[set_n], ct_n, h);
                 }
                 int y[4];
 #pragma unroll

@@ -61,13 +61,13 @@ def test_three_workgroups_per_cu_fit(wg):
 
 
 def test_no_scratch_but_where_design_says(wg):
-    """Packed stereo and eight-channel sources and 24- and 8-bit planes: no spills at all.  The 16-bit planes spill four dwords in the
-    split, the six-channel kernels (planar code 20) eight around the edge units' out-of-line loads -- outside the tiles: tolerated, bounded here."""
+    """Packed sources: no spills at all.  The planar instantiations (168 registers, the limit) spill four dwords around the split and
+    the edge units' out-of-line loads -- outside the tiles: tolerated, bounded here."""
     for name, (rows, planar, body, meta) in wg.items():
         if rows != 16:
             continue
-        if planar in (2, 20):
-            assert _field(meta, "private_segment_fixed_size") <= (16 if planar == 2 else 32), name
+        if planar in (1, 2, 3):
+            assert _field(meta, "private_segment_fixed_size") <= 16, name
             tiles = [i for i, l in enumerate(body) if "v_mfma_i32_16x16x64_i8" in l]
             between = [l for l in body[tiles[0]:tiles[-1]] if re.match(r"^\s*scratch_", l)]
             assert not between, (name, between[:4])
@@ -99,3 +99,14 @@ def test_no_floating_point_in_the_taps(wg):
     """The sums are integers end to end: no fp64 and no conversions anywhere in the kernel."""
     for name, (rows, planar, body, meta) in wg.items():
         assert not [l for l in body if re.match(r"^\s*v_(fma|fmac|mul|add|cvt)_f(64|32)", l)], name
+
+
+def test_no_operand_read_lands_in_a_register_the_code_has_moved_on_from(wg):
+    """A tile's sample operands are requested under the previous tile's matrix instructions and waited for a whole epilogue later
+    (issue_planes / take_planes): in between their registers belong to the reads in flight.  The same walk of the LDS queue the
+    block kernels are held to (test_block_kernel_asm.py: the round-3 diagnostic fault was exactly such a register, recycled) --
+    no instruction names a read's destination before a wait that covers it, in any instantiation."""
+    from test_block_kernel_asm import _uncovered_touches
+    for name, (rows, planar, body, meta) in wg.items():
+        bad = _uncovered_touches(body)
+        assert not bad, (name, bad[:3])
