@@ -307,6 +307,13 @@ uint64_t ohgpu_src_out_frames(uint32_t L, uint32_t M, uint64_t in_frames);
 int ohgpu_src_mfma_tables(uint32_t L, uint32_t M, uint32_t taps_per_phase, const int32_t* coef_q28, uint32_t max_blocks_per_row,
                           uint8_t* coef_digits, size_t coef_digits_capacity, void* steps, size_t steps_capacity,
                           size_t* coef_digits_bytes, size_t* steps_bytes, uint32_t* block_outputs);
+/* ... and the tables it makes for the same kernel's half-band form (ohpipeline_amd/csrc/src_mfma_wg_kernel.hip, HB) when the
+ * filter is a 2:1 decimator of 64 stored taps whose odd taps but the centre one (31) are zero: ONE image of the B operand's
+ * coefficient digits, [4 digits][lane = 16 g + n][16 bytes] -- K groups g = 0..2 meet the even input frames 16 (s + g) .. + 15 of
+ * step s (a row's image starts 64 frames before its block), group 3 the odd frames 16 (s + 1) .. + 15, output n taking sample n --
+ * and the accumulators' initial value 32896 * sum(c) + 2^27.  *block_outputs = outputs per block (128).
+ * OHGPU_ERR_UNSUPPORTED when the coefficients are not such a filter.  Host only. */
+int ohgpu_src_mfma_halfband_tables(const int32_t* coef_q28 /* 64 */, uint8_t* image /* 4096 bytes */, int64_t* bias, uint32_t* block_outputs);
 /* The messages of one batch may differ in layout (channels, depths, byte orders, packed or planar source): the batch is
  * planned per layout and runs one launch sequence per layout, messages of a stream in the order given. */
 int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,

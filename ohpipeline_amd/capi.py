@@ -103,6 +103,7 @@ SYMBOLS = {
     "ohgpu_src_out_frames": (C.c_uint64, [C.c_uint32, C.c_uint32, C.c_uint64]),
     "ohgpu_src_mfma_tables": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp, C.c_size_t, _vp, C.c_size_t,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
+    "ohgpu_src_mfma_halfband_tables": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),
     "ohgpu_src_batch_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
@@ -193,6 +194,15 @@ def src_mfma_tables(L, M, T, coef_q28, max_blocks_per_row=8):
     check(lib().ohgpu_src_mfma_tables(L, M, T, coef.ctypes.data, max_blocks_per_row, dig.ctypes.data, dig.nbytes, steps.ctypes.data, steps.nbytes,
                                       C.byref(nb), C.byref(ns), C.byref(lb)))
     return dig.reshape(4, L, 96), steps, lb.value
+
+
+def src_mfma_halfband_tables(coef_q28):
+    """(image [4 digits][4 K groups][16 outputs][16] int8, bias, outputs per block) -- the half-band form's host tables (no device)."""
+    coef = np.ascontiguousarray(coef_q28, dtype=np.int32)
+    image = np.zeros(4096, dtype=np.int8)
+    bias, lb = C.c_int64(0), C.c_uint32(0)
+    check(lib().ohgpu_src_mfma_halfband_tables(coef.ctypes.data, image.ctypes.data, C.byref(bias), C.byref(lb)))
+    return image.reshape(4, 4, 16, 16), int(bias.value), int(lb.value)
 
 
 def src_design(rate_in, rate_out, taps_per_phase=32, beta=9.0, f_pass=20000.0):

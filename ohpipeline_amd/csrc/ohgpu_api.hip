@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "ohgpu_internal.h"
+#include "src_mfma_common.h"
 
 namespace ohgpu {
 
@@ -765,6 +766,21 @@ int ohgpu_src_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coe
         if (steps_capacity < steps.size() * sizeof(MfStep)) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_mfma_tables: steps too small");
         memcpy(steps_out, steps.data(), steps.size() * sizeof(MfStep));
     }
+    return OHGPU_OK;
+}
+
+int ohgpu_src_mfma_halfband_tables(const int32_t* coef_q28, uint8_t* image, int64_t* bias, uint32_t* block_outputs)
+{
+    if (!coef_q28 || !image) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_mfma_halfband_tables: null argument");
+    const uint32_t L_blk = src_block_outputs(1, 6);
+    std::vector<MfStep> steps;
+    std::vector<uint8_t> amat;
+    if (L_blk == 0 || !build_mfma_halfband(coef_q28, L_blk, &steps, &amat) || steps.empty())
+        return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_mfma_halfband_tables: not a half-band decimator of 64 taps");
+    memcpy(image, amat.data(), kMfStepImage);
+    // (the steps carry the bias in three pieces, the same for every output: bits 0..15, 16..31, 32..)
+    if (bias) *bias = (int64_t)steps[0].b0[0] + ((int64_t)steps[0].b1[0] << 16) + ((int64_t)(int32_t)steps[0].b2[0] << 32);
+    if (block_outputs) *block_outputs = L_blk;
     return OHGPU_OK;
 }
 

@@ -103,3 +103,75 @@ def test_unsupported_geometries_are_refused():
     ref = oracle_lib.Src(88200, 48000)                   # 32 taps, but 15 M / L = 27 frames per tile: beyond the 64-frame window
     with pytest.raises(capi.OhGpuError):
         capi.src_mfma_tables(ref.L, ref.M, ref.T, ref.coef_q28, 8)
+
+
+def emulate_halfband_row(image, bias, L_blk, frames):
+    """The half-band form (csrc/src_mfma_wg_kernel.hip, HB) replayed from its one coefficient image: frames[64 + k] = input frame k
+    of the row (frames[0..63] its history).  A step's K groups 0..2 are the EVEN frames' chunks s .. s + 2, group 3 the ODD frames'
+    chunk s + 1; lane (g, n) of the image holds output n's sixteen coefficient digits for group g."""
+    u = frames & 0xFFFFFF
+    d = [((u & 0xFF) ^ 0x80).astype(np.uint8).view(np.int8).astype(np.int64),
+         (((u >> 8) & 0xFF) ^ 0x80).astype(np.uint8).view(np.int8).astype(np.int64),
+         ((u >> 16) & 0xFF).astype(np.uint8).view(np.int8).astype(np.int64)]
+    even = [dd[0::2] for dd in d]
+    odd = [dd[1::2] for dd in d]
+    b = [bias & 0xFFFF, (bias >> 16) & 0xFFFF, bias >> 32]
+    out = np.zeros(L_blk, dtype=np.int64)
+    for s_ in range(L_blk // 16):
+        for n in range(16):
+            acc = [b[0], 0, b[1], 0, b[2], 0]
+            for g in range(4):
+                for i in range(3):
+                    samples = even[i][16 * (s_ + g):16 * (s_ + g) + 16] if g < 3 else odd[i][16 * (s_ + 1):16 * (s_ + 1) + 16]
+                    for j in range(4):
+                        acc[i + j] += int(np.dot(image[j, g, n].astype(np.int64), samples))
+            assert all(abs(v) < 1 << 22 for v in acc), "an accumulator left the range the recombination assumes"
+            t0 = (acc[1] << 8) + acc[0]
+            uu = (acc[3] << 8) + acc[2] + (t0 >> 16)
+            w = (acc[5] << 8) + acc[4] + (uu >> 16)
+            assert abs(t0) < 1 << 31 and abs(uu) < 1 << 31 and abs(w << 4) < 1 << 31
+            y = (w << 4) | ((uu >> 12) & 15)
+            out[16 * s_ + n] = min(max(y, -(1 << 23)), (1 << 23) - 1)
+    return out
+
+
+def test_halfband_tables_reproduce_the_integer_model():
+    ref = oracle_lib.Src(96000, 48000, 64)
+    assert (ref.L, ref.M, ref.T) == (1, 2, 64)
+    image, bias, L_blk = capi.src_mfma_halfband_tables(ref.coef_q28)
+    assert L_blk == 128
+    c = ref.coef_q28.astype(np.int64)
+    assert bias == 32896 * int(c.sum()) + (1 << 27)
+    # the image recomposes to the even taps along the band of groups 0..2 and to the centre tap on the diagonal of group 3
+    rec = sum(image[j].astype(np.int64) << (8 * j) for j in range(4))        # [group][output][k]
+    for n in range(16):
+        for g in range(3):
+            for i in range(16):
+                m = 32 + n - 16 * g - i
+                assert rec[g, n, i] == (c[2 * m] if 0 <= m <= 31 else 0)
+        assert np.array_equal(rec[3, n], np.where(np.arange(16) == n, c[31], 0))
+    rng = np.random.default_rng(11)
+    M_blk = 2 * L_blk
+    n_in = 3 * M_blk + 64
+    for kind in ("noise", "extremes"):
+        if kind == "noise":
+            x = rng.integers(-(1 << 23), 1 << 23, size=n_in, dtype=np.int64)
+        else:
+            x = rng.choice(np.array([-(1 << 23), (1 << 23) - 1, 0, -1, 1, 0x7FFF80, -0x7FFF80]), size=n_in)
+        want = oracle_outputs(ref, x.astype(np.int32), 3 * L_blk)
+        for r in range(3):                                      # the stream's first block (zero history) and the two after it
+            first = r * M_blk
+            frames = np.zeros(64 + M_blk, dtype=np.int64)
+            lo = first - 64
+            src = x[max(lo, 0):first + M_blk]
+            frames[max(-lo, 0):max(-lo, 0) + src.size] = src
+            got = emulate_halfband_row(image, bias, L_blk, frames)
+            assert np.array_equal(got, want[r * L_blk:(r + 1) * L_blk]), (kind, r)
+
+
+def test_halfband_tables_refuse_other_filters():
+    ref = oracle_lib.Src(96000, 48000, 64)
+    coef = np.array(ref.coef_q28, dtype=np.int32)
+    coef[5] = 12345                                             # an odd tap that is not the centre: no longer half-band
+    with pytest.raises(capi.OhGpuError):
+        capi.src_mfma_halfband_tables(coef)
