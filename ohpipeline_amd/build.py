@@ -18,7 +18,7 @@ HEADERS = ["ohgpu_internal.h", "pcm_device.h", os.path.join(ROOT, "include", "oh
 # per input frame in a loop the scalar unit co-limits).
 SOURCE_FLAGS = {"src_lean_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions"]}
 ARCH = "gfx950"
-BLOCK_PARTS = 5                     # OHGPU_BLOCK_PARTS in csrc/src_block_common.h
+BLOCK_PARTS = 6                     # OHGPU_BLOCK_PARTS in csrc/src_block_common.h
 
 
 # The lean kernel's source leans on this toolchain's behaviour in two places: the internal option in SOURCE_FLAGS, and the

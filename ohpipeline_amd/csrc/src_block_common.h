@@ -139,4 +139,19 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(32, 5, 3, true, 3, false)      \
     X(32, 7, 3, true, 3, false)
 #endif
-#define OHGPU_BLOCK_PARTS 5
+// ... and (round 4, part 6) the layouts that were the generic kernel's: odd channel counts from big-endian S24, 16- and 32-bit big-endian
+// destinations for six and eight channels, 8-bit stereo sources.
+#ifdef OHGPU_DIAG_ONE_KERNEL
+#define OHGPU_LEAN_MORE_KERNELS(X)
+#else
+#define OHGPU_LEAN_MORE_KERNELS(X)   \
+    X(32, 3, 3, false, 3, false)     \
+    X(32, 5, 3, false, 3, false)     \
+    X(32, 7, 3, false, 3, false)     \
+    X(32, 6, 3, true, 2, false)      \
+    X(32, 8, 3, true, 2, false)      \
+    X(32, 6, 3, true, 4, false)      \
+    X(32, 8, 3, true, 4, false)      \
+    X(32, 2, 1, false, 3, false)
+#endif
+#define OHGPU_BLOCK_PARTS 6

@@ -830,12 +830,15 @@ OHGPU_LEAN_PLANAR_KERNELS(X_DEFINE)
 OHGPU_LEAN_HB_KERNELS(X_DEFINE_HB)
 #elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 5
 OHGPU_LEAN_ONLY_KERNELS(X_DEFINE)
+#elif defined(OHGPU_BLOCK_PART) && OHGPU_BLOCK_PART == 6
+OHGPU_LEAN_MORE_KERNELS(X_DEFINE)
 #elif defined(OHGPU_BLOCK_PART)
 OHGPU_BLOCK_KERNELS_2(X_DECLARE)
 OHGPU_BLOCK_KERNELS_3(X_DECLARE)
 OHGPU_LEAN_PLANAR_KERNELS(X_DECLARE)
 OHGPU_LEAN_HB_KERNELS(X_DECLARE_HB)
 OHGPU_LEAN_ONLY_KERNELS(X_DECLARE)
+OHGPU_LEAN_MORE_KERNELS(X_DECLARE)
 #endif
 
 #if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
@@ -948,6 +951,7 @@ hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
     }
     OHGPU_BLOCK_KERNELS(X)
     OHGPU_LEAN_ONLY_KERNELS(X)
+    OHGPU_LEAN_MORE_KERNELS(X)
 #undef X
     return hipErrorInvalidValue;
 }
@@ -959,6 +963,7 @@ bool src_lean_only_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_
 #define X(t, c, s_, sl, d, dl) \
     if (T == t && ch == c && sb == s_ && (src_le != 0) == sl && db == d && (dst_le != 0) == dl) return true;
     OHGPU_LEAN_ONLY_KERNELS(X)
+    OHGPU_LEAN_MORE_KERNELS(X)
 #undef X
     return false;
 }

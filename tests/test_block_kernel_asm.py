@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ohpipeline_amd", "csrc")
 OUTDIR = os.path.join(ROOT, "ohpipeline_amd", "build")
 
-PARTS = (1, 2, 3, 4, 5)           # OHGPU_BLOCK_PARTS (csrc/src_block_common.h); part 4 = the half-band instantiations, part 5 = the lean-only layouts
+PARTS = (1, 2, 3, 4, 5, 6)        # OHGPU_BLOCK_PARTS (csrc/src_block_common.h); part 4 = the half-band instantiations, parts 5 and 6 = the lean-only layouts
 SCALAR_MEM = re.compile(r"^\s*(s_load|s_buffer_load|s_memtime|s_memrealtime|s_scratch_load|s_store|s_atomic|s_dcache)")
 COUNTED_WAIT = re.compile(r"s_waitcnt lgkmcnt\(([1-9]\d*)\)")
 

@@ -75,7 +75,7 @@ def lean_instantiations():
     text = open(os.path.join(ROOT, "ohpipeline_amd", "csrc", "src_block_common.h")).read()
     out = set()
     for macro, kind in (("OHGPU_BLOCK_KERNELS_1", "block"), ("OHGPU_BLOCK_KERNELS_2", "block"), ("OHGPU_BLOCK_KERNELS_3", "block"),
-                        ("OHGPU_LEAN_PLANAR_KERNELS", "planar"), ("OHGPU_LEAN_HB_KERNELS", "halfband"), ("OHGPU_LEAN_ONLY_KERNELS", "lean_only")):
+                        ("OHGPU_LEAN_PLANAR_KERNELS", "planar"), ("OHGPU_LEAN_HB_KERNELS", "halfband"), ("OHGPU_LEAN_ONLY_KERNELS", "lean_only"), ("OHGPU_LEAN_MORE_KERNELS", "lean_only")):
         defs = [m.end() for m in re.finditer(r"#define %s\(X\)" % macro, text)]
         body = text[defs[-1]:]                                           # (the last definition: the one behind the diagnostic #else)
         body = body[:body.index("\n#")]
