@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where ohgpu_src_batch_create spends its time on the headline's 512 000 messages: rebuilds the API and the planner with
-# -DOHGPU_PLAN_TIMING (stage timings on stderr), relinks, runs tools/time_batch_create.py; restores the tree's build at the end.
+# -DOHGPU_PLAN_TIMING (stage timings on stderr), relinks, runs a short bench.py (whose plan_ms is that call); restores the tree's build at the end.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 trap 'python3 ohpipeline_amd/build.py --force > /dev/null 2>&1' EXIT
 OBJ=ohpipeline_amd/build/obj
