@@ -599,7 +599,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #endif
             }
         }
-        wg_barrier<1>();                                    // the output image has been read
+        // (the output image has been read.  Packed sources' input image is the pass's run piece for piece, and the output image is too:
+        // a lane stages into the very slots it has just emptied -- LDS operations of a wave complete in order -- so nothing has to
+        // wait for another wave here; the row-by-row images of the planar and half-band forms do)
+        if constexpr (!G::kSpan) wg_barrier<1>();
         if (u_nxt >= n_work) break;                         // (uniform)
 
         // ---- (A) + (S) the next unit: registers -> input image -> planes; then its successor's input is requested ----
