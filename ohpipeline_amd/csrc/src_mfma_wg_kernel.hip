@@ -1,6 +1,6 @@
 // src_mfma_wg_kernel.hip -- the matrix-pipe resampler (src_mfma_kernel.hip has the arithmetic: int8 digit planes, twelve
 // v_mfma_i32_16x16x64_i8 per tile of 16 outputs x 16 columns, 32-bit recombination) with the work cut for the MEMORY system:
-// one unit per WORKGROUP, five tiles per WAVE.
+// one unit per WORKGROUP, five tiles per WAVE and pass.
 //
 // Why.  With a unit per wave (src_mfma_kernel.hip) a wave reads 96 bytes of each of its 32 rows per step and writes 192 bytes of
 // each per pair of steps.  Every byte is fetched once and every sector written whole (1.09 x the algorithmic traffic), and still
@@ -9,19 +9,22 @@
 // the same bytes as one contiguous 6 KB run per wave and pair of steps takes 0.30 ms (`tools/exp_mfma.sh`, MF_DIAG_IO_CONTIG).
 // So a unit has to arrive and leave in ONE piece.
 //
-// How.  A planner unit is 64 / channels CONSECUTIVE blocks of a stream (src_plan.cpp: rows of one block; 32 for stereo), its input
-// and its output each contiguous in memory; a workgroup takes half of one at a time (14 KB in, 15 KB out).  A block is 10 steps of
+// How.  A planner unit is 30 or 32 CONSECUTIVE blocks of a stream (src_plan.cpp: rows of one block), its input and its output each
+// contiguous in memory; a workgroup takes sixteen pair-rows of one at a time -- a PASS: 14 KB in, 15 KB out.  A block is 10 steps of
 // 16 output frames, a tile 16 outputs x 16 columns = 8 channel PAIRS; a step's coefficient image is the same for every block: a
 // wave owns five of the pass's 20 tiles in step-major order and keeps the A operands of the three steps they touch in registers for
 // the whole launch -- no table is read in the loop.  Per pass the workgroup
-//   (A) copies the rows' input from registers (loaded a pass ahead, lane-contiguous) into an LDS image,
+//   (A) copies the rows' input from registers (loaded a pass ahead: packed sources as ONE run of 16-byte pieces, the union of the
+//       overlapping rows) into an LDS image,
 //   (S) splits it into the digit planes (lane = eight frames of one channel pair: src_mfma_common.h),
 //   (C) runs the 20 tiles, packed results into an LDS image of the pass's output,
 //   (D) writes that image out: 15 KB contiguous, whole 16-byte pieces, non-temporal,
-// with a workgroup barrier between the phases; the input image and the output image share their LDS (44 KB a workgroup, three
-// workgroups per CU), the next pass's input is in flight in registers during (C) and (D).
+// with a workgroup barrier between the phases (none between (D) and (A) for packed sources: a lane refills the slots it emptied);
+// the input image and the output image share their LDS (42.5 KB a workgroup, three workgroups per CU), the next pass's input is in
+// flight in registers during (C) and (D).
 // Six and eight channels (PAIRS = 3, 4) are the same sixteen pair-rows cut differently: 5 stream rows x 3 pairs (the sixteenth
-// column pair idles) or 4 x 4; only the addresses of the split's reads and of the tiles' stores know.
+// column pair idles) or 4 x 4; only the addresses of the split's reads and of the tiles' stores know.  HB is the 96 -> 48 kHz
+// half-band decimator on the same tiles (WgGeom below), PLANAR the FLAC decoder's TInt32 planes as the source.
 // Units whose input image does not lie wholly inside the source arena (kWorkEdge: the first of the first stream, the last of
 // the last) fetch their pieces through a checked, out-of-line load.
 #include <hip/hip_runtime.h>
@@ -196,11 +199,11 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     // 2 g + 1 is the next row (stereo) or the next pair of the same row (eight channels); six channels: out_at below)
     uint8_t* const out_lds = stage + ((2u * g) / (uint32_t)PAIRS) * G::kRowOut + 6u * ((2u * g) % (uint32_t)PAIRS) + G::kFb * n;
     auto pair_row_srow = [&](uint32_t ct, uint32_t q) __attribute__((always_inline)) { return (ct * 8u + 2u * g + q) / (uint32_t)PAIRS; };   // the stream row of a tile's pair-row
-    // the input image: sixteen lanes per row; lane `sub` of a row moves its pieces sub, sub + 16, .. sub + 48 and (sub < 8) sub + 64 of
-    // the row's 72 -- an instruction reads 256 contiguous bytes of every row, and a lane's addresses differ by constants
-    // (planar: a channel's 768 bytes are three rounds exactly; the second channel's come from `src_plane_stride` further on)
-    // (16 PAIRS lanes per row and 256 PAIRS bytes per round for wider frames; six channels: 240 lanes move the five rows, the last
-    // sixteen repeat pieces of the fifth)
+    // the input image row by row (planar sources and the half-band form; packed sources otherwise: the pass's one run, span_* below):
+    // 16 PAIRS lanes per row; lane `sub` of a row moves its pieces sub, sub + 16 PAIRS, .. and, the first half of them, one more --
+    // an instruction reads 256 PAIRS contiguous bytes of every row, and a lane's addresses differ by constants (planar: a channel's
+    // 768 bytes are three rounds exactly; the second channel's come from `src_plane_stride` further on; six channels: 240 lanes
+    // move the five rows, the last sixteen repeat pieces of the fifth)
     const uint32_t in_row_of = tid / G::kRowLanes, in_sub = tid - in_row_of * G::kRowLanes;
     const uint32_t in_row = in_row_of < G::kSR ? in_row_of : G::kSR - 1u;
     const uint32_t in_src = in_row * row_src_bytes + 16u * in_sub;                 // + kRound k
