@@ -176,3 +176,37 @@ def test_workgroup_matrix_kernel_takes_packed_s24_of_two_six_and_eight_channels(
     le = [noise_le(sid, per, 24) for sid in g.stream_ids]
     g.src = np.concatenate([(x if src_le else x[:, ::-1]).reshape(-1) for x in le])
     run_groups(ctx, [g], kernel="src_mfma_wg_kernel")
+
+
+@pytest.mark.parametrize("channels, src_le, dst_le", [(6, True, False), (2, False, True)])
+def test_a_plan_only_the_workgroup_kernel_reads_runs_on_the_generic_kernel_under_another_variant(ctx, channels, src_le, dst_le):
+    """Six-channel units are cut 30 rows long for the workgroup kernel, and big-endian-in / little-endian-out has no other block
+    kernel at all: such a batch, planned under variant 0 and RUN under variant 4, must not reach the lean kernel -- the library
+    says it runs the generic one (its per-message descriptors go to the device at that moment), and the audio is the same."""
+    g = bench.Group(capi, 44100, channels, range(700, 705), int(round(0.4 * 44100)), src_bits=24,
+                    src_endian=capi.ENDIAN_LITTLE if src_le else capi.ENDIAN_BIG, dst_bits=24,
+                    dst_endian=capi.ENDIAN_LITTLE if dst_le else capi.ENDIAN_BIG)
+    per = g.in_frames * channels
+    le = [noise_le(sid, per, 24) for sid in g.stream_ids]
+    g.src = np.concatenate([(x if src_le else x[:, ::-1]).reshape(-1) for x in le])
+    g.attach(ctx)
+    try:
+        assert ctx.src_kernel_name(g.batch) == "src_mfma_wg_kernel"
+        ref = O.Src(g.rate_in, bench.RATE_OUT, g.taps, bench.BETA, bench.F_PASS)
+        want = np.zeros(g.dst_bytes, dtype=np.uint8)
+        assert ref.process_batch(g.oracle_descs.view(O.SRC_MSG_DESC), g.src, want) == 0
+        ctx.set_kernel_variant(4)
+        try:
+            assert ctx.src_kernel_name(g.batch) == "src_kernel_v1"
+            ctx.memset(g.d_dst, 0, g.dst_bytes)
+            ctx.src_run(g.batch, g.d_src, g.d_dst)
+            ctx.sync()
+            assert np.array_equal(ctx.download(g.d_dst, g.dst_bytes), want)
+        finally:
+            ctx.set_kernel_variant(0)
+        ctx.memset(g.d_dst, 0, g.dst_bytes)
+        ctx.src_run(g.batch, g.d_src, g.d_dst)                  # ... and back on its own kernel
+        ctx.sync()
+        assert np.array_equal(ctx.download(g.d_dst, g.dst_bytes), want)
+    finally:
+        g.detach(ctx)

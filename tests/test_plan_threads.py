@@ -89,3 +89,20 @@ def test_a_bad_descriptor_is_reported_by_its_index_whatever_thread_finds_it():
         with pytest.raises(capi.OhGpuError) as e:
             capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
         assert f"src desc {bad}:" in str(e.value)
+
+
+@pytest.mark.parametrize("channels, unit_rows", [(6, 30), (8, 32)])
+def test_wide_plans_for_the_workgroup_kernel_are_thread_independent_and_cut_long_units(channels, unit_rows):
+    """Six and eight channels: the workgroup kernel's units are 30 / 32 rows long (src_plan.cpp), a third to a quarter of the lean
+    kernel's count, whatever the thread count; the lean kernel's plan (variant 4) keeps its own rows."""
+    ref, d, sb, db = headline_like(24, 3.0, channels=channels)
+    capi.set_plan_threads(1)
+    one = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
+    assert one["kernel"] == 3 and one["generic_pieces"] == 0
+    blocks = 24 * ((3 * 48000) // 160)                     # whole 160-output blocks of the batch
+    assert abs(one["units"] - blocks / unit_rows) <= 24 * 2 + 1, (one, blocks)
+    for threads in (3, 8, 0):
+        capi.set_plan_threads(threads)
+        assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db) == one, threads
+    lean = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, 4)
+    assert lean["kernel"] == 1 and lean["units"] < blocks / (64 // channels) + 24 * 2 + 1
