@@ -63,6 +63,15 @@ def noise_s24le(stream_id, n_subsamples):
     return b.reshape(-1)
 
 
+def noise_s16le(stream_id, n_subsamples):
+    """... the top 16 bits of the same words ("top 24 (or 16) bits")."""
+    x = lcg_block((0x9E3779B9 * (stream_id + 1)) & MASK, n_subsamples)
+    b = np.empty((x.size, 2), dtype=np.uint8)
+    b[:, 0] = (x >> 16) & 0xFF
+    b[:, 1] = (x >> 24) & 0xFF
+    return b.reshape(-1)
+
+
 def taps_for(rate_in):
     return 64 if rate_in >= 2 * RATE_OUT else 32        # 96 -> 48 kHz: twice the prototype length per phase (DESIGN.md 4)
 
@@ -137,7 +146,8 @@ class Group:
         per = self.in_frames * self.fb_src
 
         def one(k):
-            self.src[k * per:(k + 1) * per] = noise_s24le(self.stream_ids[k], self.in_frames * self.channels)
+            make = noise_s16le if self.fb_src == 2 * self.channels else noise_s24le
+            self.src[k * per:(k + 1) * per] = make(self.stream_ids[k], self.in_frames * self.channels)
         with ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0))))) as ex:     # (numpy releases the GIL in these passes)
             list(ex.map(one, range(len(self.stream_ids))))
 
@@ -204,7 +214,7 @@ def build_groups(capi, args, rank, world):
     """The rank's share of the workload as a list of Groups."""
     if args.config == 3:
         ids = range(rank * args.streams, (rank + 1) * args.streams)          # weak scaling: every rank owns `streams` of its own
-        g = Group(capi, args.rate_in, args.channels, ids, int(round(args.seconds * args.rate_in)))
+        g = Group(capi, args.rate_in, args.channels, ids, int(round(args.seconds * args.rate_in)), src_bits=getattr(args, "src_bits", BITS))
         g.fill_noise()
         return [g], "weak"
     mine, _ = config4_share(args.streams, args.seconds, rank, world)         # strong scaling: 2048 streams over the ranks, by bytes
@@ -624,7 +634,7 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
         names = {3: "configs[2]", 4: "configs[3]", 5: "configs[4]"}
         head = groups[int(np.argmax([g.algorithmic_bytes for g in groups]))]
         if args.config == 3:
-            what = (f"{args.streams} independent {'stereo' if args.channels == 2 else str(args.channels) + '-channel'} S24LE streams per GPU, "
+            what = (f"{args.streams} independent {'stereo' if args.channels == 2 else str(args.channels) + '-channel'} S{getattr(args, 'src_bits', BITS)}LE streams per GPU, "
                     f"{args.rate_in / 1000:g}->48 kHz")
         elif args.config == 4:
             what = (f"{args.streams} S24LE streams in all, by stream id 44.1 / 96 kHz x 2 / 6 / 8 channels, ->48 kHz, "
@@ -735,6 +745,7 @@ def main():
     ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the warm-up and the timed steps, so that they see the clock the chip holds under this load")
     ap.add_argument("--channels", type=int, default=2, help="config 3: channels per stream (the headline is stereo)")
     ap.add_argument("--rate-in", type=int, default=44100, help="config 3: input rate (the headline is 44100)")
+    ap.add_argument("--src-bits", type=int, default=BITS, choices=(16, 24), help="config 3: source depth (the headline is 24; 16 = CD audio into the same S24 output)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be at least 1")
@@ -762,7 +773,7 @@ def main():
     # The default line (config 3, one GPU, sizes untouched) also carries BASELINE configs[3] and configs[4], at their full size
     # (2048 streams x 10 s; 256 FLAC streams x 10 s), same process, each with its own sustain phase, steps and whole-step check.
     if rank == 0 and world == 1 and args.config == 3 and not explicit and not args.no_extra_configs and not args.no_cpu \
-            and args.channels == 2 and args.rate_in == 44100:
+            and args.channels == 2 and args.rate_in == 44100 and args.src_bits == BITS:
         result["configs"] = {}
         for cfg in (4, 5):
             t0 = time.perf_counter()

@@ -60,14 +60,18 @@ struct WgGeom {
     static_assert(ROWS == 16 || ROWS == 32, "pair-rows per workgroup");
     static_assert(PAIRS == 1 || ((PAIRS == 3 || PAIRS == 4) && PLANAR == 0 && ROWS == 16), "six and eight channels: packed, sixteen pair-rows");
     static_assert(!HB || (PLANAR == 0 && ROWS == 16), "half-band: packed, sixteen pair-rows");
+    static_assert(PLANAR >= 0 && PLANAR <= 4, "source format: 0 packed S24, 1..3 the TInt32 planes, 4 packed S16");
+    static constexpr bool kPlanes = PLANAR >= 1 && PLANAR <= 3;       // the decoder's TInt32 planes
+    static constexpr bool kS16 = PLANAR == 4;                        // packed 16-bit frames: the sample is the 16 bits shifted up a byte
     static constexpr uint32_t kSteps = HB ? 8 : 10;                   // steps (16 output frames) per block
     static constexpr uint32_t kOutFrames = 16u * kSteps;              // a block's outputs: 160, or 128
     static constexpr uint32_t kImgChunks = HB ? 20 : 12;              // chunks (16 frames) of a row's input image: frames -32 .. 159 of the row, or -64 .. 255
     static constexpr uint32_t kPlaneChunks = kImgChunks;              // ... and of its digit planes (half-band: ten of even frames, then ten of odd ones)
-    static constexpr uint32_t kFb = 6u * PAIRS;                       // bytes of a frame, in and out (24-bit samples)
+    static constexpr uint32_t kFb = 6u * PAIRS;                       // bytes of an output frame, and of a packed S24 input frame
+    static constexpr uint32_t kFbIn = kS16 ? 4u * PAIRS : kFb;        // bytes of a packed input frame
     static constexpr uint32_t kSR = ROWS / PAIRS;                     // stream rows of a pass: 16, 5 (fifteen of the sixteen pair-rows) or 4
     static constexpr uint32_t kUnitRows = PAIRS == 3 ? 30u : 32u;     // rows of a planner unit (LeanUnit: src_plan.cpp cuts them this long for this kernel): a whole number of passes
-    static constexpr uint32_t kRowIn = kImgChunks * 16u * kFb;        // bytes of a row's input image, packed
+    static constexpr uint32_t kRowIn = kImgChunks * 16u * kFbIn;      // bytes of a row's input image, packed
     static constexpr uint32_t kRowLanes = 16u * PAIRS;                // lanes that move one row of the input image, 4.5 (7.5) pieces each (planar: 6)
     static constexpr uint32_t kRound = 16u * kRowLanes;               // ... and the bytes of it one round of them moves
     static constexpr uint32_t kFullRounds = HB ? 7 : 4;               // whole rounds; then half a round
@@ -75,12 +79,13 @@ struct WgGeom {
     // frames long -- so the pass fetches their UNION, one run of at most 1024 16-byte pieces from the first row's start (four rounds
     // of the workgroup's lanes, every instruction 4 KB contiguous), and the split finds a row at r * row_src_bytes in it: a fifth
     // fewer loads and stage writes than row by row, and 5 % off the headline launch (0.317 -> 0.300 ms, same box, before the split paid for it).
-    static constexpr bool kSpan = PLANAR == 0 && !HB;
-    static constexpr uint32_t kSpanBytes = 1024u * 16u;
-    static constexpr uint32_t kInRounds = PLANAR ? 6 : (kSpan ? 4 : kFullRounds + 1);
+    static constexpr bool kSpan = !kPlanes && !HB;
+    static constexpr uint32_t kSpanRounds = kS16 ? 3 : 4;             // (16-bit stereo: at most 648 pieces)
+    static constexpr uint32_t kSpanBytes = kSpanRounds * 256u * 16u;
+    static constexpr uint32_t kInRounds = kPlanes ? 6 : (kSpan ? kSpanRounds : kFullRounds + 1);
     static constexpr uint32_t kRoundsA = HB ? 5 : kInRounds;          // half-band: the rounds of the first staging (the second: kRoundsA - 1 ..)
     static constexpr uint32_t kChunksA = HB ? 13 : kImgChunks;        // ... and the input chunks it holds whole
-    static constexpr uint32_t kRowInPitch = PLANAR ? 2 * kWgPlaneIn + 16 : (HB ? kRoundsA * kRound + 16 : kRowIn + 16);   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
+    static constexpr uint32_t kRowInPitch = kPlanes ? 2 * kWgPlaneIn + 16 : (HB ? kRoundsA * kRound + 16 : kRowIn + 16);   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
     static constexpr uint32_t kRowOut = kOutFrames * kFb;             // bytes of a row's output
     static constexpr uint32_t kCt = ROWS / 8;
     static constexpr uint32_t kWaves = 2 * kCt;
@@ -104,10 +109,10 @@ struct WgGeom {
     static constexpr uint32_t kStoreRounds = (kOutPieces + kThreads - 1) / kThreads;
     static_assert(kGroupsPerCu * kLdsBytes <= 160 * 1024, "workgroups per CU");
     static_assert(kTilesPerWave * kWaves == kSteps * kCt, "whole tiles per wave");
-    static_assert(kSR * kRowLanes <= kThreads && kRowIn == (2 * kFullRounds + 1) * 8 * 16 * PAIRS && kSubUnits * kSR == kUnitRows, "lanes per row of the input image, 4.5 (7.5) pieces each");
+    static_assert(kSR * kRowLanes <= kThreads && (kSpan || kRowIn == (2 * kFullRounds + 1) * 8 * 16 * PAIRS) && kSubUnits * kSR == kUnitRows, "lanes per row of the input image, 4.5 (7.5) pieces each");
     // (the union of a pass's rows: at most kOutFrames input frames from one row to the next -- the block geometry src_mfma_wg_supported
     // admits -- and at least 145, so that only the fourth round has pieces past its end)
-    static_assert(!kSpan || ((kSR - 1) * kOutFrames * kFb + kRowIn <= kSpanBytes && (kSR - 1) * 145 * kFb + kRowIn > 768 * 16 && kThreads == 256), "a pass's rows in four rounds");
+    static_assert(!kSpan || ((kSR - 1) * kOutFrames * kFbIn + kRowIn <= kSpanBytes && (kSR - 1) * 145 * kFbIn + kRowIn > (kSpanRounds - 1) * 256 * 16 && kThreads == 256), "a pass's rows in kSpanRounds rounds, only the last with pieces past the end");
     static_assert(!HB || (kChunksA * 16 * kFb <= kRoundsA * kRound && (kChunksA * 16 * kFb) >= (kRoundsA - 1) * kRound), "the two stagings meet in chunk 13");
 };
 
@@ -143,7 +148,7 @@ __device__ __noinline__ u32x4 wg_load_piece_checked(const uint8_t* __restrict__ 
     return u32x4{w[0], w[1], w[2], w[3]};
 }
 
-// PLANAR: 0 = packed 24-bit stereo frames (SRC_LE: their byte order); 1 + k = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32 (one per
+// PLANAR (the source format): 0 = packed 24-bit frames, 4 = packed 16-bit stereo frames (SRC_LE: their byte order); 1 + k = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32 (one per
 // channel, `src_plane_stride` apart, host byte order), the sample being the low 24 - 8 k bits of a plane's value shifted up k bytes
 // (k = 0, 1, 2 for 24-, 16- and 8-bit streams: CodecFlac::CallbackWrite's pack, Flac.cpp:379-417, folded into the load).
 template <int ROWS, int PLANAR, int PAIRS, bool HB, bool SRC_LE, bool DST_LE>
@@ -217,7 +222,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t sp_span0 = sp_srow * row_src_bytes + 6u * sp_pair;               // (kSpan: the pair-row's first frame in the pass's run)
     // kSpan: the run's pieces -- the rows' union, rounded up to whole pieces (src_mfma_wg_unit_inside leaves the 15 bytes that can add)
     const uint32_t span_pieces = ((G::kSR - 1u) * row_src_bytes + G::kRowIn + 15u) >> 4;
-    const uint32_t span_p3 = 768u + tid < span_pieces ? 768u + tid : tid;           // (the fourth round's lanes past the end repeat their first piece)
+    constexpr uint32_t kSpanLast = (G::kSpan ? G::kSpanRounds - 1u : 0u) * 256u;
+    const uint32_t span_p3 = kSpanLast + tid < span_pieces ? kSpanLast + tid : tid;  // (the last round's lanes past the end repeat their first piece)
 
     // pack: a frame's six bytes from its two 24-bit values, L then R, each most significant byte first (big endian) or last
     constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;       // byte of the 24-bit value that is memory byte 0, 1, 2
@@ -255,12 +261,12 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             // the slack behind a row's last frame
 #pragma unroll
             for (int k = 0; k < (int)G::kInRounds; k++) {
-                const int64_t at = PLANAR ? (int64_t)(in_src + 256u * (uint32_t)(k % 3)) + (int64_t)(k / 3) * w.plane_stride
-                                 : G::kSpan ? (int64_t)(16u * (k < 3 ? tid + 256u * (uint32_t)k : span_p3))
+                const int64_t at = G::kPlanes ? (int64_t)(in_src + 256u * (uint32_t)(k % 3)) + (int64_t)(k / 3) * w.plane_stride
+                                 : G::kSpan ? (int64_t)(16u * (k + 1 < (int)G::kInRounds ? tid + 256u * (uint32_t)k : span_p3))
                                           : (int64_t)(k < (int)G::kFullRounds ? in_src + G::kRound * (uint32_t)k : in_src + in_last);
                 raw[k] = wg_load_piece_checked(src, w.src0 + at, src_arena_bytes);
             }
-        } else if constexpr (PLANAR != 0) {
+        } else if constexpr (G::kPlanes) {
             const uint32_t o = mf_here(in_src);
             const uint8_t* const base1 = base + w.plane_stride;
 #pragma unroll
@@ -271,8 +277,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             if constexpr (G::kSpan) {
                 const uint32_t o = mf_here(16u * tid);
 #pragma unroll
-                for (int k = 0; k < 3; k++) raw[k] = *(const u32x4_u*)(base + o + 4096 * k);
-                raw[3] = *(const u32x4_u*)(base + mf_here(16u * span_p3));
+                for (int k = 0; k + 1 < (int)G::kInRounds; k++) raw[k] = *(const u32x4_u*)(base + o + 4096 * k);
+                raw[G::kInRounds - 1] = *(const u32x4_u*)(base + mf_here(16u * span_p3));
             } else {
                 const uint32_t o = mf_here(in_src);
 #pragma unroll
@@ -286,12 +292,12 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #ifdef MF_DIAG_NO_STAGE
         return;
 #endif
-        if constexpr (PLANAR != 0) {
+        if constexpr (G::kPlanes) {
 #pragma unroll
             for (int k = 0; k < 6; k++) *(u32x4*)(stage + in_lds + (k / 3) * kWgPlaneIn + 256 * (k % 3)) = raw[k];
         } else if constexpr (G::kSpan) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) *(u32x4*)(stage + 16u * tid + 4096 * k) = raw[k];      // (piece for piece: a wave writes a contiguous KB)
+            for (int k = 0; k < (int)G::kInRounds; k++) *(u32x4*)(stage + 16u * tid + 4096 * k) = raw[k];      // (piece for piece: a wave writes a contiguous KB)
         }
     };
     // half-band: the image in two sections over the same LDS -- section 0 = the lanes' rounds 0..4 (bytes 0 .. 5 kRound of every row:
@@ -350,10 +356,32 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         // the stream's block 0: the frames before it (chunks 0 and 1 of row 0) read as zeros
         const bool zero = first && sp_srow == 0 && hc < 4u;
         uint32_t pl[6][2];                                  // [3 * channel + byte of the 24-bit sample, least significant first... in memory order for packed][frames 0-3, 4-7]
-        if constexpr (PLANAR != 0) {
+        if constexpr (G::kS16) {
+            // 16-bit stereo: a frame is one dword {L lo, L hi, R lo, R hi} (or hi first); a 4 x 4 byte transpose per four frames gives the
+            // four byte planes, and the 24-bit sample is the 16 bits over a zero byte -- digit 0 is the offset digit of zero everywhere
+            const uint8_t* const from = stage + sp_span0 + 32u * hc;
+            const u32x4 lo4 = *(const u32x4_a4*)from, hi4 = *(const u32x4_a4*)(from + 16);
+            const uint32_t f[8] = {zero ? 0u : lo4.x, zero ? 0u : lo4.y, zero ? 0u : lo4.z, zero ? 0u : lo4.w,
+                                   zero ? 0u : hi4.x, zero ? 0u : hi4.y, zero ? 0u : hi4.z, zero ? 0u : hi4.w};
+            uint32_t by[4][2];                               // [byte of the frame][frames 0-3, 4-7]
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t p01 = mf_perm(f[4 * q + 1], f[4 * q], 0x05010400u), q01 = mf_perm(f[4 * q + 1], f[4 * q], 0x07030602u);
+                const uint32_t p23 = mf_perm(f[4 * q + 3], f[4 * q + 2], 0x05010400u), q23 = mf_perm(f[4 * q + 3], f[4 * q + 2], 0x07030602u);
+                by[0][q] = mf_perm(p23, p01, 0x05040100u); by[1][q] = mf_perm(p23, p01, 0x07060302u);
+                by[2][q] = mf_perm(q23, q01, 0x05040100u); by[3][q] = mf_perm(q23, q01, 0x07060302u);
+            }
+            // pl[3 * channel + byte of the 24-bit sample, least significant first] (stored below as if the source were little endian)
+            constexpr int kLo = SRC_LE ? 0 : 1, kHi = SRC_LE ? 1 : 0;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                pl[0][q] = 0u; pl[1][q] = by[kLo][q]; pl[2][q] = by[kHi][q];
+                pl[3][q] = 0u; pl[4][q] = by[2 + kLo][q]; pl[5][q] = by[2 + kHi][q];
+            }
+        } else if constexpr (G::kPlanes) {
             // eight frames of each channel, 4 bytes apiece: a 4 x 4 byte transpose per four frames (two permute levels) of which the
             // sample's bytes are kept -- byte b of the plane value is byte b + k of the 24-bit sample
-            constexpr int kShift = PLANAR - 1;
+            constexpr int kShift = G::kPlanes ? PLANAR - 1 : 0;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 const uint8_t* const from = stage + sp_row * G::kRowInPitch + c * kWgPlaneIn + 32u * hc;
@@ -413,7 +441,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         uint8_t* const to = pl_lds + c * G::kChunk + (((hc & 1u) * G::kHalf + sp_row * 16u) ^ ((c & 1u) * 128u));     // + digit * kDigit
 #pragma unroll
         for (int bpos = 0; bpos < 3; bpos++) {
-            const int digit = (SRC_LE || PLANAR) ? bpos : 2 - bpos;
+            const int digit = (SRC_LE || PLANAR) ? bpos : 2 - bpos;     // (planes and 16-bit frames arrive least significant byte first)
             const uint32_t flip = digit < 2 ? 0x80808080u : 0u;
             *(u32x4*)(to + digit * G::kDigit) = u32x4{pl[bpos][0] ^ flip, pl[bpos][1] ^ flip, pl[3 + bpos][0] ^ flip, pl[3 + bpos][1] ^ flip};
         }
@@ -578,7 +606,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 
         // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
         // unit's input -- requested a whole phase (C) ago -- is waited for HERE, in front of the stores, not behind them ----
-        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
+        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
+        if constexpr (G::kInRounds > 3) asm volatile("" : "+v"(raw[3]));
         if constexpr (G::kInRounds > 4) asm volatile("" : "+v"(raw[4]));
         if constexpr (G::kInRounds > 5) asm volatile("" : "+v"(raw[5]));
         if constexpr (G::kInRounds > 6) asm volatile("" : "+v"(raw[6]), "+v"(raw[7]));
@@ -624,16 +653,18 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 
 bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar, bool halfband)
 {
-    // (planar: sb is the stream's sample size, 1..3 bytes, whatever the planes hold above it; packed: stereo, six or eight channels of S24)
-    const bool layout = planar ? (ch == 2 && sb >= 1 && sb <= 3 && !halfband) : ((ch == 2 || ch == 6 || ch == 8) && sb == 3);
+    // (planar: sb is the stream's sample size, 1..3 bytes, whatever the planes hold above it; packed: stereo, six or eight channels of
+    // S24, and 16-bit stereo through the polyphase filters)
+    const bool layout = planar ? (ch == 2 && sb >= 1 && sb <= 3 && !halfband)
+                               : (((ch == 2 || ch == 6 || ch == 8) && sb == 3) || (ch == 2 && sb == 2 && !halfband));
     if (halfband) return layout && db == 3 && L_blk == 128u && M_blk == 256u;          // (2:1: WgGeom<.., HB>)
     return layout && db == 3 && L_blk == 160u && (M_blk + 31u) / 16u + 1u == 12u;     // (160 outputs from at most 160 inputs + 32 of history: twelve chunks)
 }
 
 // does a unit's input image -- `unit_rows` rows of 192 (half-band: 320) frames, whatever the number of blocks the unit holds -- lie inside the arena?
-bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, uint32_t unit_rows, bool planar, uint64_t plane_stride, bool halfband)
+bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, uint32_t sb, uint32_t unit_rows, bool planar, uint64_t plane_stride, bool halfband)
 {
-    const uint64_t row_in = planar ? kWgPlaneIn : (halfband ? 320u : 192u) * 3u * ch, last_plane = planar ? plane_stride : 0;
+    const uint64_t row_in = planar ? kWgPlaneIn : (halfband ? 320u : 192u) * sb * ch, last_plane = planar ? plane_stride : 0;
     // (packed: a pass's rows are fetched as one run of 16-byte pieces from the first row's start: the last piece may reach 15 bytes further)
     return src_row0 >= 0 && unit_rows >= 1 && (uint64_t)src_row0 + last_plane + (uint64_t)(unit_rows - 1u) * row_src_bytes + row_in + (planar ? 0u : 15u) <= src_arena_bytes;
 }
@@ -645,7 +676,7 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, PAIRS, HB, SRC_LE, DST_LE>;
     const SrcFastPlan& f = b->fast;
     if (f.n_lean == 0) return hipSuccess;
-    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, PLANAR != 0, HB) || p.channels != 2u * PAIRS || f.wg_unit_rows != G::kUnitRows) return hipErrorInvalidValue;
+    if (!src_mfma_wg_supported(p.L_blk, p.M_blk, p.channels, p.sb, p.db, G::kPlanes, HB) || p.channels != 2u * PAIRS || f.wg_unit_rows != G::kUnitRows) return hipErrorInvalidValue;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     const uint32_t n_units = f.n_lean * G::kSubUnits;                // (edge units included: their loads are checked)
     uint32_t gsz = G::kGroupsPerCu * cus;                     // as many workgroups as the LDS holds
@@ -654,7 +685,7 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s,
                        (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
-                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * (PLANAR ? 4u : G::kFb), p.src_arena_bytes);
+                       (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * (G::kPlanes ? 4u : G::kFbIn), p.src_arena_bytes);
     return hipGetLastError();
 }
 
@@ -679,6 +710,11 @@ hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const 
         }
     }
     const bool hb = b->fast.mfma_wg_halfband;
+    if (prm.sb == 2) {                                       // packed 16-bit stereo (WgGeom: source format 4)
+        if (prm.channels != 2 || hb) return hipErrorInvalidValue;
+        if (prm.src_le) return prm.dst_le ? launch_wg_one<4, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<4, 1, false, true, false>(ctx, b, prm, s);
+        return prm.dst_le ? launch_wg_one<4, 1, false, false, true>(ctx, b, prm, s) : launch_wg_one<4, 1, false, false, false>(ctx, b, prm, s);
+    }
     switch (prm.channels) {
     case 2: return hb ? launch_wg_packed<1, true>(ctx, b, prm, s) : launch_wg_packed<1, false>(ctx, b, prm, s);
     case 6: return hb ? launch_wg_packed<3, true>(ctx, b, prm, s) : launch_wg_packed<3, false>(ctx, b, prm, s);

@@ -110,7 +110,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const bool lean_only = planar ? (T == 32 && ch == 2 && sb != 4 && db == 3) : (!block_ok && src_lean_only_supported(T, ch, sb, src_le, db, dst_le));
     // (a layout only the workgroup matrix kernel has -- big-endian S24 to little-endian S24: planned like a lean-only one, kept only if
     // that kernel takes it, and run on the generic kernel under any variant that asks for another)
-    const bool wg_only = !block_ok && !lean_only && !planar && (T == 32 || (T == 64 && flt->mf_halfband)) && (ch == 2 || ch == 6 || ch == 8) && sb == 3 && db == 3;
+    const bool wg_only = !block_ok && !lean_only && !planar && db == 3 &&
+                         (((T == 32 || (T == 64 && flt->mf_halfband)) && (ch == 2 || ch == 6 || ch == 8) && sb == 3) || (T == 32 && ch == 2 && sb == 2));
     if (!block_ok && !lean_only && !wg_only) return OHGPU_OK;
     const uint32_t sb_geo = planar ? 3u : sb;                           // (round 1's geometry: only its rows and ring are used)
     const uint32_t sb_lean = planar ? 0u : sb;                          // (LeanGeom: 0 = planar)
@@ -152,7 +153,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // (and the half-band 2:1 decimator, from its own tables: build_mfma_halfband)
     const bool wg_hb = flt->mf_halfband && T == 64 && !planar;
     const bool wg_tables = lean && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (T == 32 || wg_hb) && rows == 64u / ch;
-    const bool wg_wide = !planar && (ch > 2 || wg_hb) && (M_blk + T) * fb_src < (1u << 24);
+    const bool wg_wide = !planar && (ch > 2 || wg_hb || sb == 2) && (M_blk + T) * fb_src < (1u << 24);     // (and 16-bit stereo)
     const bool mfma_wg = wg_tables && (planar || mfma || wg_wide) && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db, planar, wg_hb) &&
                          !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
     if (wg_only && !mfma_wg) return OHGPU_OK;
@@ -409,7 +410,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             else if (unit_leaves_arena(segs[r.seg].src_base, u.src_plane_stride, bk, n_rows, kb)) u.flags |= kWorkChecked;
             // the workgroup kernel reads 32 rows' worth of input per unit whatever the unit holds and checks nothing: the (at most two)
             // units of a batch for which that leaves the arena stay with the unit-per-wave kernel
-            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, ch, rows, planar, (uint64_t)(ch - 1) * u.src_plane_stride, wg_hb)) u.flags |= kWorkEdge;
+            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, ch, sb, rows, planar, (uint64_t)(ch - 1) * u.src_plane_stride, wg_hb)) u.flags |= kWorkEdge;
             if (u.flags & kWorkRamped) {
                 // one plane of multipliers per ramped unit -- n_rows * L_blk entries (uint16, 0xffff = no ramp on that frame), in
                 // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16

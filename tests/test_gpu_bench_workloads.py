@@ -210,3 +210,24 @@ def test_a_plan_only_the_workgroup_kernel_reads_runs_on_the_generic_kernel_under
         assert np.array_equal(ctx.download(g.d_dst, g.dst_bytes), want)
     finally:
         g.detach(ctx)
+
+
+@pytest.mark.parametrize("src_le", [True, False], ids=["sle", "sbe"])
+@pytest.mark.parametrize("dst_le", [True, False], ids=["dle", "dbe"])
+@pytest.mark.parametrize("n_streams, seconds", [(3, 0.31), (14, 0.83)])
+def test_workgroup_matrix_kernel_takes_packed_16_bit_stereo(ctx, src_le, dst_le, n_streams, seconds):
+    """CD audio -- 44.1 kHz 16-bit stereo, either byte order -- to 48 kHz S24: the sample is the 16 bits over a zero byte, the same
+    tiles; src_mfma_wg_kernel runs it (the lean kernel under variant 4) and both are the integer model's bytes."""
+    g = bench.Group(capi, 44100, 2, range(500, 500 + n_streams), int(round(seconds * 44100)), src_bits=16,
+                    src_endian=capi.ENDIAN_LITTLE if src_le else capi.ENDIAN_BIG, dst_bits=24,
+                    dst_endian=capi.ENDIAN_LITTLE if dst_le else capi.ENDIAN_BIG)
+    per = g.in_frames * 2
+    le = [noise_le(sid, per, 16) for sid in g.stream_ids]
+    g.src = np.concatenate([(x if src_le else x[:, ::-1]).reshape(-1) for x in le])
+    run_groups(ctx, [g], kernel="src_mfma_wg_kernel")
+    if not dst_le:                                              # (S16 -> S24 LE has no lean instantiation: that batch is the workgroup kernel's alone)
+        ctx.set_kernel_variant(4)
+        try:
+            run_groups(ctx, [g], kernel="src_lean_kernel")
+        finally:
+            ctx.set_kernel_variant(0)
