@@ -778,8 +778,8 @@ int ohgpu_src_mfma_halfband_tables(const int32_t* coef_q28, uint8_t* image, int6
     if (L_blk == 0 || !build_mfma_halfband(coef_q28, L_blk, &steps, &amat) || steps.empty())
         return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_mfma_halfband_tables: not a half-band decimator of 64 taps");
     memcpy(image, amat.data(), kMfStepImage);
-    // (the steps carry the bias in three pieces, the same for every output: bits 0..15, 16..31, 32..)
-    if (bias) *bias = (int64_t)steps[0].b0[0] + ((int64_t)steps[0].b1[0] << 16) + ((int64_t)(int32_t)steps[0].b2[0] << 32);
+    // (the steps carry the bias in pieces, the same for every output: bits 0..15 and, signed, bits 16..)
+    if (bias) *bias = (int64_t)steps[0].b0[0] + ((int64_t)(int32_t)steps[0].b1[0]) * 65536 + ((int64_t)(int32_t)steps[0].b2[0]) * 4294967296ll;
     if (block_outputs) *block_outputs = L_blk;
     return OHGPU_OK;
 }

@@ -94,7 +94,8 @@ struct RampJob {              // ramp_plane_kernel: frames [i0, i0 + count) of o
 static_assert(sizeof(SegMsg) == 24 && sizeof(SrcWork) == 32 && sizeof(SrcSeg) == 24 && sizeof(LeanUnit) == 32 && sizeof(RampJob) == 32, "plan layouts");
 struct MfStep {               // src_mfma_kernel: one step = 16 consecutive output frames of a row (the same for every row: rows start at phase 0)
     uint32_t aoff[16];        // output m's A row: byte offset into a digit's table, phase * 96 + (31 + k0 - n0(m))
-    uint32_t b0[16], b1[16], b2[16];   // its accumulators' initial values: bits 0..15, 16..31, 32.. of 32896 * sum(c[phase]) + 2^27
+    uint32_t b0[16], b1[16], b2[16];   // its accumulators' initial values: bits 0..15 and (signed) bits 16.. of 32896 * sum(c[phase]) + 2^27 -- below 2^28, so
+                              // that class 2's accumulator holds them beside its own 2^22 -- and zero (b2: a third read per tile until round 4's end)
     uint32_t kc;              // the step's window is input chunks kc .. kc + 3 (a chunk = 16 frames; frame 0 of chunk 0 = the row's frame -32)
     uint32_t pad[7];
 };

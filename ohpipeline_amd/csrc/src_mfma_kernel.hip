@@ -457,7 +457,7 @@ bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q
         }
         // the offset digits' constant (128 + 128 * 256 per sample) and the rounding
         bias[p] = 32896 * sum + ((int64_t)1 << 27);
-        if (bias[p] < -((int64_t)1 << 46) || bias[p] > ((int64_t)1 << 46)) return false;
+        if (bias[p] < -((int64_t)1 << 44) || bias[p] > ((int64_t)1 << 44)) return false;      // (its bits 16.. ride in ONE accumulator: MfStep)
     }
     const uint32_t n_steps = (L_blk / 16) * kb_cap;
     steps->assign(n_steps, MfStep());
@@ -475,8 +475,8 @@ bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q
             if (o < 0 || o > 32) return false;                        // (a ratio this tiling does not hold: 15 M / L must stay below 17)
             s.aoff[m] = p * 96 + (uint32_t)o;
             s.b0[m] = (uint32_t)(bias[p] & 0xffff);
-            s.b1[m] = (uint32_t)((bias[p] >> 16) & 0xffff);
-            s.b2[m] = (uint32_t)(int32_t)(bias[p] >> 32);
+            s.b1[m] = (uint32_t)(int32_t)(bias[p] >> 16);
+            s.b2[m] = 0;
         }
     }
     return true;
@@ -499,7 +499,7 @@ bool build_mfma_halfband(const int32_t* coef_q28, uint32_t L_blk, std::vector<Mf
         sum += c;
     }
     const int64_t bias = 32896 * sum + ((int64_t)1 << 27);
-    if (bias < -((int64_t)1 << 46) || bias > ((int64_t)1 << 46)) return false;
+    if (bias < -((int64_t)1 << 44) || bias > ((int64_t)1 << 44)) return false;
     amat->assign(kMfStepImage, 0);
     for (uint32_t gq = 0; gq < 4; gq++)
         for (uint32_t n = 0; n < 16; n++)
@@ -522,8 +522,8 @@ bool build_mfma_halfband(const int32_t* coef_q28, uint32_t L_blk, std::vector<Mf
         st.kc = t;                                                                                // even chunks t .. t + 2, odd chunk t + 1
         for (uint32_t m = 0; m < 16; m++) {
             st.b0[m] = (uint32_t)(bias & 0xffff);
-            st.b1[m] = (uint32_t)((bias >> 16) & 0xffff);
-            st.b2[m] = (uint32_t)(int32_t)(bias >> 32);
+            st.b1[m] = (uint32_t)(int32_t)(bias >> 16);
+            st.b2[m] = 0;
         }
     }
     return true;

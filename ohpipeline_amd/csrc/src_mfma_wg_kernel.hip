@@ -97,8 +97,12 @@ struct WgGeom {
     static constexpr uint32_t kChunk = 2 * kHalf;
     static constexpr uint32_t kDigit = kPlaneChunks * kChunk;
     static constexpr uint32_t kPlaneBytes = 3 * kDigit;
-    static constexpr uint32_t kBiasSteps = HB ? 1 : kSteps;           // [step][b0, b1, b2][output 16][4 copies] dwords: an output's value as the four-register C operand of its tile
-    static constexpr uint32_t kBiasBytes = kBiasSteps * 768;
+    // [step][b0, b1][output 16][4 copies] dwords: an output's two initial values as the four-register C operands of its tile (bits 16.. of
+    // the constant ride in ONE accumulator, MfStep: two 16-byte reads per tile, not three; half-band: the same for every output and step --
+    // they stay in eight registers, no table)
+    static constexpr uint32_t kBiasSteps = HB ? 0 : kSteps;
+    static constexpr uint32_t kBiasStep = 512;
+    static constexpr uint32_t kBiasBytes = kBiasSteps * kBiasStep;
     static constexpr uint32_t kInBytes = kSpan ? kSpanBytes : kSR * kRowInPitch;   // the input image ...
     static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOut;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
     static constexpr uint32_t kStageBytes = kInBytes > kOutBytes ? kInBytes : kOutBytes;
@@ -172,9 +176,9 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t step0 = tile0 / G::kCt;
 
     // the accumulators' initial values (MfStep::b0..b2) of the block's steps
-    for (uint32_t i = tid; i < G::kBiasSteps * 48u; i += G::kThreads) {
-        const uint32_t t = i / 48u, r = i - 48u * t;
-        const uint32_t v = steps[t].b0[r];                 // (b0, b1, b2 lie one after the other)
+    for (uint32_t i = tid; i < G::kBiasSteps * 32u; i += G::kThreads) {
+        const uint32_t t = i / 32u, r = i - 32u * t;
+        const uint32_t v = steps[t].b0[r];                 // (b0 and b1 lie one after the other)
         ((u32x4*)bias_lds)[i] = u32x4{v, v, v, v};
     }
     // this wave's A operands, for good
@@ -199,7 +203,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     // (half-band: K groups 0..2 are the even-frame chunks kc .. kc + 2, group 3 the odd-frame chunk kc + 1 = plane chunk 10 + kc + 1)
     const uint32_t g_chunk = HB ? (g < 3u ? g : 11u) : g;
     const uint8_t* const b_lds = pl_lds + g_chunk * G::kChunk + n * 8u;           // + kc * chunk + digit * kDigit + ((half * kHalf + tile * 128) ^ parity of the chunk * 128)
-    const uint8_t* const my_bias = bias_lds + 16u * n;                            // + step * 768: b0; b1 at + 256, b2 at + 512
+    const uint8_t* const my_bias = bias_lds + 16u * n;                            // + step * 512: b0; b1 at + 256
+    // (half-band: the two values, once)
+    const int hb0 = HB ? (int)steps[0].b0[n] : 0, hb1 = HB ? (int)steps[0].b1[n] : 0;
+    const v4i hb_s0 = v4i{hb0, hb0, hb0, hb0}, hb_s2 = v4i{hb1, hb1, hb1, hb1};
     // where the lane's frame of pair-row 2 g lies in the output image (+ 16 frames per step; + 8 pair-rows per column tile; the pair-row
     // 2 g + 1 is the next row (stereo) or the next pair of the same row (eight channels); six channels: out_at below)
     uint8_t* const out_lds = stage + ((2u * g) / (uint32_t)PAIRS) * G::kRowOut + 6u * ((2u * g) % (uint32_t)PAIRS) + G::kFb * n;
@@ -530,9 +537,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                 constexpr uint32_t set = (kFirst + i) / G::kCt - kFirst / G::kCt, ct = (kFirst + i) % G::kCt;
                 static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
                 const uint32_t step = step0 + set;
-                const uint8_t* const bi = my_bias + (HB ? 0u : step * 768u);
-                v4i s0 = *(const v4i*)bi, s1 = v4i{0, 0, 0, 0}, s2 = *(const v4i*)(bi + 256), s3 = v4i{0, 0, 0, 0},
-                    s4 = *(const v4i*)(bi + 512), s5 = v4i{0, 0, 0, 0};
+                const uint8_t* const bi = my_bias + step * G::kBiasStep;
+                v4i s0, s1 = v4i{0, 0, 0, 0}, s2, s3 = v4i{0, 0, 0, 0}, s4 = v4i{0, 0, 0, 0}, s5 = v4i{0, 0, 0, 0};
+                if constexpr (HB) { s0 = hb_s0; s2 = hb_s2; }
+                else { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + 256); }
                 const v4i (&c)[4] = a[HB ? 0 : set];
                 s0 = MF_MFMA(bd[0], c[0], s0);
                 s1 = MF_MFMA(bd[0], c[1], s1);

@@ -49,11 +49,13 @@ def emulate_row(dig, steps, L_blk, kb, frames):
             p, o = divmod(aoff, 96)
             a = [dig[j, p, o:o + 64].astype(np.int64) for j in range(4)]
             win = [dd[k0:k0 + 64] for dd in d]
-            s = [int(st["b0"][m]), 0, int(st["b1"][m]), 0, int(st["b2"][m]), 0]
+            init = [int(st["b0"][m]), 0, int(np.int32(st["b1"][m])), 0, int(np.int32(st["b2"][m])), 0]
+            assert 0 <= init[0] < 1 << 16 and abs(init[2]) < 1 << 28 and init[4] == 0     # the constant: 16 bits, the rest in ONE accumulator
+            s = list(init)
             for i in range(3):
                 for j in range(4):
                     s[i + j] += int(np.dot(a[j], win[i]))
-            assert all(abs(v) < 1 << 22 for v in s), "an accumulator left the range the recombination assumes"
+            assert all(abs(v - b) < 1 << 22 for v, b in zip(s, init)), "a sum of products left the range the recombination assumes"
             t0 = (s[1] << 8) + s[0]
             uu = (s[3] << 8) + s[2] + (t0 >> 16)
             w = (s[5] << 8) + s[4] + (uu >> 16)
@@ -115,7 +117,8 @@ def emulate_halfband_row(image, bias, L_blk, frames):
          ((u >> 16) & 0xFF).astype(np.uint8).view(np.int8).astype(np.int64)]
     even = [dd[0::2] for dd in d]
     odd = [dd[1::2] for dd in d]
-    b = [bias & 0xFFFF, (bias >> 16) & 0xFFFF, bias >> 32]
+    b = [bias & 0xFFFF, bias >> 16, 0]                        # as the kernel carries it: 16 bits in class 0's accumulator, the rest in class 2's
+    assert abs(b[1]) < 1 << 28
     out = np.zeros(L_blk, dtype=np.int64)
     for s_ in range(L_blk // 16):
         for n in range(16):
@@ -125,7 +128,7 @@ def emulate_halfband_row(image, bias, L_blk, frames):
                     samples = even[i][16 * (s_ + g):16 * (s_ + g) + 16] if g < 3 else odd[i][16 * (s_ + 1):16 * (s_ + 1) + 16]
                     for j in range(4):
                         acc[i + j] += int(np.dot(image[j, g, n].astype(np.int64), samples))
-            assert all(abs(v) < 1 << 22 for v in acc), "an accumulator left the range the recombination assumes"
+            assert all(abs(v - i0) < 1 << 22 for v, i0 in zip(acc, [b[0], 0, b[1], 0, b[2], 0])), "a sum of products left the range the recombination assumes"
             t0 = (acc[1] << 8) + acc[0]
             uu = (acc[3] << 8) + acc[2] + (t0 >> 16)
             w = (acc[5] << 8) + acc[4] + (uu >> 16)
