@@ -231,3 +231,66 @@ def test_workgroup_matrix_kernel_takes_packed_16_bit_stereo(ctx, src_le, dst_le,
             run_groups(ctx, [g], kernel="src_lean_kernel")
         finally:
             ctx.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("rate, channels, src_bits", [(44100, 2, 24), (44100, 6, 24), (44100, 8, 24), (96000, 2, 24), (96000, 6, 24),
+                                                      (96000, 8, 24), (44100, 2, 16)])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_ragged_messages_and_arbitrary_ramps_on_the_workgroup_kernel(ctx, rate, channels, src_bits, seed):
+    """Not the host model's schedule: every stream cut into messages of 1 .. 700 output frames at random, any message ramped with
+    any endpoints (up, down, flat, one frame long), a few of them empty, streams of different lengths in one arena -- so that units
+    meet ramps anywhere, block-unaligned heads and tails go to the generic kernel mid-stream, and the last unit of a stream holds
+    any number of blocks.  The workgroup kernel runs the whole blocks; every byte is the integer model's."""
+    rng = np.random.default_rng(1000 * seed + channels + src_bits + rate // 1000)
+    ref = O.Src(rate, bench.RATE_OUT, bench.taps_for(rate), bench.BETA, bench.F_PASS)
+    L, M = ref.L, ref.M
+    fb_s, fb_d = channels * src_bits // 8, channels * 3
+    descs, src_parts, sp, dp = [], [], 0, 0
+    for s in range(9):
+        in_frames = int(rng.integers(int(0.05 * rate), int(0.6 * rate)))
+        out_total = (in_frames * L + M - 1) // M
+        x = noise_le(4000 + 97 * seed + s, in_frames * channels, src_bits).reshape(-1)
+        first = 0
+        while first < out_total:
+            n = int(min(out_total - first, rng.integers(1, 701)))
+            if rng.random() < 0.03:
+                n = 0                                            # an empty message, in the stream's order
+            d = np.zeros(1, dtype=capi.SRC_MSG_DESC)
+            d["src_offset"], d["src_frame0"], d["src_frames"] = sp, 0, in_frames
+            d["out_frame0"], d["dst_offset"], d["n_frames"] = first, dp + first * fb_d, n
+            if rng.random() < 0.3 and n > 0:
+                d["flags"] = capi.FLAG_RAMP
+                a, b = (int(v) for v in rng.choice([0, 1, 5, 8191, 8192, 12345, O.RAMP_MAX - 1, O.RAMP_MAX], size=2))
+                d["ramp_start"], d["ramp_end"] = a, b
+            else:
+                d["ramp_start"] = d["ramp_end"] = O.RAMP_MAX
+            d["attenuation"], d["channels"], d["src_bits"], d["src_endian"] = 256, channels, src_bits, capi.ENDIAN_LITTLE
+            d["dst_bits"], d["dst_endian"] = 24, capi.ENDIAN_BIG
+            descs.append(d)
+            first += n
+        src_parts.append(x)
+        pad = (-x.size) % 16
+        src_parts.append(np.zeros(pad, dtype=np.uint8))
+        sp += x.size + pad
+        dp += out_total * fb_d
+    descs = np.concatenate(descs)
+    src = np.concatenate(src_parts)
+    h = ctx.src_create(L, M, ref.T, ref.coef_q28)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dp)
+    ctx.memset(d_dst, 0xA5, dp)
+    b = ctx.src_batch(h, descs, src.size, dp)
+    try:
+        assert ctx.src_kernel_name(b) == "src_mfma_wg_kernel"
+        assert ctx.src_plan(b)["block_kernel_out_frames"] > 0 and ctx.src_plan(b)["generic_pieces"] > 0
+        ctx.src_run(b, d_src, d_dst)
+        ctx.sync()
+        got = ctx.download(d_dst, dp)
+        want = np.full(dp, 0xA5, dtype=np.uint8)
+        assert ref.process_batch(descs.view(O.SRC_MSG_DESC), src, want) == 0
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (int(bad.size), int(bad[0]))
+    finally:
+        ctx.batch_destroy(b)
+        ctx.src_destroy(h)
+        ctx.free(d_src)
+        ctx.free(d_dst)
