@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=3.0)
     ap.add_argument("--first-seed", type=int, default=1001)
     a = ap.parse_args()
+    import test_gpu_bench_workloads as B
     import test_gpu_flywheel as F
     import test_gpu_fmt as M
     import test_gpu_parity as P
@@ -25,7 +26,8 @@ def main():
     from ohpipeline_amd import capi
     ctx = capi.Context(0)
     deadline = time.time() + a.minutes * 60
-    seed, counts = a.first_seed - 1, {"src_tilings": 0, "long_rows": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0}
+    seed, counts = a.first_seed - 1, {"src_tilings": 0, "long_rows": 0, "songcast": 0, "pcm_matrix": 0, "flywheel": 0, "fmt_mixed": 0, "wg_ragged": 0}
+    wg_formats = [(44100, 2, 24), (44100, 6, 24), (44100, 8, 24), (96000, 2, 24), (96000, 6, 24), (96000, 8, 24), (44100, 2, 16)]
     layouts = ["stereo_s24", "six_s24", "halfband_stereo", "halfband_eight", "mono_s16", "stereo_s32", "planar16", "five_s24"]
     real_rng = np.random.default_rng
     formats = [(48000, 24, 2), (44100, 16, 2), (96000, 32, 2), (44100, 24, 1), (48000, 24, 6), (48000, 32, 8), (44100, 16, 6), (48000, 8, 2), (192000, 24, 2)]
@@ -40,6 +42,9 @@ def main():
         if seed % 4 == 0:                                    # round 3: rows of several blocks, forced onto small batches, by layout
             P.test_long_row_units_match_the_oracle(ctx, layouts[(seed // 4) % len(layouts)], seed)
             counts["long_rows"] += 1
+        if seed % 2 == 0:                                    # round 4: ragged messages and arbitrary ramps on the workgroup matrix kernel, by format
+            B.test_ragged_messages_and_arbitrary_ramps_on_the_workgroup_kernel(ctx, *wg_formats[(seed // 2) % len(wg_formats)], seed)
+            counts["wg_ragged"] += 1
         rng = np.random.default_rng(seed)
         w = S.Workload()
         for k in range(int(rng.integers(1, 12))):
