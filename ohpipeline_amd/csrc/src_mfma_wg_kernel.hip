@@ -283,9 +283,18 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         } else {
             if constexpr (G::kSpan) {
                 const uint32_t o = mf_here(16u * tid);
+                // (stereo: non-temporal -- a piece is read once, but for the 32 frames of history two passes share, 1.4 % of a pass's 2352,
+                // and need not stay in a cache: -0.7 % on the headline.  Six and eight channels, whose passes are five and four rows, share
+                // 4-5 %: there the plain load is the better one, by as much)
+                if constexpr (PAIRS == 1) {
 #pragma unroll
-                for (int k = 0; k + 1 < (int)G::kInRounds; k++) raw[k] = *(const u32x4_u*)(base + o + 4096 * k);
-                raw[G::kInRounds - 1] = *(const u32x4_u*)(base + mf_here(16u * span_p3));
+                    for (int k = 0; k + 1 < (int)G::kInRounds; k++) raw[k] = __builtin_nontemporal_load((const u32x4_u*)(base + o + 4096 * k));
+                    raw[G::kInRounds - 1] = __builtin_nontemporal_load((const u32x4_u*)(base + mf_here(16u * span_p3)));
+                } else {
+#pragma unroll
+                    for (int k = 0; k + 1 < (int)G::kInRounds; k++) raw[k] = *(const u32x4_u*)(base + o + 4096 * k);
+                    raw[G::kInRounds - 1] = *(const u32x4_u*)(base + mf_here(16u * span_p3));
+                }
             } else {
                 const uint32_t o = mf_here(in_src);
 #pragma unroll
