@@ -858,3 +858,24 @@ def test_long_row_units_match_the_oracle(ctx, layout, seed):
     assert np.array_equal(outs[0], outs[1])
     ctx.free(d_src); ctx.free(d_dst)
     ctx.src_destroy(h)
+
+
+def test_destroyed_batches_give_their_device_blocks_to_the_next(vctx):
+    """A context keeps the blocks of destroyed pcm / fmt / flywheel batches (descriptors, plan arrays) by size class and hands them to
+    the next batch of that size: after the first creation a loop of create -> run -> destroy allocates nothing on the device
+    (ohgpu_device_allocations stops moving), the outputs stay the oracle's, and a LARGER batch still gets what it needs."""
+    rng = np.random.default_rng(5)
+    descs, src, dst_bytes = matrix_descs(rng, [16, 24], [2, 6], [43, 220], [LE, BE], [(24, BE), (16, LE)])
+    want = oracle_pcm(descs, src, dst_bytes)
+    assert np.array_equal(run_pcm(vctx, descs, src, dst_bytes), want)
+    after_first = vctx.device_allocations()
+    for _ in range(20):
+        assert np.array_equal(run_pcm(vctx, descs, src, dst_bytes), want)
+    assert vctx.device_allocations() == after_first
+    big = np.concatenate([descs] * 40)                            # another size class
+    assert np.array_equal(run_pcm(vctx, big, src, dst_bytes), want)
+    grown = vctx.device_allocations()
+    assert grown >= after_first                                   # (more, unless an earlier test of this context left blocks of that class behind)
+    assert np.array_equal(run_pcm(vctx, big, src, dst_bytes), want)
+    assert np.array_equal(run_pcm(vctx, descs, src, dst_bytes), want)
+    assert vctx.device_allocations() == grown
