@@ -445,9 +445,65 @@ def cadence(ctx, capi, g, calls=200):
 
     def q(v, p):
         return round(float(np.percentile(v, p)), 1)
-    return {"what": f"{n} streams x one 5 ms message per call ({nf} output frames each), {calls} calls, wall clock per call",
-            "period_us": 5000, "host_buffers_us": {"median": q(host, 50), "p99": q(host, 99)},
-            "resident_launch_us": {"median": q(res, 50), "p99": q(res, 99)}}
+    out = {"what": f"{n} streams x one 5 ms message per call ({nf} output frames each), {calls} calls, wall clock per call",
+           "period_us": 5000, "host_buffers_us": {"median": q(host, 50), "p99": q(host, 99)},
+           "resident_launch_us": {"median": q(res, 50), "p99": q(res, 99)}}
+    out["adapter"] = cadence_adapter(g, calls)
+    return out
+
+
+def cadence_adapter(g, ticks=200):
+    """The same regime through the C++ host adapter (libohhost.so), as the reference's driver thread would meet it: per stream a
+    SampleRateConverter element whose output becomes a playable (PreDriver.cpp:115-133), per 5 ms tick every stream is fed its
+    next 5 ms of input and ALL the playables are read with ONE PlayableBatch::Run (MsgPlayable::Read per message on the driver
+    thread in the reference: Msg.cpp:2646-2653, AnimatorBasic.cpp:77-142) -- message objects, window packing, one C-ABI call per
+    filter, the callbacks' copy-out included.  Two lanes' whole output is checked against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from ohpipeline_amd import hostmodel
+    n = len(g.stream_ids)
+    if g.planar or g.src_bits not in (16, 24, 32):
+        return None
+    in_per_tick = g.rate_in // 200
+    ticks = min(ticks, g.in_frames // in_per_tick)
+    lane_stride = g.in_frames * g.fb_src
+    out_stride = 4096
+    src = g.src.view(np.uint8).reshape(-1)
+    out = np.zeros(n * out_stride, dtype=np.uint8)
+    t_us, kept = [], {0: [], n - 1: []}
+    with hostmodel.LiveDriver(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch_device_count()), n, g.rate_in, RATE_OUT, g.channels,
+                              g.src_bits, g.src_endian == O.ENDIAN_LITTLE, 24) as live:
+        for k in range(ticks):
+            t0 = time.perf_counter()
+            nbytes = live.tick(src[k * in_per_tick * g.fb_src:], lane_stride, in_per_tick, out, out_stride)
+            t_us.append((time.perf_counter() - t0) * 1e6)
+            for lane in kept:
+                kept[lane].append(out[lane * out_stride:lane * out_stride + int(nbytes[lane])].copy())
+        st = live.stats()
+    ok = True
+    ref = O.Src(g.rate_in, RATE_OUT, g.taps, BETA, F_PASS)
+    for lane, parts in kept.items():
+        got = np.concatenate(parts)
+        d = np.zeros(1, dtype=O.SRC_MSG_DESC)
+        frames_in = ticks * in_per_tick
+        d["src_offset"], d["src_frames"], d["n_frames"] = lane * lane_stride, frames_in, ref.out_frames(frames_in)
+        d["attenuation"], d["channels"], d["src_bits"], d["src_endian"] = 256, g.channels, g.src_bits, g.src_endian
+        d["dst_bits"], d["dst_endian"] = 24, O.ENDIAN_BIG
+        want = np.zeros(int(d["n_frames"][0]) * g.channels * 3, dtype=np.uint8)
+        ok = ok and ref.process_batch(d, src, want) == 0 and got.size == want.size and np.array_equal(got, want)
+
+    def q(v, p):
+        return round(float(np.percentile(v, p)), 1)
+    steady = t_us[10:]
+    return {"what": f"{n} SampleRateConverter lanes behind one driver thread, one PlayableBatch::Run per 5 ms tick, {ticks} ticks, through libohhost.so",
+            "adapter_us": {"median": q(steady, 50), "p99": q(steady, 99)}, "resampler_calls_per_tick": round(st["src_calls"] / ticks, 3),
+            "filters": st["filters"], "h2d_bytes_per_tick": int(st["h2d_bytes"] / ticks), "d2h_bytes_per_tick": int(st["d2h_bytes"] / ticks),
+            "device_allocations": st["device_allocs"], "check": "bit-exact vs oracle (2 lanes)" if ok else "MISMATCH"}
+
+
+def torch_device_count():
+    import torch
+    return torch.cuda.device_count()
 
 
 def end_to_end(ctx, capi, g):

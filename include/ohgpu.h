@@ -159,7 +159,12 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch);
 int ohgpu_batch_info(const ohgpu_batch* batch, uint64_t* n_msgs, uint64_t* in_frames, uint64_t* out_frames,
                      uint64_t* src_bytes_touched, uint64_t* dst_bytes_written);
 
-/* Convenience for hosts that hold host buffers (a live pipeline's 5 ms cadence): H2D, run, D2H, sync. */
+/* Convenience for hosts that hold host buffers (a live pipeline's 5 ms cadence: the driver thread's MsgPlayable::Read of a
+ * period, Msg.cpp:2646-2653, for as many playables as the caller brings): H2D, run, D2H, sync.  Of dst_host only the bytes the
+ * messages' outputs cover are written (in ONE copy when the outputs tile a span of it, whatever their order).  The device arenas
+ * the audio passes through belong to the context and are kept from call to call -- a steady caller allocates nothing per period
+ * (ohgpu_device_allocations) -- and src_host / dst_host may be pageable or pinned (ohgpu_malloc_host: no staging copy).
+ * The same holds for the three *_process_host calls below. */
 int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
                            const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
 
@@ -324,10 +329,16 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
  * ohgpu_flywheel_batch_run (the batch owns Burg's workspace). */
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
 
-/* Host-buffer convenience (a live pipeline's 5 ms cadence): H2D, run, D2H, sync.  dst_host bytes that no message
- * covers are preserved. */
+/* Host-buffer convenience (a live pipeline's 5 ms cadence): H2D, run, D2H, sync, as ohgpu_pcm_process_host.  dst_host bytes
+ * that no message covers are preserved.  src_host need only hold each message's WINDOW (ohgpu_src_msg_desc: src_frame0 /
+ * src_frames), not the stream's history: host/SampleRateConverter.cpp packs the windows of a period's messages back to back. */
 int ohgpu_src_process_host(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
                            const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes);
+
+/* What the *_process_host calls of this context have moved so far: their number, how many of them were ohgpu_src_process_host,
+ * and the bytes copied to and from the device for audio (descriptors and plans not counted).  A driver's handle on "one call per
+ * filter per period, windows only" (tests/cpp/test_host.cpp, bench.py's cadence.adapter). */
+int ohgpu_host_transfer_stats(ohgpu_ctx* ctx, uint64_t* calls, uint64_t* src_calls, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
 
 /* How a resampler batch was planned: output frames handled by the block kernel, and the number of message pieces
  * (block-unaligned heads/tails, unsupported layouts) left to the generic kernel. */

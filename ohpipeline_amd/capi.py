@@ -115,6 +115,7 @@ SYMBOLS = {
     "ohgpu_measure_shader_clock": (C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
     "ohgpu_device_allocations": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ohgpu_src_process_host": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
+    "ohgpu_host_transfer_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ohgpu_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
 }
 
@@ -425,6 +426,12 @@ class Context:
         n = C.c_uint64(0)
         check(lib().ohgpu_device_allocations(self._h, C.byref(n)))
         return int(n.value)
+
+    def host_transfer_stats(self):
+        """What the *_process_host calls of this context moved so far (ohgpu_host_transfer_stats)."""
+        v = [C.c_uint64(0) for _ in range(4)]
+        check(lib().ohgpu_host_transfer_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("calls", "src_calls", "h2d_bytes", "d2h_bytes"), (int(x.value) for x in v)))
 
     def shader_clock_mhz(self, stream=None):
         mhz = C.c_double(0)

@@ -9,8 +9,11 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -28,26 +31,27 @@ static int g_plan_threads = 0;
 int plan_thread_cap() { return g_plan_threads; }
 
 // ---- the planning pool: up to 15 helper threads, started on first use, one job at a time (callers queue on a mutex) ----
+// The pool is a heap object that is never destroyed: its helpers are detached and sleep in `wake` between jobs, and a mutex or a
+// condition variable must not be destroyed under a sleeper (glibc's pthread_cond_destroy waits for them) -- least of all in a forked
+// child's exit(), whose copy of the object still counts the parent's sleepers but has none of its threads.  A child gets a pool of
+// its own (pthread_atfork): the parent's is left where it lies.
 namespace {
 struct PlanPool {
     std::mutex one_job;                       // a job owns the pool from start to finish
     std::mutex m;
     std::condition_variable wake, done;
-    std::vector<std::thread*> threads;          // (pointers: a forked child has the objects but not the threads, and abandons them)
-    long owner_pid = 0;
+    unsigned n_helpers = 0;
     void (*job)(void*, unsigned) = nullptr;
     void* arg = nullptr;
     unsigned n_thr = 0;                       // ranges of the current job (helpers run ranges 1 .. n_thr - 1)
     uint64_t generation = 0;
     unsigned pending = 0;
-    bool quit = false;
     void helper(unsigned id)                  // id = 1 .. 15
     {
         uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            wake.wait(lk, [&] { return quit || generation != seen; });
-            if (quit) return;
+            wake.wait(lk, [&] { return generation != seen; });
             seen = generation;
             if (id < n_thr) {
                 void (*j)(void*, unsigned) = job;
@@ -64,8 +68,7 @@ struct PlanPool {
         std::lock_guard<std::mutex> hold(one_job);
         {
             std::unique_lock<std::mutex> lk(m);
-            if (owner_pid != (long)getpid()) { threads.clear(); owner_pid = (long)getpid(); pending = 0; }
-            while (threads.size() + 1 < n) { const unsigned id = (unsigned)threads.size() + 1; threads.push_back(new std::thread([this, id] { helper(id); })); }
+            while (n_helpers + 1 < n) { const unsigned id = ++n_helpers; std::thread([this, id] { helper(id); }).detach(); }
             job = j; arg = a; n_thr = n; pending = n - 1;
             generation++;
         }
@@ -74,20 +77,52 @@ struct PlanPool {
         std::unique_lock<std::mutex> lk(m);
         done.wait(lk, [&] { return pending == 0; });
     }
-    ~PlanPool()
-    {
-        { std::lock_guard<std::mutex> lk(m); quit = true; }
-        wake.notify_all();
-        if (owner_pid == (long)getpid()) for (std::thread* t : threads) { t->join(); delete t; }
-    }
 };
-PlanPool g_pool;
+std::atomic<PlanPool*> g_pool{nullptr};
+std::once_flag g_pool_once;
+PlanPool& pool()
+{
+    std::call_once(g_pool_once, [] {
+        g_pool.store(new PlanPool());
+        // (a fork taken while a job runs leaves the child a locked copy: it is abandoned with the rest)
+        (void)pthread_atfork(nullptr, nullptr, [] { g_pool.store(new PlanPool()); });
+    });
+    return *g_pool.load();
+}
 }  // namespace
 
 void run_on_pool(unsigned n_thr, void (*job)(void* arg, unsigned t), void* arg)
 {
     if (n_thr <= 1) { job(arg, 0); return; }
-    g_pool.run(n_thr > 16 ? 16 : n_thr, job, arg);
+    pool().run(n_thr > 16 ? 16 : n_thr, job, arg);
+}
+
+// The CPUs this process may keep busy: the affinity mask's, capped by the container's CPU quota (cgroup v2 cpu.max; v1
+// cpu.cfs_quota_us / cpu.cfs_period_us) -- a box of 256 logical CPUs whose container is granted sixteen runs sixteen planner threads'
+// worth of work however many are started.  Callers that share the grant (one rank per GPU on one host) divide it themselves:
+// ohgpu_set_plan_threads.
+unsigned usable_cpus()
+{
+    static const unsigned cached = [] {
+        unsigned n = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+        double quota = 0.0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char a[64] = "";
+            long long period = 0;
+            if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) quota = atof(a) / (double)period;
+            fclose(f);
+        } else {
+            long long q = -1, per = 0;
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+            if (q > 0 && per > 0) quota = (double)q / (double)per;
+        }
+        if (quota >= 1.0 && (unsigned)(quota + 0.5) < n) n = (unsigned)(quota + 0.5);
+        return n ? n : 1u;
+    }();
+    return cached;
 }
 
 int set_error(int code, const char* fmt, ...)
@@ -169,6 +204,9 @@ int ohgpu_shutdown(ohgpu_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     hipFree(ctx->d_ramp_table);
     for (auto& list : ctx->cache.idle) for (void* p : list) (void)hipFree(p);
+    if (ctx->stage.d_src) (void)hipFree(ctx->stage.d_src);
+    if (ctx->stage.d_dst) (void)hipFree(ctx->stage.d_dst);
+    if (ctx->stage.h_bounce) (void)hipHostFree(ctx->stage.h_bounce);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return OHGPU_OK;
@@ -358,9 +396,12 @@ hipError_t ctx_dev_alloc(ohgpu_ctx* ctx, void** p, size_t bytes)
     while (c < DevCache::kClasses && ((size_t)256 << c) < bytes) c++;
     DevCache& k = ctx->cache;
     std::lock_guard<std::mutex> hold(k.m);
-    if (c < DevCache::kClasses && !k.idle[c].empty()) {
-        *p = k.idle[c].back();
-        k.idle[c].pop_back();
+    // (an idle block of the request's class, or of one of the two above it: a caller whose batches straddle a class boundary from one
+    // period to the next -- a plan of 60 KB, then one of 70 -- is served by what the larger of them left behind)
+    for (int q = c; q < DevCache::kClasses && q <= c + 2; q++) {
+        if (k.idle[q].empty()) continue;
+        *p = k.idle[q].back();
+        k.idle[q].pop_back();
         return hipSuccess;
     }
     const hipError_t e = hipMalloc(p, c < DevCache::kClasses ? ((size_t)256 << c) : bytes);
@@ -382,6 +423,69 @@ void ctx_dev_free(ohgpu_ctx* ctx, void* p)
     }
     if (it != k.cls.end()) k.cls.erase(it);
     (void)hipFree(p);
+}
+
+// one of HostStage's buffers, at least `bytes` long: kept while it is, replaced by one half as large again when it is not
+static int stage_reserve(ohgpu_ctx* ctx, void** p, size_t* cap, size_t bytes, bool pinned_host)
+{
+    if (*cap >= bytes && *p) return OHGPU_OK;
+    if (*p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)(pinned_host ? hipHostFree(*p) : hipFree(*p));
+        *p = nullptr; *cap = 0;
+    }
+    size_t want = bytes + bytes / 2;
+    if (want < (64u << 10)) want = 64u << 10;
+    want = (want + 4095) & ~(size_t)4095;
+    const hipError_t e = pinned_host ? hipHostMalloc(p, want, hipHostMallocDefault) : hipMalloc(p, want);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE, "host-buffer staging (%zu bytes): %s", want, hipGetErrorString(e));
+    }
+    *cap = want;
+    if (!pinned_host) { std::lock_guard<std::mutex> hold(ctx->cache.m); ctx->cache.device_allocs++; }
+    return OHGPU_OK;
+}
+
+int host_roundtrip(ohgpu_ctx* ctx, const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes,
+                   std::vector<std::pair<uint64_t, uint64_t>>& ranges, const std::function<int(const void*, void*)>& run)
+{
+    HostStage& st = ctx->stage;
+    st.calls++;
+    int err = stage_reserve(ctx, &st.d_src, &st.src_cap, src_bytes ? src_bytes : 1, false);
+    if (err == OHGPU_OK) err = stage_reserve(ctx, &st.d_dst, &st.dst_cap, dst_bytes ? dst_bytes : 1, false);
+    if (err != OHGPU_OK) return err;
+    hipStream_t s = ctx->stream;
+    if (src_bytes) {
+        OHGPU_HIP_TRY(hipMemcpyAsync(st.d_src, src_host, src_bytes, hipMemcpyHostToDevice, s));
+        st.h2d_bytes += src_bytes;
+    }
+    // the covered runs of the destination, merged where they touch or overlap
+    std::sort(ranges.begin(), ranges.end());
+    std::vector<std::pair<uint64_t, uint64_t>> runs;                  // [lo, hi)
+    for (const auto& r : ranges) {
+        if (r.second == 0) continue;
+        if (!runs.empty() && r.first <= runs.back().second) runs.back().second = std::max(runs.back().second, r.first + r.second);
+        else runs.emplace_back(r.first, r.first + r.second);
+    }
+    err = run(st.d_src, st.d_dst);
+    if (err != OHGPU_OK) { (void)hipStreamSynchronize(s); return err; }
+    if (runs.empty()) { OHGPU_HIP_TRY(hipStreamSynchronize(s)); return OHGPU_OK; }
+    const uint64_t lo = runs.front().first, hi = runs.back().second;
+    if (runs.size() == 1) {                                           // the outputs tile [lo, hi): one copy, straight home
+        OHGPU_HIP_TRY(hipMemcpyAsync((uint8_t*)dst_host + lo, (const uint8_t*)st.d_dst + lo, hi - lo, hipMemcpyDeviceToHost, s));
+        st.d2h_bytes += hi - lo;
+        OHGPU_HIP_TRY(hipStreamSynchronize(s));
+        return OHGPU_OK;
+    }
+    // holes between the outputs: the span comes back to the bounce buffer in one copy, the covered runs go home from there
+    err = stage_reserve(ctx, &st.h_bounce, &st.bounce_cap, hi - lo, true);
+    if (err != OHGPU_OK) { (void)hipStreamSynchronize(s); return err; }
+    OHGPU_HIP_TRY(hipMemcpyAsync(st.h_bounce, (const uint8_t*)st.d_dst + lo, hi - lo, hipMemcpyDeviceToHost, s));
+    st.d2h_bytes += hi - lo;
+    OHGPU_HIP_TRY(hipStreamSynchronize(s));
+    for (const auto& r : runs) memcpy((uint8_t*)dst_host + r.first, (const uint8_t*)st.h_bounce + (r.first - lo), r.second - r.first);
+    return OHGPU_OK;
 }
 
 }  // namespace ohgpu
@@ -497,9 +601,9 @@ int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
     // (its blocks go back to the context's cache, for the next batch to write into: nothing of this one may still be running --
     // what hipFree used to see to by itself)
     if (batch->d_descs || batch->kind == kBatchPcm || batch->kind == kBatchFlywheel || batch->kind == kBatchFmt) (void)hipDeviceSynchronize();
+    if (batch->kind == kBatchSrc) free_src_fast(ctx, batch);          // (waits for the batch's last launch: before its event goes)
     if (batch->last_done) hipEventDestroy(batch->last_done);
     if (batch->d_descs) ctx_dev_free(ctx, batch->d_descs);
-    if (batch->kind == kBatchSrc) free_src_fast(batch);
     if (batch->kind == kBatchPcm) free_pcm_line(ctx, batch);
     if (batch->kind == kBatchFlywheel) free_flywheel(ctx, batch);
     if (batch->kind == kBatchFmt) { free_fmt_line(ctx, batch); free_pcm_line(ctx, batch); }
@@ -520,20 +624,6 @@ int ohgpu_batch_info(const ohgpu_batch* b, uint64_t* n_msgs, uint64_t* in_frames
     return OHGPU_OK;
 }
 
-// Do the messages' outputs tile [0, total) exactly?  Then the host-buffer calls need not upload the destination first (they
-// do so to keep the bytes no message covers as the caller gave them).
-static bool outputs_tile(std::vector<std::pair<uint64_t, uint64_t>>& ranges, uint64_t total)
-{
-    std::sort(ranges.begin(), ranges.end());
-    uint64_t pos = 0;
-    for (const auto& r : ranges) {
-        if (r.second == 0) continue;
-        if (r.first != pos) return false;
-        pos += r.second;
-    }
-    return pos == total;
-}
-
 int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n,
                            const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes)
 {
@@ -541,19 +631,10 @@ int ohgpu_pcm_process_host(ohgpu_ctx* ctx, const ohgpu_msg_desc* descs, size_t n
     ohgpu_batch* b = nullptr;
     int err = ohgpu_pcm_batch_create(ctx, descs, n, src_bytes, dst_bytes, &b);
     if (err != OHGPU_OK) return err;
-    void *d_src = nullptr, *d_dst = nullptr;
-    err = ohgpu_malloc(ctx, src_bytes, &d_src);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
-    if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
     std::vector<std::pair<uint64_t, uint64_t>> out(n);
     for (size_t i = 0; i < n; i++) out[i] = {descs[i].dst_offset, (uint64_t)descs[i].n_frames * descs[i].channels * (descs[i].dst_bits / 8)};
-    if (err == OHGPU_OK && dst_bytes && !outputs_tile(out, dst_bytes))
-        err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);  // bytes no message covers stay as given
-    if (err == OHGPU_OK) err = ohgpu_pcm_batch_run(ctx, b, d_src, d_dst, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
-    if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
-    if (d_src) hipFree(d_src);
-    if (d_dst) hipFree(d_dst);
+    err = host_roundtrip(ctx, src_host, src_bytes, dst_host, dst_bytes, out,
+                         [&](const void* d_src, void* d_dst) { return ohgpu_pcm_batch_run(ctx, b, d_src, d_dst, nullptr); });
     ohgpu_batch_destroy(ctx, b);
     return err;
 }
@@ -709,16 +790,10 @@ int ohgpu_flywheel_process_host(ohgpu_ctx* ctx, const ohgpu_flywheel_desc* descs
     ohgpu_batch* b = nullptr;
     int err = ohgpu_flywheel_batch_create(ctx, descs, n, src_bytes, dst_bytes, &b);
     if (err != OHGPU_OK) return err;
-    void *d_src = nullptr, *d_dst = nullptr;
-    err = ohgpu_malloc(ctx, src_bytes, &d_src);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
-    if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);
-    if (err == OHGPU_OK) err = ohgpu_flywheel_batch_run(ctx, b, d_src, d_dst, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
-    if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
-    if (d_src) hipFree(d_src);
-    if (d_dst) hipFree(d_dst);
+    std::vector<std::pair<uint64_t, uint64_t>> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = {descs[i].dst_offset, (uint64_t)descs[i].out_frames * descs[i].channels * 4u};
+    err = host_roundtrip(ctx, src_host, src_bytes, dst_host, dst_bytes, out,
+                         [&](const void* d_src, void* d_dst) { return ohgpu_flywheel_batch_run(ctx, b, d_src, d_dst, nullptr); });
     ohgpu_batch_destroy(ctx, b);
     return err;
 }
@@ -1273,21 +1348,23 @@ int ohgpu_src_process_host(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
     ohgpu_batch* b = nullptr;
     int err = ohgpu_src_batch_create(ctx, src, descs, n, src_bytes, dst_bytes, &b);
     if (err != OHGPU_OK) return err;
-    void *d_src = nullptr, *d_dst = nullptr;
-    err = ohgpu_malloc(ctx, src_bytes, &d_src);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
-    if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
+    ctx->stage.src_calls++;
     std::vector<std::pair<uint64_t, uint64_t>> out(n);
     for (size_t i = 0; i < n; i++) out[i] = {descs[i].dst_offset, (uint64_t)descs[i].n_frames * descs[i].channels * (descs[i].dst_bits / 8)};
-    if (err == OHGPU_OK && dst_bytes && !outputs_tile(out, dst_bytes))
-        err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);  // bytes no message covers stay as given
-    if (err == OHGPU_OK) err = ohgpu_src_batch_run(ctx, b, d_src, d_dst, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
-    if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
-    if (d_src) hipFree(d_src);
-    if (d_dst) hipFree(d_dst);
+    err = host_roundtrip(ctx, src_host, src_bytes, dst_host, dst_bytes, out,
+                         [&](const void* d_src, void* d_dst) { return ohgpu_src_batch_run(ctx, b, d_src, d_dst, nullptr); });
     ohgpu_batch_destroy(ctx, b);
     return err;
+}
+
+int ohgpu_host_transfer_stats(ohgpu_ctx* ctx, uint64_t* calls, uint64_t* src_calls, uint64_t* h2d_bytes, uint64_t* d2h_bytes)
+{
+    if (!ctx) return set_error(OHGPU_ERR_INVALID, "ohgpu_host_transfer_stats: null context");
+    if (calls) *calls = ctx->stage.calls;
+    if (src_calls) *src_calls = ctx->stage.src_calls;
+    if (h2d_bytes) *h2d_bytes = ctx->stage.h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = ctx->stage.d2h_bytes;
+    return OHGPU_OK;
 }
 
 }  // extern "C"

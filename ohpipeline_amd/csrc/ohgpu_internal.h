@@ -6,10 +6,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/ohgpu.h"
@@ -155,10 +157,11 @@ struct SrcFastPlan {
 };
 
 int plan_thread_cap();     // ohgpu_set_plan_threads (0: no cap)
-// How many threads a host loop over n independent items is worth (at least `per_thread` items each, at most 16 and what the host has)
+// How many threads a host loop over n independent items is worth (at least `per_thread` items each, at most 16 and what the host grants the process)
+unsigned usable_cpus();    // csrc/ohgpu_api.hip: the affinity mask's CPUs, capped by the container's CPU quota
 inline unsigned plan_threads(size_t n, size_t per_thread)
 {
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = usable_cpus();
     size_t t = n / (per_thread ? per_thread : 1);
     if (t < 1) t = 1;
     if (t > 16) t = 16;
@@ -312,8 +315,21 @@ struct DevCache {
 };
 }  // namespace ohgpu
 
+namespace ohgpu {
+// What the host-buffer calls (ohgpu_*_process_host: a driver thread's period with host memory on its side of the boundary) keep
+// from call to call: the two device arenas the audio passes through and a pinned bounce buffer, each grown with headroom when a
+// call needs more -- so that a steady caller allocates nothing per period -- and the bytes those calls moved over the link.
+struct HostStage {
+    void*  d_src = nullptr;    size_t src_cap = 0;
+    void*  d_dst = nullptr;    size_t dst_cap = 0;
+    void*  h_bounce = nullptr; size_t bounce_cap = 0;
+    uint64_t h2d_bytes = 0, d2h_bytes = 0, calls = 0, src_calls = 0;
+};
+}  // namespace ohgpu
+
 struct ohgpu_ctx {
     ohgpu::DevCache cache;
+    ohgpu::HostStage stage;
     int          device;
     hipStream_t  stream;          // the context's own stream (used when the caller passes NULL)
     uint16_t*    d_ramp_table;    // 512 x u16 (RampArray.h:7-74)
@@ -413,6 +429,12 @@ int plan_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_flywheel_desc* des
 void free_flywheel(ohgpu_ctx* ctx, ohgpu_batch* b);
 hipError_t ctx_dev_alloc(ohgpu_ctx* ctx, void** p, size_t bytes);     // csrc/ohgpu_api.hip: DevCache
 void ctx_dev_free(ohgpu_ctx* ctx, void* p);
+// The body of every ohgpu_*_process_host (csrc/ohgpu_api.hip): src_host goes to the context's source arena, `run` launches on the
+// context's stream with the two device arenas, and the bytes the call's outputs cover -- `ranges` = (dst_offset, bytes) per output,
+// any order -- come back: in one copy straight into dst_host when they tile a span of it, through the pinned bounce buffer run by
+// run otherwise.  dst_host bytes no output covers are never written.  Synchronises.
+int host_roundtrip(ohgpu_ctx* ctx, const void* src_host, uint64_t src_bytes, void* dst_host, uint64_t dst_bytes,
+                   std::vector<std::pair<uint64_t, uint64_t>>& ranges, const std::function<int(const void* d_src, void* d_dst)>& run);
 hipError_t launch_flywheel(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, const ohgpu_src* src_filter,
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
@@ -447,7 +469,7 @@ int  design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, do
 struct PlanDigest { uint64_t hash, units, pieces, ramp_jobs; int kernel; };   // ohgpu_src_plan_digest: a plan without a device
 int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, const DevSrcDesc* dev, PlanDigest* digest = nullptr);
 
-void free_src_fast(ohgpu_batch* b);
+void free_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b);
 void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b);
 
 }  // namespace ohgpu

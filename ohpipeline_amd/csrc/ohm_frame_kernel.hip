@@ -583,16 +583,17 @@ int ohgpu_ohm_process_host(ohgpu_ctx* ctx, const ohgpu_ohm_stream* streams, size
     ohgpu_batch* b = nullptr;
     int err = ohgpu_ohm_batch_create(ctx, streams, n_streams, frames, n_frames, fragments, n_fragments, src_bytes, dst_bytes, &b);
     if (err != OHGPU_OK) return err;
-    void *d_src = nullptr, *d_dst = nullptr;
-    err = ohgpu_malloc(ctx, src_bytes, &d_src);
-    if (err == OHGPU_OK) err = ohgpu_malloc(ctx, dst_bytes, &d_dst);
-    if (err == OHGPU_OK && src_bytes) err = ohgpu_memcpy_h2d(ctx, d_src, src_host, src_bytes, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_h2d(ctx, d_dst, dst_host, dst_bytes, nullptr);   // bytes no frame covers stay as given
-    if (err == OHGPU_OK) err = ohgpu_ohm_batch_run(ctx, b, d_src, d_dst, nullptr);
-    if (err == OHGPU_OK && dst_bytes) err = ohgpu_memcpy_d2h(ctx, dst_host, d_dst, dst_bytes, nullptr);
-    if (err == OHGPU_OK) err = ohgpu_stream_sync(ctx, nullptr);
-    if (d_src) ohgpu_free(ctx, d_src);
-    if (d_dst) ohgpu_free(ctx, d_dst);
+    // (a frame's datagram = header + the audio of its fragments: the bytes the call hands back; bytes no frame covers stay as given)
+    std::vector<std::pair<uint64_t, uint64_t>> out(n_frames);
+    for (size_t i = 0; i < n_frames && err == OHGPU_OK; i++) {
+        uint32_t samples = 0, header = 0, total = 0;
+        for (uint32_t k = 0; k < frames[i].n_fragments; k++) samples += fragments[frames[i].first_fragment + k].n_frames;
+        err = ohgpu_ohm_frame_layout(&streams[frames[i].stream], samples, &header, &total);
+        out[i] = {frames[i].dst_offset, total};
+    }
+    if (err == OHGPU_OK)
+        err = ohgpu::host_roundtrip(ctx, src_host, src_bytes, dst_host, dst_bytes, out,
+                                    [&](const void* d_src, void* d_dst) { return ohgpu_ohm_batch_run(ctx, b, d_src, d_dst, nullptr); });
     ohgpu_batch_destroy(ctx, b);
     return err;
 }

@@ -426,24 +426,29 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
 }
 
 // ---- host: the tables ----
-// Balanced base-256 digits of a Q28 coefficient: c = e0 + e1 2^8 + e2 2^16 + e3 2^24, e0..e2 in [-128, 127].
-static void coef_digits(int32_t c, int8_t e[4])
+// Balanced base-256 digits of a Q28 coefficient: c = e0 + e1 2^8 + e2 2^16 + e3 2^24, e0..e2 in [-128, 127].  False when the top
+// digit -- what is left after the three balanced ones -- is no int8: the coefficients from -(128 << 24) - 0x808080 to
+// (127 << 24) + 0x7f7f7f have digits (a value above that carries into a top digit of 128, which the cast would wrap to -128).
+static bool coef_digits(int32_t c, int8_t e[4])
 {
     int64_t v = c;
-    for (int j = 0; j < 4; j++) {
-        int d = (int)(int8_t)(uint8_t)(v & 0xff);
-        if (j == 3) d = (int)v;
+    for (int j = 0; j < 3; j++) {
+        const int d = (int)(int8_t)(uint8_t)(v & 0xff);
         e[j] = (int8_t)d;
         v = (v - d) >> 8;
     }
+    e[3] = (int8_t)v;
+    return v >= -128 && v <= 127;
 }
 
 bool build_mfma_tables(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, uint32_t L_blk, uint32_t kb_cap,
                        std::vector<uint8_t>* adig, std::vector<MfStep>* steps)
 {
     if (T != 32 || L == 0 || M == 0 || L_blk == 0 || (L_blk % 16) != 0 || (L_blk % L) != 0 || kb_cap == 0) return false;
-    for (size_t i = 0; i < (size_t)L * T; i++)
-        if (coef_q28[i] > (127 << 24) + 0x7fffff || coef_q28[i] < -(127 << 24)) return false;     // the top digit is an int8
+    for (size_t i = 0; i < (size_t)L * T; i++) {
+        int8_t e[4];
+        if (!coef_digits(coef_q28[i], e)) return false;                                           // the top digit is an int8
+    }
     adig->assign((size_t)4 * L * 96, 0);
     std::vector<int64_t> bias(L);
     for (uint32_t p = 0; p < L; p++) {
@@ -494,7 +499,8 @@ bool build_mfma_halfband(const int32_t* coef_q28, uint32_t L_blk, std::vector<Mf
     int64_t sum = 0;
     for (uint32_t k = 0; k < 64; k++) {
         const int32_t c = coef_q28[k];
-        if (c > (127 << 24) + 0x7fffff || c < -(127 << 24)) return false;                        // the top digit is an int8
+        int8_t e4[4];
+        if (!coef_digits(c, e4)) return false;                                                    // the top digit is an int8
         if ((k & 1u) && k != 31 && c != 0) return false;                                          // not a half-band filter
         sum += c;
     }

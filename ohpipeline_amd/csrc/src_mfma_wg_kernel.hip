@@ -125,6 +125,11 @@ constexpr bool kDiagSplitGeneric = true;            // (timing experiments: ster
 #else
 constexpr bool kDiagSplitGeneric = false;
 #endif
+#ifdef MF_WG_LATE_LOADS
+constexpr bool kLateLoads = true;                   // (A/B: the next unit's loads issued behind the split, as in round 4)
+#else
+constexpr bool kLateLoads = false;
+#endif
 #ifndef MF_DIAG_BARRIER_MASK
 #define MF_DIAG_BARRIER_MASK 0xf
 #endif
@@ -623,6 +628,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 
         // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
         // unit's input -- requested a whole phase (C) ago -- is waited for HERE, in front of the stores, not behind them ----
+        // (the unit after the next: its descriptor is asked for here, a phase before its loads are issued)
+        const uint32_t u_n2 = u_nxt + n_groups;
+        Unit wk_n2 = wk;
+        if constexpr (G::kSpan && !kLateLoads) wk_n2 = fetch_unit(u_n2 < n_work ? u_n2 : u_cur);
         asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
         if constexpr (G::kInRounds > 3) asm volatile("" : "+v"(raw[3]));
         if constexpr (G::kInRounds > 4) asm volatile("" : "+v"(raw[4]));
@@ -655,12 +664,26 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         if (u_nxt >= n_work) break;                         // (uniform)
 
         // ---- (A) + (S) the next unit: registers -> input image -> planes; then its successor's input is requested ----
+        if constexpr (G::kSpan && !kLateLoads) {
+            // ... requested as soon as the registers are free -- behind the stage's writes, in front of the split -- so that it is in
+            // flight for (S) and (C), not for (C) alone (round 5: 0.3011 -> 0.3001 ms on the headline, same box, three alternating pairs;
+            // that this is all it gains says the launch does not wait for its loads: tools/micro/run_copy.hip)
+            stage_input(raw);
+            issue_input(wk_n2, raw);
+            wg_barrier<2>();
+            split_all(wk_nxt.first);
+            wk = wk_nxt;
+            wk_nxt = wk_n2;
+            u_cur = u_nxt;
+            u_nxt += n_groups;
+        } else {
         stage_and_split(raw, wk_nxt.first);
         wk = wk_nxt;
         u_cur = u_nxt;
         u_nxt += n_groups;
         wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
         issue_input(wk_nxt, raw);
+        }
 #ifndef MF_WG_NO_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif

@@ -19,11 +19,14 @@
 
 namespace ohgpu {
 
-void free_src_fast(ohgpu_batch* b)
+void free_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b)
 {
     SrcFastPlan& f = b->fast;
-    if (f.planes_ready) (void)hipEventDestroy(f.planes_ready);
-    if (f.d_slab) (void)hipFree(f.d_slab);                            // (every d_* below points into it; hipFree waits for the device)
+    // (every d_* below points into the slab, and the slab goes back to the context's cache of device blocks for the next batch to
+    // write into: nothing of this one may still be running -- the planes' fill, the last launch)
+    if (f.planes_ready) { (void)hipEventSynchronize(f.planes_ready); (void)hipEventDestroy(f.planes_ready); }
+    if (f.d_slab && b->last_done) (void)hipEventSynchronize(b->last_done);
+    if (f.d_slab) { if (ctx) ctx_dev_free(ctx, f.d_slab); else (void)hipFree(f.d_slab); }
     f = SrcFastPlan();
 }
 
@@ -51,12 +54,13 @@ struct Slab {
         tail_at = {dptr, (host.size() + 255) & ~(size_t)255};
         tail = bytes;
     }
-    int upload(void** slab)
+    int upload(ohgpu_ctx* ctx, void** slab)
     {
         *slab = nullptr;
         if (host.empty() && tail == 0) return OHGPU_OK;
         const size_t total = tail ? tail_at.second + tail : host.size();
-        hipError_t e = hipMalloc(slab, total);
+        // (from the context's cache of device blocks: a caller that makes a batch per driver period allocates once)
+        hipError_t e = ctx ? ctx_dev_alloc(ctx, slab, total) : hipMalloc(slab, total);
         if (e == hipSuccess && !host.empty()) e = hipMemcpy(*slab, host.data(), host.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess && tail) *tail_at.first = (uint8_t*)*slab + tail_at.second;
         if (e != hipSuccess) return set_error(e == hipErrorOutOfMemory ? OHGPU_ERR_NOMEM : OHGPU_ERR_DEVICE,
@@ -574,8 +578,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     slab.add(ramp_jobs, &f.d_ramp_jobs);
     slab.reserve((plane_entries ? plane_entries : 8) * sizeof(uint16_t), &f.d_planes);
     mark("slab");
-    int err = slab.upload(&f.d_slab);
-    if (err != OHGPU_OK) { free_src_fast(b); return err; }
+    int err = slab.upload(ctx, &f.d_slab);
+    if (err != OHGPU_OK) { free_src_fast(ctx, b); return err; }
     mark("upload");
     {   // the planes: preset to "no ramp", then RampApplicator's multiplier for every frame of a ramped message (device)
         hipStream_t s0 = ctx ? ctx->stream : nullptr;
@@ -584,7 +588,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         // (not waited for here: a run of the batch waits for this event on its own stream, on the device)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f.planes_ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(f.planes_ready, s0);
-        if (e != hipSuccess) { free_src_fast(b); return set_error(OHGPU_ERR_DEVICE, "ramp planes: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { free_src_fast(ctx, b); return set_error(OHGPU_ERR_DEVICE, "ramp planes: %s", hipGetErrorString(e)); }
     }
     mark("planes");
 #ifdef OHGPU_PLAN_TIMING

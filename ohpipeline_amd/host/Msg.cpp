@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <map>
 
 #include "../../include/ohgpu.h"
@@ -300,8 +301,43 @@ void MsgPlayable::Read(IPcmProcessor& aProcessor)
 }
 
 // ---------------------------------------------------------------- PlayableBatch
+struct PlayableBatch::WindowRun {
+    SampleRateConverterStream* stream;
+    TUint64 firstFrame;              // the union window of the run's items: input frames [firstFrame, firstFrame + frames)
+    TUint frames;
+    TUint64 nextOut;                 // the output frame an item must start at to join the run
+    TUint64 srcOffset;               // of the window, in its group's part of the source arena
+};
+
+struct PlayableBatch::Group {
+    const SrcFilter* filter = nullptr;                    // nullptr: the plain audio (one ohgpu_pcm_process_host)
+    std::vector<size_t> items;
+    std::vector<ohgpu_msg_desc> pcm;
+    std::vector<ohgpu_src_msg_desc> src;
+    std::vector<WindowRun> runs;
+    std::vector<size_t> runOf;                            // per resampled item: its run
+    TUint64 srcBase = 0, srcBytes = 0, dstBase = 0, dstBytes = 0;
+    void Clear() { items.clear(); pcm.clear(); src.clear(); runs.clear(); runOf.clear(); srcBase = srcBytes = dstBase = dstBytes = 0; }
+};
+
+struct PlayableBatch::Scratch {
+    std::deque<Group> groups;                             // [0] the plain audio, [1 + k] the k-th filter met (a deque: Take's references stay valid)
+    size_t used = 0;
+    std::map<const DecodedAudio*, TUint64> audioBase;
+    Group& Take(const SrcFilter* aFilter)
+    {
+        for (size_t g = 0; g < used; g++) if (groups[g].filter == aFilter) return groups[g];
+        if (used == groups.size()) groups.emplace_back();
+        Group& g = groups[used++];
+        g.Clear();
+        g.filter = aFilter;
+        return g;
+    }
+};
+
 PlayableBatch::PlayableBatch(MsgFactory& aFactory)
     : iFactory(aFactory)
+    , iScratch(new Scratch())
 {
 }
 
@@ -322,7 +358,7 @@ void PlayableBatch::SetOutputFormat(TUint aBitDepth, AudioDataEndian aEndian)
 
 void PlayableBatch::Add(MsgPlayable* aPlayable, IPcmProcessor& aProcessor)
 {
-    iItems.push_back({aPlayable, &aProcessor});
+    iItems.push_back({aPlayable, &aProcessor, 0, 0});
 }
 
 static uint8_t GpuEndian(AudioDataEndian aEndian)
@@ -333,98 +369,139 @@ static uint8_t GpuEndian(AudioDataEndian aEndian)
 void PlayableBatch::Run()
 {
     ohgpu_ctx* ctx = iFactory.Gpu();
-    // ---- lay out the arenas: every distinct DecodedAudio once in the source arena, outputs back to back ----
-    std::vector<TByte> src;
-    std::map<const DecodedAudio*, TUint64> audioBase;
-    std::vector<ohgpu_msg_desc> descs;
-    std::vector<size_t> descItem;
-    struct SrcGroup { std::vector<ohgpu_src_msg_desc> descs; std::vector<size_t> item; std::vector<TByte> in; };
-    std::map<SampleRateConverterStream*, SrcGroup> groups;
-    std::vector<TUint64> outOffset(iItems.size());
-    std::vector<TUint> outBits(iItems.size());
-    TUint64 dstBytes = 0;
+    Scratch& sc = *iScratch;
+    sc.used = 0;
+    sc.audioBase.clear();
+    // ---- who goes with whom: the plain audio in one call, the rate-converted audio in one call per filter.  Within a group the
+    // outputs lie back to back in the order the items came (they tile the group's span of the destination: one copy back), and
+    // of the sources each distinct DecodedAudio lies there once, each run of consecutive outputs of a stream as ONE window ----
+    Group& plain = sc.Take(nullptr);
     for (size_t i = 0; i < iItems.size(); i++) {
         const PlayableWork& w = iItems[i].playable->Work();
-        const TUint srcBits = w.resampled ? 24 : w.bitDepth;
-        outBits[i] = (iOutBits == 0) ? w.bitDepth : iOutBits;
-        outOffset[i] = dstBytes;
-        dstBytes += (TUint64)w.frames * w.channels * (outBits[i] / 8);
-        dstBytes = (dstBytes + 63) & ~(TUint64)63;                    // keeps every message's output line-aligned
+        iItems[i].outBits = (iOutBits == 0) ? w.bitDepth : iOutBits;
         if (w.frames == 0) {
             continue;
         }
+        Group& g = w.resampled ? sc.Take(&w.stream->Filter()) : plain;
+        g.items.push_back(i);
         if (w.resampled) {
-            SrcGroup& g = groups[w.stream.get()];
-            ohgpu_src_msg_desc d;
-            memset(&d, 0, sizeof(d));
-            w.stream->DescribeWindow(w.outFrame0, w.frames, d);       // src_offset/src_frame0/src_frames within the stream's history
-            d.out_frame0 = w.outFrame0;
-            d.dst_offset = outOffset[i];
-            d.n_frames = w.frames;
-            d.ramp_start = (uint16_t)w.ramp.Start();
-            d.ramp_end = (uint16_t)w.ramp.End();
-            d.attenuation = OHGPU_UNITY_ATTENUATION;
-            d.channels = (uint8_t)w.channels;
-            d.src_bits = (uint8_t)w.stream->SourceBitDepth();
-            d.src_endian = GpuEndian(w.stream->SourceEndian());
-            d.dst_bits = (uint8_t)outBits[i];
-            d.dst_endian = GpuEndian(iOutEndian);
-            d.flags = w.ramp.IsEnabled() ? OHGPU_FLAG_RAMP : 0;
-            g.descs.push_back(d);
-            g.item.push_back(i);
-            (void)srcBits;
-            continue;
-        }
-        ohgpu_msg_desc d;
-        memset(&d, 0, sizeof(d));
-        d.dst_offset = outOffset[i];
-        d.n_frames = w.frames;
-        d.ramp_start = (uint16_t)w.ramp.Start();
-        d.ramp_end = (uint16_t)w.ramp.End();
-        d.attenuation = (uint16_t)w.attenuation;
-        d.channels = (uint8_t)w.channels;
-        d.src_bits = (uint8_t)w.bitDepth;
-        d.dst_bits = (uint8_t)outBits[i];
-        d.dst_endian = GpuEndian(iOutEndian);
-        d.src_endian = OHGPU_ENDIAN_BIG;
-        if (w.silence) {
-            d.flags = OHGPU_FLAG_SILENCE;
-        }
-        else {
-            auto it = audioBase.find(w.audio.get());
-            if (it == audioBase.end()) {
-                it = audioBase.emplace(w.audio.get(), (TUint64)src.size()).first;
-                src.insert(src.end(), w.audio->Ptr(0), w.audio->Ptr(0) + w.audio->Bytes());
+            TUint64 first = 0;
+            TUint frames = 0;
+            w.stream->Window(w.outFrame0, w.frames, first, frames);
+            if (!g.runs.empty() && g.runs.back().stream == w.stream.get() && g.runs.back().nextOut == w.outFrame0) {
+                WindowRun& r = g.runs.back();                              // follows on: the window grows, the history is not repeated
+                r.frames = (TUint)(first + frames - r.firstFrame);
+                r.nextOut += w.frames;
             }
-            d.src_offset = it->second + w.offsetBytes;
-            d.src_endian = GpuEndian(w.audio->Endian());
-            d.flags = w.ramp.IsEnabled() ? OHGPU_FLAG_RAMP : 0;
+            else {
+                g.runs.push_back({w.stream.get(), first, frames, w.outFrame0 + w.frames, 0});
+            }
+            g.runOf.push_back(g.runs.size() - 1);
         }
-        descs.push_back(d);
-        descItem.push_back(i);
+        else if (!w.silence && sc.audioBase.find(w.audio.get()) == sc.audioBase.end()) {
+            sc.audioBase.emplace(w.audio.get(), g.srcBytes);
+            g.srcBytes += (w.audio->Bytes() + 15u) & ~15u;
+        }
     }
-    std::vector<TByte> dst((size_t)dstBytes);
-    if (!descs.empty()) {
-        const int err = ohgpu_pcm_process_host(ctx, descs.data(), descs.size(), src.data(), src.size(), dst.data(), dst.size());
-        ASSERT(err == OHGPU_OK);
+    TUint64 srcTotal = 0, dstTotal = 0;
+    for (size_t k = 0; k < sc.used; k++) {
+        Group& g = sc.groups[k];
+        for (WindowRun& r : g.runs) {
+            r.srcOffset = g.srcBytes;
+            g.srcBytes += ((TUint64)r.frames * r.stream->FrameBytes() + 15u) & ~(TUint64)15u;
+        }
+        for (size_t i : g.items) {
+            const PlayableWork& w = iItems[i].playable->Work();
+            iItems[i].outOffset = g.dstBytes;                            // (within the group, for now)
+            g.dstBytes += (TUint64)w.frames * w.channels * (iItems[i].outBits / 8);
+        }
+        g.srcBase = srcTotal;
+        g.dstBase = dstTotal;
+        srcTotal += (g.srcBytes + 63u) & ~(TUint64)63u;
+        dstTotal += (g.dstBytes + 63u) & ~(TUint64)63u;
     }
-    for (auto& kv : groups) {
-        SampleRateConverterStream* stream = kv.first;
-        SrcGroup& g = kv.second;
-        const int err = ohgpu_src_process_host(ctx, stream->Filter(), g.descs.data(), g.descs.size(),
-                                               stream->HistoryPtr(), stream->HistoryBytes(), dst.data(), dst.size());
-        ASSERT(err == OHGPU_OK);
+    TByte* src = nullptr;
+    TByte* dst = nullptr;
+    iFactory.ReserveArena((size_t)srcTotal, (size_t)dstTotal, src, dst);
+    // ---- the descriptors, and the sources into the arena ----
+    for (const auto& kv : sc.audioBase) {
+        memcpy(src + plain.srcBase + kv.second, kv.first->Ptr(0), kv.first->Bytes());
+    }
+    for (size_t k = 0; k < sc.used; k++) {
+        Group& g = sc.groups[k];
+        for (const WindowRun& r : g.runs) {
+            r.stream->CopyFrames(r.firstFrame, r.frames, src + g.srcBase + r.srcOffset);
+        }
+        size_t nthResampled = 0;
+        for (size_t i : g.items) {
+            const PlayableWork& w = iItems[i].playable->Work();
+            if (w.resampled) {
+                const WindowRun& r = g.runs[g.runOf[nthResampled++]];
+                ohgpu_src_msg_desc d;
+                memset(&d, 0, sizeof(d));
+                d.src_offset = r.srcOffset;
+                d.src_frame0 = r.firstFrame;
+                d.src_frames = r.frames;
+                d.out_frame0 = w.outFrame0;
+                d.dst_offset = iItems[i].outOffset;
+                d.n_frames = w.frames;
+                d.ramp_start = (uint16_t)w.ramp.Start();
+                d.ramp_end = (uint16_t)w.ramp.End();
+                d.attenuation = OHGPU_UNITY_ATTENUATION;
+                d.channels = (uint8_t)w.channels;
+                d.src_bits = (uint8_t)w.stream->SourceBitDepth();
+                d.src_endian = GpuEndian(w.stream->SourceEndian());
+                d.dst_bits = (uint8_t)iItems[i].outBits;
+                d.dst_endian = GpuEndian(iOutEndian);
+                d.flags = w.ramp.IsEnabled() ? OHGPU_FLAG_RAMP : 0;
+                g.src.push_back(d);
+            }
+            else {
+                ohgpu_msg_desc d;
+                memset(&d, 0, sizeof(d));
+                d.dst_offset = iItems[i].outOffset;
+                d.n_frames = w.frames;
+                d.ramp_start = (uint16_t)w.ramp.Start();
+                d.ramp_end = (uint16_t)w.ramp.End();
+                d.attenuation = (uint16_t)w.attenuation;
+                d.channels = (uint8_t)w.channels;
+                d.src_bits = (uint8_t)w.bitDepth;
+                d.dst_bits = (uint8_t)iItems[i].outBits;
+                d.dst_endian = GpuEndian(iOutEndian);
+                d.src_endian = OHGPU_ENDIAN_BIG;
+                if (w.silence) {
+                    d.flags = OHGPU_FLAG_SILENCE;
+                }
+                else {
+                    d.src_offset = sc.audioBase[w.audio.get()] + w.offsetBytes;
+                    d.src_endian = GpuEndian(w.audio->Endian());
+                    d.flags = w.ramp.IsEnabled() ? OHGPU_FLAG_RAMP : 0;
+                }
+                g.pcm.push_back(d);
+            }
+            iItems[i].outOffset += g.dstBase;                            // (from here on: in the arena)
+        }
+        // ---- the group's one call: its part of the source arena in, its span of the destination back ----
+        if (!g.pcm.empty()) {
+            const int err = ohgpu_pcm_process_host(ctx, g.pcm.data(), g.pcm.size(), src + g.srcBase, g.srcBytes, dst + g.dstBase, g.dstBytes);
+            ASSERT(err == OHGPU_OK);
+        }
+        if (!g.src.empty()) {
+            const int err = ohgpu_src_process_host(ctx, g.filter->handle, g.src.data(), g.src.size(), src + g.srcBase, g.srcBytes,
+                                                   dst + g.dstBase, g.dstBytes);
+            ASSERT(err == OHGPU_OK);
+        }
     }
     // ---- deliver, message by message, with the reference's callback sequence (Msg.cpp:2646-2653, 2753-2786, 2874-2893) ----
     for (size_t i = 0; i < iItems.size(); i++) {
         MsgPlayable* playable = iItems[i].playable;
         IPcmProcessor& proc = *iItems[i].processor;
         const PlayableWork& w = playable->Work();
-        const TUint subsampleBytes = outBits[i] / 8;
+        const TUint subsampleBytes = iItems[i].outBits / 8;
         const TUint outFrameBytes = subsampleBytes * w.channels;
-        const TByte* out = dst.data() + outOffset[i];
         proc.BeginBlock();
         if (w.frames > 0) {
+            const TByte* out = dst + iItems[i].outOffset;
             const TUint srcFrameBytes = (w.bitDepth / 8) * w.channels;
             TUint framesPerFragment;
             if (w.silence) {
@@ -467,6 +544,11 @@ MsgFactory::MsgFactory(int aDevice)
 MsgFactory::~MsgFactory()
 {
     if (iCtx != nullptr) {
+        for (auto& kv : iFilters) {
+            ohgpu_src_destroy(iCtx, kv.second.handle);
+        }
+        if (iArenaSrc != nullptr) ohgpu_free_host(iCtx, iArenaSrc);
+        if (iArenaDst != nullptr) ohgpu_free_host(iCtx, iArenaDst);
         ohgpu_shutdown(iCtx);
     }
 }
@@ -475,6 +557,60 @@ ohgpu_ctx* MsgFactory::Gpu() const
 {
     ASSERT(iCtx != nullptr);        // a control-plane-only factory (device < 0) cannot read audio
     return iCtx;
+}
+
+const SrcFilter& MsgFactory::SharedFilter(TUint aRateIn, TUint aRateOut, TUint aTapsPerPhase, double aBeta, double aPassHz)
+{
+    std::lock_guard<std::mutex> hold(iFilterLock);
+    const auto key = std::make_tuple(aRateIn, aRateOut, aTapsPerPhase, aBeta, aPassHz);
+    auto it = iFilters.find(key);
+    if (it == iFilters.end()) {
+        // designed once per conversion, on the host (Kaiser-windowed sinc, Q28: DESIGN.md section 4), uploaded once
+        SrcFilter f;
+        uint32_t L = 0, M = 0;
+        int err = ohgpu_src_design(aRateIn, aRateOut, aTapsPerPhase, aBeta, aPassHz, nullptr, 0, &L, &M);
+        ASSERT(err == OHGPU_OK);
+        std::vector<int32_t> coef((size_t)L * aTapsPerPhase);
+        err = ohgpu_src_design(aRateIn, aRateOut, aTapsPerPhase, aBeta, aPassHz, coef.data(), coef.size(), &L, &M);
+        ASSERT(err == OHGPU_OK);
+        err = ohgpu_src_create(Gpu(), L, M, aTapsPerPhase, coef.data(), &f.handle);
+        ASSERT(err == OHGPU_OK);
+        f.L = L;
+        f.M = M;
+        f.T = aTapsPerPhase;
+        it = iFilters.emplace(key, f).first;                               // (std::map: the reference handed out stays valid)
+    }
+    return it->second;
+}
+
+TUint MsgFactory::FilterCount() const
+{
+    std::lock_guard<std::mutex> hold(iFilterLock);
+    return (TUint)iFilters.size();
+}
+
+void MsgFactory::ReserveArena(size_t aSrcBytes, size_t aDstBytes, TByte*& aSrc, TByte*& aDst)
+{
+    auto grow = [this](TByte*& aBuf, size_t& aHave, size_t aWant) {
+        if (aHave >= aWant && aBuf != nullptr) {
+            return;
+        }
+        if (aBuf != nullptr) {
+            ohgpu_free_host(Gpu(), aBuf);
+            aBuf = nullptr;
+        }
+        size_t bytes = aWant + aWant / 2;
+        if (bytes < 65536) bytes = 65536;
+        void* p = nullptr;
+        const int err = ohgpu_malloc_host(Gpu(), bytes, &p);
+        ASSERT(err == OHGPU_OK);
+        aBuf = (TByte*)p;
+        aHave = bytes;
+    };
+    grow(iArenaSrc, iArenaSrcBytes, aSrcBytes);
+    grow(iArenaDst, iArenaDstBytes, aDstBytes);
+    aSrc = iArenaSrc;
+    aDst = iArenaDst;
 }
 
 MsgMode* MsgFactory::CreateMsgMode(const ModeInfo& aInfo)

@@ -22,8 +22,11 @@
 #pragma once
 
 #include <atomic>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "OhTypes.h"
@@ -44,6 +47,13 @@ class MsgAudioEncoded; class MsgMetaText; class MsgStreamInterrupted; class MsgH
 class MsgDecodedStream; class MsgAudioPcm; class MsgAudioDsd; class MsgSilence; class MsgPlayable; class MsgQuit;
 class MsgFactory;
 class SampleRateConverterStream;
+
+/** A designed polyphase filter on the device (include/ohgpu.h: ohgpu_src), kept by the factory and shared by every stream of the
+ *  same conversion: streams that share a filter can share a launch. */
+struct SrcFilter {
+    ohgpu_src* handle = nullptr;
+    TUint L = 0, M = 0, T = 0;
+};
 
 class IMsgProcessor;
 
@@ -334,9 +344,14 @@ private:
     TUint iJiffies;
 };
 
-/** Reads many playables -- typically one per stream per driver period -- in ONE launch, then replays each one's
- *  BeginBlock / ProcessFragment* / EndBlock sequence in the order they were added.  Output depth/endian default to
- *  the playable's own (pass-through); SetOutputFormat asks the device for the conversion the processor would do. */
+/** Reads many playables -- typically one per stream per driver period -- then replays each one's BeginBlock /
+ *  ProcessFragment* / EndBlock sequence in the order they were added (Msg.cpp:2646-2653, 2753-2786 per message, on the driver's
+ *  thread: AnimatorBasic.cpp:77-142).  One device call for all the plain audio and ONE PER FILTER for the rate-converted audio, however
+ *  many streams share it: what goes to the device is each message's window of input (SampleRateConverterStream::Window), packed
+ *  back to back in the factory's pinned arena, and what comes back is the messages' output and nothing else.  Output depth/endian
+ *  default to the playable's own (pass-through); SetOutputFormat asks the device for the conversion the processor would do.
+ *  The fragments handed to the processors point into the factory's arena: valid until the factory's next Run (the reference
+ *  lends a Brx for the call only, Msg.h:1204-1240).  A batch object may be reused period after period: it keeps its scratch. */
 class PlayableBatch {
 public:
     explicit PlayableBatch(MsgFactory& aFactory);
@@ -346,11 +361,15 @@ public:
     void Run();                                                        // launches, waits, delivers, releases
     TUint Count() const { return (TUint)iItems.size(); }
 private:
-    struct Item { MsgPlayable* playable; IPcmProcessor* processor; };
+    struct Item { MsgPlayable* playable; IPcmProcessor* processor; TUint64 outOffset; TUint outBits; };
+    struct WindowRun;                                                  // consecutive items of one stream whose outputs follow on: one window
+    struct Group;                                                      // the items one device call serves
     MsgFactory& iFactory;
     std::vector<Item> iItems;
     TUint iOutBits = 0;
     AudioDataEndian iOutEndian = AudioDataEndian::Big;
+    struct Scratch;
+    std::unique_ptr<Scratch> iScratch;
 };
 
 class MsgFactory {                                       // Msg.h:1987-2075 (the creators the PCM path uses)
@@ -375,8 +394,19 @@ public:
     MsgFlush* CreateMsgFlush(TUint aId) { return new MsgFlush(aId); }
     MsgWait* CreateMsgWait() { return new MsgWait(); }
     ohgpu_ctx* Gpu() const;
+    /** The filter of a conversion, designed and uploaded on first use and kept for the factory's lifetime. */
+    const SrcFilter& SharedFilter(TUint aRateIn, TUint aRateOut, TUint aTapsPerPhase, double aBeta, double aPassHz);
+    TUint FilterCount() const;
+    /** The driver thread's pinned staging for host-buffer reads (PlayableBatch::Run): at least the sizes asked for, kept and grown
+     *  with headroom.  Like the ohgpu_ctx it belongs to one thread at a time. */
+    void ReserveArena(size_t aSrcBytes, size_t aDstBytes, TByte*& aSrc, TByte*& aDst);
 private:
     ohgpu_ctx* iCtx;
+    mutable std::mutex iFilterLock;
+    std::map<std::tuple<TUint, TUint, TUint, double, double>, SrcFilter> iFilters;
+    TByte* iArenaSrc = nullptr;
+    TByte* iArenaDst = nullptr;
+    size_t iArenaSrcBytes = 0, iArenaDstBytes = 0;
 };
 
 // ---- element plumbing (Msg.h:1475-1525, 1844-1856; Msg.cpp:3585-3705) ----

@@ -1,6 +1,7 @@
 // SampleRateConverter.cpp -- see SampleRateConverter.h.
 #include "SampleRateConverter.h"
 
+#include <algorithm>
 #include <cstring>
 
 #include "../../include/ohgpu.h"
@@ -11,53 +12,64 @@ namespace Media {
 // ---------------------------------------------------------------- SampleRateConverterStream
 SampleRateConverterStream::SampleRateConverterStream(MsgFactory& aFactory, TUint aRateIn, TUint aRateOut, TUint aChannels,
                                                      TUint aBitDepth, AudioDataEndian aEndian, TUint aTapsPerPhase,
-                                                     double aBeta, double aPassHz)
-    : iFactory(aFactory)
-    , iFilter(nullptr)
-    , iL(0), iM(0), iT(aTapsPerPhase)
-    , iChannels(aChannels), iBitDepth(aBitDepth), iEndian(aEndian)
-    , iFrame0(0), iFrames(0)
+                                                     double aBeta, double aPassHz, TUint aHistoryMs)
+    : SampleRateConverterStream(aFactory.SharedFilter(aRateIn, aRateOut, aTapsPerPhase, aBeta, aPassHz), aRateIn, aChannels, aBitDepth,
+                                aEndian, aHistoryMs)
 {
-    uint32_t L = 0, M = 0;
-    int err = ohgpu_src_design(aRateIn, aRateOut, aTapsPerPhase, aBeta, aPassHz, nullptr, 0, &L, &M);
-    ASSERT(err == OHGPU_OK);
-    std::vector<int32_t> coef((size_t)L * aTapsPerPhase);
-    err = ohgpu_src_design(aRateIn, aRateOut, aTapsPerPhase, aBeta, aPassHz, coef.data(), coef.size(), &L, &M);
-    ASSERT(err == OHGPU_OK);
-    err = ohgpu_src_create(iFactory.Gpu(), L, M, aTapsPerPhase, coef.data(), &iFilter);
-    ASSERT(err == OHGPU_OK);
-    iL = L;
-    iM = M;
 }
 
-SampleRateConverterStream::~SampleRateConverterStream()
+SampleRateConverterStream::SampleRateConverterStream(const SrcFilter& aFilter, TUint aRateIn, TUint aChannels, TUint aBitDepth,
+                                                     AudioDataEndian aEndian, TUint aHistoryMs)
+    : iFilter(aFilter)
+    , iChannels(aChannels), iBitDepth(aBitDepth), iFrameBytes(aChannels * (aBitDepth / 8))
+    , iEndian(aEndian)
+    , iCapacity(0), iFrames(0)
 {
-    ohgpu_src_destroy(iFactory.Gpu(), iFilter);
+    // what a window may reach back over: the history asked for, and never less than a filter length and two maximal messages
+    iCapacity = (TUint64)aRateIn * aHistoryMs / 1000;
+    const TUint64 least = (TUint64)iFilter.T + 2 * (DecodedAudio::kMaxBytes / iFrameBytes + 1);
+    if (iCapacity < least) iCapacity = least;
+    iRing.resize((size_t)(iCapacity * iFrameBytes));
 }
 
 TUint64 SampleRateConverterStream::Append(const TByte* aData, TUint aBytes)
 {
-    const TUint frameBytes = iChannels * (iBitDepth / 8);
-    ASSERT(aBytes % frameBytes == 0);
-    // keep what later messages can still need: two seconds' worth is far beyond any pipeline's buffering
-    const TUint64 keepFrames = 2 * 192000;
-    if (iFrames > 2 * keepFrames) {
-        const TUint64 drop = iFrames - keepFrames;
-        iHistory.erase(iHistory.begin(), iHistory.begin() + (size_t)(drop * frameBytes));
-        iFrame0 += drop;
-        iFrames -= drop;
-    }
-    iHistory.insert(iHistory.end(), aData, aData + aBytes);
-    iFrames += aBytes / frameBytes;
-    return ohgpu_src_out_frames(iL, iM, iFrame0 + iFrames);
+    ASSERT(aBytes % iFrameBytes == 0);
+    TUint64 frames = aBytes / iFrameBytes;
+    ASSERT(frames <= iCapacity);
+    std::lock_guard<std::mutex> hold(iLock);
+    const TUint64 at = iFrames % iCapacity;
+    const TUint64 head = std::min(frames, iCapacity - at);            // up to the ring's end, the rest from its start
+    memcpy(&iRing[(size_t)(at * iFrameBytes)], aData, (size_t)(head * iFrameBytes));
+    if (frames > head) memcpy(&iRing[0], aData + head * iFrameBytes, (size_t)((frames - head) * iFrameBytes));
+    iFrames += frames;
+    return ohgpu_src_out_frames(iFilter.L, iFilter.M, iFrames);
 }
 
-void SampleRateConverterStream::DescribeWindow(TUint64 aOut0, TUint aCount, ohgpu_src_msg_desc& aDesc) const
+TUint64 SampleRateConverterStream::InputFrames() const
 {
-    (void)aOut0; (void)aCount;
-    aDesc.src_offset = 0;
-    aDesc.src_frame0 = iFrame0;
-    aDesc.src_frames = iFrames;
+    std::lock_guard<std::mutex> hold(iLock);
+    return iFrames;
+}
+
+void SampleRateConverterStream::Window(TUint64 aOut0, TUint aCount, TUint64& aFirst, TUint& aFrames) const
+{
+    ASSERT(aCount != 0);
+    const TUint64 newestOfFirst = aOut0 * iFilter.M / iFilter.L;                      // n0 of the run's first output
+    const TUint64 newestOfLast = (aOut0 + aCount - 1) * iFilter.M / iFilter.L;        // ... of its last
+    aFirst = newestOfFirst >= iFilter.T - 1 ? newestOfFirst - (iFilter.T - 1) : 0;
+    aFrames = (TUint)(newestOfLast - aFirst + 1);
+}
+
+void SampleRateConverterStream::CopyFrames(TUint64 aFirst, TUint aFrames, TByte* aDst) const
+{
+    std::lock_guard<std::mutex> hold(iLock);
+    ASSERT(aFirst + aFrames <= iFrames);                               // the output exists only once its input has arrived
+    ASSERT(aFirst + iCapacity >= iFrames);                             // ... and the ring must not have gone round over it
+    const TUint64 at = aFirst % iCapacity;
+    const TUint64 head = std::min<TUint64>(aFrames, iCapacity - at);
+    memcpy(aDst, &iRing[(size_t)(at * iFrameBytes)], (size_t)(head * iFrameBytes));
+    if (aFrames > head) memcpy(aDst + head * iFrameBytes, &iRing[0], (size_t)((aFrames - head) * iFrameBytes));
 }
 
 // ---------------------------------------------------------------- SampleRateConverter

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "Msg.h"
@@ -19,32 +20,41 @@ struct ohgpu_src_msg_desc;
 namespace OpenHome {
 namespace Media {
 
-/** Input history + filter of one rate-converted stream (shared by the output messages that refer to it). */
+/** Input history of one rate-converted stream (shared by the output messages that refer to it); the filter is the factory's,
+ *  shared by every stream of the same conversion (MsgFactory::SharedFilter).
+ *  The history is a ring of aHistoryMs of input (default two seconds: far beyond what a pipeline buffers between this element and
+ *  its driver -- Pipeline.h:97-109's reservoirs hold well under one).  A reader asks for the WINDOW of input a run of output frames
+ *  is made of and copies just that (PlayableBatch::Run packs a period's windows back to back: a kilobyte or two per 5 ms message, not
+ *  the history).  Append is called by the element's puller thread, the window calls by the driver's thread: both take iLock. */
 class SampleRateConverterStream {
 public:
     SampleRateConverterStream(MsgFactory& aFactory, TUint aRateIn, TUint aRateOut, TUint aChannels, TUint aBitDepth,
-                              AudioDataEndian aEndian, TUint aTapsPerPhase, double aBeta, double aPassHz);
-    ~SampleRateConverterStream();
+                              AudioDataEndian aEndian, TUint aTapsPerPhase, double aBeta, double aPassHz, TUint aHistoryMs = 2000);
+    /** ... over a filter the caller holds (what the factory's cache hands out; a test's own). */
+    SampleRateConverterStream(const SrcFilter& aFilter, TUint aRateIn, TUint aChannels, TUint aBitDepth, AudioDataEndian aEndian,
+                              TUint aHistoryMs = 2000);
     /** Appends input frames; returns how many output frames exist now (ceil(in*L/M)). */
     TUint64 Append(const TByte* aData, TUint aBytes);
-    TUint64 InputFrames() const { return iFrame0 + iFrames; }
-    /** Fills src_offset / src_frame0 / src_frames for the window output frames [aOut0, aOut0+aCount) need. */
-    void DescribeWindow(TUint64 aOut0, TUint aCount, ohgpu_src_msg_desc& aDesc) const;
-    const ohgpu_src* Filter() const { return iFilter; }
-    const TByte* HistoryPtr() const { return iHistory.data(); }
-    TUint64 HistoryBytes() const { return iHistory.size(); }
+    TUint64 InputFrames() const;
+    /** The input frames [aFirst, aFirst + aFrames) that output frames [aOut0, aOut0 + aCount) are made of (DESIGN.md section 4:
+     *  n0(m) = floor(m * M / L); output m reads n0(m) - T + 1 .. n0(m); frames before the stream's start do not exist). */
+    void Window(TUint64 aOut0, TUint aCount, TUint64& aFirst, TUint& aFrames) const;
+    /** Copies input frames [aFirst, aFirst + aFrames) to aDst; ASSERTs that the ring still holds them. */
+    void CopyFrames(TUint64 aFirst, TUint aFrames, TByte* aDst) const;
+    const SrcFilter& Filter() const { return iFilter; }
+    TUint FrameBytes() const { return iFrameBytes; }
     TUint SourceBitDepth() const { return iBitDepth; }
     AudioDataEndian SourceEndian() const { return iEndian; }
-    TUint L() const { return iL; }
-    TUint M() const { return iM; }
+    TUint L() const { return iFilter.L; }
+    TUint M() const { return iFilter.M; }
 private:
-    MsgFactory& iFactory;
-    ohgpu_src* iFilter;
-    TUint iL, iM, iT;
-    TUint iChannels, iBitDepth;
-    AudioDataEndian iEndian;
-    std::vector<TByte> iHistory;     // frames [iFrame0, iFrame0 + iFrames)
-    TUint64 iFrame0, iFrames;
+    const SrcFilter& iFilter;
+    const TUint iChannels, iBitDepth, iFrameBytes;
+    const AudioDataEndian iEndian;
+    mutable std::mutex iLock;
+    std::vector<TByte> iRing;        // frame f lives at (f % iCapacity) * iFrameBytes
+    TUint64 iCapacity;               // frames
+    TUint64 iFrames;                 // appended so far: the ring holds [max(0, iFrames - iCapacity), iFrames)
 };
 
 class SampleRateConverter : public PipelineElement, public IPipelineElementUpstream {

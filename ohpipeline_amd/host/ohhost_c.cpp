@@ -1,9 +1,15 @@
 // ohhost_c.cpp -- C entry points over the host adapter, for scripted callers (tests, bench.py).
 // Exceptions never cross this boundary: AssertionFailed -> -1, SampleRateInvalid -> -2.
 #include <cstdint>
+#include <cstring>
+#include <deque>
+#include <memory>
 #include <vector>
 
+#include "../../include/ohgpu.h"
+#include "Msg.h"
 #include "Ramp.h"
+#include "SampleRateConverter.h"
 
 using namespace OpenHome;
 using namespace OpenHome::Media;
@@ -91,6 +97,123 @@ int ohhost_stream_ramp_schedule(const uint32_t* sizes, uint32_t n, uint32_t up_j
         for (TUint acc = 0; downFirst > upLast && acc < down_jiffies; downFirst--) acc += sizes[downFirst - 1];
         run(0, upLast, Ramp::kMin, Ramp::EUp);
         run(downFirst, n, Ramp::kMax, Ramp::EDown);
+        return 0;
+    });
+}
+
+}  // extern "C"
+
+// ---- a driver thread's period over many rate-converted streams, for scripted callers (bench.py's cadence.adapter): `lanes`
+// chains of SampleRateConverter -> CreatePlayable (PreDriver.cpp:115-133's one line) behind one factory = one GPU context, read
+// with ONE PlayableBatch::Run per tick, the way AnimatorBasic.cpp:77-142 reads one.
+namespace {
+
+class CopyOut : public IPcmProcessor {
+public:
+    TByte* iDst = nullptr;
+    uint32_t iBytes = 0, iCap = 0;
+    void BeginBlock() override {}
+    void ProcessFragment(const Brx& aData, TUint, TUint) override { Take(aData); }
+    void ProcessSilence(const Brx& aData, TUint, TUint) override { Take(aData); }
+    void EndBlock() override {}
+    void Flush() override {}
+private:
+    void Take(const Brx& aData)
+    {
+        ASSERT(iBytes + aData.Bytes() <= iCap);
+        memcpy(iDst + iBytes, aData.Ptr(), aData.Bytes());
+        iBytes += aData.Bytes();
+    }
+};
+
+struct LiveLane : public IPipelineElementUpstream {
+    LiveLane(MsgFactory& aFactory, TUint aRateOut, TUint aTaps) : iSrc(aFactory, *this, aRateOut, aTaps) {}
+    Msg* Pull() override { ASSERT(!iPending.empty()); Msg* m = iPending.front(); iPending.pop_front(); return m; }
+    SampleRateConverter iSrc;
+    std::deque<Msg*> iPending;
+    CopyOut iSink;
+};
+
+}  // namespace
+
+struct ohhost_live {
+    std::unique_ptr<MsgFactory> factory;
+    std::unique_ptr<PlayableBatch> batch;
+    std::vector<std::unique_ptr<LiveLane>> lanes;
+    TUint rateIn = 0, channels = 0, bits = 0;
+    AudioDataEndian endian = AudioDataEndian::Little;
+};
+
+extern "C" {
+
+int ohhost_live_create(int device, uint32_t lanes, uint32_t rate_in, uint32_t rate_out, uint32_t channels, uint32_t bits,
+                       uint32_t little_endian, uint32_t out_bits, ohhost_live** out)
+{
+    OHHOST_TRY({
+        std::unique_ptr<ohhost_live> live(new ohhost_live());
+        live->factory.reset(new MsgFactory(device));
+        live->batch.reset(new PlayableBatch(*live->factory));
+        live->batch->SetOutputFormat(out_bits, AudioDataEndian::Big);
+        live->rateIn = rate_in; live->channels = channels; live->bits = bits;
+        live->endian = little_endian ? AudioDataEndian::Little : AudioDataEndian::Big;
+        for (uint32_t l = 0; l < lanes; l++) {
+            live->lanes.emplace_back(new LiveLane(*live->factory, rate_out, rate_in == 2 * rate_out ? 64 : 32));
+            DecodedStreamInfo info;
+            info.iStreamId = l + 1; info.iBitDepth = bits; info.iSampleRate = rate_in; info.iNumChannels = channels;
+            live->lanes.back()->iPending.push_back(live->factory->CreateMsgDecodedStream(info));
+        }
+        *out = live.release();
+        return 0;
+    });
+}
+
+// One driver period.  Lane l is fed `frames` input frames from input + l * in_lane_stride; whatever audio that makes available on
+// every lane is read with ONE PlayableBatch::Run and lands at output + l * out_lane_stride (out_bytes[l] bytes of it).
+int ohhost_live_tick(ohhost_live* live, const uint8_t* input, uint64_t in_lane_stride, uint32_t frames, uint8_t* output,
+                     uint64_t out_lane_stride, uint32_t* out_bytes)
+{
+    OHHOST_TRY({
+        const TUint frameBytes = live->channels * (live->bits / 8);
+        ASSERT(frames * frameBytes <= DecodedAudio::kMaxBytes);
+        for (size_t l = 0; l < live->lanes.size(); l++) {
+            LiveLane& lane = *live->lanes[l];
+            lane.iPending.push_back(live->factory->CreateMsgAudioPcm(Brn(input + l * in_lane_stride, frames * frameBytes), live->channels,
+                                                                     live->rateIn, live->bits, live->endian, 0));
+            lane.iSink.iDst = output + l * out_lane_stride;
+            lane.iSink.iBytes = 0;
+            lane.iSink.iCap = (uint32_t)out_lane_stride;
+            while (!lane.iPending.empty()) {
+                Msg* msg = lane.iSrc.Pull();
+                if (KindOf(msg) == MsgKind::AudioPcm) live->batch->Add(static_cast<MsgAudioPcm*>(msg)->CreatePlayable(), lane.iSink);
+                else msg->RemoveRef();
+            }
+        }
+        live->batch->Run();
+        for (size_t l = 0; l < live->lanes.size(); l++) out_bytes[l] = live->lanes[l]->iSink.iBytes;
+        return 0;
+    });
+}
+
+int ohhost_live_stats(ohhost_live* live, uint64_t* src_calls, uint64_t* h2d_bytes, uint64_t* d2h_bytes, uint64_t* device_allocs, uint32_t* filters)
+{
+    OHHOST_TRY({
+        uint64_t calls = 0;
+        if (ohgpu_host_transfer_stats(live->factory->Gpu(), &calls, src_calls, h2d_bytes, d2h_bytes) != OHGPU_OK) return -4;
+        if (ohgpu_device_allocations(live->factory->Gpu(), device_allocs) != OHGPU_OK) return -4;
+        *filters = live->factory->FilterCount();
+        return 0;
+    });
+}
+
+int ohhost_live_destroy(ohhost_live* live)
+{
+    OHHOST_TRY({
+        if (live != nullptr) {
+            for (auto& lane : live->lanes) for (Msg* m : lane->iPending) m->RemoveRef();
+            live->lanes.clear();
+            live->batch.reset();
+            delete live;
+        }
         return 0;
     });
 }

@@ -34,8 +34,60 @@ def lib():
         L.ohhost_stream_ramp_schedule.restype = C.c_int
         L.ohhost_stream_ramp_schedule.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ohhost_live_create.restype = C.c_int
+        L.ohhost_live_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_void_p)]
+        L.ohhost_live_tick.restype = C.c_int
+        L.ohhost_live_tick.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ohhost_live_stats.restype = C.c_int
+        L.ohhost_live_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4 + [C.POINTER(C.c_uint32)]
+        L.ohhost_live_destroy.restype = C.c_int
+        L.ohhost_live_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+class LiveDriver:
+    """`lanes` chains of SampleRateConverter -> CreatePlayable behind one MsgFactory (one GPU context), read with ONE
+    PlayableBatch::Run per tick: the C++ adapter's live path, as a driver thread would use it (host/ohhost_c.cpp)."""
+
+    def __init__(self, device, lanes, rate_in, rate_out, channels, bits, little_endian=True, out_bits=24):
+        self._h = C.c_void_p()
+        rc = lib().ohhost_live_create(device, lanes, rate_in, rate_out, channels, bits, 1 if little_endian else 0, out_bits, C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"ohhost_live_create failed: {rc}")
+        self.lanes = lanes
+        self.frame_bytes = channels * (bits // 8)
+        self._out_bytes = np.zeros(lanes, dtype=np.uint32)
+
+    def tick(self, input_u8, in_lane_stride, frames, output_u8, out_lane_stride):
+        """Feeds every lane `frames` input frames (lane l from input_u8[l * in_lane_stride:]), reads all lanes' audio in one
+        PlayableBatch::Run; lane l's output lands at output_u8[l * out_lane_stride:].  Returns the bytes per lane (uint32 array)."""
+        rc = lib().ohhost_live_tick(self._h, input_u8.ctypes.data_as(C.c_void_p), in_lane_stride, frames,
+                                    output_u8.ctypes.data_as(C.c_void_p), out_lane_stride, self._out_bytes.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"ohhost_live_tick failed: {rc}")
+        return self._out_bytes
+
+    def stats(self):
+        v = [C.c_uint64(0) for _ in range(4)]
+        f = C.c_uint32(0)
+        rc = lib().ohhost_live_stats(self._h, *[C.byref(x) for x in v], C.byref(f))
+        if rc != 0:
+            raise RuntimeError(f"ohhost_live_stats failed: {rc}")
+        return dict(src_calls=int(v[0].value), h2d_bytes=int(v[1].value), d2h_bytes=int(v[2].value), device_allocs=int(v[3].value),
+                    filters=int(f.value))
+
+    def close(self):
+        if self._h:
+            lib().ohhost_live_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def stream_ramp_schedule(sizes_jiffies, up_jiffies, down_jiffies):

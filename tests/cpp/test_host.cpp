@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/ohgpu.h"
 #include "../../ohpipeline_amd/host/DecodedAudioAggregator.h"
 #include "../../ohpipeline_amd/host/FlywheelRamper.h"
 #include "../../ohpipeline_amd/host/Msg.h"
@@ -514,6 +515,204 @@ private:
     DriverEdge iPreDriver;
     std::deque<Msg*> iPending;
     std::vector<TByte> iInput;
+};
+
+// A rate-converted stream's history is a ring, and a reader is handed the window of input its outputs are made of -- not the
+// history (round 5).  CPU: the ring against a linear copy of everything appended, over several turns of the ring, in ragged pieces;
+// the window against the specification's two lines; what is gone, or not there yet, asserts.
+static void SuiteSrcStreamRing()
+{
+    SrcFilter flt;                                   // (no device behind it: the ring and the window arithmetic need none)
+    flt.L = 160; flt.M = 147; flt.T = 32;
+    SampleRateConverterStream st(flt, 44100, 2, 24, AudioDataEndian::Little, 100);      // 100 ms = 4410 frames of history
+    std::vector<TByte> all;
+    uint32_t x = 99;
+    TUint64 outSeen = 0;
+    for (TUint piece = 0; piece < 400; piece++) {
+        x = x * 1664525u + 1013904223u;
+        const TUint frames = 1 + (x >> 16) % 300;
+        std::vector<TByte> data(frames * 6);
+        for (auto& b : data) { x = x * 1664525u + 1013904223u; b = (TByte)(x >> 24); }
+        all.insert(all.end(), data.begin(), data.end());
+        const TUint64 avail = st.Append(data.data(), (TUint)data.size());
+        TEST(avail == (all.size() / 6 * 160 + 146) / 147);
+        TEST(st.InputFrames() == all.size() / 6);
+        if (avail == outSeen) continue;
+        // the window of the outputs that have just become available, against first principles
+        TUint64 first = 0; TUint n = 0;
+        st.Window(outSeen, (TUint)(avail - outSeen), first, n);
+        const TUint64 n0First = outSeen * 147 / 160, n0Last = (avail - 1) * 147 / 160;
+        TEST(first == (n0First >= 31 ? n0First - 31 : 0) && first + n == n0Last + 1);
+        TEST(first + n <= all.size() / 6);                        // an output exists only once its newest input has arrived
+        std::vector<TByte> got((size_t)n * 6);
+        st.CopyFrames(first, n, got.data());
+        TEST(memcmp(got.data(), &all[(size_t)first * 6], got.size()) == 0);
+        outSeen = avail;
+    }
+    TEST(all.size() / 6 > 10 * 4410);                             // the ring went round many times
+    const TUint64 frames = all.size() / 6;
+    std::vector<TByte> buf(4410 * 6);
+    st.CopyFrames(frames - 4410, 4410, buf.data());               // the whole ring, across its seam
+    TEST(memcmp(buf.data(), &all[(size_t)(frames - 4410) * 6], buf.size()) == 0);
+    TEST_THROWS(st.CopyFrames(frames - 4411, 10, buf.data()), AssertionFailed);     // overwritten
+    TEST_THROWS(st.CopyFrames(frames - 5, 10, buf.data()), AssertionFailed);        // not appended yet
+    TUint64 f0 = 0; TUint n0 = 0;
+    st.Window(0, 1, f0, n0);
+    TEST(f0 == 0 && n0 == 1);                                     // the stream's first output: one input frame, zeros before it
+    st.Window(35, 240, f0, n0);
+    TEST(f0 == 35 * 147 / 160 - 31 && f0 + n0 == (35 + 239) * 147 / 160 + 1);
+}
+
+// 256 live rate-converted streams behind ONE driver thread (round 5): every lane is SampleRateConverter -> the fade-in fixture ->
+// the driver edge, a tick feeds every lane 5 ms of input and reads what comes out of all of them with ONE PlayableBatch::Run.
+// Three layouts over two conversions (44.1 -> 48 kHz: S24LE and S16BE stereo; 96 -> 48 kHz: S24LE stereo), so the factory holds two
+// filters whatever the number of streams, and a tick is two resampler calls through the C ABI, not 256; what crosses the link
+// per tick is the messages' windows, not the streams' histories; nothing is allocated on the device after the first ticks.
+// Every lane's output is bit-exact against the oracle run over that lane's whole input.
+class SuiteManyResampledLanesGpu {
+    struct Lane : public IPipelineElementUpstream {
+        Lane(MsgFactory& aFactory, TUint aRateIn, TUint aBits, AudioDataEndian aEndian)
+            : rateIn(aRateIn), bits(aBits), endian(aEndian), src(aFactory, *this, 48000, aRateIn == 96000 ? 64 : 32)
+            , fade(src, Jiffies::kPerMs * 50, Jiffies::kPerMs * 20), edge(fade) {}
+        Msg* Pull() override { ASSERT(!pending.empty()); Msg* m = pending.front(); pending.pop_front(); return m; }
+        TUint rateIn, bits;
+        AudioDataEndian endian;
+        SampleRateConverter src;
+        FadeInAtStreamStart fade;
+        DriverEdge edge;
+        std::deque<Msg*> pending;
+        std::vector<TByte> input, got;
+        std::vector<ohp_src_msg_desc> descs;
+        TUint64 outFrames = 0;
+        uint32_t x = 0;
+        TUint filled = 0;
+        ProcessorPcmBufTest sinks[4];
+    };
+public:
+    explicit SuiteManyResampledLanesGpu(MsgFactory& aFactory) : iFactory(aFactory) {}
+    void Run()
+    {
+        const TUint kLanes = 256, kTicks = 200;
+        const TUint filtersBefore = iFactory.FilterCount();
+        std::vector<std::unique_ptr<Lane>> lanes;
+        for (TUint l = 0; l < kLanes; l++) {
+            const TUint kind = l % 8;                        // 6 of 8: 44.1 kHz S24LE; 1: 44.1 kHz S16BE; 1: 96 kHz S24LE
+            lanes.emplace_back(new Lane(iFactory, kind == 7 ? 96000 : 44100, kind == 6 ? 16 : 24,
+                                        kind == 6 ? AudioDataEndian::Big : AudioDataEndian::Little));
+            Lane& lane = *lanes.back();
+            lane.x = 0x9E3779B9u * (l + 1);
+            DecodedStreamInfo info;
+            info.iStreamId = l + 1; info.iBitDepth = lane.bits; info.iSampleRate = lane.rateIn; info.iNumChannels = 2; info.iLive = true;
+            lane.pending.push_back(iFactory.CreateMsgDecodedStream(info));
+        }
+        PlayableBatch batch(iFactory);                        // one object, reused tick after tick
+        uint64_t allocsAfterWarmup = 0, allocsSeen = 0, windowBytes = 0, h2dTotal = 0;
+        TBool allocsFlat = true;
+        TUint srcCallsPerTickMax = 0, srcCallsPerTickMin = 1000, sawStreams = 0, maxPlayablesPerTick = 0;
+        TBool h2dWithinBudget = true;
+        for (TUint tick = 0; tick < kTicks; tick++) {
+            uint64_t tickWindowBytes = 0;
+            TUint playables = 0;
+            for (auto& lp : lanes) {
+                Lane& lane = *lp;
+                const TUint frames = lane.rateIn / 200;       // 5 ms
+                const TUint sb = lane.bits / 8;
+                std::vector<TByte> data(frames * 2 * sb);
+                for (size_t i = 0; i < data.size(); i += sb) {
+                    lane.x = lane.x * 1664525u + 1013904223u;
+                    for (TUint b = 0; b < sb; b++) {          // the sample's bytes, least significant first or last
+                        const TByte v = (TByte)(lane.x >> (32 - 8 * sb + 8 * b));
+                        data[i + (lane.endian == AudioDataEndian::Little ? b : sb - 1 - b)] = v;
+                    }
+                }
+                lane.input.insert(lane.input.end(), data.begin(), data.end());
+                lane.pending.push_back(iFactory.CreateMsgAudioPcm(Brn(data.data(), (TUint)data.size()), 2, lane.rateIn, lane.bits, lane.endian, 0));
+                TUint n = 0;
+                while (!lane.pending.empty() || lane.fade.Holding()) {
+                    Msg* msg = lane.edge.Pull();
+                    if (MsgPlayable* p = dynamic_cast<MsgPlayable*>(msg)) {
+                        ohp_src_msg_desc d;
+                        memset(&d, 0, sizeof(d));
+                        d.src_frames = lane.input.size() / (2 * sb); d.out_frame0 = lane.outFrames; d.dst_offset = lane.outFrames * 6;
+                        d.n_frames = p->Bytes() / 6; d.ramp_start = (uint16_t)p->Ramp().Start(); d.ramp_end = (uint16_t)p->Ramp().End();
+                        d.attenuation = 256; d.channels = 2; d.src_bits = (uint8_t)lane.bits;
+                        d.src_endian = lane.endian == AudioDataEndian::Little ? OHP_ENDIAN_LITTLE : OHP_ENDIAN_BIG;
+                        d.dst_bits = 24; d.dst_endian = OHP_ENDIAN_BIG; d.flags = p->Ramp().IsEnabled() ? OHP_FLAG_RAMP : 0;
+                        lane.descs.push_back(d);
+                        // what this message needs of its stream's input (the specification's window), for the link's budget
+                        const TUint64 L = lane.rateIn == 96000 ? 1 : 160, M = lane.rateIn == 96000 ? 2 : 147, T = lane.rateIn == 96000 ? 64 : 32;
+                        const TUint64 hi = (d.out_frame0 + d.n_frames - 1) * M / L, n0 = d.out_frame0 * M / L;
+                        tickWindowBytes += (hi - (n0 >= T - 1 ? n0 - (T - 1) : 0) + 1) * 2 * sb;
+                        lane.outFrames += d.n_frames;
+                        ASSERT(n < 4);
+                        batch.Add(p, lane.sinks[n++]);
+                        playables++;
+                    }
+                    else {
+                        if (MsgDecodedStream* s = dynamic_cast<MsgDecodedStream*>(msg)) {
+                            TEST(s->StreamInfo().SampleRate() == 48000 && s->StreamInfo().BitDepth() == 24);
+                            sawStreams++;
+                        }
+                        msg->RemoveRef();
+                    }
+                }
+                lane.filled = n;                              // (how many sinks of this lane the tick filled)
+            }
+            uint64_t calls0 = 0, src0 = 0, h2d0 = 0, d2h0 = 0, calls1 = 0, src1 = 0, h2d1 = 0, d2h1 = 0;
+            ohgpu_host_transfer_stats(iFactory.Gpu(), &calls0, &src0, &h2d0, &d2h0);
+            batch.Run();                                      // THE tick: every lane's audio in one go
+            ohgpu_host_transfer_stats(iFactory.Gpu(), &calls1, &src1, &h2d1, &d2h1);
+            for (auto& lp : lanes) {
+                Lane& lane = *lp;
+                const TUint n = lane.filled;
+                for (TUint k = 0; k < n; k++) lane.got.insert(lane.got.end(), lane.sinks[k].Ptr(), lane.sinks[k].Ptr() + lane.sinks[k].Buf().Bytes());
+            }
+            srcCallsPerTickMax = std::max(srcCallsPerTickMax, (TUint)(src1 - src0));
+            srcCallsPerTickMin = std::min(srcCallsPerTickMin, (TUint)(src1 - src0));
+            TEST(calls1 - calls0 == src1 - src0);             // nothing but resampled audio here: no other device call
+            if ((h2d1 - h2d0) * 10 > tickWindowBytes * 12) h2dWithinBudget = false;
+            TEST(d2h1 - d2h0 <= (uint64_t)playables * 241 * 6 + 256);      // the outputs and nothing else
+            windowBytes += tickWindowBytes;
+            h2dTotal += h2d1 - h2d0;
+            maxPlayablesPerTick = std::max(maxPlayablesPerTick, playables);
+            uint64_t allocs = 0;
+            ohgpu_device_allocations(iFactory.Gpu(), &allocs);
+            if (allocs != allocsSeen) { printf("SuiteManyResampledLanesGpu: tick %u: %llu device allocations so far\n", tick, (unsigned long long)allocs); allocsSeen = allocs; }
+            if (tick == 11) allocsAfterWarmup = allocs;       // (the fade-in's ten messages split one of them: the arenas have seen their largest tick)
+            if (tick > 11 && allocs != allocsAfterWarmup) allocsFlat = false;
+        }
+        TEST(allocsFlat);                                     // nothing is allocated on the device once the first ticks have sized the arenas
+        TEST(sawStreams == kLanes);
+        TEST(iFactory.FilterCount() == filtersBefore + 2 || iFactory.FilterCount() == 2);      // two conversions, 256 streams
+        TEST(srcCallsPerTickMax == 2 && srcCallsPerTickMin == 2);                             // one C-ABI resampler call per filter per tick
+        TEST(h2dWithinBudget);                                                                // windows only: <= 1.2 x their bytes, every tick
+        TEST(h2dTotal * 10 <= windowBytes * 11);
+        TEST(maxPlayablesPerTick >= kLanes);
+        printf("SuiteManyResampledLanesGpu: %u lanes x %u ticks, %.1f KB of windows and %.1f KB over the link per tick, 2 resampler calls per tick\n",
+               kLanes, kTicks, windowBytes / 1024.0 / kTicks, h2dTotal / 1024.0 / kTicks);
+        // every lane against the oracle over the lane's whole input
+        ohp_src* ref441 = ohp_src_new(44100, 48000, 32, 9.0, 20000.0);
+        ohp_src* ref96 = ohp_src_new(96000, 48000, 64, 9.0, 20000.0);
+        TUint lanesOk = 0, rampedOk = 0;
+        for (auto& lp : lanes) {
+            Lane& lane = *lp;
+            for (auto& d : lane.descs) d.src_frames = lane.input.size() / (2 * (lane.bits / 8));
+            std::vector<TByte> want(lane.got.size());
+            const int rc = ohp_src_msg_process_batch(lane.rateIn == 96000 ? ref96 : ref441, lane.descs.data(), lane.descs.size(), lane.input.data(), want.data());
+            const TUint64 expect = lane.rateIn == 96000 ? (TUint64)kTicks * 240 : ((TUint64)kTicks * 220 * 160 + 146) / 147;
+            if (rc == 0 && lane.outFrames == expect && lane.got.size() == lane.outFrames * 6 && memcmp(lane.got.data(), want.data(), want.size()) == 0) lanesOk++;
+            TUint ramped = 0;
+            for (auto& d : lane.descs) if (d.flags & OHP_FLAG_RAMP) ramped += d.n_frames;
+            if (ramped == 50 * 48) rampedOk++;                // the live stream's 50 ms fade-in, at the OUTPUT rate
+        }
+        ohp_src_delete(ref441);
+        ohp_src_delete(ref96);
+        TEST(lanesOk == kLanes);
+        TEST(rampedOk == kLanes);
+        for (auto& lp : lanes) { lp->pending.push_back(iFactory.CreateMsgQuit()); lp->edge.Pull()->RemoveRef(); }
+    }
+private:
+    MsgFactory& iFactory;
 };
 
 // ------------------------------------------------------------------------------------------- FlywheelRamper (N1)
@@ -1914,6 +2113,7 @@ int main(int argc, char** argv)
             SuiteStarvationRamper starvation(control);
             starvation.RunControl();
             SuiteIdleLaneDoesNotStallTheTick(control);
+            SuiteSrcStreamRing();
         }
         if (gpu) {
             MsgFactory f(0);
@@ -1922,6 +2122,8 @@ int main(int argc, char** argv)
             ramper.Run();
             SuiteSrcGpu src(f);
             src.Run();
+            SuiteManyResampledLanesGpu manyResampled(f);
+            manyResampled.Run();
             SuiteFlywheelGpu(f);
             SuiteStarvationRescueGpu(f);
             SuiteManyLanesStarveTogetherGpu(f);

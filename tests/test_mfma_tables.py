@@ -178,3 +178,31 @@ def test_halfband_tables_refuse_other_filters():
     coef[5] = 12345                                             # an odd tap that is not the centre: no longer half-band
     with pytest.raises(capi.OhGpuError):
         capi.src_mfma_halfband_tables(coef)
+
+
+def test_a_coefficient_whose_top_digit_is_no_int8_is_refused():
+    """(127 << 24) + 0x7f7f7f is the largest coefficient with balanced digits; one above it carries into a top digit of 128, which an
+    int8 cast would wrap to -128 (round 4 accepted up to (127 << 24) + 0x7fffff and made silently wrong tables).  The extremes that
+    do have digits recompose; a second tap cancels the first in the bias sum, so that only the digit test can refuse."""
+    L, M, T = 160, 147, 32
+    base = np.zeros(L * T, dtype=np.int32)
+    top = (127 << 24) + 0x7F7F7F
+    for c, partner, ok in ((top, -top, True), (top + 1, -(top + 1), False), ((127 << 24) + 0x7FFFFF, -(127 << 24) - 0x7FFFFF, False),
+                           (-(1 << 31), top, True)):               # (every negative int32 has digits: the bottom of the range is -(128 << 24) - 0x808080)
+        coef = base.copy()
+        coef[5], coef[6] = c, partner
+        if not ok:
+            with pytest.raises(capi.OhGpuError):
+                capi.src_mfma_tables(L, M, T, coef, 8)
+            continue
+        dig, _, _ = capi.src_mfma_tables(L, M, T, coef, 8)
+        rec = sum(dig[j, 0, 32:64].astype(np.int64) << (8 * j) for j in range(4))[::-1]
+        assert rec[5] == c and rec[6] == partner
+    hb = np.zeros(64, dtype=np.int32)
+    hb[0], hb[2] = top + 1, -(top + 1)
+    with pytest.raises(capi.OhGpuError):
+        capi.src_mfma_halfband_tables(hb)
+    hb[0], hb[2] = top, -top
+    image, _, _ = capi.src_mfma_halfband_tables(hb)
+    rec = sum(image[j].astype(np.int64) << (8 * j) for j in range(4))
+    assert rec[2, 0, 0] == top          # K group 2, output 0, sample 0 meets tap 2 * (32 + 0 - 32 - 0) = 0
