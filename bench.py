@@ -36,6 +36,7 @@ BITS = 24
 BETA, F_PASS = 9.0, 20000.0
 OUT_FRAMES_PER_MSG = 240            # 5 ms at 48 kHz (CodecController.cpp:792-793 chunking, at the output rate)
 JIFFIES_PER_MS = 56448
+HOST_THREADS = None                 # a rank's share of the host's CPUs (main(): quota / ranks on this host); None = no cap
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 LCG_A, LCG_C, MASK = 1664525, 1013904223, 0xFFFFFFFF
 
@@ -148,7 +149,7 @@ class Group:
         def one(k):
             make = noise_s16le if self.fb_src == 2 * self.channels else noise_s24le
             self.src[k * per:(k + 1) * per] = make(self.stream_ids[k], self.in_frames * self.channels)
-        with ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0))))) as ex:     # (numpy releases the GIL in these passes)
+        with ThreadPoolExecutor(max(1, min(32, HOST_THREADS or len(os.sched_getaffinity(0))))) as ex:     # (numpy releases the GIL in these passes; a rank's share of the host: main())
             list(ex.map(one, range(len(self.stream_ids))))
 
     def attach(self, ctx):
@@ -574,6 +575,62 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
+def cgroup_quota_cpus():
+    """The container's CPU quota in CPUs (cgroup v2 cpu.max, v1 cfs quota), or None when there is none."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return max(1, int(round(q / per))) if q > 0 and per > 0 else None
+    except Exception:
+        return None
+
+
+def parse_cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def host_share(local_world, pci_bus_id=None, sysfs="/sys/bus/pci/devices"):
+    """What one of `local_world` ranks on this host may use of it: `threads` = the CPUs the process may keep busy (its affinity mask,
+    capped by the container's CPU quota) divided among the ranks -- planner threads, noise / decoder pools -- and `cpus` = the CPUs
+    nearest the rank's GPU (the PCI device's local_cpulist) among those it may run on, or None when the topology cannot be read or
+    leaves nothing (then the rank stays where it is)."""
+    allowed = set(os.sched_getaffinity(0))
+    budget = len(allowed)
+    quota = cgroup_quota_cpus()
+    if quota is not None:
+        budget = min(budget, quota)
+    threads = max(1, budget // max(1, local_world))
+    cpus = None
+    if pci_bus_id:
+        try:
+            near = parse_cpulist(open(os.path.join(sysfs, pci_bus_id, "local_cpulist")).read()) & allowed
+            if near and near != allowed:
+                cpus = sorted(near)
+        except Exception:
+            cpus = None
+    return {"threads": threads, "cpus": cpus, "cpu_budget": budget, "quota_cpus": quota, "local_world": local_world}
+
+
+def slowest_rank(dist, *figures):
+    """Host-side figures of a multi-rank job (plan_ms, plan_ms_first, config 5's decode seconds): the job's is the slowest rank's."""
+    import torch
+    t = torch.tensor([float(f) for f in figures], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` (N > 1) without a launcher around it: start the N ranks as a CHILD process -- before this
     process has imported the C ABI or touched HIP, and never by exec -- relay rank 0's JSON line, exit with the child's code."""
@@ -658,6 +715,9 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
         tot = torch.tensor([frames_all, subs_all], dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         frames_all, subs_all = float(tot[0]), float(tot[1])
+        # a launch waits for the slowest rank's plan, and config 5's step for the slowest rank's decode: the maxima are the job's
+        plan_ms_max, plan_ms_first_max, decode_s_max = slowest_rank(dist, float(sum(g.plan_ms for g in groups)), float(sum(g.plan_ms_first for g in groups)),
+                                                                    flac.decode_s if flac is not None else 0.0)
         if not args.no_cpu:
             first = [ctx.download(g.d_dst, g.out_total * g.fb_dst) for g in groups]
             okt = torch.tensor([1.0 if rank_check(groups, first) else 0.0], dtype=torch.float64)
@@ -684,6 +744,8 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     plan_ms = float(sum(g.plan_ms for g in groups))
     plan_ms_first = float(sum(g.plan_ms_first for g in groups))
+    if dist is not None:
+        plan_ms, plan_ms_first = plan_ms_max, plan_ms_first_max       # (the slowest rank's)
 
     result = None
     if rank == 0:
@@ -746,6 +808,15 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
         }
         if flac is not None:
             result["config"]["flac"] = flac.report(grp_ms[-1])
+            if dist is not None:
+                result["config"]["flac"]["host_decode"]["seconds_max_over_ranks"] = round(decode_s_max, 3)
+        share = getattr(args, "host_share", None)
+        if share is not None:
+            result["host"] = {"plan_threads": min(16, share["threads"]) if world > 1 else "library default (<= 16, <= the CPU quota)",
+                              "feeder_threads": share["threads"] if world > 1 else None, "ranks_on_host": share["local_world"],
+                              "cpu_budget": share["cpu_budget"], "cgroup_quota_cpus": share["quota_cpus"],
+                              "pinned_to_cpus_near_gpu": (f"{len(share['cpus'])} CPUs" if (world > 1 and share["cpus"]) else None),
+                              "plan_ms": "max over ranks" if world > 1 else "this rank"}
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and args.config == 3 and world == 1:
             # `traffic` is a counter measurement of THIS workload taken in separate --pmc passes (tools/profile_bench.sh), not of
@@ -825,6 +896,25 @@ def main():
     from ohpipeline_amd import capi
     ctx = capi.Context(local_rank % max(capi.device_count(), 1) if world > 1 else 0)   # fewer GPUs than ranks (a rehearsal): shared
     ctx.set_kernel_variant(args.variant)
+    # One rank per GPU, several ranks per host: each takes its share of the CPUs the container grants -- the planner's pool
+    # (ohgpu_set_plan_threads), the noise generator's and the FLAC decoder's -- and stays near its GPU where the topology says where
+    # that is.  Eight ranks that each start sixteen planner threads and thirty-two feeders on a sixteen-CPU grant would only queue.
+    global HOST_THREADS
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    try:
+        bus = ctx.pci_bus_id()
+    except Exception:
+        bus = None
+    share = host_share(local_world, bus)
+    if world > 1:
+        if share["cpus"]:
+            try:
+                os.sched_setaffinity(0, share["cpus"])
+            except OSError:
+                share["cpus"] = None
+        HOST_THREADS = share["threads"]
+        capi.set_plan_threads(min(16, share["threads"]))
+    args.host_share = share
     result, ok = measure(capi, ctx, args, rank, world, dist)
     # The default line (config 3, one GPU, sizes untouched) also carries BASELINE configs[3] and configs[4], at their full size
     # (2048 streams x 10 s; 256 FLAC streams x 10 s), same process, each with its own sustain phase, steps and whole-step check.

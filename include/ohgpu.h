@@ -126,6 +126,9 @@ int         ohgpu_device_count(void);                       /* >= 0, or OHGPU_ER
 int         ohgpu_init(int device, ohgpu_ctx** ctx);         /* OHGPU_ERR_NO_DEVICE when there is no GPU */
 int         ohgpu_shutdown(ohgpu_ctx* ctx);
 int         ohgpu_device_name(ohgpu_ctx* ctx, char* buf, size_t buf_bytes);
+/* The device's PCI address, "0000:c1:00.0", lower case: a host that runs one rank per GPU finds the CPUs nearest the device under
+ * /sys/bus/pci/devices/<address>/local_cpulist (bench.py pins each rank's planner and feeder threads there). */
+int         ohgpu_device_pci_bus_id(ohgpu_ctx* ctx, char* buf, size_t buf_bytes);
 
 /* ---- plumbing: device memory, streams, events (thin wrappers, so hosts need no HIP headers) ---- */
 int ohgpu_malloc(ohgpu_ctx* ctx, size_t bytes, void** dptr);
@@ -357,10 +360,14 @@ int ohgpu_set_plan_threads(int threads);
 
 /* The plan ohgpu_src_batch_create would make for these messages, as a 64-bit hash of its unit list, ramp jobs and generic-kernel
  * pieces -- computed on the host alone (no context, no device): what tests/test_plan_threads.py compares across thread counts.
- * `kernel` is set to the newest kernel the plan serves: 3 / 2 / 1 / 0 for src_mfma_wg_kernel / src_mfma_kernel / src_lean_kernel / round 1's or none
- * (which one runs is the run-time variant's choice among those). */
+ * coef_q28 (L * taps_per_phase of them) describes the filter as ohgpu_src_create would -- the half-band form, the matrix kernels'
+ * tables, the gain bound -- so that the plan is the one a real batch gets; NULL stands for a polyphase filter of sane gain with
+ * no special structure.  num_cus is the device's CU count (the long-unit schedule aims at one long unit per wave): 0 = 256.
+ * `kernel` is set to the newest kernel the plan serves: 3 / 2 / 1 / 0 for src_mfma_wg_kernel / src_mfma_kernel / src_lean_kernel /
+ * round 1's or none (which one runs is the run-time variant's choice among those). */
 int ohgpu_src_plan_digest(uint32_t L, uint32_t M, uint32_t taps_per_phase, const ohgpu_src_msg_desc* descs, size_t n,
                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, int kernel_variant,
+                          const int32_t* coef_q28, int num_cus,
                           uint64_t* digest, uint64_t* units, uint64_t* generic_pieces, int* kernel);
 
 /* Which kernel ohgpu_src_batch_run launches for the batch's whole phase-aligned blocks under the context's current kernel
@@ -387,7 +394,9 @@ int ohgpu_device_allocations(ohgpu_ctx* ctx, uint64_t* count);
  * batch of thousands of units gets otherwise -- so that tests reach that path with small inputs; results are identical);
  * 4 = round 2's fp64 "lean" block kernel where round 4's matrix-pipe kernels (24-bit stereo) would run, for A/B;
  * 5 = round 4's matrix-pipe kernel with a unit per wave (src_mfma_kernel) where the unit-per-workgroup one (src_mfma_wg_kernel,
- * the default) would run.  Variants 2..5 take effect for batches created while they are set (they shape the plan). */
+ * the default) would run.  Variants 2..5 shape the plan of batches created while they are set; the variant in force when a batch is
+ * RUN chooses among the kernels its plan serves (ohgpu_src_batch_kernel_name says which) -- a batch planned for the workgroup kernel
+ * alone (six and eight channels, the layouts only it has) runs on the generic kernel under any other variant. */
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant);
 
 #ifdef __cplusplus

@@ -66,6 +66,7 @@ SYMBOLS = {
     "ohgpu_init": (C.c_int, [C.c_int, _vpp]),
     "ohgpu_shutdown": (C.c_int, [_vp]),
     "ohgpu_device_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "ohgpu_device_pci_bus_id": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "ohgpu_malloc": (C.c_int, [_vp, C.c_size_t, _vpp]),
     "ohgpu_free": (C.c_int, [_vp, _vp]),
     "ohgpu_malloc_host": (C.c_int, [_vp, C.c_size_t, _vpp]),
@@ -110,7 +111,7 @@ SYMBOLS = {
     "ohgpu_src_batch_units": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_set_plan_threads": (C.c_int, [C.c_int]),
     "ohgpu_src_plan_digest": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int,
-                                        _u64p, _u64p, _u64p, C.POINTER(C.c_int)]),
+                                        _vp, C.c_int, _u64p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "ohgpu_src_batch_kernel_name": (C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t]),
     "ohgpu_measure_shader_clock": (C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
     "ohgpu_device_allocations": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
@@ -176,11 +177,15 @@ def set_plan_threads(threads):
     check(lib().ohgpu_set_plan_threads(int(threads)))
 
 
-def src_plan_digest(L, M, T, descs, src_arena_bytes, dst_arena_bytes, kernel_variant=0):
-    """The plan ohgpu_src_batch_create would make, hashed on the host (no device): {digest, units, generic_pieces, kernel}."""
+def src_plan_digest(L, M, T, descs, src_arena_bytes, dst_arena_bytes, kernel_variant=0, coef_q28=None, num_cus=0):
+    """The plan ohgpu_src_batch_create would make, hashed on the host (no device): {digest, units, generic_pieces, kernel}.
+    coef_q28: the filter's coefficients (the plan then is exactly a real batch's: half-band form, tables, gain); None = a plain
+    polyphase filter of sane gain.  num_cus: the device's CU count (0 = 256)."""
     d = np.ascontiguousarray(descs)
+    coef = None if coef_q28 is None else np.ascontiguousarray(coef_q28, dtype=np.int32)
     h, u, p, k = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)
     check(lib().ohgpu_src_plan_digest(L, M, T, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes, dst_arena_bytes, kernel_variant,
+                                      None if coef is None else coef.ctypes.data_as(C.c_void_p), num_cus,
                                       C.byref(h), C.byref(u), C.byref(p), C.byref(k)))
     return {"digest": int(h.value), "units": int(u.value), "generic_pieces": int(p.value), "kernel": int(k.value)}
 
@@ -426,6 +431,11 @@ class Context:
         n = C.c_uint64(0)
         check(lib().ohgpu_device_allocations(self._h, C.byref(n)))
         return int(n.value)
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(64)
+        check(lib().ohgpu_device_pci_bus_id(self._h, buf, 64))
+        return buf.value.decode()
 
     def host_transfer_stats(self):
         """What the *_process_host calls of this context moved so far (ohgpu_host_transfer_stats)."""

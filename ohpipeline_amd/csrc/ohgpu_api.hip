@@ -219,6 +219,14 @@ int ohgpu_device_name(ohgpu_ctx* ctx, char* buf, size_t buf_bytes)
     return OHGPU_OK;
 }
 
+int ohgpu_device_pci_bus_id(ohgpu_ctx* ctx, char* buf, size_t buf_bytes)
+{
+    if (!ctx || !buf || buf_bytes < 16) return set_error(OHGPU_ERR_INVALID, "ohgpu_device_pci_bus_id: bad argument");
+    OHGPU_HIP_TRY(hipDeviceGetPCIBusId(buf, (int)buf_bytes, ctx->device));
+    for (char* c = buf; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');     // (sysfs spells it in lower case)
+    return OHGPU_OK;
+}
+
 int ohgpu_set_kernel_variant(ohgpu_ctx* ctx, int variant)
 {
     if (!ctx || variant < 0 || variant > 5) return set_error(OHGPU_ERR_INVALID, "ohgpu_set_kernel_variant: bad argument");
@@ -859,6 +867,56 @@ int ohgpu_src_mfma_halfband_tables(const int32_t* coef_q28, uint8_t* image, int6
     return OHGPU_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// What the planner and the dispatch look at in a filter, from its coefficients alone (no device): the exactness bound's figure, the
+// half-band structure, and whether the matrix-pipe kernels' tables exist for it (and which).  ohgpu_src_create and
+// ohgpu_src_plan_digest both come through here, so that the digest's plan IS the plan.  Returns false with the error set.
+struct SrcTables { std::vector<uint8_t> amat; std::vector<MfStep> steps; bool made = false; };
+bool src_describe(uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, ohgpu_src* s, SrcTables* tables, const char* who)
+{
+    int64_t max_sum_abs = 0;
+    for (uint32_t p = 0; p < L; p++) {
+        int64_t sabs = 0;
+        for (uint32_t k = 0; k < T; k++) {
+            const int32_t q = coef_q28[(size_t)p * T + k];
+            sabs += q < 0 ? -(int64_t)q : (int64_t)q;
+        }
+        if (sabs > max_sum_abs) max_sum_abs = sabs;
+        if (sabs >= ((int64_t)1 << 30)) {
+            set_error(OHGPU_ERR_INVALID, "%s: phase %u has sum|c| = %lld >= 2^30 (exact fp64 accumulation bound)", who, p, (long long)sabs);
+            return false;
+        }
+    }
+    s->L = L; s->M = M; s->T = T;
+    s->max_sum_abs = max_sum_abs;
+    // a half-band 2:1 decimator (what ohgpu_src_design makes for 96 -> 48 kHz): of its odd taps only the centre one is not zero
+    s->halfband = L == 1 && M == 2 && T == 64 && coef_q28[T - 1] == 0;
+    for (uint32_t k = 1; k < T && s->halfband; k += 2)
+        if (k != T / 2 - 1 && coef_q28[k] != 0) s->halfband = false;
+    // the matrix-pipe kernels' digit tables, for the block length the planner gives 24-bit stereo output (rows of up to 8 blocks)
+    const uint32_t mf_L_blk = (T == 32 || s->halfband) ? src_block_outputs(L, 6) : 0;
+    std::vector<uint8_t> adig;
+    s->mf_halfband = false;
+    s->mf_L_blk = 0; s->mf_kb_cap = 0;
+    if (mf_L_blk != 0 && s->halfband) {
+        tables->made = build_mfma_halfband(coef_q28, mf_L_blk, &tables->steps, &tables->amat);
+        s->mf_halfband = tables->made;
+    } else if (mf_L_blk != 0 && build_mfma_tables(L, M, T, coef_q28, mf_L_blk, 8, &adig, &tables->steps)) {
+        build_mfma_images(adig, tables->steps, L, &tables->amat);
+        tables->made = true;
+    }
+    if (tables->made) {
+        s->mf_L_blk = mf_L_blk;
+        s->mf_kb_cap = s->mf_halfband ? 1 : 8;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
 int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const int32_t* coef_q28, ohgpu_src** out)
 {
     CTX_GUARD("ohgpu_src_create");
@@ -868,51 +926,21 @@ int ohgpu_src_create(ohgpu_ctx* ctx, uint32_t L, uint32_t M, uint32_t T, const i
     if (L == 0 || M == 0 || M >= (1u << 15) || T == 0 || (uint64_t)L * T > (1u << 22))
         return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: bad geometry L=%u M=%u T=%u", L, M, T);
     const size_t n = (size_t)L * T;
-    std::vector<double> cd(n);
-    int64_t max_sum_abs = 0;
-    for (uint32_t p = 0; p < L; p++) {
-        int64_t sabs = 0;
-        for (uint32_t k = 0; k < T; k++) {
-            const int32_t q = coef_q28[(size_t)p * T + k];
-            sabs += q < 0 ? -(int64_t)q : (int64_t)q;
-            cd[(size_t)p * T + k] = (double)q;
-        }
-        if (sabs > max_sum_abs) max_sum_abs = sabs;
-        if (sabs >= ((int64_t)1 << 30))
-            return set_error(OHGPU_ERR_INVALID, "ohgpu_src_create: phase %u has sum|c| = %lld >= 2^30 (exact fp64 accumulation bound)", p, (long long)sabs);
-    }
     ohgpu_src* s = new (std::nothrow) ohgpu_src();
     if (!s) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_create: out of host memory");
-    s->L = L; s->M = M; s->T = T;
-    s->max_sum_abs = max_sum_abs;
-    // a half-band 2:1 decimator (what ohgpu_src_design makes for 96 -> 48 kHz): of its odd taps only the centre one is not zero
-    s->halfband = L == 1 && M == 2 && T == 64 && coef_q28[T - 1] == 0;
-    for (uint32_t k = 1; k < T && s->halfband; k += 2)
-        if (k != T / 2 - 1 && coef_q28[k] != 0) s->halfband = false;
+    SrcTables tables;
+    if (!src_describe(L, M, T, coef_q28, s, &tables, "ohgpu_src_create")) { delete s; return OHGPU_ERR_INVALID; }
+    std::vector<double> cd(n);
+    for (size_t i = 0; i < n; i++) cd[i] = (double)coef_q28[i];
     hipError_t e = hipMalloc((void**)&s->d_coef, n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_coef_q28, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(s->d_coef, cd.data(), n * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_coef_q28, coef_q28, n * sizeof(int32_t), hipMemcpyHostToDevice);
-    // src_mfma_kernel's digit tables, for the block length the planner gives 24-bit stereo output (rows of up to 8 blocks)
-    std::vector<uint8_t> adig;
-    std::vector<MfStep> steps;
-    const uint32_t mf_L_blk = (T == 32 || s->halfband) ? src_block_outputs(L, 6) : 0;
-    std::vector<uint8_t> amat;
-    bool tables = false;
-    if (e == hipSuccess && mf_L_blk != 0 && s->halfband) {
-        tables = build_mfma_halfband(coef_q28, mf_L_blk, &steps, &amat);
-        s->mf_halfband = tables;
-    } else if (e == hipSuccess && mf_L_blk != 0 && build_mfma_tables(L, M, T, coef_q28, mf_L_blk, 8, &adig, &steps)) {
-        build_mfma_images(adig, steps, L, &amat);
-        tables = true;
-    }
-    if (tables) {
-        e = hipMalloc((void**)&s->d_mf_amat, amat.size());
-        if (e == hipSuccess) e = hipMalloc((void**)&s->d_mf_steps, steps.size() * sizeof(MfStep));
-        if (e == hipSuccess) e = hipMemcpy(s->d_mf_amat, amat.data(), amat.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(s->d_mf_steps, steps.data(), steps.size() * sizeof(MfStep), hipMemcpyHostToDevice);
-        s->mf_L_blk = mf_L_blk;
-        s->mf_kb_cap = s->mf_halfband ? 1 : 8;
+    if (e == hipSuccess && tables.made) {
+        e = hipMalloc((void**)&s->d_mf_amat, tables.amat.size());
+        if (e == hipSuccess) e = hipMalloc((void**)&s->d_mf_steps, tables.steps.size() * sizeof(MfStep));
+        if (e == hipSuccess) e = hipMemcpy(s->d_mf_amat, tables.amat.data(), tables.amat.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->d_mf_steps, tables.steps.data(), tables.steps.size() * sizeof(MfStep), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
         if (s->d_coef) hipFree(s->d_coef);
@@ -1166,20 +1194,30 @@ int ohgpu_set_plan_threads(int threads)
 
 int ohgpu_src_plan_digest(uint32_t L, uint32_t M, uint32_t taps_per_phase, const ohgpu_src_msg_desc* descs, size_t n,
                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, int kernel_variant,
+                          const int32_t* coef_q28, int num_cus,
                           uint64_t* digest, uint64_t* units, uint64_t* generic_pieces, int* kernel)
 {
-    if (!descs || n == 0 || L == 0 || M == 0 || taps_per_phase == 0) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_plan_digest: bad argument");
-    // a filter and a context as far as the planner looks at them: no device behind either
+    if (!descs || n == 0 || L == 0 || M == 0 || taps_per_phase == 0 || (uint64_t)L * taps_per_phase > (1u << 22))
+        return set_error(OHGPU_ERR_INVALID, "ohgpu_src_plan_digest: bad argument");
+    // a filter and a context as far as the planner looks at them: no device behind either.  With the coefficients the filter is
+    // described exactly as ohgpu_src_create describes it (src_describe: the half-band form, the tables, the gain); without them it
+    // is "a polyphase filter of sane gain whose tables exist if its geometry allows".
     ohgpu_src flt{};
-    flt.L = L; flt.M = M; flt.T = taps_per_phase;
-    flt.max_sum_abs = (int64_t)1 << 28;
-    flt.halfband = false;
-    flt.mf_L_blk = taps_per_phase == 32 ? src_block_outputs(L, 6) : 0;
-    flt.mf_kb_cap = 8;
-    flt.d_mf_amat = flt.mf_L_blk ? (uint8_t*)&flt : nullptr;         // (only its being there is looked at)
+    SrcTables tables;
+    if (coef_q28) {
+        if (!src_describe(L, M, taps_per_phase, coef_q28, &flt, &tables, "ohgpu_src_plan_digest")) return OHGPU_ERR_INVALID;
+    } else {
+        flt.L = L; flt.M = M; flt.T = taps_per_phase;
+        flt.max_sum_abs = (int64_t)1 << 28;
+        flt.halfband = false;
+        flt.mf_L_blk = taps_per_phase == 32 ? src_block_outputs(L, 6) : 0;
+        flt.mf_kb_cap = 8;
+        tables.made = flt.mf_L_blk != 0;
+    }
+    flt.d_mf_amat = tables.made ? (uint8_t*)&flt : nullptr;         // (only its being there is looked at)
     ohgpu_ctx ctx{};
     ctx.variant = kernel_variant;
-    ctx.num_cus = 256;
+    ctx.num_cus = num_cus > 0 ? num_cus : 256;
     ohgpu_batch b;
     b.kind = kBatchSrc; b.n = n; b.src = &flt; b.src_arena_bytes = src_arena_bytes; b.dst_arena_bytes = dst_arena_bytes; b.uniform = true;
     std::unique_ptr<DevSrcDesc[]> dev(new (std::nothrow) DevSrcDesc[n]);
@@ -1225,14 +1263,32 @@ int ohgpu_src_batch_units(const ohgpu_batch* b, uint64_t* units, uint64_t* long_
     return OHGPU_OK;
 }
 
-static const char* src_kernel_of(const ohgpu_ctx* ctx, const ohgpu_batch* b)
+// Which kernel runs a (uniform) resampled batch's whole blocks: ONE decision, taken from the plan (what it serves: made under the
+// variant in force at creation) and the variant in force NOW, and used by the launch and by the name a benchmark prints alike.
+enum SrcKernel { kSrcGeneric, kSrcWg, kSrcMfma, kSrcLean, kSrcBlock };
+static SrcKernel src_kernel_choice(const ohgpu_ctx* ctx, const ohgpu_batch* b, bool arena_aligned = true)
 {
-    if (ctx->variant == 1 || !b->fast.enabled || (b->fast.wg_only && ctx->variant != 0)) return "src_kernel_v1";
-    if (b->fast.mfma_wg && ctx->variant == 0) return "src_mfma_wg_kernel";
-    if (b->fast.mfma && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 5)) return "src_mfma_kernel";
-    if (b->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 5 || b->fast.lean_only || !b->fast.d_work)) return "src_lean_kernel";
-    return "src_block_kernel";
+    const int v = ctx->variant;
+    // (the block kernels' staging moves aligned 16-byte pieces of the arena; a plan for the workgroup kernel alone has nothing for
+    // a variant that asks for another)
+    if (v == 1 || !b->fast.enabled || !arena_aligned || (b->fast.wg_only && v != 0)) return kSrcGeneric;
+    if (b->fast.mfma_wg && v == 0) return kSrcWg;                                         // the taps on the matrix pipe (round 4), a unit per workgroup
+    if (b->fast.mfma && (v == 0 || v == 3 || v == 5)) return kSrcMfma;                   // ... a unit per wave (variant 5, and where the workgroup kernel's block geometry does not hold)
+    if (b->fast.lean && (v != 2 || b->fast.lean_only || !b->fast.d_work)) return kSrcLean;   // round 2's, under every variant but 2 -- and under 2 where round 1's has no layout or no tables
+    if (b->fast.d_work) return kSrcBlock;                                                  // round 1's (variant 2; a filter beyond the lean kernel's rounding bound under any)
+    return kSrcGeneric;
 }
+static const char* src_kernel_name(SrcKernel k)
+{
+    switch (k) {
+    case kSrcWg: return "src_mfma_wg_kernel";
+    case kSrcMfma: return "src_mfma_kernel";
+    case kSrcLean: return "src_lean_kernel";
+    case kSrcBlock: return "src_block_kernel";
+    default: return "src_kernel_v1";
+    }
+}
+static const char* src_kernel_of(const ohgpu_ctx* ctx, const ohgpu_batch* b) { return src_kernel_name(src_kernel_choice(ctx, b)); }
 
 int ohgpu_src_batch_kernel_name(ohgpu_ctx* ctx, const ohgpu_batch* batch, char* out, size_t cap)
 {
@@ -1310,22 +1366,18 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         }
         return OHGPU_OK;
     }
-    const bool aligned = ((uintptr_t)src_base & 15u) == 0;          // the staging loads move aligned 16-byte pieces of the arena
-    if (ctx->variant != 1 && batch->fast.enabled && aligned && !(batch->fast.wg_only && ctx->variant != 0)) {
+    const SrcKernel which = src_kernel_choice(ctx, batch, ((uintptr_t)src_base & 15u) == 0);
+    if (which != kSrcGeneric) {
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
         if (claim != OHGPU_OK) return claim;
         if (batch->fast.planes_ready) OHGPU_HIP_TRY(hipStreamWaitEvent(s, batch->fast.planes_ready, 0));     // (the ramp planes are filled on the context's stream)
-        // whole phase-aligned blocks on the block kernel (variant 2: round 1's), block-unaligned heads/tails on the generic one
-        if (batch->fast.mfma_wg && ctx->variant == 0)                                                                  // 24-bit stereo: the taps on the matrix pipe (round 4), a unit per workgroup
-            OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
-        else if (batch->fast.mfma && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 5))   // ... a unit per wave (variant 5, and where the workgroup kernel's block geometry does not hold)
-            OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
-        else if (batch->fast.lean && (ctx->variant == 0 || ctx->variant == 3 || ctx->variant == 4 || batch->fast.lean_only))    // (round 1's kernel reads neither planes nor the lean-only layouts; variant 4: the lean kernel where round 4's would run)
-            OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
-        else if (batch->fast.d_work)
-            OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
-        else                                                                                           // (round 1's kernel asked for a batch planned without its tables)
-            OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+        // whole phase-aligned blocks on the chosen block kernel, block-unaligned heads/tails on the generic one
+        switch (which) {
+        case kSrcWg: OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+        case kSrcMfma: OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+        case kSrcLean: OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+        default: OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+        }
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         launched(batch, s);
     } else {

@@ -87,6 +87,21 @@ struct WgGeom {
     static constexpr uint32_t kChunksA = HB ? 13 : kImgChunks;        // ... and the input chunks it holds whole
     static constexpr uint32_t kRowInPitch = kPlanes ? 2 * kWgPlaneIn + 16 : (HB ? kRoundsA * kRound + 16 : kRowIn + 16);   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
     static constexpr uint32_t kRowOut = kOutFrames * kFb;             // bytes of a row's output
+    // ... and the distance between two rows of the OUTPUT IMAGE in LDS: the same, unless MF_WG_OUT_PAD is set.  Six channels: frames 18
+    // bytes apart put two of a row's sixteen frames of a step into every bank, and with rows 2880 bytes = 720 dwords apart (16 mod 32)
+    // the two pair-rows a 32-lane half of the epilogue's 2-byte stores serves land on the same banks again -- 5.25 LDS cycles per
+    // store by the bank model where stereo's take 4 and eight channels' 2; rows 64 bytes further apart meet them at 4
+    // (tools/micro/lds_conflicts.py).  Built and measured in round 5 (the image then is no longer the output piece for piece: phase (D)
+    // finds piece f at (f / 180) * pitch + 16 (f % 180) and the barrier between (D) and (A) is back): bit-exact, and config 4's
+    // six-channel 44.1 kHz group took 1.2965 / 1.2822 / 1.2840 ms with the pad against 1.2770 / 1.2782 / 1.2828 without, same box, turn
+    // and turn about -- a 2- to 3-way conflict on a 2-byte store costs no time (the store's four cycles are its data's way to the LDS,
+    // MI355X_MICROARCH.md), the barrier costs what it cost before.  Not the default.
+#ifdef MF_WG_OUT_PAD
+    static constexpr uint32_t kRowOutPitch = kRowOut + (PAIRS == 3 && !HB ? 64u : 0u);
+#else
+    static constexpr uint32_t kRowOutPitch = kRowOut;
+#endif
+    static constexpr bool kOutLinear = kRowOutPitch == kRowOut;
     static constexpr uint32_t kCt = ROWS / 8;
     static constexpr uint32_t kWaves = 2 * kCt;
     static constexpr uint32_t kThreads = 64 * kWaves;                 // = 16 * ROWS
@@ -104,7 +119,7 @@ struct WgGeom {
     static constexpr uint32_t kBiasStep = 512;
     static constexpr uint32_t kBiasBytes = kBiasSteps * kBiasStep;
     static constexpr uint32_t kInBytes = kSpan ? kSpanBytes : kSR * kRowInPitch;   // the input image ...
-    static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOut;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
+    static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOutPitch;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
     static constexpr uint32_t kStageBytes = kInBytes > kOutBytes ? kInBytes : kOutBytes;
     static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kBiasBytes;
     static constexpr uint32_t kGroupsPerCu = ROWS == 32 ? 2 : 3;
@@ -214,7 +229,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const v4i hb_s0 = v4i{hb0, hb0, hb0, hb0}, hb_s2 = v4i{hb1, hb1, hb1, hb1};
     // where the lane's frame of pair-row 2 g lies in the output image (+ 16 frames per step; + 8 pair-rows per column tile; the pair-row
     // 2 g + 1 is the next row (stereo) or the next pair of the same row (eight channels); six channels: out_at below)
-    uint8_t* const out_lds = stage + ((2u * g) / (uint32_t)PAIRS) * G::kRowOut + 6u * ((2u * g) % (uint32_t)PAIRS) + G::kFb * n;
+    uint8_t* const out_lds = stage + ((2u * g) / (uint32_t)PAIRS) * G::kRowOutPitch + 6u * ((2u * g) % (uint32_t)PAIRS) + G::kFb * n;
     auto pair_row_srow = [&](uint32_t ct, uint32_t q) __attribute__((always_inline)) { return (ct * 8u + 2u * g + q) / (uint32_t)PAIRS; };   // the stream row of a tile's pair-row
     // the input image row by row (planar sources and the half-band form; packed sources otherwise: the pass's one run, span_* below):
     // 16 PAIRS lanes per row; lane `sub` of a row moves its pieces sub, sub + 16 PAIRS, .. and, the first half of them, one more --
@@ -594,7 +609,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     }
                 }
                 // pack: two permutes and three 16-bit stores per frame into the output image (a frame starts on an even byte)
-                uint8_t* const os = out_lds + ct * ((8u / (uint32_t)(PAIRS == 3 ? 1 : PAIRS)) * G::kRowOut) + 16u * G::kFb * step;
+                uint8_t* const os = out_lds + ct * ((8u / (uint32_t)(PAIRS == 3 ? 1 : PAIRS)) * G::kRowOutPitch) + 16u * G::kFb * step;
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const uint32_t lo = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_lo);
@@ -604,9 +619,9 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     uint32_t at;
                     if constexpr (PAIRS == 3) {                      // (a tile's eight pair-rows start anywhere in a row of three)
                         const uint32_t pr = ct * 8u + 2u * g + (uint32_t)q, sr = pr / 3u;
-                        at = (uint32_t)(uintptr_t)(lds_u8_t)(stage + sr * G::kRowOut + 6u * (pr - 3u * sr) + G::kFb * n + 16u * G::kFb * step);
+                        at = (uint32_t)(uintptr_t)(lds_u8_t)(stage + sr * G::kRowOutPitch + 6u * (pr - 3u * sr) + G::kFb * n + 16u * G::kFb * step);
                     } else {
-                        at = (uint32_t)(uintptr_t)(lds_u8_t)(os + q * (PAIRS == 1 ? G::kRowOut : 6u));
+                        at = (uint32_t)(uintptr_t)(lds_u8_t)(os + q * (PAIRS == 1 ? G::kRowOutPitch : 6u));
                     }
                     asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:2\n\tds_write_b16 %0, %2 offset:4"
                                  : : "v"(at), "v"(lo), "v"(hi) : "memory");
@@ -645,7 +660,12 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             for (int k = 0; k < (int)G::kStoreRounds; k++) {
                 uint32_t f = G::kThreads * k + tid;
                 if (f >= G::kOutPieces) f = G::kOutPieces - 1;
-                op[k] = *(const u32x4*)(stage + 16u * f);
+                if constexpr (G::kOutLinear) {
+                    op[k] = *(const u32x4*)(stage + 16u * f);
+                } else {
+                    const uint32_t row = f / (G::kRowOut / 16u);
+                    op[k] = *(const u32x4*)(stage + row * G::kRowOutPitch + 16u * (f - row * (G::kRowOut / 16u)));
+                }
             }
 #pragma unroll
             for (int k = 0; k < (int)G::kStoreRounds; k++) {
@@ -660,7 +680,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         // (the output image has been read.  Packed sources' input image is the pass's run piece for piece, and the output image is too:
         // a lane stages into the very slots it has just emptied -- LDS operations of a wave complete in order -- so nothing has to
         // wait for another wave here; the row-by-row images of the planar and half-band forms do)
-        if constexpr (!G::kSpan) wg_barrier<1>();
+        if constexpr (!G::kSpan || !G::kOutLinear) wg_barrier<1>();
         if (u_nxt >= n_work) break;                         // (uniform)
 
         // ---- (A) + (S) the next unit: registers -> input image -> planes; then its successor's input is requested ----

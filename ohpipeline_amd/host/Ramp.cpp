@@ -151,29 +151,16 @@ TBool Ramp::Set(TUint aStart, TUint aFragmentSize, TUint aRemainingDuration, EDi
     aSplit.Reset();
     aSplitPos = 0xffffffff;
 
-    // How far this fragment moves the ramp: its share of what is left, rounded UP so that a ramp always
-    // completes within its duration (Msg.cpp:603-605); the overshoot that rounding can cause is clamped.
-    const TUint toGo = (aDirection == EDown) ? aStart : kMax - aStart;
-    const TUint delta = static_cast<TUint>((static_cast<TUint64>(toGo) * aFragmentSize + aRemainingDuration - 1) / aRemainingDuration);
-    TUint newEnd;
-    if (aDirection == EDown) {
-        if (delta > aStart) {
-            ASSERT(delta - aStart <= aFragmentSize - 1);     // more than rounding error would be a caller bug
-            newEnd = kMin;
-        }
-        else {
-            newEnd = aStart - delta;
-        }
-    }
-    else {
-        if (aStart + delta > kMax) {
-            ASSERT(aStart + delta - kMax <= aFragmentSize - 1);
-            newEnd = kMax;
-        }
-        else {
-            newEnd = aStart + delta;
-        }
-    }
+    // Where this fragment leaves the ramp: it moves by its share of what is still to go -- toGo * fragment / remaining, rounded UP, so
+    // that a ramp always completes within its duration (Msg.cpp:603-605) -- as ONE signed step from aStart, held to the scale.  What
+    // the hold takes away is the rounding's overshoot and never more than a fragment's worth of it: anything larger is a caller's
+    // inconsistent duration, and asserts as the reference's two branches do (Msg.cpp:606-628).
+    const TInt64 sign = (aDirection == EDown) ? -1 : 1;
+    const TUint64 toGo = (aDirection == EDown) ? aStart - kMin : kMax - aStart;
+    const TInt64 landed = (TInt64)aStart + sign * (TInt64)((toGo * aFragmentSize + aRemainingDuration - 1) / aRemainingDuration);
+    const TInt64 held = std::min<TInt64>(std::max<TInt64>(landed, kMin), kMax);
+    ASSERT((TUint64)(sign * (landed - held)) <= (TUint64)(TUint)(aFragmentSize - 1));
+    const TUint newEnd = (TUint)held;
 
     if (iDirection == ENone) {
         iDirection = aDirection;

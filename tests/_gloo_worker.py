@@ -74,7 +74,28 @@ def main():
         biggest = max(bench.stream_weight(*bench.config4_stream(s), 0.05) for s in range(12))
         balanced = max(sizes) - min(sizes) <= 2 * biggest            # as even as whole streams allow
         res["config4"] = bool(union == whole and len(union) == 12 and scaling4 == "strong" and balanced)
-        print(json.dumps({"ok": bool(res["config3"] and res["config4"]), "streams": len(union), "max": t.item(), **res}))
+    # the host's CPUs are shared by the ranks: every rank takes budget / world threads (planner pool, feeder pools) and, where the
+    # topology is readable, the CPUs nearest its GPU (a sysfs tree of the test's making stands in for /sys/bus/pci/devices);
+    # rank 0's line carries the SLOWEST rank's plan and decode times (bench.slowest_rank: what bench.measure reports at N > 1)
+    allowed = sorted(os.sched_getaffinity(0))
+    share = bench.host_share(world, f"0000:0{rank}:00.0", os.environ["OHGPU_TEST_SYSFS"])
+    budget = len(allowed)
+    quota = bench.cgroup_quota_cpus()
+    if quota is not None:
+        budget = min(budget, quota)
+    share_ok = share["threads"] == max(1, budget // world) and share["local_world"] == world
+    near = allowed[rank::world]                                    # what the test's sysfs tree says is near this rank's GPU
+    share_ok = share_ok and (share["cpus"] == near or (share["cpus"] is None and near == allowed))
+    unreadable = bench.host_share(world, "0000:ff:00.0", os.environ["OHGPU_TEST_SYSFS"])
+    share_ok = share_ok and unreadable["cpus"] is None and unreadable["threads"] == share["threads"]
+    capi.set_plan_threads(min(16, share["threads"]))                # (what bench.main does with it)
+    slow = bench.slowest_rank(dist, 1.5 + rank, 2.5 + 2 * rank, 0.25 * (world - rank))
+    oks = [None] * world
+    dist.all_gather_object(oks, bool(share_ok))
+    if rank == 0:
+        res["host_share"] = all(oks) and slow == [1.5 + (world - 1), 2.5 + 2 * (world - 1), 0.25 * world]
+        print(json.dumps({"ok": bool(res["config3"] and res["config4"] and res["host_share"]), "streams": len(union), "max": t.item(), **res,
+                          "threads_per_rank": share["threads"]}))
     dist.destroy_process_group()
 
 

@@ -587,6 +587,41 @@ def test_src_batch_can_be_run_repeatedly(ctx):
     ctx.src_destroy(h)
 
 
+@pytest.mark.parametrize("created_under", [0, 4, 2])
+def test_a_batch_created_under_one_variant_runs_under_every_other(ctx, created_under):
+    """The variant in force when a batch is RUN chooses among the kernels its plan serves (one decision for the launch and for the
+    name: src_kernel_choice); whatever it chooses, the bytes are the oracle's.  Stereo S24, ramped messages included, created under
+    the default / the lean kernel's plan / round 1's, run under every variant."""
+    h, ref = make_src(ctx, 44100, 48000, 32)
+    in_frames, n_streams = 8820, 24
+    src = np.concatenate([W.noise_pcm(300 + s, in_frames, 2, 24, LE) for s in range(n_streams)])
+    out_total = ref.out_frames(in_frames)
+    sched = W.ramp_schedule((out_total + 239) // 240, 240 * 1176, 20 * O.JIFFIES_PER_MS, 40 * O.JIFFIES_PER_MS)
+    descs, sbytes, dbytes, _, _ = W.src_stream_descs(n_streams, in_frames, ref.L, ref.M, 240, 2, 24, LE, 24, BE, sched)
+    want = oracle_src(ref, descs, src, dbytes)
+    d_src, d_dst = ctx.upload(src), ctx.malloc(dbytes)
+    try:
+        ctx.set_kernel_variant(created_under)
+        b = ctx.src_batch(h, descs, src.size, dbytes)
+        names = {}
+        for run_under in (0, 2, 3, 4, 5, 1):
+            ctx.set_kernel_variant(run_under)
+            names[run_under] = ctx.src_kernel_name(b)
+            ctx.memset(d_dst, 0xA5, dbytes)
+            ctx.src_run(b, d_src, d_dst)
+            assert np.array_equal(ctx.download(d_dst, dbytes), want), (created_under, run_under, names[run_under])
+        assert names[1] == "src_kernel_v1"
+        if created_under == 0:
+            assert names[0] == "src_mfma_wg_kernel" and names[5] == "src_mfma_kernel" and names[4] == "src_lean_kernel" and names[2] == "src_lean_kernel", names
+        if created_under == 2:
+            assert names[2] == "src_block_kernel" and names[4] == "src_lean_kernel", names
+        ctx.batch_destroy(b)
+    finally:
+        ctx.set_kernel_variant(0)
+        ctx.free(d_src); ctx.free(d_dst)
+        ctx.src_destroy(h)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_src_block_kernel_irregular_message_tilings(ctx, seed):
     """The block kernel under message layouts the bench never produces: messages of 1..700 frames in random order of

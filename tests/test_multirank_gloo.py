@@ -25,11 +25,33 @@ def test_two_ranks_shard_streams_without_collectives():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "_gloo_worker.py")]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    # a stand-in for /sys/bus/pci/devices: GPU r's local_cpulist = every second CPU the test may run on, from the r-th
+    import tempfile
+    allowed = sorted(os.sched_getaffinity(0))
+    with tempfile.TemporaryDirectory() as sysfs:
+        for r in range(2):
+            os.makedirs(os.path.join(sysfs, f"0000:0{r}:00.0"))
+            with open(os.path.join(sysfs, f"0000:0{r}:00.0", "local_cpulist"), "w") as f:
+                f.write(",".join(str(c) for c in allowed[r::2]) + "\n")
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OHGPU_TEST_SYSFS=sysfs))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
-    assert res == {"ok": True, "streams": 12, "max": 2.0, "config3": True, "config4": True}
+    threads = res.pop("threads_per_rank")
+    assert res == {"ok": True, "streams": 12, "max": 2.0, "config3": True, "config4": True, "host_share": True}
+    import bench
+    budget = min(len(allowed), bench.cgroup_quota_cpus() or len(allowed))
+    assert threads == max(1, budget // 2)                          # each of the two ranks: half of what the container grants
+
+
+def test_host_share_divides_the_quota_and_reads_cpulists():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    one = bench.host_share(1)
+    eight = bench.host_share(8)
+    assert one["threads"] >= eight["threads"] >= 1 and eight["threads"] == max(1, one["cpu_budget"] // 8)
+    assert one["cpus"] is None                                      # no device named: the rank stays where it is
 
 
 def test_partition_by_bytes_is_contiguous_complete_and_even():

@@ -106,3 +106,44 @@ def test_wide_plans_for_the_workgroup_kernel_are_thread_independent_and_cut_long
         assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db) == one, threads
     lean = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, 4)
     assert lean["kernel"] == 1 and lean["units"] < blocks / (64 // channels) + 24 * 2 + 1
+
+
+@pytest.mark.parametrize("channels", [2, 6, 8])
+def test_the_half_band_plans_that_ship_are_thread_independent(channels):
+    """96 -> 48 kHz (config 4's second half): with the filter's coefficients the digest plans as ohgpu_src_create's filter would be
+    planned for -- the half-band tables, the workgroup kernel's 128-output blocks, 30 / 32-row units for six and eight channels --
+    and not, as without them, for a plain 64-tap filter (round 4's digest never planned these: the advisor's finding)."""
+    ref = O.Src(96000, 48000, 64)
+    in_frames = 3 * 96000
+    out_total = (in_frames * ref.L + ref.M - 1) // ref.M
+    n_msgs = (out_total + 239) // 240
+    sched = W.ramp_schedule(n_msgs, 240 * 1176, 50 * 56448, 500 * 56448)
+    d, sb, db, _, _ = W.src_stream_descs(24, in_frames, ref.L, ref.M, 240, channels, 24, O.ENDIAN_LITTLE, 24, O.ENDIAN_BIG,
+                                         schedule=sched, dtype=capi.SRC_MSG_DESC)
+    capi.set_plan_threads(1)
+    one = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, coef_q28=ref.coef_q28)
+    assert one["kernel"] == 3, one                               # src_mfma_wg_kernel, half-band form
+    blocks = 24 * (out_total // 128)
+    rows = {2: 32, 6: 30, 8: 32}[channels]
+    assert abs(one["units"] - blocks / rows) <= 24 * 2 + 1, (one, blocks)
+    plain = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)   # the same messages, no coefficients: another filter, another plan
+    assert plain["kernel"] != 3 and plain["digest"] != one["digest"]
+    for threads in (2, 5, 16, 0):
+        capi.set_plan_threads(threads)
+        assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, coef_q28=ref.coef_q28) == one, threads
+    # a 64-tap table that is NOT half-band keeps the plain kernels (and says so)
+    broken = np.array(ref.coef_q28, dtype=np.int32)
+    broken[5] = 777
+    capi.set_plan_threads(1)
+    assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, coef_q28=broken)["kernel"] != 3
+
+
+def test_the_long_unit_schedule_follows_the_device_size():
+    """Variant 4's lean plan cuts one long unit per wave: the number of waves is the CU count's, which the digest now takes."""
+    ref, d, sb, db = headline_like(96, 4.0)
+    capi.set_plan_threads(1)
+    big = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, 4, coef_q28=ref.coef_q28, num_cus=256)
+    small = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, 4, coef_q28=ref.coef_q28, num_cus=64)
+    assert big["digest"] != small["digest"]
+    capi.set_plan_threads(6)
+    assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, 4, coef_q28=ref.coef_q28, num_cus=64) == small

@@ -7,6 +7,7 @@
 set -e
 cd "$(dirname "$0")/.."
 TAG=$1; shift
+bash tools/check_diag_flags.sh "$@"
 OBJ=ohpipeline_amd/build/obj
 python3 ohpipeline_amd/build.py > /dev/null                      # (the tree's objects are current)
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I include"

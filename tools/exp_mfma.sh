@@ -8,6 +8,7 @@ OBJ=ohpipeline_amd/build/obj
 STEPS=${MF_EXP_STEPS:-200}
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I include"
 for set in "$@"; do
+  bash tools/check_diag_flags.sh $set || { echo "[$set]: refused"; continue; }
   envs=""; flags=""
   for w in $set; do case "$w" in -*) flags="$flags $w";; *=*) envs="$envs $w";; esac; done
   $CC $flags -x hip -c ohpipeline_amd/csrc/src_mfma_kernel.hip -o /tmp/mf_exp.o 2> /tmp/mf_exp.err || { echo "[$set]: build failed"; tail -5 /tmp/mf_exp.err; continue; }

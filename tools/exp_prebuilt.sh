@@ -15,7 +15,7 @@ for r in $(seq 1 ${ROUNDS:-2}); do
 import json,sys
 t=sys.stdin.read()
 try:
-    d=json.loads(t); r=d['roofline']; print(r['kernel_avg_ms'], r.get('kernel_median_ms'), r.get('kernel_min_ms'), r['frac'], d.get('check'), r.get('shader_clock_mhz'))
+    d=json.loads(t); r=d['roofline']; print(r['kernel_avg_ms'], r.get('kernel_median_ms'), r.get('kernel_min_ms'), r['frac'], d.get('check'), r.get('shader_clock_mhz'), 'plan_ms', d.get('plan_ms'), [(g.get('rate_in'), g.get('channels'), g.get('kernel_ms')) for g in d.get('config', {}).get('groups', [])])
 except Exception as e:
     print('FAILED', e, t[-300:])
 " || { tail -5 /tmp/exp_err.txt; }
