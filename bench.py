@@ -170,6 +170,39 @@ class Group:
         self.plan_ms_first = times[0]
         self.plan_ms = sorted(times)[1]
         self.info, self.plan = ctx.batch_info(self.batch), ctx.src_plan(self.batch)
+        self.plan_ms_repeat = self._repeat_ms(ctx)
+
+    def _repeat_ms(self, ctx):
+        """What the NEXT period of the same streams costs a caller that keeps its batch: the group's messages one whole period (a
+        whole number of blocks) further on -- a batch of its own here, because the bench's own starts its streams, which a period in
+        the middle of them does not -- then ohgpu_src_batch_advance by a period and ohgpu_src_batch_set_ramps with every message's
+        endpoints: wall clock, median of three.  (Other arena positions cost nothing: they are the base pointers of the launch.)"""
+        if self.planar:
+            return None
+        try:
+            L_blk, M_blk = ctx.src_batch_block(self.batch)
+            if self.out_total % L_blk or self.in_frames % M_blk or self.out_total // L_blk != self.in_frames // M_blk:
+                return None
+            blocks, hist = self.out_total // L_blk, M_blk
+            d = self.descs.copy()
+            d["out_frame0"] += self.out_total
+            d["src_frame0"] = self.in_frames - hist                  # the buffer: a block of history, then the period
+            d["src_frames"] = self.in_frames + hist
+            n = len(self.stream_ids)
+            for s in range(n):
+                d["src_offset"][s * self.n_msgs:(s + 1) * self.n_msgs] = s * (self.in_frames + hist) * self.fb_src
+            b2 = ctx.src_batch(self.h, d, n * (self.in_frames + hist) * self.fb_src, self.dst_bytes)
+            starts, ends = np.ascontiguousarray(d["ramp_start"]), np.ascontiguousarray(d["ramp_end"])
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.src_batch_advance(b2, blocks)
+                ctx.src_batch_set_ramps(b2, starts, ends)
+                times.append((time.perf_counter() - t0) * 1e3)
+            ctx.batch_destroy(b2)
+            return sorted(times)[1]
+        except Exception:
+            return None
 
     def detach(self, ctx):
         ctx.batch_destroy(self.batch)
@@ -773,6 +806,8 @@ def measure(capi, ctx, args, rank, world, dist, light=False):
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "plan_ms": round(plan_ms, 3),                    # ohgpu_src_batch_create for the step's batches (median of three creations): once, reused by every launch
             "plan_ms_first": round(plan_ms_first, 3),        # ... and the process's first creation of them
+            # ... and what the same batch costs for the next period of the same streams (ohgpu_src_batch_advance + _set_ramps)
+            "plan_ms_repeat": (round(float(sum(g.plan_ms_repeat for g in groups)), 3) if all(g.plan_ms_repeat is not None for g in groups) else None),
             "msubsamples_per_s": round(subs_all * args.steps / elapsed / 1e6, 3),   # frames x channels
             "higher_is_better": True,
             "scaling": scaling,
@@ -929,7 +964,7 @@ def main():
                 r, sub_ok = measure(capi, ctx, sub, rank, world, dist, light=True)
                 ok = ok and sub_ok
                 entry = {"metric": r["metric"], "workload": r["config"]["workload"], "value": r["value"], "ms_per_step": r["ms_per_step"],
-                         "kernel_avg_ms": r["roofline"]["kernel_avg_ms"], "plan_ms": r["plan_ms"], "plan_ms_first": r["plan_ms_first"], "frac": r["roofline"]["frac"],
+                         "kernel_avg_ms": r["roofline"]["kernel_avg_ms"], "plan_ms": r["plan_ms"], "plan_ms_first": r["plan_ms_first"], "plan_ms_repeat": r.get("plan_ms_repeat"), "frac": r["roofline"]["frac"],
                          "fp64_frac": r["roofline"]["fp64_frac"], "achieved_gbps": r["roofline"]["achieved"], "scaling": r["scaling"],
                          "check": r.get("check"), "cpu_baseline": {k: r["cpu_baseline"][k] for k in ("value", "cores")},
                          "groups": [{k: g[k] for k in ("rate_in", "channels", "src_bits", "streams", "taps_per_phase", "kernel_ms", "gbps", "generic_pieces")}

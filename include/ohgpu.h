@@ -323,7 +323,11 @@ int ohgpu_src_mfma_tables(uint32_t L, uint32_t M, uint32_t taps_per_phase, const
  * OHGPU_ERR_UNSUPPORTED when the coefficients are not such a filter.  Host only. */
 int ohgpu_src_mfma_halfband_tables(const int32_t* coef_q28 /* 64 */, uint8_t* image /* 4096 bytes */, int64_t* bias, uint32_t* block_outputs);
 /* The messages of one batch may differ in layout (channels, depths, byte orders, packed or planar source): the batch is
- * planned per layout and runs one launch sequence per layout, messages of a stream in the order given. */
+ * planned per layout and runs one launch sequence per layout, messages of a stream in the order given.
+ * What a batch keeps: its plan (a record per unit of 30-32 blocks, per ramped message and unit, per block-unaligned message end) on
+ * the device and a copy of the ramp records on the host -- nothing per message, unless it is the generic kernel's batch (created
+ * while ohgpu_set_kernel_variant(1) is in force, or of a layout no block kernel has: 56 bytes a message on the host, and on the
+ * device from its first run). */
 int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t n,
                            uint64_t src_arena_bytes, uint64_t dst_arena_bytes, ohgpu_batch** batch);
 /* A batch may be run any number of times, one launch at a time (it owns device-side work counters): launches of the same
@@ -331,6 +335,26 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
  * OHGPU_ERR_INVALID (nothing is launched).  Different batches are independent.  The same holds for
  * ohgpu_flywheel_batch_run (the batch owns Burg's workspace). */
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+
+/* ---- the same batch, the next period ----
+ * A caller that brings new audio every period in the same shape -- the same streams, the same tiling into messages, a whole number
+ * of blocks further on in every stream -- need not plan again:
+ *   - other arena positions: pass other base pointers to ohgpu_src_batch_run (the source's 16-byte aligned);
+ *   - further on in the streams: ohgpu_src_batch_advance.  Every message's out_frame0 grows by blocks * block_outputs and its
+ *     src_frame0 by blocks * block_inputs (ohgpu_src_batch_block), offsets and windows as they were: the plan names no absolute
+ *     position (a unit is where its rows lie in the arenas, a ramp job where its frames lie in its message), and a whole number of
+ *     blocks later every message has the phase it had -- so the call checks that this is such a batch and changes nothing.
+ *     OHGPU_ERR_INVALID for a batch that holds a stream's first message (its window is zeros where the next period's is history),
+ *     OHGPU_ERR_UNSUPPORTED for one without a block-kernel plan;
+ *   - other ramp endpoints (the flags stay: which messages are ramped is the plan's shape): ohgpu_src_batch_set_ramps, one pair per
+ *     message in the batch's order (those of unramped messages are not looked at).  Rewrites the ramp jobs and the generic-kernel
+ *     pieces on the device and refills the multiplier planes; waits for the batch's last launch first.  Not for a batch of several
+ *     layouts.
+ * Anything else -- another tiling, other flags, other streams -- is another batch.  tests/test_plan_threads.py holds the plan of a
+ * shifted period to the digest of the period it was made for; tests/test_gpu_parity.py runs both calls against the oracle. */
+int ohgpu_src_batch_block(const ohgpu_batch* batch, uint32_t* block_outputs, uint32_t* block_inputs);
+int ohgpu_src_batch_advance(ohgpu_ctx* ctx, ohgpu_batch* batch, uint64_t blocks);
+int ohgpu_src_batch_set_ramps(ohgpu_ctx* ctx, ohgpu_batch* batch, const uint16_t* ramp_start, const uint16_t* ramp_end, size_t n);
 
 /* Host-buffer convenience (a live pipeline's 5 ms cadence): H2D, run, D2H, sync, as ohgpu_pcm_process_host.  dst_host bytes
  * that no message covers are preserved.  src_host need only hold each message's WINDOW (ohgpu_src_msg_desc: src_frame0 /

@@ -110,6 +110,9 @@ SYMBOLS = {
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_src_batch_units": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_set_plan_threads": (C.c_int, [C.c_int]),
+    "ohgpu_src_batch_block": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ohgpu_src_batch_advance": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "ohgpu_src_batch_set_ramps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t]),
     "ohgpu_src_plan_digest": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int,
                                         _vp, C.c_int, _u64p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "ohgpu_src_batch_kernel_name": (C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t]),
@@ -402,6 +405,20 @@ class Context:
         check(lib().ohgpu_src_batch_create(self._h, src, d.ctypes.data_as(C.c_void_p), d.size, src_arena_bytes,
                                            dst_arena_bytes, C.byref(b)))
         return b
+
+    def src_batch_block(self, batch):
+        lo, mi = C.c_uint32(0), C.c_uint32(0)
+        check(lib().ohgpu_src_batch_block(batch, C.byref(lo), C.byref(mi)))
+        return int(lo.value), int(mi.value)
+
+    def src_batch_advance(self, batch, blocks):
+        check(lib().ohgpu_src_batch_advance(self._h, batch, blocks))
+
+    def src_batch_set_ramps(self, batch, ramp_start, ramp_end):
+        a = np.ascontiguousarray(ramp_start, dtype=np.uint16)
+        e = np.ascontiguousarray(ramp_end, dtype=np.uint16)
+        assert a.size == e.size
+        check(lib().ohgpu_src_batch_set_ramps(self._h, batch, a.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p), a.size))
 
     def src_process_host(self, src, descs, src_bytes, dst_bytes_array):
         """ohgpu_src_process_host: host buffers in, host buffers out (validation, upload, launch, download, sync in one call)."""

@@ -361,7 +361,15 @@ hipError_t launch_fmt_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
 {
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     uint32_t grid = (b->fmtline.n_chunks + kFmtWaves - 1) / kFmtWaves;
-    if (grid > cus * 8) grid = cus * 8;
+    // Workgroups per CU, as for pcm_line_kernel (round 5): the register-only stereo kernels are streaming copies with a byte shuffle
+    // in the middle, and the memory system serves those best from few workgroups -- a11's unpack 0.160-0.167 ms at eight per CU,
+    // 0.147-0.152 at four (0.66-0.69 -> 0.72-0.75 of 8 TB/s); a14's pack 0.170 -> 0.163 at six; the staged generic kernel keeps eight.
+#ifdef OHGPU_LINE_FMT_GROUPS_PER_CU
+    const uint32_t per_cu = OHGPU_LINE_FMT_GROUPS_PER_CU;
+#else
+    const uint32_t per_cu = b->fmtline.group_kind == OHGPU_FMT_UNPACK_PLANAR ? 4u : (b->fmtline.group_kind == OHGPU_FMT_FLAC_PACK ? 6u : 8u);
+#endif
+    if (grid > cus * per_cu) grid = cus * per_cu;
     const FmtChunk* recs = (const FmtChunk*)b->fmtline.d_chunks;
     const uint32_t nr = b->fmtline.n_chunks;
     if (b->fmtline.group_kind == OHGPU_FMT_UNPACK_PLANAR) {

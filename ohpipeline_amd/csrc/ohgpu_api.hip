@@ -968,18 +968,10 @@ int ohgpu_src_destroy(ohgpu_ctx* ctx, ohgpu_src* src)
 
 }  // extern "C"
 
-namespace {
+namespace ohgpu {
 
-struct SrcRangeResult {
-    int err = OHGPU_OK;
-    char msg[512] = "";
-    uint64_t in_frames = 0, out_frames = 0, src_bytes_touched = 0, dst_bytes_written = 0;
-    uint32_t max_frames = 0;
-    bool uniform = true;
-    void fail(int code) { err = code; snprintf(msg, sizeof(msg), "%s", ohgpu_last_error()); }
-};
-
-// messages [lo, hi) of a resampled batch: validation (ohgpu.h: ohgpu_src_msg_desc) and the device form of each
+// messages [lo, hi) of a resampled batch: validation (ohgpu.h: ohgpu_src_msg_desc), the batch's totals, whether they come in the
+// planner's order (a message against its predecessor: src_msg_before) -- and, where `dev` is given, the generic kernel's form of each
 void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t lo_i, size_t hi_i, uint64_t src_arena_bytes,
                      uint64_t dst_arena_bytes, DevSrcDesc* dev, SrcRangeResult* out)
 {
@@ -1026,8 +1018,6 @@ void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size
                              (unsigned long long)d.dst_offset, (unsigned long long)dst_bytes, (unsigned long long)dst_arena_bytes));
             return;
         }
-        DevSrcDesc& o = dev[i];
-        memset(&o, 0, sizeof(o));
         if (d.n_frames > 0) {
             const uint64_t t_first = d.out_frame0 * M, t_last = (d.out_frame0 + d.n_frames - 1) * M;
             const int64_t n0_first = (int64_t)(t_first / L), n0_last = (int64_t)(t_last / L);
@@ -1042,35 +1032,95 @@ void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size
                                  (long long)n0_last, (unsigned long long)(d.src_frame0 + d.src_frames)));
                 return;
             }
-            o.in_rel0 = n0_first - (int64_t)d.src_frame0;
-            o.phase0 = (uint32_t)(t_first % L);
             const int64_t lo = n_lo < 0 ? 0 : n_lo;
             r.in_frames += (uint64_t)(n0_last - n0_first + 1);   // new input frames this message advances over
             r.src_bytes_touched += (uint64_t)(n0_last - lo + 1) * (planar ? 4ull * d.channels : fb_src);
         }
-        o.src_offset = d.src_offset;
-        o.dst_offset = d.dst_offset;
-        o.n_frames = d.n_frames;
-        o.ramp_i0 = 0;
-        o.ramp_n = d.n_frames;
-        o.ramp_start = d.ramp_start;
-        o.ramp_end = d.ramp_end;
-        o.channels = d.channels;
-        o.src_bits = d.src_bits;
-        o.src_endian = d.src_endian;
-        o.dst_bits = d.dst_bits;
-        o.dst_endian = d.dst_endian;
-        o.flags = d.flags;
-        o.plane_frames = (uint32_t)(d.src_plane_stride >> 2);
+        if (dev) dev[i] = src_convert_desc(d, L, M);
         r.out_frames += d.n_frames;
         r.dst_bytes_written += dst_bytes;
         if (d.n_frames > r.max_frames) r.max_frames = d.n_frames;
         if (d.channels != d0.channels || d.src_bits != d0.src_bits || d.src_endian != d0.src_endian || d.dst_bits != d0.dst_bits ||
             d.dst_endian != d0.dst_endian || planar != ((d0.flags & OHGPU_FLAG_SRC_PLANAR32) != 0)) r.uniform = false;
+        // (the planner's order, message against predecessor -- the range's first against the last of the range before it: a caller
+        // that lists its streams one after the other, each in time order, spares the planner its own pass and the sort)
+        if (i > 0 && r.ordered && src_msg_before(descs[i], descs[i - 1], planar ? 4u : (uint32_t)fb_src, (uint32_t)fb_dst)) r.ordered = false;
     }
 }
 
-}  // namespace
+// A resampled batch's messages checked and -- if they share a layout -- planned (b->fast), by the shorter of two routes; the batch's
+// totals, `uniform` and layout fields are set.  `dev`: where to put the generic kernel's form of every message (null: nowhere).
+// `digest`: the plan hashed instead of uploaded (ohgpu_src_plan_digest: ctx has no device behind it).
+int src_check_and_plan(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, DevSrcDesc* dev, PlanDigest* digest)
+{
+    const ohgpu_src* src = b->src;
+    auto layout_of_first = [&] {
+        const ohgpu_src_msg_desc& d0 = descs[0];
+        b->channels = d0.channels; b->src_bits = d0.src_bits; b->src_endian = d0.src_endian;
+        b->dst_bits = d0.dst_bits; b->dst_endian = d0.dst_endian;
+        b->src_planar = (d0.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
+    };
+#ifdef OHGPU_PLAN_TIMING
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+#endif
+    // A large batch is 64 bytes a message to read -- 32 MB for the headline's half a million -- and both the checks and the planner's
+    // cut into segments are bound by exactly that.  So the planner is let loose on the messages FIRST, on the usual caller's terms
+    // (one layout, streams one after the other in time order), and checks each message itself the first time it looks at it; a batch
+    // that is not what it assumed -- several layouts, another order, a layout no block kernel has -- goes the two-pass way below.
+    if (!dev && n >= 4096) {
+        SrcRangeResult first;
+        src_check_range(src, descs, 0, 1, b->src_arena_bytes, b->dst_arena_bytes, nullptr, &first);      // (its layout is the batch's: the planner's geometry needs it sane)
+        if (first.err != OHGPU_OK) return set_error(first.err, "%s", first.msg);
+        layout_of_first();
+        PlanFusedCheck fused;
+        fused.src = src;
+        const int err = plan_src_fast(ctx, b, descs, n, true, digest, &fused);
+#ifdef OHGPU_PLAN_TIMING
+        fprintf(stderr, "[plan timing] check fused with the plan: %.2f ms (checked %d, retry %d)\n", since(tp0), (int)fused.checked, (int)fused.retry);
+#endif
+        if (err != OHGPU_OK) return err;
+        if (fused.checked && fused.total.err != OHGPU_OK) return set_error(fused.total.err, "%s", fused.total.msg);
+        if (fused.checked && !fused.retry) {
+            b->in_frames = fused.total.in_frames; b->out_frames = fused.total.out_frames;
+            b->src_bytes_touched = fused.total.src_bytes_touched; b->dst_bytes_written = fused.total.dst_bytes_written;
+            b->max_frames = fused.total.max_frames;
+            return OHGPU_OK;                                 // (checked and uniform; a plan, or none: no whole block anywhere -- the generic kernel's batch)
+        }
+    }
+    // every message checked on its own: in ranges, on as many threads as the batch is worth (the first error in message order is the
+    // one reported); then the plan
+    bool ordered = true;
+    {
+        const unsigned n_thr = plan_threads(n, 16384);
+        std::vector<SrcRangeResult> res(n_thr);
+        parallel_ranges(n, n_thr, [&](unsigned t, size_t lo, size_t hi) { src_check_range(src, descs, lo, hi, b->src_arena_bytes, b->dst_arena_bytes, dev, &res[t]); });
+        b->in_frames = b->out_frames = b->src_bytes_touched = b->dst_bytes_written = 0;
+        b->max_frames = 0;
+        b->uniform = true;
+        for (const SrcRangeResult& r : res) {
+            if (r.err != OHGPU_OK) return set_error(r.err, "%s", r.msg);
+            b->in_frames += r.in_frames; b->out_frames += r.out_frames;
+            b->src_bytes_touched += r.src_bytes_touched; b->dst_bytes_written += r.dst_bytes_written;
+            if (r.max_frames > b->max_frames) b->max_frames = r.max_frames;
+            b->uniform = b->uniform && r.uniform;
+            ordered = ordered && r.ordered;
+        }
+        if (n > 0) layout_of_first();
+    }
+#ifdef OHGPU_PLAN_TIMING
+    const auto tp1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[plan timing] validate%s %.2f ms\n", dev ? "+convert" : "", since(tp0));
+#endif
+    int err = OHGPU_OK;
+    if (b->uniform && n > 0) err = plan_src_fast(ctx, b, descs, n, ordered, digest);
+#ifdef OHGPU_PLAN_TIMING
+    fprintf(stderr, "[plan timing] plan_src_fast %.2f ms\n", since(tp1));
+#endif
+    return err;
+}
+
+}  // namespace ohgpu
 
 extern "C" {
 
@@ -1089,48 +1139,17 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
     b->src_arena_bytes = src_arena_bytes;
     b->dst_arena_bytes = dst_arena_bytes;
     b->uniform = true;
-#ifdef OHGPU_PLAN_TIMING
-    const auto tp0 = std::chrono::steady_clock::now();
-#endif
-    // every message is checked and converted on its own: in ranges, on as many threads as the batch is worth (the first error in
-    // message order is the one reported)
-    b->host_descs.reset((DevSrcDesc*)host_alloc_huge((n ? n : 1) * sizeof(DevSrcDesc)));     // (not zeroed here: the ranges' threads touch their own pages)
-    if (!b->host_descs) { delete b; return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory"); }
-    DevSrcDesc* const dev = b->host_descs.get();
-    {
-        const unsigned n_thr = plan_threads(n, 16384);
-        std::vector<SrcRangeResult> res(n_thr);
-        parallel_ranges(n, n_thr, [&](unsigned t, size_t lo, size_t hi) { src_check_range(src, descs, lo, hi, src_arena_bytes, dst_arena_bytes, dev, &res[t]); });
-        for (const SrcRangeResult& r : res) {
-            if (r.err != OHGPU_OK) { const int err = set_error(r.err, "%s", r.msg); delete b; return err; }
-            b->in_frames += r.in_frames; b->out_frames += r.out_frames;
-            b->src_bytes_touched += r.src_bytes_touched; b->dst_bytes_written += r.dst_bytes_written;
-            if (r.max_frames > b->max_frames) b->max_frames = r.max_frames;
-            b->uniform = b->uniform && r.uniform;
-        }
-        if (n > 0) {
-            const ohgpu_src_msg_desc& d0 = descs[0];
-            b->channels = d0.channels; b->src_bits = d0.src_bits; b->src_endian = d0.src_endian;
-            b->dst_bits = d0.dst_bits; b->dst_endian = d0.dst_endian;
-            b->src_planar = (d0.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
-        }
-    }
-#ifdef OHGPU_PLAN_TIMING
-    const auto tp1 = std::chrono::steady_clock::now();
-#endif
-    // (the device copy of the per-message descriptors is the generic kernel's: it is made when that kernel first runs the whole batch)
-    int err = OHGPU_OK;
-#ifdef OHGPU_PLAN_TIMING
-    const auto tp2 = std::chrono::steady_clock::now();
-#endif
-    if (b->uniform) err = plan_src_fast(ctx, b, descs, n, dev);
-#ifdef OHGPU_PLAN_TIMING
-    {
-        const auto tp3 = std::chrono::steady_clock::now();
-        auto ms = [](auto a, auto c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-        fprintf(stderr, "[plan timing] validate+convert %.2f ms, descriptor upload %.2f ms, plan_src_fast %.2f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
-    }
-#endif
+    // The generic kernel's per-message form (56 bytes a message: 28 MB written for the headline's half a million, half of a checking
+    // pass's time) is made only where that kernel will run the whole batch: a batch created while variant 1 is in force, or one no
+    // block kernel takes (below).  A batch planned for the block kernels keeps nothing per message.
+    const bool keep_generic = ctx->variant == 1;
+    auto convert_all = [&]() -> bool {
+        b->host_descs.reset((DevSrcDesc*)host_alloc_huge((n ? n : 1) * sizeof(DevSrcDesc)));     // (not zeroed here: the ranges' threads touch their own pages)
+        return b->host_descs != nullptr;
+    };
+    if (keep_generic && !convert_all()) { delete b; return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory"); }
+    int err = src_check_and_plan(ctx, b, descs, n, b->host_descs.get(), nullptr);
+    if (err != OHGPU_OK) { delete b; return err; }
     if (err == OHGPU_OK && !b->uniform) {
         // Mixed layouts (channel counts, depths, byte orders, planar or packed sources): the block kernels are instantiated per
         // layout, so the batch becomes one uniform batch per layout, messages in their given order.  (More than 32 layouts: the
@@ -1154,6 +1173,16 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
                 err = ohgpu_src_batch_create(ctx, src, groups[g].data(), groups[g].size(), src_arena_bytes, dst_arena_bytes, &part);
                 if (err == OHGPU_OK) b->parts.push_back(part);
             }
+        }
+    }
+    if (err == OHGPU_OK && !b->host_descs && !b->fast.enabled && b->parts.empty() && n > 0) {
+        // no block kernel takes this batch (a layout none is instantiated for, more than 32 layouts, nothing block-aligned): the generic
+        // kernel will run it whole, from its own form of the messages -- made now, in a second pass over descriptors known to be good
+        if (!convert_all()) err = set_error(OHGPU_ERR_NOMEM, "ohgpu_src_batch_create: out of host memory");
+        else {
+            DevSrcDesc* const dev = b->host_descs.get();
+            const uint64_t L = src->L, M = src->M;
+            parallel_ranges(n, plan_threads(n, 16384), [&](unsigned, size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) dev[i] = src_convert_desc(descs[i], L, M); });
         }
     }
     if (err != OHGPU_OK) {
@@ -1220,23 +1249,9 @@ int ohgpu_src_plan_digest(uint32_t L, uint32_t M, uint32_t taps_per_phase, const
     ctx.num_cus = num_cus > 0 ? num_cus : 256;
     ohgpu_batch b;
     b.kind = kBatchSrc; b.n = n; b.src = &flt; b.src_arena_bytes = src_arena_bytes; b.dst_arena_bytes = dst_arena_bytes; b.uniform = true;
-    std::unique_ptr<DevSrcDesc[]> dev(new (std::nothrow) DevSrcDesc[n]);
-    if (!dev) return set_error(OHGPU_ERR_NOMEM, "ohgpu_src_plan_digest: out of host memory");
-    const unsigned n_thr = plan_threads(n, 16384);
-    std::vector<SrcRangeResult> res(n_thr);
-    parallel_ranges(n, n_thr, [&](unsigned t, size_t lo, size_t hi) { src_check_range(&flt, descs, lo, hi, src_arena_bytes, dst_arena_bytes, dev.get(), &res[t]); });
-    for (const SrcRangeResult& r : res) {
-        if (r.err != OHGPU_OK) return set_error(r.err, "%s", r.msg);
-        b.uniform = b.uniform && r.uniform;
-    }
-    const ohgpu_src_msg_desc& d0 = descs[0];
-    b.channels = d0.channels; b.src_bits = d0.src_bits; b.src_endian = d0.src_endian; b.dst_bits = d0.dst_bits; b.dst_endian = d0.dst_endian;
-    b.src_planar = (d0.flags & OHGPU_FLAG_SRC_PLANAR32) != 0;
     PlanDigest pd{};
-    if (b.uniform) {
-        const int err = plan_src_fast(&ctx, &b, descs, n, dev.get(), &pd);
-        if (err != OHGPU_OK) return err;
-    }
+    const int err = src_check_and_plan(&ctx, &b, descs, n, nullptr, &pd);
+    if (err != OHGPU_OK) return err;
     if (digest) *digest = pd.hash;
     if (units) *units = pd.units;
     if (generic_pieces) *generic_pieces = pd.pieces;
@@ -1381,6 +1396,11 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         launched(batch, s);
     } else {
+        if (!batch->host_descs)
+            return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_batch_run: this batch was planned for the block kernels and keeps no per-message descriptors for the "
+                             "generic kernel, which %s asks for: create it while ohgpu_set_kernel_variant(1) is in force%s",
+                             ctx->variant == 1 ? "kernel variant 1" : (batch->fast.wg_only ? "this kernel variant (the plan is the workgroup matrix kernel's alone)" : "a source arena that is not 16-byte aligned"),
+                             ctx->variant == 1 ? "" : ", or run it under the variant / with the alignment it was planned for");
         {   // (the whole batch on the generic kernel: its per-message descriptors go to the device the first time this happens)
             std::lock_guard<std::mutex> hold(batch->lazy);
             if (!batch->d_descs && batch->n) {
@@ -1389,6 +1409,72 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
             }
         }
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->d_descs, batch->n, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
+    }
+    return OHGPU_OK;
+}
+
+int ohgpu_src_batch_block(const ohgpu_batch* b, uint32_t* block_outputs, uint32_t* block_inputs)
+{
+    if (!b || b->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_block: not a src batch");
+    const ohgpu_batch* p = b->parts.empty() ? b : b->parts[0];
+    if (!p->fast.enabled) return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_batch_block: the batch has no block-kernel plan");
+    for (const ohgpu_batch* q : b->parts)
+        if (!q->fast.enabled || q->fast.params.L_blk != p->fast.params.L_blk) return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_batch_block: the batch's layouts are cut into blocks of different lengths");
+    if (block_outputs) *block_outputs = p->fast.params.L_blk;
+    if (block_inputs) *block_inputs = p->fast.params.M_blk;
+    return OHGPU_OK;
+}
+
+int ohgpu_src_batch_advance(ohgpu_ctx* ctx, ohgpu_batch* b, uint64_t blocks)
+{
+    CTX_GUARD("ohgpu_src_batch_advance");
+    if (!b || b->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_advance: not a src batch");
+    std::vector<ohgpu_batch*> all(b->parts.begin(), b->parts.end());
+    if (all.empty()) all.push_back(b);
+    for (const ohgpu_batch* p : all) {
+        if (!p->fast.enabled)
+            return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_batch_advance: the batch (or one of its layouts) has no block-kernel plan: its generic-kernel descriptors hold the positions themselves");
+        if (p->fast.stream_start)
+            return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_advance: a message of the batch starts its stream (its filter window reaches in front of input frame 0, "
+                             "read as zeros): the same window a period later holds real history the batch's source windows do not declare");
+    }
+    // Nothing of the plan names an absolute position: a unit is where its rows lie in the two arenas, a ramp job where its frames lie in
+    // their message, a generic-kernel piece its window relative to the buffer -- and a whole number of blocks later every message has
+    // the phase it had.  The plan IS the next period's plan.
+    for (ohgpu_batch* p : all) p->fast.advanced_blocks += blocks;
+    if (all[0] != b) b->fast.advanced_blocks += blocks;
+    return OHGPU_OK;
+}
+
+int ohgpu_src_batch_set_ramps(ohgpu_ctx* ctx, ohgpu_batch* b, const uint16_t* ramp_start, const uint16_t* ramp_end, size_t n)
+{
+    CTX_GUARD("ohgpu_src_batch_set_ramps");
+    if (!b || b->kind != kBatchSrc || !ramp_start || !ramp_end) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_set_ramps: bad argument");
+    if (n != b->n) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_set_ramps: %zu endpoints for a batch of %zu messages", n, b->n);
+    if (!b->parts.empty()) return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_batch_set_ramps: a batch of several layouts (create one batch per layout to re-ramp it)");
+    SrcFastPlan& f = b->fast;
+    // (only the messages that carry a ramp are looked at: the flags are the plan's)
+    for (uint32_t m : f.job_msg) if (ramp_start[m] > OHGPU_RAMP_MAX || ramp_end[m] > OHGPU_RAMP_MAX) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_set_ramps: message %u: ramp beyond Ramp::kMax", m);
+    for (uint32_t m : f.rem_msg) if (ramp_start[m] > OHGPU_RAMP_MAX || ramp_end[m] > OHGPU_RAMP_MAX) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_set_ramps: message %u: ramp beyond Ramp::kMax", m);
+    if (b->last_done) OHGPU_HIP_TRY(hipEventSynchronize(b->last_done));          // (the batch's last launch reads what is rewritten here)
+    hipStream_t s0 = ctx->stream;
+    if (f.enabled) {
+        for (size_t k = 0; k < f.host_jobs.size(); k++) { f.host_jobs[k].ramp_start = ramp_start[f.job_msg[k]]; f.host_jobs[k].ramp_end = ramp_end[f.job_msg[k]]; }
+        for (size_t k = 0; k < f.host_rem.size(); k++) { f.host_rem[k].ramp_start = ramp_start[f.rem_msg[k]]; f.host_rem[k].ramp_end = ramp_end[f.rem_msg[k]]; }
+        if (!f.host_jobs.empty()) {
+            OHGPU_HIP_TRY(hipMemcpyAsync(f.d_ramp_jobs, f.host_jobs.data(), f.host_jobs.size() * sizeof(RampJob), hipMemcpyHostToDevice, s0));
+            OHGPU_HIP_TRY(hipMemsetAsync(f.d_planes, 0xff, (f.plane_entries ? f.plane_entries : 8) * sizeof(uint16_t), s0));
+            OHGPU_HIP_TRY(launch_ramp_planes(ctx, f.d_ramp_jobs, (uint32_t)f.host_jobs.size(), f.d_planes, s0));
+        }
+        if (!f.host_rem.empty()) OHGPU_HIP_TRY(hipMemcpyAsync(f.d_rem, f.host_rem.data(), f.host_rem.size() * sizeof(DevSrcDesc), hipMemcpyHostToDevice, s0));
+        if (f.planes_ready) OHGPU_HIP_TRY(hipEventRecord(f.planes_ready, s0));       // (a run on any stream waits for this: the new planes)
+        OHGPU_HIP_TRY(hipStreamSynchronize(s0));                                    // (the host copies above are the caller's to change again)
+    }
+    if (b->host_descs) {                                                           // the generic kernel's form of every message (a batch created under variant 1)
+        DevSrcDesc* const dev = b->host_descs.get();
+        for (size_t i = 0; i < n; i++) { dev[i].ramp_start = ramp_start[i]; dev[i].ramp_end = ramp_end[i]; }
+        std::lock_guard<std::mutex> hold(b->lazy);
+        if (b->d_descs) OHGPU_HIP_TRY(hipMemcpy(b->d_descs, dev, n * sizeof(DevSrcDesc), hipMemcpyHostToDevice));
     }
     return OHGPU_OK;
 }

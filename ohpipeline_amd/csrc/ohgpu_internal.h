@@ -2,7 +2,9 @@
 #pragma once
 
 #include <sys/mman.h>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -154,6 +156,16 @@ struct SrcFastPlan {
     void*    d_rem = nullptr;     // DevSrcDesc[] the generic kernel finishes (block-unaligned heads and tails)
     size_t   n_rem = 0;
     uint64_t fast_out_frames = 0;
+    // host copies of what carries the messages' ramp endpoints on the device, and whose they are (the caller's message index):
+    // ohgpu_src_batch_set_ramps rewrites them; `stream_start`: some message's filter window reaches in front of its stream's first
+    // frame (such a batch cannot be advanced: ohgpu_src_batch_advance)
+    std::vector<RampJob> host_jobs;
+    std::vector<uint32_t> job_msg;
+    std::vector<DevSrcDesc> host_rem;
+    std::vector<uint32_t> rem_msg;
+    size_t   plane_entries = 0;
+    bool     stream_start = false;
+    uint64_t advanced_blocks = 0;       // ohgpu_src_batch_advance: blocks added to every message's position since creation
 };
 
 int plan_thread_cap();     // ohgpu_set_plan_threads (0: no cap)
@@ -225,6 +237,7 @@ struct PcmLinePlan {
     bool     prefixed = false;    // chunks carry prefixes (d_prefix): only this kernel writes them
     uint32_t n_chunks = 0;
     uint32_t list_first[kLineLists] = {}, list_count[kLineLists] = {};   // d_chunks[list_first[k], + list_count[k]): one launch each
+    uint8_t  list_heavy[kLineLists] = {};   // ... and the share of each list's subsamples, in percent, that is ramped or attenuated (the launch's occupancy)
     void*    d_chunks = nullptr;
     void*    d_prefix = nullptr;  // the prefix blob
 };
@@ -466,8 +479,71 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
 void build_ramp_table(uint16_t out[512]);
 int  design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, double f_pass,
                 std::vector<int32_t>* coef_q28, uint32_t* L, uint32_t* M);
+// What a pass over messages [lo, hi) of a resampled batch finds (src_check_range, csrc/ohgpu_api.hip): the first bad descriptor's
+// error, the batch's totals, whether the messages share descs[0]'s layout and come in the planner's order.
+struct SrcRangeResult {
+    int err = OHGPU_OK;
+    char msg[512] = "";
+    uint64_t in_frames = 0, out_frames = 0, src_bytes_touched = 0, dst_bytes_written = 0;
+    uint32_t max_frames = 0;
+    bool uniform = true;
+    bool ordered = true;        // every message of the range is not before its predecessor in the planner's order (meaningful for a uniform batch)
+    void fail(int code) { err = code; snprintf(msg, sizeof(msg), "%s", ohgpu_last_error()); }
+};
+void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t lo_i, size_t hi_i, uint64_t src_arena_bytes,
+                     uint64_t dst_arena_bytes, DevSrcDesc* dev, SrcRangeResult* out);
+// The planner checking the messages ITSELF, in the pass that cuts them into segments (a batch of half a million descriptors is 32 MB:
+// a pass of its own over them is a third of the plan's time).  In: the filter (the arenas are the batch's).  Out: `checked` = every
+// message was visited; `total` = what src_check_range found over all of them (its err / msg = the first bad descriptor's, in message
+// order); `retry` = the messages are not what this pass assumes -- one layout, the planner's order -- and the caller must take the
+// two-pass route (validation, then plan_src_fast with what it found).
+struct PlanFusedCheck {
+    const ohgpu_src* src = nullptr;
+    bool checked = false, retry = false;
+    SrcRangeResult total;
+};
 struct PlanDigest { uint64_t hash, units, pieces, ramp_jobs; int kernel; };   // ohgpu_src_plan_digest: a plan without a device
-int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, const DevSrcDesc* dev, PlanDigest* digest = nullptr);
+// `ordered`: the caller's messages are known to be in the planner's order already (src_msg_before never holds for a message against
+// its predecessor: the validation pass looked), so the planner neither checks nor sorts
+int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, bool ordered, PlanDigest* digest = nullptr, PlanFusedCheck* fused = nullptr);
+
+// The generic kernel's form of a (validated) resampled message: everything 64-bit that can be precomputed on the host.
+inline DevSrcDesc src_convert_desc(const ohgpu_src_msg_desc& d, uint64_t L, uint64_t M)
+{
+    DevSrcDesc o;
+    memset(&o, 0, sizeof(o));
+    if (d.n_frames > 0) {
+        const uint64_t t_first = d.out_frame0 * M;
+        o.in_rel0 = (int64_t)(t_first / L) - (int64_t)d.src_frame0;
+        o.phase0 = (uint32_t)(t_first % L);
+    }
+    o.src_offset = d.src_offset;
+    o.dst_offset = d.dst_offset;
+    o.n_frames = d.n_frames;
+    o.ramp_i0 = 0;
+    o.ramp_n = d.n_frames;
+    o.ramp_start = d.ramp_start;
+    o.ramp_end = d.ramp_end;
+    o.channels = d.channels;
+    o.src_bits = d.src_bits;
+    o.src_endian = d.src_endian;
+    o.dst_bits = d.dst_bits;
+    o.dst_endian = d.dst_endian;
+    o.flags = d.flags;
+    o.plane_frames = (uint32_t)(d.src_plane_stride >> 2);
+    return o;
+}
+// The planner's order of a uniform batch's messages: by stream -- identified by where its absolute frame 0 lives in the two arenas
+// (and, planar, by the distance between its planes) -- then by output position.
+inline bool src_msg_before(const ohgpu_src_msg_desc& x, const ohgpu_src_msg_desc& y, uint32_t fb_src, uint32_t fb_dst)
+{
+    const int64_t sx = (int64_t)x.src_offset - (int64_t)(x.src_frame0 * fb_src), sy = (int64_t)y.src_offset - (int64_t)(y.src_frame0 * fb_src);
+    if (sx != sy) return sx < sy;
+    if (x.src_plane_stride != y.src_plane_stride) return x.src_plane_stride < y.src_plane_stride;
+    const int64_t dx = (int64_t)x.dst_offset - (int64_t)(x.out_frame0 * fb_dst), dy = (int64_t)y.dst_offset - (int64_t)(y.out_frame0 * fb_dst);
+    if (dx != dy) return dx < dy;
+    return x.out_frame0 < y.out_frame0;
+}
 
 void free_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b);
 void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b);

@@ -264,7 +264,10 @@ hipError_t launch_ohm_wide(const ohgpu_ctx* ctx, const void* d_recs, uint32_t n_
 {
     if (n_recs == 0) return hipSuccess;
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
-    const uint32_t blocks = (n_recs + 3) / 4 < cus * 8 ? (n_recs + 3) / 4 : cus * 8;                  // 8 workgroups = 32 waves fill a CU
+#ifndef OHGPU_LINE_OHM_GROUPS_PER_CU
+#define OHGPU_LINE_OHM_GROUPS_PER_CU 4                                                            // (round 5: four workgroups per CU serve a streaming kernel better than eight: six-channel frames 0.293-0.311 -> 0.276-0.290 ms)
+#endif
+    const uint32_t blocks = (n_recs + 3) / 4 < cus * OHGPU_LINE_OHM_GROUPS_PER_CU ? (n_recs + 3) / 4 : cus * OHGPU_LINE_OHM_GROUPS_PER_CU;
     hipLaunchKernelGGL(ohm_wide_kernel, dim3(blocks), dim3(256), 0, s, (const OhmSelRec*)d_recs, n_recs,
                        (const uint16_t*)ctx->d_ramp_table, src, dst, prefix);
     return hipGetLastError();

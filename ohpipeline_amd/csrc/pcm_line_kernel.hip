@@ -639,6 +639,13 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
     for (uint32_t k = 0; k < kLineLists; k++) {
         b->line.list_first[k] = (uint32_t)all.size();
         b->line.list_count[k] = (uint32_t)lists[k].size();
+        // (how much of the list is arithmetic -- ramped or attenuated chunks -- by subsamples: decides the launch's occupancy)
+        uint64_t sub_all = 0, sub_heavy = 0;
+        for (const PcmChunk& c : lists[k]) {
+            sub_all += c.nq;
+            if ((c.flags & kChunkRamp) || c.attenuation != OHGPU_UNITY_ATTENUATION) sub_heavy += c.nq;
+        }
+        b->line.list_heavy[k] = sub_all ? (uint8_t)((sub_heavy * 100 + sub_all / 2) / sub_all) : 0;
         all.insert(all.end(), lists[k].begin(), lists[k].end());
         if (all.size() > 0xffffffffull) return OHGPU_OK;
     }
@@ -664,11 +671,21 @@ int plan_pcm_line(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_msg_desc* descs, s
 }
 
 template <int SB, int DB>
-static hipError_t launch_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32_t first, uint32_t count, const uint8_t* src, uint8_t* dst, hipStream_t s)
+static hipError_t launch_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32_t first, uint32_t count, uint32_t heavy_percent, const uint8_t* src, uint8_t* dst, hipStream_t s)
 {
     const uint32_t cus = ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u;
     uint32_t grid = (count + kLineWaves - 1) / kLineWaves;
-    if (grid > cus * 8) grid = cus * 8;                                 // 8 workgroups = 32 waves fill a CU
+    // Workgroups per CU.  A launch of byte shuffles is a streaming copy, and the memory system serves a copy best from FEW, long-lived
+    // workgroups (tools/micro/run_copy.hip: the same bytes at 5.6 TB/s from two to four workgroups per CU, 4.6-4.9 from eight to
+    // thirty-two): four per CU took the default mix (5 % of the messages ramped) from 0.2877 to 0.2723 ms, same box, turn and turn
+    // about (three: 0.2872, two: 0.366).  A launch whose chunks are mostly ramped or attenuated has arithmetic to hide behind other
+    // waves' loads: every message ramped 0.2949 at eight per CU, 0.2877 at six, 0.3167 at four.
+#ifdef OHGPU_LINE_GROUPS_PER_CU
+    const uint32_t per_cu = OHGPU_LINE_GROUPS_PER_CU;
+#else
+    const uint32_t per_cu = heavy_percent >= 30u ? 6u : 4u;
+#endif
+    if (grid > cus * per_cu) grid = cus * per_cu;
     hipLaunchKernelGGL((pcm_line_kernel<SB, DB>), dim3(grid), dim3(kLineWaves * 64), 0, s,
                        (const PcmChunk*)b->line.d_chunks + first, count, src, dst, ctx->d_ramp_table, (const uint8_t*)b->line.d_prefix);
     return hipGetLastError();
@@ -681,8 +698,8 @@ hipError_t launch_pcm_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
         if (count == 0) continue;
         hipError_t e = hipSuccess;
         switch (k) {
-        case 0: e = launch_line<0, 0>(ctx, b, first, count, src, dst, s); break;
-#define X(S, D) case 1 + (S - 2) * 3 + (D - 2): e = launch_line<S, D>(ctx, b, first, count, src, dst, s); break;
+        case 0: e = launch_line<0, 0>(ctx, b, first, count, b->line.list_heavy[k], src, dst, s); break;
+#define X(S, D) case 1 + (S - 2) * 3 + (D - 2): e = launch_line<S, D>(ctx, b, first, count, b->line.list_heavy[k], src, dst, s); break;
         X(2, 2) X(2, 3) X(2, 4) X(3, 2) X(3, 3) X(3, 4) X(4, 2) X(4, 3) X(4, 4)
 #undef X
         }

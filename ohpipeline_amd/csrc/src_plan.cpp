@@ -70,11 +70,14 @@ struct Slab {
     }
 };
 
+// a ramp job as the planner carries it: the device's record and the message (the caller's index) whose ramp it applies -- what
+// ohgpu_src_batch_set_ramps needs to give the job new endpoints
+struct PlanJob : RampJob { uint32_t msg; };
+
 // piece [m_lo, m_hi) of message d (device form dv) for the generic kernel
-static DevSrcDesc make_piece(const ohgpu_src_msg_desc& d, const DevSrcDesc& dv, uint64_t m_lo, uint64_t m_hi,
-                             uint64_t L, uint64_t M)
+static DevSrcDesc make_piece(const ohgpu_src_msg_desc& d, uint64_t m_lo, uint64_t m_hi, uint64_t L, uint64_t M)
 {
-    DevSrcDesc o = dv;
+    DevSrcDesc o = src_convert_desc(d, L, M);
     const uint64_t t_first = m_lo * M;
     o.in_rel0 = (int64_t)(t_first / L) - (int64_t)d.src_frame0;
     o.phase0 = (uint32_t)(t_first % L);
@@ -96,7 +99,7 @@ static uint32_t src_block_outputs_for(uint32_t L, uint32_t fb_dst, uint32_t min_
 }
 uint32_t src_block_outputs(uint32_t L, uint32_t fb_dst) { return src_block_outputs_for(L, fb_dst, 128); }
 
-int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, const DevSrcDesc* dev, PlanDigest* digest)
+int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, bool ordered, PlanDigest* digest, PlanFusedCheck* fused)
 {
     SrcFastPlan& f = b->fast;
     f = SrcFastPlan();
@@ -192,17 +195,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         if (dx != dy) return dx < dy;
         return descs[x].out_frame0 < descs[y].out_frame0;
     };
-    // (a caller that lists its streams one after the other, each in time order -- the usual case -- is in order already: one
-    // linear pass instead of a sort of half a million messages)
-    {
-        const unsigned n_thr = plan_threads(n, 32768);
-        std::vector<char> sorted(n_thr, 1);
-        parallel_ranges(n, n_thr, [&](unsigned t, size_t lo, size_t hi) {
-            for (size_t k = lo > 0 ? lo : 1; k < hi && sorted[t]; k++)               // (k against k - 1: the ranges' seams are the next range's first test)
-                if (before(order[k], order[k - 1])) sorted[t] = 0;
-        });
-        if (std::find(sorted.begin(), sorted.end(), 0) != sorted.end()) std::sort(order.begin(), order.end(), before);
-    }
+    // (a caller that lists its streams one after the other, each in time order -- the usual case -- is in order already, and the
+    // validation pass has seen that: no pass of this planner's, no sort of half a million messages)
+    if (!ordered) std::sort(order.begin(), order.end(), before);
 
     mark("order");
     struct SegRun { uint32_t seg; uint64_t blk_lo, blk_hi; uint32_t work_begin; };   // a segment's whole blocks and where its units start in `work`
@@ -213,13 +208,24 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         std::vector<uint32_t> seg_plane_stride;         // planar batches: bytes between a segment's planes
         std::vector<SrcWork> work;
         std::vector<DevSrcDesc> rem;
+        std::vector<uint32_t> rem_msg;                  // ... and the message (the caller's index) each piece is a part of
+        bool stream_start = false;                      // a message whose filter window reaches in front of its stream's first frame
         uint64_t fast_frames = 0;
+        // the workgroup kernel's plan (every unit one of `work`'s, rows of one block): its units, ramp jobs and planes are made where
+        // the work units are, in the same pass over the messages -- indices local to the stretch, as everything here
+        std::vector<LeanUnit> units;
+        std::vector<PlanJob> jobs;
+        size_t planes = 0;
+        bool ok = true;
+        // the fused check (PlanFusedCheck): what the stretch's messages were found to be, and the next one not yet looked at
+        SrcRangeResult chk;
+        size_t checked_upto = 0;
     };
     // lean kernel: one plane of multipliers per ramped unit -- rows * L_blk entries (uint16, 0xffff = no ramp on that frame)
     // (the kernel loads eight entries at a time; a row is a whole number of loads when L_blk is a multiple of 8, else the slack covers the last one)
     // (the multipliers themselves are computed on the device, csrc/ramp_plane_kernel.hip: the planner only says which message
     // covers which stretch of which plane)
-    std::vector<RampJob> ramp_jobs;
+    std::vector<PlanJob> ramp_jobs;
     size_t plane_entries = 0;
 
     // the lean kernel's staging moves, per stage q, the aligned 16-byte pieces that hold each row's frames: does every one of
@@ -246,16 +252,73 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         return p.n_frames != 0 && d.n_frames != 0 && src_base_of(d) == src_base_of(p) && dst_base_of(d) == dst_base_of(p) &&
                d.out_frame0 == p.out_frame0 + p.n_frames && d.src_plane_stride == p.src_plane_stride;
     };
+    // One lean / matrix-kernel unit: `n_rows` rows of `kb` consecutive blocks from block `bk` of the stream whose absolute frame 0
+    // lives at (sbase, dbase); `flags` = what is known of it already (kWorkRamped | kWorkChecked), `mi` .. `msg_end` the positions in
+    // `order` of the messages from the one that holds its first output frame on.  A ramped unit gets a plane of multipliers -- n_rows *
+    // L_blk entries (uint16, 0xffff = no ramp on that frame), in whole 16-byte pieces; the kernel addresses a plane as planes + plane *
+    // plane_stride with a stride of 16 -- and one job per ramped message that reaches into it.
+    auto emit_unit = [&](std::vector<LeanUnit>& units_out, std::vector<PlanJob>& jobs_out, size_t& planes_out, int64_t sbase, int64_t dbase,
+                         uint32_t plane_stride_bytes, uint64_t bk, uint32_t n_rows, uint32_t kb, uint32_t flags, uint32_t mi, uint32_t msg_end) -> bool {
+        LeanUnit u;
+        u.src_row0 = sbase + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
+        u.dst_row0 = dbase + (int64_t)(bk * L_blk) * fb_dst;
+        u.n_blocks = n_rows;
+        u.flags = (kb << 8) | (bk == 0 ? (uint32_t)kWorkFirst : 0u) | (flags & (kWorkRamped | kWorkChecked));
+        u.plane = 0;
+        u.src_plane_stride = planar ? plane_stride_bytes : 0u;
+        // the workgroup kernel reads 32 rows' worth of input per unit whatever the unit holds and checks nothing: the (at most two)
+        // units of a batch for which that leaves the arena fetch their pieces through the checked load
+        if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, ch, sb, rows, planar, (uint64_t)(ch - 1) * u.src_plane_stride, wg_hb)) u.flags |= kWorkEdge;
+        if (u.flags & kWorkRamped) {
+            const uint64_t u_lo = bk * L_blk, u_hi = (bk + (uint64_t)n_rows * kb) * L_blk;
+            const size_t per = (((size_t)n_rows * kb * L_blk + 8) + 7) & ~(size_t)7;
+            if (planes_out / 8 + per / 8 > 0xffffffffull) return false;
+            u.plane = (uint32_t)(planes_out / 8);
+            for (uint32_t m = mi; m < msg_end && descs[order[m]].out_frame0 < u_hi; m++) {
+                const ohgpu_src_msg_desc& d = descs[order[m]];
+                if (!(d.flags & OHGPU_FLAG_RAMP)) continue;
+                const uint64_t lo = std::max<uint64_t>(d.out_frame0, u_lo), hi = std::min<uint64_t>(d.out_frame0 + d.n_frames, u_hi);
+                if (hi <= lo) continue;
+                PlanJob j;
+                memset(&j, 0, sizeof(j));
+                j.msg = order[m];
+                j.plane_entry = planes_out + (lo - u_lo);
+                j.i0 = (uint32_t)(lo - d.out_frame0); j.count = (uint32_t)(hi - lo); j.n = d.n_frames;
+                uint32_t sh = 0;                        // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
+                magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &j.m_n1, &sh);
+                j.s_n1 = (uint8_t)sh; j.ramp_start = d.ramp_start; j.ramp_end = d.ramp_end;
+                jobs_out.push_back(j);
+            }
+            planes_out += per;
+        }
+        units_out.push_back(u);
+        return true;
+    };
+    // (the workgroup kernel's units are `work`'s one for one -- rows of one block, kb_max = 1 below -- and round 1's arrays are not
+    // made for such a plan: its units come out of the pass that finds them)
+    const bool direct_units = mfma_wg;
+    // (fused check: a message is validated the first time the pass looks at it -- in message order, each once; a stretch stops at its
+    // first bad descriptor, or at the first that is not of the batch's layout or out of order)
+    auto looked_at = [&](Stretch& o, size_t k) -> bool {
+        if (!fused || k < o.checked_upto) return true;
+        src_check_range(fused->src, descs, k, k + 1, b->src_arena_bytes, b->dst_arena_bytes, nullptr, &o.chk);
+        o.checked_upto = k + 1;
+        return o.chk.err == OHGPU_OK && o.chk.uniform && o.chk.ordered;
+    };
     auto plan_stretch = [&](size_t i_begin, size_t i_end, Stretch& o) {
             size_t i = i_begin;
+            o.checked_upto = i_begin;
             while (i < i_end) {
+            if (!looked_at(o, i)) return;
             // grow a run of messages that tile a contiguous output range of one stream
             size_t e = i + 1;
             const ohgpu_src_msg_desc& d0 = descs[order[i]];
             const int64_t sbase = src_base_of(d0), dbase = dst_base_of(d0);
+            if (d0.n_frames != 0 && (d0.out_frame0 * M) / L < T - 1u) o.stream_start = true;     // (a run's first message reaches furthest back)
             uint64_t next_out = d0.out_frame0 + d0.n_frames;
             bool zero_len = d0.n_frames == 0;
             while (!zero_len && e < i_end) {
+                if (!looked_at(o, e)) return;
                 const ohgpu_src_msg_desc& d = descs[order[e]];
                 if (d.n_frames == 0 || src_base_of(d) != sbase || dst_base_of(d) != dbase || d.out_frame0 != next_out ||
                     d.src_plane_stride != d0.src_plane_stride) break;
@@ -293,7 +356,8 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                     w.flags = ramped ? kWorkRamped : 0u;
                     w.plane = 0; w.pad = 0;
                     if (unit_leaves_arena(sbase, d0.src_plane_stride, bk, w.n_blocks, 1)) w.flags |= kWorkChecked;
-                    o.work.push_back(w);
+                    if (direct_units) o.ok = o.ok && emit_unit(o.units, o.jobs, o.planes, sbase, dbase, (uint32_t)d0.src_plane_stride, bk, w.n_blocks, 1, w.flags, mi, sg.msg_end);
+                    else o.work.push_back(w);
                 }
                 o.fast_frames += (blk_hi - blk_lo) * L_blk;
             } else {
@@ -304,9 +368,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 const ohgpu_src_msg_desc& d = descs[order[k]];
                 if (d.n_frames == 0) continue;
                 const uint64_t lo = d.out_frame0, hi = d.out_frame0 + d.n_frames;
-                if (!fast_ok) { o.rem.push_back(make_piece(d, dev[order[k]], lo, hi, L, M)); continue; }
-                if (lo < fast_lo) o.rem.push_back(make_piece(d, dev[order[k]], lo, std::min(hi, fast_lo), L, M));
-                if (hi > fast_hi) o.rem.push_back(make_piece(d, dev[order[k]], std::max(lo, fast_hi), hi, L, M));
+                if (!fast_ok) { o.rem.push_back(make_piece(d, lo, hi, L, M)); o.rem_msg.push_back(order[k]); continue; }
+                if (lo < fast_lo) { o.rem.push_back(make_piece(d, lo, std::min(hi, fast_lo), L, M)); o.rem_msg.push_back(order[k]); }
+                if (hi > fast_hi) { o.rem.push_back(make_piece(d, std::max(lo, fast_hi), hi, L, M)); o.rem_msg.push_back(order[k]); }
             }
             i = e;
         }
@@ -326,16 +390,32 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             for (size_t t = lo; t < hi; t++) if (cut[t] < cut[t + 1]) plan_stretch(cut[t], cut[t + 1], parts[t]);
         });
     }
+    if (fused) {
+        // (stretches are in message order and each stopped at its first bad descriptor: the first stretch with one holds the batch's first)
+        for (const Stretch& o : parts) {
+            if (o.chk.err != OHGPU_OK) { fused->total.err = o.chk.err; memcpy(fused->total.msg, o.chk.msg, sizeof(o.chk.msg)); break; }
+            if (!o.chk.uniform || !o.chk.ordered) { fused->retry = true; break; }
+            fused->total.in_frames += o.chk.in_frames; fused->total.out_frames += o.chk.out_frames;
+            fused->total.src_bytes_touched += o.chk.src_bytes_touched; fused->total.dst_bytes_written += o.chk.dst_bytes_written;
+            if (o.chk.max_frames > fused->total.max_frames) fused->total.max_frames = o.chk.max_frames;
+        }
+        fused->checked = true;
+        if (fused->total.err != OHGPU_OK || fused->retry) return OHGPU_OK;      // (the caller reports the error, or takes the two-pass route)
+    }
     std::vector<SrcSeg> segs;
     std::vector<SegRun> seg_runs;
     std::vector<uint32_t> seg_plane_stride;
     std::vector<SrcWork> work;
     std::vector<DevSrcDesc> rem;
+    std::vector<uint32_t> rem_msg;
+    bool stream_start = false;
     uint64_t fast_frames = 0;
+    std::vector<LeanUnit> lean_units;
     {
-        size_t n_segs = 0, n_work0 = 0, n_rem = 0;
-        for (const Stretch& o : parts) { n_segs += o.segs.size(); n_work0 += o.work.size(); n_rem += o.rem.size(); }
+        size_t n_segs = 0, n_work0 = 0, n_rem = 0, n_units0 = 0, n_jobs0 = 0;
+        for (const Stretch& o : parts) { n_segs += o.segs.size(); n_work0 += o.work.size(); n_rem += o.rem.size(); n_units0 += o.units.size(); n_jobs0 += o.jobs.size(); }
         segs.reserve(n_segs); seg_runs.reserve(n_segs); seg_plane_stride.reserve(n_segs); work.reserve(n_work0); rem.reserve(n_rem);
+        lean_units.reserve(n_units0); ramp_jobs.reserve(n_jobs0);
         for (size_t t = 0; t < parts.size(); t++) {
             Stretch& o = parts[t];
             const uint32_t seg_base = (uint32_t)segs.size(), work_base = (uint32_t)work.size();
@@ -344,11 +424,19 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             seg_plane_stride.insert(seg_plane_stride.end(), o.seg_plane_stride.begin(), o.seg_plane_stride.end());
             for (SrcWork w : o.work) { w.seg += seg_base; work.push_back(w); }
             rem.insert(rem.end(), o.rem.begin(), o.rem.end());
+            rem_msg.insert(rem_msg.end(), o.rem_msg.begin(), o.rem_msg.end());
+            stream_start = stream_start || o.stream_start;
             fast_frames += o.fast_frames;
+            // (the workgroup kernel's units: a stretch's planes and jobs count from zero and go behind its predecessors')
+            if (!o.ok || (plane_entries + o.planes) / 8 > 0xffffffffull) return OHGPU_OK;
+            const uint32_t plane_base = (uint32_t)(plane_entries / 8);
+            for (LeanUnit& u : o.units) { if (u.flags & kWorkRamped) u.plane += plane_base; lean_units.push_back(u); }
+            for (PlanJob& j : o.jobs) { j.plane_entry += plane_entries; ramp_jobs.push_back(j); }
+            plane_entries += o.planes;
         }
         parts.clear();
     }
-    if (work.empty()) return OHGPU_OK;
+    if (direct_units ? lean_units.empty() : work.empty()) return OHGPU_OK;
     mark("segments");
     // ---- the lean kernel's units.  A unit is `rows` rows; a row is `kb` CONSECUTIVE blocks of its stream.  With kb = 1 (round
     // 2) every block pays a filter length of warm-up advances and re-reads that much history (32 frames per 147), and every
@@ -357,7 +445,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // work allows (claimed first: every wave starts on one), everything else -- what does not divide, and the ramped units,
     // which stay one block long because a long unit would run the ramp path for all its outputs -- as one-block units for
     // the waves to level out on.
-    std::vector<LeanUnit> lean_units;
     if (lean) {
         const uint32_t waves = (ctx && ctx->num_cus > 0 ? (uint32_t)ctx->num_cus : 256u) * (mfma ? mf_max_waves : lean_max_waves);
         // Same-box A/Bs on the headline workload, alternating passes, +-0.2 % within a box.  Eleven waves per CU
@@ -395,60 +482,26 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             long_target = kb_long > 1 ? (uint64_t)waves * n_rounds : 0;
         }
         uint64_t long_cut = 0;
-        lean_units.reserve(work.size());
+        if (!direct_units) lean_units.reserve(work.size());
         // (a unit goes to `units_out`, its ramp jobs to `jobs_out`, its plane behind `planes_out` entries: the batch's own arrays, or a
         // thread's share of them that is put behind the others' afterwards)
-        auto emit_to = [&](std::vector<LeanUnit>& units_out, std::vector<RampJob>& jobs_out, size_t& planes_out,
+        auto emit_to = [&](std::vector<LeanUnit>& units_out, std::vector<PlanJob>& jobs_out, size_t& planes_out,
                            const SegRun& r, uint64_t bk, uint32_t n_rows, uint32_t kb, const SrcWork* w1) -> bool {
-            std::vector<LeanUnit>& lean_units = units_out;
-            std::vector<RampJob>& ramp_jobs = jobs_out;
-            size_t& plane_entries = planes_out;
-            LeanUnit u;
-            u.src_row0 = segs[r.seg].src_base + ((int64_t)(bk * M_blk) - (int64_t)T) * fb_src;
-            u.dst_row0 = segs[r.seg].dst_base + (int64_t)(bk * L_blk) * fb_dst;
-            u.n_blocks = n_rows;
-            u.flags = (kb << 8) | (bk == 0 ? (uint32_t)kWorkFirst : 0u);
-            u.plane = 0;
-            u.src_plane_stride = planar ? seg_plane_stride[r.seg] : 0u;
-            if (w1) u.flags |= w1->flags & (kWorkRamped | kWorkChecked);
-            else if (unit_leaves_arena(segs[r.seg].src_base, u.src_plane_stride, bk, n_rows, kb)) u.flags |= kWorkChecked;
-            // the workgroup kernel reads 32 rows' worth of input per unit whatever the unit holds and checks nothing: the (at most two)
-            // units of a batch for which that leaves the arena stay with the unit-per-wave kernel
-            if (mfma_wg && !src_mfma_wg_unit_inside(u.src_row0, M_blk * fb_src, b->src_arena_bytes, ch, sb, rows, planar, (uint64_t)(ch - 1) * u.src_plane_stride, wg_hb)) u.flags |= kWorkEdge;
-            if (u.flags & kWorkRamped) {
-                // one plane of multipliers per ramped unit -- n_rows * L_blk entries (uint16, 0xffff = no ramp on that frame), in
-                // whole 16-byte pieces; the kernel addresses a plane as planes + plane * plane_stride with a stride of 16
-                const SrcSeg& sg = segs[r.seg];
-                const uint64_t u_lo = bk * L_blk, u_hi = (bk + n_rows) * L_blk;
-                const size_t per = (((size_t)n_rows * L_blk + 8) + 7) & ~(size_t)7;
-                if (plane_entries / 8 + per / 8 > 0xffffffffull) return false;
-                u.plane = (uint32_t)(plane_entries / 8);
-                for (uint32_t m = w1->msg_first; m < sg.msg_end && descs[order[m]].out_frame0 < u_hi; m++) {
-                    const ohgpu_src_msg_desc& d = descs[order[m]];
-                    if (!(d.flags & OHGPU_FLAG_RAMP)) continue;
-                    const uint64_t lo = std::max<uint64_t>(d.out_frame0, u_lo), hi = std::min<uint64_t>(d.out_frame0 + d.n_frames, u_hi);
-                    if (hi <= lo) continue;
-                    RampJob j;
-                    memset(&j, 0, sizeof(j));
-                    j.plane_entry = plane_entries + (lo - u_lo);
-                    j.i0 = (uint32_t)(lo - d.out_frame0); j.count = (uint32_t)(hi - lo); j.n = d.n_frames;
-                    uint32_t sh = 0;                        // RampApplicator divides by n - 1 per frame (Msg.cpp:835): exact multiplier instead
-                    magic_u31(d.n_frames > 1 ? d.n_frames - 1 : 1, &j.m_n1, &sh);
-                    j.s_n1 = (uint8_t)sh; j.ramp_start = d.ramp_start; j.ramp_end = d.ramp_end;
-                    ramp_jobs.push_back(j);
-                }
-                plane_entries += per;
-            }
-            lean_units.push_back(u);
-            return true;
+            uint32_t flags = 0;
+            if (w1) flags = w1->flags & (kWorkRamped | kWorkChecked);
+            else if (unit_leaves_arena(segs[r.seg].src_base, planar ? seg_plane_stride[r.seg] : 0u, bk, n_rows, kb)) flags = kWorkChecked;
+            return emit_unit(units_out, jobs_out, planes_out, segs[r.seg].src_base, segs[r.seg].dst_base, seg_plane_stride[r.seg], bk, n_rows, kb, flags,
+                             w1 ? w1->msg_first : segs[r.seg].msg_begin, segs[r.seg].msg_end);
         };
         auto emit = [&](const SegRun& r, uint64_t bk, uint32_t n_rows, uint32_t kb, const SrcWork* w1) -> bool {
             return emit_to(lean_units, ramp_jobs, plane_entries, r, bk, n_rows, kb, w1);
         };
-        if (kb_long == 1 && seg_runs.size() >= 64) {
+        if (direct_units) {
+            // (made with the segments, above)
+        } else if (kb_long == 1 && seg_runs.size() >= 64) {
             // every unit is one of `work`'s: the segments' runs in ranges, side by side; a range's planes and jobs count from zero and
             // are moved behind its predecessors' when the ranges are put together, in order -- the arrays one thread makes
-            struct Share { std::vector<LeanUnit> units; std::vector<RampJob> jobs; size_t planes = 0; bool ok = true; };
+            struct Share { std::vector<LeanUnit> units; std::vector<PlanJob> jobs; size_t planes = 0; bool ok = true; };
             const unsigned n_thr = plan_threads(work.size(), 2048);
             std::vector<Share> shares(n_thr);
             parallel_ranges(seg_runs.size(), n_thr, [&](unsigned t, size_t lo, size_t hi) {
@@ -466,7 +519,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 if (!sh.ok || (plane_entries + sh.planes) / 8 > 0xffffffffull) return OHGPU_OK;
                 const uint32_t plane_base = (uint32_t)(plane_entries / 8);
                 for (LeanUnit& u : sh.units) { if (u.flags & kWorkRamped) u.plane += plane_base; lean_units.push_back(u); }
-                for (RampJob& j : sh.jobs) { j.plane_entry += plane_entries; ramp_jobs.push_back(j); }
+                for (PlanJob& j : sh.jobs) { j.plane_entry += plane_entries; ramp_jobs.push_back(j); }
                 plane_entries += sh.planes;
             }
         } else for (const SegRun& r : seg_runs) {
@@ -524,6 +577,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         });
 
     mark("units");
+    const std::vector<RampJob> dev_jobs(ramp_jobs.begin(), ramp_jobs.end());        // (the device's records)
     if (digest) {
         // (ohgpu_src_plan_digest: what the plan consists of, hashed; nothing goes to a device)
         auto fnv = [](uint64_t h, const void* p, size_t bytes) {
@@ -533,10 +587,12 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         };
         uint64_t h = 1469598103934665603ull;
         h = fnv(h, lean_units.data(), lean_units.size() * sizeof(LeanUnit));
-        h = fnv(h, work.data(), work.size() * sizeof(SrcWork));
-        h = fnv(h, segs.data(), segs.size() * sizeof(SrcSeg));
+        if (round1) {                                       // (round 1's arrays are part of a plan only where they go to the device)
+            h = fnv(h, work.data(), work.size() * sizeof(SrcWork));
+            h = fnv(h, segs.data(), segs.size() * sizeof(SrcSeg));
+        }
         h = fnv(h, rem.data(), rem.size() * sizeof(DevSrcDesc));
-        h = fnv(h, ramp_jobs.data(), ramp_jobs.size() * sizeof(RampJob));
+        h = fnv(h, dev_jobs.data(), dev_jobs.size() * sizeof(RampJob));
         h = fnv(h, &plane_entries, sizeof(plane_entries));
         digest->hash = h;
         digest->units = lean ? lean_units.size() : work.size();
@@ -575,7 +631,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     if (lean) slab.add(lean_units, &f.d_lean_units);
     slab.add(rem, &f.d_rem);
     slab.add(std::vector<uint32_t>(2, 0u), &f.d_counter);            // {units claimed, waves finished}: zero between launches
-    slab.add(ramp_jobs, &f.d_ramp_jobs);
+    slab.add(dev_jobs, &f.d_ramp_jobs);
     slab.reserve((plane_entries ? plane_entries : 8) * sizeof(uint16_t), &f.d_planes);
     mark("slab");
     int err = slab.upload(ctx, &f.d_slab);
@@ -597,6 +653,15 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     fprintf(stderr, "[plan timing]   slab %zu bytes, %zu units, %zu ramp jobs, %zu plane entries\n", slab.host.size(), lean_units.size(), ramp_jobs.size(), plane_entries);
 #endif
     f.enabled = true;
+    // (what ohgpu_src_batch_set_ramps and ohgpu_src_batch_advance go by: small next to the messages -- a job per ramped message and
+    // unit, a piece per block-unaligned message end)
+    f.host_jobs = dev_jobs;
+    f.job_msg.resize(ramp_jobs.size());
+    for (size_t k = 0; k < ramp_jobs.size(); k++) f.job_msg[k] = ramp_jobs[k].msg;
+    f.host_rem = rem;
+    f.rem_msg = rem_msg;
+    f.plane_entries = plane_entries;
+    f.stream_start = stream_start;
     f.T = T;
     f.n_work = (uint32_t)work.size();
     f.n_lean = (uint32_t)lean_units.size();

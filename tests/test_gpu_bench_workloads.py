@@ -179,10 +179,12 @@ def test_workgroup_matrix_kernel_takes_packed_s24_of_two_six_and_eight_channels(
 
 
 @pytest.mark.parametrize("channels, src_le, dst_le", [(6, True, False), (2, False, True)])
-def test_a_plan_only_the_workgroup_kernel_reads_runs_on_the_generic_kernel_under_another_variant(ctx, channels, src_le, dst_le):
+def test_a_plan_only_the_workgroup_kernel_reads_never_reaches_another_kernel(ctx, channels, src_le, dst_le):
     """Six-channel units are cut 30 rows long for the workgroup kernel, and big-endian-in / little-endian-out has no other block
-    kernel at all: such a batch, planned under variant 0 and RUN under variant 4, must not reach the lean kernel -- the library
-    says it runs the generic one (its per-message descriptors go to the device at that moment), and the audio is the same."""
+    kernel at all: such a batch, planned under variant 0 and RUN under variant 4, must not reach the lean kernel.  A batch planned
+    for the block kernels keeps no per-message descriptors (round 5: their conversion was half the validation pass), so the generic
+    kernel cannot take it either: the run is REFUSED, loudly, nothing is launched -- and the same batch created while variant 4 (or
+    1) is in force runs, bit-exact."""
     g = bench.Group(capi, 44100, channels, range(700, 705), int(round(0.4 * 44100)), src_bits=24,
                     src_endian=capi.ENDIAN_LITTLE if src_le else capi.ENDIAN_BIG, dst_bits=24,
                     dst_endian=capi.ENDIAN_LITTLE if dst_le else capi.ENDIAN_BIG)
@@ -195,15 +197,25 @@ def test_a_plan_only_the_workgroup_kernel_reads_runs_on_the_generic_kernel_under
         ref = O.Src(g.rate_in, bench.RATE_OUT, g.taps, bench.BETA, bench.F_PASS)
         want = np.zeros(g.dst_bytes, dtype=np.uint8)
         assert ref.process_batch(g.oracle_descs.view(O.SRC_MSG_DESC), g.src, want) == 0
-        ctx.set_kernel_variant(4)
-        try:
-            assert ctx.src_kernel_name(g.batch) == "src_kernel_v1"
-            ctx.memset(g.d_dst, 0, g.dst_bytes)
-            ctx.src_run(g.batch, g.d_src, g.d_dst)
-            ctx.sync()
-            assert np.array_equal(ctx.download(g.d_dst, g.dst_bytes), want)
-        finally:
-            ctx.set_kernel_variant(0)
+        for other in (4, 1):
+            ctx.set_kernel_variant(other)
+            try:
+                assert ctx.src_kernel_name(g.batch) == "src_kernel_v1"
+                ctx.memset(g.d_dst, 0x5A, g.dst_bytes)
+                with pytest.raises(capi.OhGpuError) as e:
+                    ctx.src_run(g.batch, g.d_src, g.d_dst)
+                assert e.value.code == capi.ERR_UNSUPPORTED and "ohgpu_set_kernel_variant(1)" in str(e.value)
+                ctx.sync()
+                assert np.all(ctx.download(g.d_dst, g.dst_bytes) == 0x5A)         # nothing was launched
+                # ... created under that variant, the same messages run (the lean kernel where it has the layout, else the generic one)
+                b2 = ctx.src_batch(g.h, g.descs, g.src.size, g.dst_bytes)
+                ctx.memset(g.d_dst, 0, g.dst_bytes)
+                ctx.src_run(b2, g.d_src, g.d_dst)
+                ctx.sync()
+                assert np.array_equal(ctx.download(g.d_dst, g.dst_bytes), want), other
+                ctx.batch_destroy(b2)
+            finally:
+                ctx.set_kernel_variant(0)
         ctx.memset(g.d_dst, 0, g.dst_bytes)
         ctx.src_run(g.batch, g.d_src, g.d_dst)                  # ... and back on its own kernel
         ctx.sync()

@@ -534,11 +534,13 @@ def test_src_one_batch_of_mixed_layouts_runs_on_the_block_kernels(ctx):
     want = oracle_src(ref, descs, src, dp)
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, f"{bad.size} mismatches, first {bad[:5]}"
-    ctx.set_kernel_variant(1)
+    ctx.set_kernel_variant(1)                                    # (the generic kernel's own form of the messages is kept by a batch CREATED under variant 1)
     try:
+        b1 = ctx.src_batch(h, descs, src.size, dp)
         ctx.memset(d_dst, 0xA5, dp)
-        ctx.src_run(b, d_src, d_dst)
+        ctx.src_run(b1, d_src, d_dst)
         assert np.array_equal(ctx.download(d_dst, dp), want)
+        ctx.batch_destroy(b1)
     finally:
         ctx.set_kernel_variant(0)
     ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
@@ -587,6 +589,84 @@ def test_src_batch_can_be_run_repeatedly(ctx):
     ctx.src_destroy(h)
 
 
+@pytest.mark.parametrize("rate,taps,ch", [(44100, 32, 2), (96000, 64, 6), (44100, 32, 8)])
+def test_the_same_batch_serves_the_next_period_and_other_ramps(ctx, rate, taps, ch):
+    """A bulk caller's period after period: the same streams, the same tiling, a whole number of blocks on, new audio in the same
+    arena -- ohgpu_src_batch_advance checks that the batch is of that kind and the plan is run again as it stands; other ramp
+    endpoints on the same messages go in with ohgpu_src_batch_set_ramps.  Every period against the oracle run on that period's
+    descriptors; a batch that holds a stream's start refuses to advance."""
+    h, ref = make_src(ctx, rate, 48000, taps)
+    n_streams, period_blocks = 9, 23
+    fb = ch * 3
+    whole = [W.noise_pcm(900 + s, 200000, ch, 24, LE) for s in range(n_streams)]
+
+    # geometry from the library
+    probe, sbytes, dbytes, out_total, n_msgs = W.src_stream_descs(n_streams, 40000, ref.L, ref.M, 240, ch, 24, LE, 24, BE, None)
+    b0 = ctx.src_batch(h, probe, sbytes, dbytes)
+    L_blk, M_blk = ctx.src_batch_block(b0)
+    with pytest.raises(capi.OhGpuError) as e:                   # (it starts its streams: zeros in front of block 0 are not history)
+        ctx.src_batch_advance(b0, 1)
+    assert e.value.code == capi.ERR_INVALID
+    ctx.batch_destroy(b0)
+    out_frames = period_blocks * L_blk
+    hist = M_blk + taps                                         # input frames held in front of the period's first
+    win = period_blocks * M_blk + hist
+
+    def make(first_block, ramp_pair):
+        n_m = (out_frames + 239) // 240
+        d = np.zeros(n_streams * n_m, dtype=O.SRC_MSG_DESC)
+        first = np.arange(n_m) * 240
+        for s in range(n_streams):
+            sl = slice(s * n_m, (s + 1) * n_m)
+            d["src_offset"][sl] = s * win * fb
+            d["src_frame0"][sl] = first_block * M_blk - hist
+            d["src_frames"][sl] = win
+            d["out_frame0"][sl] = first_block * L_blk + first
+            d["dst_offset"][sl] = (s * out_frames + first) * fb
+            d["n_frames"][sl] = np.minimum(240, out_frames - first)
+        d["attenuation"], d["channels"], d["src_bits"], d["src_endian"], d["dst_bits"], d["dst_endian"] = 256, ch, 24, LE, 24, BE
+        d["ramp_start"], d["ramp_end"] = O.RAMP_MAX, O.RAMP_MAX
+        ramped = (np.arange(d.size) % 7) < 2                    # two messages in seven carry a ramp
+        d["flags"] = np.where(ramped, O.FLAG_RAMP, 0)
+        d["ramp_start"] = np.where(ramped, ramp_pair[0], d["ramp_start"])
+        d["ramp_end"] = np.where(ramped, ramp_pair[1], d["ramp_end"])
+        arena = np.concatenate([w[(first_block * M_blk - hist) * fb:(first_block * M_blk - hist + win) * fb] for w in whole])
+        return d, arena
+
+    d1, arena1 = make(3, (16384, 2000))
+    dbytes = n_streams * out_frames * fb
+    d_src, d_dst = ctx.upload(arena1), ctx.malloc(dbytes)
+    b = ctx.src_batch(h, d1, arena1.size, dbytes)
+    assert ctx.src_plan(b)["block_kernel_out_frames"] > 0
+    try:
+        ctx.memset(d_dst, 0xA5, dbytes)
+        ctx.src_run(b, d_src, d_dst)
+        assert np.array_equal(ctx.download(d_dst, dbytes), oracle_src(ref, d1, arena1, dbytes))
+        at = 3
+        for step, ramps in ((period_blocks, None), (5, (100, 16000)), (period_blocks, (7000, 7000))):
+            at += step
+            ctx.src_batch_advance(b, step)
+            if ramps is not None:
+                dn, arena = make(at, ramps)
+                ctx.src_batch_set_ramps(b, dn["ramp_start"], dn["ramp_end"])
+            else:
+                dn, arena = make(at, (16384, 2000))
+            ctx.free(d_src)
+            d_src = ctx.upload(arena)
+            ctx.memset(d_dst, 0xA5, dbytes)
+            ctx.src_run(b, d_src, d_dst)
+            assert np.array_equal(ctx.download(d_dst, dbytes), oracle_src(ref, dn, arena, dbytes)), (at, ramps)
+        with pytest.raises(capi.OhGpuError):
+            ctx.src_batch_set_ramps(b, dn["ramp_start"][:-1], dn["ramp_end"][:-1])          # one pair per message, no fewer
+        bad = dn["ramp_start"].copy()
+        bad[0] = 20000                                            # (message 0 is ramped: beyond Ramp::kMax)
+        with pytest.raises(capi.OhGpuError):
+            ctx.src_batch_set_ramps(b, bad, dn["ramp_end"])
+    finally:
+        ctx.batch_destroy(b); ctx.free(d_src); ctx.free(d_dst)
+        ctx.src_destroy(h)
+
+
 @pytest.mark.parametrize("created_under", [0, 4, 2])
 def test_a_batch_created_under_one_variant_runs_under_every_other(ctx, created_under):
     """The variant in force when a batch is RUN chooses among the kernels its plan serves (one decision for the launch and for the
@@ -604,13 +684,23 @@ def test_a_batch_created_under_one_variant_runs_under_every_other(ctx, created_u
         ctx.set_kernel_variant(created_under)
         b = ctx.src_batch(h, descs, src.size, dbytes)
         names = {}
-        for run_under in (0, 2, 3, 4, 5, 1):
+        for run_under in (0, 2, 3, 4, 5):
             ctx.set_kernel_variant(run_under)
             names[run_under] = ctx.src_kernel_name(b)
             ctx.memset(d_dst, 0xA5, dbytes)
             ctx.src_run(b, d_src, d_dst)
             assert np.array_equal(ctx.download(d_dst, dbytes), want), (created_under, run_under, names[run_under])
-        assert names[1] == "src_kernel_v1"
+        # the generic kernel needs its own form of every message, which only a batch created under variant 1 keeps: refused, not guessed
+        ctx.set_kernel_variant(1)
+        assert ctx.src_kernel_name(b) == "src_kernel_v1"
+        with pytest.raises(capi.OhGpuError) as e:
+            ctx.src_run(b, d_src, d_dst)
+        assert e.value.code == capi.ERR_UNSUPPORTED
+        b1 = ctx.src_batch(h, descs, src.size, dbytes)
+        ctx.memset(d_dst, 0xA5, dbytes)
+        ctx.src_run(b1, d_src, d_dst)
+        assert np.array_equal(ctx.download(d_dst, dbytes), want)
+        ctx.batch_destroy(b1)
         if created_under == 0:
             assert names[0] == "src_mfma_wg_kernel" and names[5] == "src_mfma_kernel" and names[4] == "src_lean_kernel" and names[2] == "src_lean_kernel", names
         if created_under == 2:

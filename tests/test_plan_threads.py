@@ -147,3 +147,42 @@ def test_the_long_unit_schedule_follows_the_device_size():
     assert big["digest"] != small["digest"]
     capi.set_plan_threads(6)
     assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, 4, coef_q28=ref.coef_q28, num_cus=64) == small
+
+
+def test_a_period_a_whole_number_of_blocks_later_has_the_same_plan():
+    """ohgpu_src_batch_advance's ground: nothing of a plan names an absolute position -- a unit is where its rows lie in the arenas, a
+    ramp job where its frames lie in its message, a generic-kernel piece its window relative to the buffer -- so the messages of the
+    next period (every out_frame0 a whole number of blocks on, every src_frame0 the same number of input blocks on, offsets as
+    they were) plan to the very same arrays.  Not so for a period that starts its streams (block 0's rows read zeros in front)."""
+    ref, d, sb, db = headline_like(48, 2.0)
+    L_blk, M_blk = 160, 147
+    assert ref.L == 160 and ref.M == 147
+
+    def shifted(blocks, history_blocks=1):
+        # every stream's period: the same messages `blocks` blocks on; the buffer holds one block of history in front of what it held
+        s = d.copy()
+        s["out_frame0"] += blocks * L_blk
+        s["src_frame0"] += (blocks - history_blocks) * M_blk
+        s["src_frames"] += history_blocks * M_blk
+        per = int(s["src_frames"][0]) * 6
+        n_msgs = d.size // 48
+        for k in range(48):
+            s["src_offset"][k * n_msgs:(k + 1) * n_msgs] = k * per
+        return s, 48 * per
+
+    capi.set_plan_threads(1)
+    a, sba = shifted(10)
+    b_, sbb = shifted(27)
+    one = capi.src_plan_digest(ref.L, ref.M, ref.T, a, sba, db, coef_q28=ref.coef_q28)
+    assert one["units"] > 0 and one["kernel"] == 3
+    assert capi.src_plan_digest(ref.L, ref.M, ref.T, b_, sbb, db, coef_q28=ref.coef_q28) == one
+    capi.set_plan_threads(5)
+    assert capi.src_plan_digest(ref.L, ref.M, ref.T, b_, sbb, db, coef_q28=ref.coef_q28) == one
+    # ... other ramp endpoints change the jobs' endpoints and nothing else: the same units, the same pieces
+    c = b_.copy()
+    c["ramp_start"] = np.where(c["flags"] & 1, 9000, c["ramp_start"])
+    other = capi.src_plan_digest(ref.L, ref.M, ref.T, c, sbb, db, coef_q28=ref.coef_q28)
+    assert other["units"] == one["units"] and other["generic_pieces"] == one["generic_pieces"] and other["digest"] != one["digest"]
+    # the streams' own first period is another plan (kWorkFirst)
+    capi.set_plan_threads(1)
+    assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, coef_q28=ref.coef_q28)["digest"] != one["digest"]
