@@ -901,7 +901,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5), help="BASELINE.json configs[config-1]: 3 = the headline")
     ap.add_argument("--seconds", type=float, default=None, help="audio per stream (default: 10 s)")
     ap.add_argument("--streams", type=int, default=None, help="config 3/5: streams per GPU (256); config 4: streams in all (2048)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 2 round 1's block kernel, 4 round 2's lean kernel, 5 round 4's unit-per-wave matrix kernel)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 tuned, 1 generic v1, 4 round 2's lean kernel; 2 and 5 -- round 1's block kernel, round 4's unit-per-wave matrix kernel -- in a legacy build only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / check, end_to_end and cadence legs (profiling runs)")
     ap.add_argument("--no-extra-configs", action="store_true", help="the default line without its `configs` object (configs[3] and configs[4] at full size)")
     ap.add_argument("--sustain", type=float, default=1.0, help="seconds of back-to-back launches before the warm-up and the timed steps, so that they see the clock the chip holds under this load")

@@ -11,7 +11,12 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libohgpu.so")
 
 HIP_SOURCES = ["ohgpu_api.hip", "pcm_kernels.hip", "pcm_line_kernel.hip", "flywheel_kernel.hip", "fmt_line_kernel.hip", "ohm_frame_kernel.hip", "ramp_plane_kernel.hip", "host_design.cpp", "src_plan.cpp", "src_block_kernel.hip", "src_lean_kernel.hip", "src_mfma_kernel.hip", "src_mfma_wg_kernel.hip"]
-PARTED = ("src_block_kernel.hip", "src_lean_kernel.hip")     # compiled once per part of the instantiation list (csrc/src_block_common.h)
+# Rounds 1's block kernel and round 4's unit-per-wave matrix kernel are retired from the shipped library (round 5): their device code
+# is compiled only with OHGPU_LEGACY=1 in the environment (-DOHGPU_LEGACY_KERNELS: ohgpu_set_kernel_variant 2 and 5 then select them,
+# for same-box A/Bs).  What the planner takes from their files -- layout lists, geometry, the matrix kernels' host tables -- is
+# compiled always.
+LEGACY = os.environ.get("OHGPU_LEGACY", "") not in ("", "0")
+PARTED = ("src_block_kernel.hip", "src_lean_kernel.hip") if LEGACY else ("src_lean_kernel.hip",)     # compiled once per part of the instantiation list (csrc/src_block_common.h)
 HEADERS = ["ohgpu_internal.h", "pcm_device.h", os.path.join(ROOT, "include", "ohgpu.h")]
 # Per-source flags.  The lean kernel's per-frame control flow is wave-uniform (scalar compares); LLVM's structurizer
 # rewrites uniform diamonds into flag-and-test chains unless told to leave uniform regions alone (3-4 scalar instructions
@@ -76,7 +81,7 @@ def build(force=False, verbose=False, save_temps=False):
     obj_dir = os.path.join(PKG, "build", "obj")
     os.makedirs(obj_dir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-             *os.environ.get("OHGPU_EXTRA_FLAGS", "").split(),
+             *os.environ.get("OHGPU_EXTRA_FLAGS", "").split(), *(["-DOHGPU_LEGACY_KERNELS"] if LEGACY else []),
              "-Wall", "-Wno-inline-asm", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include")]
     if save_temps:
         flags += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]

@@ -1288,9 +1288,13 @@ static SrcKernel src_kernel_choice(const ohgpu_ctx* ctx, const ohgpu_batch* b, b
     // a variant that asks for another)
     if (v == 1 || !b->fast.enabled || !arena_aligned || (b->fast.wg_only && v != 0)) return kSrcGeneric;
     if (b->fast.mfma_wg && v == 0) return kSrcWg;                                         // the taps on the matrix pipe (round 4), a unit per workgroup
+#ifdef OHGPU_LEGACY_KERNELS
     if (b->fast.mfma && (v == 0 || v == 3 || v == 5)) return kSrcMfma;                   // ... a unit per wave (variant 5, and where the workgroup kernel's block geometry does not hold)
     if (b->fast.lean && (v != 2 || b->fast.lean_only || !b->fast.d_work)) return kSrcLean;   // round 2's, under every variant but 2 -- and under 2 where round 1's has no layout or no tables
     if (b->fast.d_work) return kSrcBlock;                                                  // round 1's (variant 2; a filter beyond the lean kernel's rounding bound under any)
+#else
+    if (b->fast.lean) return kSrcLean;                                                     // round 2's, under every other variant (rounds 1's and 4's unit-per-wave kernels: legacy builds)
+#endif
     return kSrcGeneric;
 }
 static const char* src_kernel_name(SrcKernel k)
@@ -1389,9 +1393,11 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         // whole phase-aligned blocks on the chosen block kernel, block-unaligned heads/tails on the generic one
         switch (which) {
         case kSrcWg: OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+#ifdef OHGPU_LEGACY_KERNELS
         case kSrcMfma: OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
-        case kSrcLean: OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
-        default: OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+        case kSrcBlock: OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+#endif
+        default: OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
         }
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
         launched(batch, s);

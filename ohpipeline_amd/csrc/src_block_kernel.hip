@@ -1,6 +1,10 @@
 // src_block_kernel.hip -- round 1's resample -> ramp -> pack kernel ("block kernel").  Since round 2 the batches run on
-// src_lean_kernel.hip; this one stays for filters whose phase sums break the lean kernel's rounding bias (sum|c| >= 2^29) and as
-// the same-box A/B reference (ohgpu_set_kernel_variant(ctx, 2)).
+// src_lean_kernel.hip, since round 4 on src_mfma_wg_kernel.hip; RETIRED from the shipped library in round 5: the kernel, its
+// instantiations and its launcher are compiled only with -DOHGPU_LEGACY_KERNELS (OHGPU_LEGACY=1 python ohpipeline_amd/build.py, or
+// tools/build_variant.sh: the same-box A/B reference, ohgpu_set_kernel_variant(ctx, 2)).  What the planner still takes from this
+// file is compiled always: which layouts the block kernels' main list holds (src_block_supported) and the rows / ring geometry the
+// lean kernel shares with it (src_block_geometry).  A filter whose phase sums break the lean kernel's rounding bias (sum|c| >= 2^29)
+// runs on the generic kernel in the shipped library.
 //
 // Mapping (DESIGN.md "Resampler kernel"):
 //   * A stream's output is cut into BLOCKS of L_blk frames that start where the polyphase phase is 0
@@ -132,6 +136,7 @@ struct BlockGeom {
     static constexpr int MSG_SLOTS = 32;                // messages of a wave's output range kept in LDS
 };
 
+#ifdef OHGPU_LEGACY_KERNELS
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
 __global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
 void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
@@ -561,7 +566,10 @@ OHGPU_BLOCK_KERNELS_2(X_DECLARE)
 OHGPU_BLOCK_KERNELS_3(X_DECLARE)
 #endif
 
+#endif   // OHGPU_LEGACY_KERNELS
+
 #if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
+#ifdef OHGPU_LEGACY_KERNELS
 // Launch shape: up to MAX_WAVES waves per workgroup (what the LDS left by the coefficient table allows), one
 // workgroup per CU, waves loop over the work units; a small batch is spread as one-wave workgroups instead.
 static void launch_shape(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32_t* grid, uint32_t* waves, uint32_t* lds)
@@ -590,6 +598,8 @@ static hipError_t launch_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const S
                        (uint32_t*)b->fast.d_counter);
     return hipGetLastError();
 }
+
+#endif   // OHGPU_LEGACY_KERNELS
 
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le)
 {
@@ -622,6 +632,7 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     return true;
 }
 
+#ifdef OHGPU_LEGACY_KERNELS
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
 {
     if (!b->fast.enabled || b->fast.n_work == 0) return hipSuccess;
@@ -637,6 +648,8 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
 #undef X
     return hipErrorInvalidValue;
 }
+
+#endif   // OHGPU_LEGACY_KERNELS
 
 #endif   // host code: part 1 (or the single translation unit)
 

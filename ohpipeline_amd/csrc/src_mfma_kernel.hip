@@ -1,5 +1,11 @@
 // src_mfma_kernel.hip -- round 4's resample -> ramp -> pack kernel for 24-bit stereo: the taps on the MATRIX pipe.
 //
+// RETIRED from the shipped library in round 5: src_mfma_wg_kernel.hip (a unit per WORKGROUP) serves every layout this kernel did,
+// edge units included.  The device kernel and its launcher are compiled only with -DOHGPU_LEGACY_KERNELS (OHGPU_LEGACY=1 python
+// ohpipeline_amd/build.py, or tools/build_variant.sh: the A/B reference, ohgpu_set_kernel_variant(ctx, 5)); what is compiled
+// always is the HOST half both matrix kernels share -- the coefficients' digit tables and step images (build_mfma_tables,
+// build_mfma_images, build_mfma_halfband) -- and this text, which is where the arithmetic is explained.
+//
 // Why.  The lean kernel (src_lean_kernel.hip) computes an output as 32 dependent v_fmac_f64 per lane; three rounds of work on
 // it ended at 0.37-0.40 of the HBM roofline with the per-output loop, not the memory system, as the bound.
 // The sums are exact integers, y = sum_k c[p][k] x[n0 - k] with Q28 coefficients and 24-bit samples, so they can be written in
@@ -79,6 +85,7 @@ __device__ __noinline__ u32x4 mf_load_piece_checked(const uint8_t* __restrict__ 
     return u32x4{w[0], w[1], w[2], w[3]};
 }
 
+#ifdef OHGPU_LEGACY_KERNELS                         // (the unit-per-wave kernel: retired from the shipped library in round 5, see the head of this file)
 template <bool SRC_LE, bool DST_LE>
 __global__ __launch_bounds__(OHGPU_MFMA_WAVES * 64)
 void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
@@ -425,6 +432,8 @@ void src_mfma_kernel(const LeanUnit* __restrict__ units, const uint32_t n_work,
     }
 }
 
+#endif   // OHGPU_LEGACY_KERNELS
+
 // ---- host: the tables ----
 // Balanced base-256 digits of a Q28 coefficient: c = e0 + e1 2^8 + e2 2^16 + e3 2^24, e0..e2 in [-128, 127].  False when the top
 // digit -- what is left after the three balanced ones -- is no int8: the coefficients from -(128 << 24) - 0x808080 to
@@ -560,6 +569,7 @@ void src_mfma_geometry(uint32_t* rows, uint32_t* wave_lds_bytes, uint32_t* max_w
     *max_waves = OHGPU_MFMA_WAVES;
 }
 
+#ifdef OHGPU_LEGACY_KERNELS
 template <bool SRC_LE, bool DST_LE>
 static hipError_t launch_mfma_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s, uint32_t first_unit)
 {
@@ -591,5 +601,7 @@ hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uin
     if (prm.src_le) return prm.dst_le ? launch_mfma_one<true, true>(ctx, b, prm, s, first_unit) : launch_mfma_one<true, false>(ctx, b, prm, s, first_unit);
     return prm.dst_le ? launch_mfma_one<false, true>(ctx, b, prm, s, first_unit) : launch_mfma_one<false, false>(ctx, b, prm, s, first_unit);
 }
+
+#endif   // OHGPU_LEGACY_KERNELS
 
 }  // namespace ohgpu

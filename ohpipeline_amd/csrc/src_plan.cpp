@@ -152,8 +152,15 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // a unit's input and output are each one contiguous run, and no unit whose 32-row input image leaves the arena.
     uint32_t mf_rows = 0, mf_wave_lds = 0, mf_max_waves = 0;
     src_mfma_geometry(&mf_rows, &mf_wave_lds, &mf_max_waves);
-    const bool mfma = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (L_blk >> 4) <= 16u &&      // (the kernel's bias table: one block's steps)
-                      mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
+    // (mf_layout: 24-bit stereo through the 32-tap tiling -- the layout the unit-per-wave kernel was written for and the workgroup
+    // kernel's first; `mfma`: that kernel itself is in this library, which since round 5 it is only in a legacy build)
+    const bool mf_layout = lean && !planar && src_mfma_supported(T, ch, sb, db) && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (L_blk >> 4) <= 16u &&      // (the kernel's bias table: one block's steps)
+                           mf_rows == rows && (M_blk + T) * fb_src < (1u << 24);
+#ifdef OHGPU_LEGACY_KERNELS
+    const bool mfma = mf_layout;
+#else
+    const bool mfma = false;
+#endif
     // (a planar source -- the FLAC decoder's planes -- is the workgroup kernel's too: its split reads the planes; the unit-per-wave
     // kernel has no such form, so with variants 3..5 a planar batch stays on the lean kernel)
     // (six and eight channels too: the same tiles over channel PAIRS, units of 64 / channels rows as the lean kernel's)
@@ -161,7 +168,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const bool wg_hb = flt->mf_halfband && T == 64 && !planar;
     const bool wg_tables = lean && flt->d_mf_amat != nullptr && flt->mf_L_blk == L_blk && (T == 32 || wg_hb) && rows == 64u / ch;
     const bool wg_wide = !planar && (ch > 2 || wg_hb || sb == 2) && (M_blk + T) * fb_src < (1u << 24);     // (and 16-bit stereo)
-    const bool mfma_wg = wg_tables && (planar || mfma || wg_wide) && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db, planar, wg_hb) &&
+    const bool mfma_wg = wg_tables && (planar || mf_layout || wg_wide) && src_mfma_wg_supported(L_blk, M_blk, ch, sb, db, planar, wg_hb) &&
                          !(ctx && (ctx->variant == 5 || ctx->variant == 3 || ctx->variant == 4 || ctx->variant == 2));
     if (wg_only && !mfma_wg) return OHGPU_OK;
     // The workgroup kernel walks a unit in passes of 16, 5 or 4 rows (WgGeom::kSR) and does not care how many a unit holds: six- and
@@ -569,7 +576,12 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     }
     // (segments, messages and one-block work units are round 1's kernel's: they go to the device only for a batch planned while
     // ohgpu_set_kernel_variant(2) is in force, or one the lean kernel cannot run -- 12 MB of the headline's plan, and most of the time its upload took)
+#ifdef OHGPU_LEGACY_KERNELS
     const bool round1 = block_ok && ((ctx && ctx->variant == 2) || !lean);      // (a filter the lean kernel's rounding does not hold runs on round 1's whatever the variant)
+#else
+    const bool round1 = false;                                                  // (round 1's kernel is not in this library: legacy builds only)
+    if (!lean) return OHGPU_OK;                                                 // (a filter beyond the lean kernel's rounding bound: the generic kernel's)
+#endif
     // (round 1's kernel, variant 2, keeps one-block units; ramped first, partly filled units last)
     if (round1)
         std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {

@@ -7,7 +7,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ohpipeline_amd", "csrc")
-FAMILIES = re.compile(r"\b(MF_(?:DIAG|WG|LOAD|STORE)_[A-Z0-9_]+|OHGPU_DIAG(?:_[A-Z0-9_]+)?|OHGPU_WG_ROWS|OHGPU_PLAN_TIMING|OHGPU_LINE_[A-Z_]*GROUPS_PER_CU)\b")
+FAMILIES = re.compile(r"\b(MF_(?:DIAG|WG|LOAD|STORE)_[A-Z0-9_]+|OHGPU_DIAG(?:_[A-Z0-9_]+)?|OHGPU_WG_ROWS|OHGPU_PLAN_TIMING|OHGPU_LINE_[A-Z_]*GROUPS_PER_CU|OHGPU_LEGACY_KERNELS)\b")
 
 
 def listed():

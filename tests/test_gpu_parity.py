@@ -701,10 +701,12 @@ def test_a_batch_created_under_one_variant_runs_under_every_other(ctx, created_u
         ctx.src_run(b1, d_src, d_dst)
         assert np.array_equal(ctx.download(d_dst, dbytes), want)
         ctx.batch_destroy(b1)
+        # (rounds 1's block kernel and round 4's unit-per-wave matrix kernel are retired from the shipped library: variants 2 and 5,
+        # like 3 and 4, run the lean kernel on a plan the workgroup kernel does not take)
         if created_under == 0:
-            assert names[0] == "src_mfma_wg_kernel" and names[5] == "src_mfma_kernel" and names[4] == "src_lean_kernel" and names[2] == "src_lean_kernel", names
-        if created_under == 2:
-            assert names[2] == "src_block_kernel" and names[4] == "src_lean_kernel", names
+            assert names[0] == "src_mfma_wg_kernel" and all(names[v] == "src_lean_kernel" for v in (2, 3, 4, 5)), names
+        else:
+            assert all(names[v] == "src_lean_kernel" for v in (0, 2, 3, 4, 5)), names
         ctx.batch_destroy(b)
     finally:
         ctx.set_kernel_variant(0)
