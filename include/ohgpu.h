@@ -387,16 +387,17 @@ int ohgpu_set_plan_threads(int threads);
  * coef_q28 (L * taps_per_phase of them) describes the filter as ohgpu_src_create would -- the half-band form, the matrix kernels'
  * tables, the gain bound -- so that the plan is the one a real batch gets; NULL stands for a polyphase filter of sane gain with
  * no special structure.  num_cus is the device's CU count (the long-unit schedule aims at one long unit per wave): 0 = 256.
- * `kernel` is set to the newest kernel the plan serves: 3 / 1 / 0 for src_mfma_wg_kernel / src_lean_kernel / none (2 = the retired
- * unit-per-wave matrix kernel, legacy builds only); which one runs is the run-time variant's choice among those. */
+ * `kernel` is set to the newest kernel the plan serves: 3 / 1 / 0 for src_mfma_wg_kernel / src_lean_kernel / round 1's fallback or
+ * none (2 = the retired unit-per-wave matrix kernel, legacy builds only); which one runs is the run-time variant's choice among those. */
 int ohgpu_src_plan_digest(uint32_t L, uint32_t M, uint32_t taps_per_phase, const ohgpu_src_msg_desc* descs, size_t n,
                           uint64_t src_arena_bytes, uint64_t dst_arena_bytes, int kernel_variant,
                           const int32_t* coef_q28, int num_cus,
                           uint64_t* digest, uint64_t* units, uint64_t* generic_pieces, int* kernel);
 
 /* Which kernel ohgpu_src_batch_run launches for the batch's whole phase-aligned blocks under the context's current kernel
- * variant: "src_mfma_wg_kernel", "src_lean_kernel" or "src_kernel_v1" (the generic one alone; a legacy build also knows
- * "src_mfma_kernel" and "src_block_kernel"); a batch of several layouts names its parts' kernels, comma separated.  A measurement's label (bench.py), nothing the
+ * variant: "src_mfma_wg_kernel", "src_lean_kernel", "src_block_kernel" (round 1's: the fallback for a filter whose phase sums reach
+ * 2^29, beyond the lean kernel's exact rounding -- five stereo layouts) or "src_kernel_v1" (the generic one alone; a legacy build
+ * also knows "src_mfma_kernel"); a batch of several layouts names its parts' kernels, comma separated.  A measurement's label (bench.py), nothing the
  * data path depends on.  The name is written to out[0, cap) NUL-terminated (truncated if it does not fit). */
 int ohgpu_src_batch_kernel_name(ohgpu_ctx* ctx, const ohgpu_batch* batch, char* out, size_t cap);
 
@@ -417,9 +418,10 @@ int ohgpu_device_allocations(ohgpu_ctx* ctx, uint64_t* count);
  * long-row unit schedule forced onto batches of any size (a resampled batch created while 3 is set cuts every run of plain units
  * into rows of three blocks -- what only a batch of thousands of units gets otherwise -- so that tests reach that path with small
  * inputs; results are identical); 4 = round 2's fp64 "lean" block kernel where round 4's matrix-pipe kernel would run, for A/B.
- * 2 and 5 select round 1's block kernel and round 4's unit-per-wave matrix kernel, which are RETIRED from the shipped library
- * (round 5): only a legacy build has them (OHGPU_LEGACY=1 python ohpipeline_amd/build.py); in the shipped library both values
- * behave as 4.  Variants 2..5 shape the plan of batches created while they are set; the variant in force when a batch is RUN
+ * 2 and 5 select round 1's block kernel and round 4's unit-per-wave matrix kernel, which are RETIRED as selectable kernels
+ * (round 5): only a legacy build takes the two values (OHGPU_LEGACY=1 python ohpipeline_amd/build.py); in the shipped library both
+ * behave as 4.  (Round 1's kernel stays in the shipped library for five stereo layouts as the fallback for filters beyond the
+ * lean kernel's rounding bound, whatever the variant.)  Variants 2..5 shape the plan of batches created while they are set; the variant in force when a batch is RUN
  * chooses among the kernels its plan serves (ohgpu_src_batch_kernel_name says which).  A batch planned for the workgroup kernel
  * alone (six and eight channels, the layouts only it has) is REFUSED under any other variant (OHGPU_ERR_UNSUPPORTED, nothing is
  * launched): create it under the variant it is to run under. */

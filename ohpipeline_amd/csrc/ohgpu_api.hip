@@ -1293,7 +1293,8 @@ static SrcKernel src_kernel_choice(const ohgpu_ctx* ctx, const ohgpu_batch* b, b
     if (b->fast.lean && (v != 2 || b->fast.lean_only || !b->fast.d_work)) return kSrcLean;   // round 2's, under every variant but 2 -- and under 2 where round 1's has no layout or no tables
     if (b->fast.d_work) return kSrcBlock;                                                  // round 1's (variant 2; a filter beyond the lean kernel's rounding bound under any)
 #else
-    if (b->fast.lean) return kSrcLean;                                                     // round 2's, under every other variant (rounds 1's and 4's unit-per-wave kernels: legacy builds)
+    if (b->fast.lean) return kSrcLean;                                                     // round 2's, under every other variant (rounds 1's and 4's unit-per-wave kernels as variants: legacy builds)
+    if (b->fast.d_work) return kSrcBlock;                                                  // round 1's: the fallback for a filter beyond the lean kernel's rounding bound
 #endif
     return kSrcGeneric;
 }
@@ -1395,8 +1396,8 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         case kSrcWg: OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
 #ifdef OHGPU_LEGACY_KERNELS
         case kSrcMfma: OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
-        case kSrcBlock: OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
 #endif
+        case kSrcBlock: OHGPU_HIP_TRY(launch_src_block(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
         default: OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
         }
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));

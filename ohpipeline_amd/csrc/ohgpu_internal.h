@@ -137,8 +137,7 @@ struct SrcFastPlan {
     bool     wg_only = false;     // ... or no block kernel but src_mfma_wg_kernel has one: any variant that asks for another kernel gets the generic one
     uint32_t lean_coef_lds_bytes = 0, lean_wave_lds_bytes = 0, lean_max_waves = 0;
     bool     mfma = false;        // ... and its layout is one src_mfma_kernel (round 4) serves: same units and planes, the filter's digit tables
-    uint32_t n_wg = 0;            // mfma_wg: lean units [0, n_wg) are src_mfma_wg_kernel's, [n_wg, n_lean) the edge units src_mfma_kernel runs
-    bool     mfma_wg = false;     // ... as src_mfma_wg_kernel cuts them: one unit per workgroup (rows of ONE block; units that leave the arena are the generic kernel's)
+    bool     mfma_wg = false;     // ... as src_mfma_wg_kernel cuts them: one unit per workgroup (rows of ONE block; the units whose input image leaves the arena -- kWorkEdge, in front of the list -- run on it too, through its checked loads)
     bool     mfma_wg_halfband = false;   // ... in its half-band form (the filter's tables are build_mfma_halfband's)
     uint32_t wg_unit_rows = 0;    // ... and the rows its units were cut to (WgGeom::kUnitRows: the launch checks)
     const void* d_mf_amat = nullptr;   // (owned by the ohgpu_src)
@@ -453,7 +452,7 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
                          const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
-hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit = 0);   // csrc/src_mfma_kernel.hip (units [first_unit, n_lean))
+hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit = 0);   // csrc/src_mfma_kernel.hip, legacy builds only (units [first_unit, n_lean))
 hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_wg_kernel.hip
 bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar, bool halfband);
 bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, uint32_t sb, uint32_t unit_rows, bool planar, uint64_t plane_stride, bool halfband);
@@ -470,6 +469,7 @@ bool src_lean_geometry(uint32_t L, uint32_t T, bool halfband, uint32_t ch, uint3
                        uint32_t* rows, uint32_t* in_blocks, uint32_t* stage_frames, uint32_t* ring_bytes, uint32_t* coef_lds_bytes,
                        uint32_t* wave_lds_bytes, uint32_t* max_waves);
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
+bool src_block_built(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);   // ... and round 1's kernel itself is in this library for the layout (the fallback list; a legacy build: the whole list)
 bool src_lean_only_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_lean_halfband_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le);
 bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32_t db, uint32_t out_per_drain,

@@ -64,7 +64,7 @@ static constexpr int lean_in_blocks_planar(int ch) { return ((lean_stage_frames(
 enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output range
        kWorkChecked = 2u,     // some staging piece of the unit lies outside the source arena (ends of the arena)
        kWorkFirst = 4u,       // LeanUnit only: row 0 is its stream's block 0 (the frames before it read as zeros)
-       kWorkEdge = 8u };      // LeanUnit of a src_mfma_wg_kernel plan: the unit's 32-row input image leaves the arena -- src_mfma_kernel runs it
+       kWorkEdge = 8u };      // LeanUnit of a src_mfma_wg_kernel plan: the unit's 32-row input image leaves the arena -- that kernel fetches its pieces through its checked, out-of-line load
 
 }  // namespace ohgpu
 
@@ -101,6 +101,16 @@ enum { kWorkRamped = 1u,      // a ramped message overlaps the unit's output ran
     X(32, 2, 2, false, 2, false)
 #endif
 #define OHGPU_BLOCK_KERNELS(X) OHGPU_BLOCK_KERNELS_1(X) OHGPU_BLOCK_KERNELS_2(X) OHGPU_BLOCK_KERNELS_3(X)
+// Round 1's block kernel in the SHIPPED library (round 5: retired as a selectable variant, legacy builds have the whole list above):
+// only as the fallback for a filter whose phase sums reach 2^29 -- beyond the lean kernel's rounding bias, which is what keeps its
+// fp64 sums exact -- and only for the stereo layouts such a filter is likely to meet.  ohgpu_src_design's own 48 -> 44.1 kHz and
+// 32 -> 48 kHz filters are such filters (sum|c| = 2.02 and 2.40 x 2^28); without these they would run on the generic kernel.
+#define OHGPU_BLOCK_FALLBACK_KERNELS(X) \
+    X(32, 2, 3, true, 3, false)         \
+    X(32, 2, 3, true, 3, true)          \
+    X(32, 2, 3, false, 3, false)        \
+    X(32, 2, 2, true, 3, false)         \
+    X(32, 2, 2, false, 3, false)
 // the lean kernel's planar-source instantiations (source bytes 0 = the TInt32 planes of OHGPU_FLAG_SRC_PLANAR32), compiled with part 3
 #ifdef OHGPU_DIAG_ONE_KERNEL
 #define OHGPU_LEAN_PLANAR_KERNELS(X)

@@ -1,10 +1,12 @@
 // src_block_kernel.hip -- round 1's resample -> ramp -> pack kernel ("block kernel").  Since round 2 the batches run on
-// src_lean_kernel.hip, since round 4 on src_mfma_wg_kernel.hip; RETIRED from the shipped library in round 5: the kernel, its
-// instantiations and its launcher are compiled only with -DOHGPU_LEGACY_KERNELS (OHGPU_LEGACY=1 python ohpipeline_amd/build.py, or
-// tools/build_variant.sh: the same-box A/B reference, ohgpu_set_kernel_variant(ctx, 2)).  What the planner still takes from this
-// file is compiled always: which layouts the block kernels' main list holds (src_block_supported) and the rows / ring geometry the
-// lean kernel shares with it (src_block_geometry).  A filter whose phase sums break the lean kernel's rounding bias (sum|c| >= 2^29)
-// runs on the generic kernel in the shipped library.
+// src_lean_kernel.hip, since round 4 on src_mfma_wg_kernel.hip.  RETIRED as a selectable kernel in round 5: its nineteen
+// instantiations and ohgpu_set_kernel_variant(ctx, 2) exist only in a legacy build (-DOHGPU_LEGACY_KERNELS: OHGPU_LEGACY=1 python
+// ohpipeline_amd/build.py, or tools/build_variant.sh -- the same-box A/B reference).  What the shipped library keeps of it:
+//   * the FALLBACK for filters whose phase sums break the lean kernel's rounding bias (sum|c| >= 2^29: this kernel rounds by
+//     add-floor-convert and is exact up to the design's own bound of 2^30) -- five stereo instantiations
+//     (OHGPU_BLOCK_FALLBACK_KERNELS), one translation unit.  ohgpu_src_design's 48 -> 44.1 kHz and 32 -> 48 kHz filters are such;
+//   * what the planner takes from this file: which layouts the block kernels' main list holds (src_block_supported) and the rows /
+//     ring geometry the lean kernel shares with it (src_block_geometry).
 //
 // Mapping (DESIGN.md "Resampler kernel"):
 //   * A stream's output is cut into BLOCKS of L_blk frames that start where the polyphase phase is 0
@@ -136,7 +138,6 @@ struct BlockGeom {
     static constexpr int MSG_SLOTS = 32;                // messages of a wave's output range kept in LDS
 };
 
-#ifdef OHGPU_LEGACY_KERNELS
 template <int T, int CH, int SB, bool SRC_LE, int DB, bool DST_LE>
 __global__ __launch_bounds__((BlockGeom<T, CH>::MAX_WAVES * 64))
 void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict__ msgs, const SrcWork* __restrict__ work,
@@ -553,6 +554,7 @@ void src_block_kernel(const SrcSeg* __restrict__ segs, const SegMsg* __restrict_
 // The list is compiled in parts so that the build can run them side by side (ohpipeline_amd/build.py compiles this file
 // once per part with -DOHGPU_BLOCK_PART=k): part 1 also holds the host code and only DECLARES the other parts' kernels;
 // parts 2.. hold nothing but their kernels.  Without the macro (tools, tests) the file is one translation unit.
+#ifdef OHGPU_LEGACY_KERNELS
 #define OHGPU_KERNEL_ARGS const SrcSeg*, const SegMsg*, const SrcWork*, uint32_t, const double*, const uint16_t*, const uint8_t*, \
                           uint8_t*, uint64_t, int, int, uint32_t, uint32_t, uint32_t, uint32_t*
 #define X_DEFINE(t, c, s_, sl, d, dl) template __global__ void src_block_kernel<t, c, s_, sl, d, dl>(OHGPU_KERNEL_ARGS);
@@ -566,10 +568,9 @@ OHGPU_BLOCK_KERNELS_2(X_DECLARE)
 OHGPU_BLOCK_KERNELS_3(X_DECLARE)
 #endif
 
-#endif   // OHGPU_LEGACY_KERNELS
+#endif   // OHGPU_LEGACY_KERNELS (the shipped library: one translation unit, the fallback list's kernels instantiated by their launches below)
 
 #if !defined(OHGPU_BLOCK_PART) || OHGPU_BLOCK_PART == 1
-#ifdef OHGPU_LEGACY_KERNELS
 // Launch shape: up to MAX_WAVES waves per workgroup (what the LDS left by the coefficient table allows), one
 // workgroup per CU, waves loop over the work units; a small batch is spread as one-wave workgroups instead.
 static void launch_shape(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32_t* grid, uint32_t* waves, uint32_t* lds)
@@ -598,8 +599,6 @@ static hipError_t launch_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const S
                        (uint32_t*)b->fast.d_counter);
     return hipGetLastError();
 }
-
-#endif   // OHGPU_LEGACY_KERNELS
 
 bool src_block_supported(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le)
 {
@@ -632,7 +631,22 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
     return true;
 }
 
+// the kernels THIS library has: the whole list in a legacy build, the fallback list otherwise
 #ifdef OHGPU_LEGACY_KERNELS
+#define OHGPU_BLOCK_BUILT(X) OHGPU_BLOCK_KERNELS(X)
+#else
+#define OHGPU_BLOCK_BUILT(X) OHGPU_BLOCK_FALLBACK_KERNELS(X)
+#endif
+
+bool src_block_built(uint32_t T, uint32_t ch, uint32_t sb, uint32_t src_le, uint32_t db, uint32_t dst_le)
+{
+#define X(t, c, s_, sl, d, dl) \
+    if (T == t && ch == c && sb == s_ && (src_le != 0) == sl && db == d && (dst_le != 0) == dl) return true;
+    OHGPU_BLOCK_BUILT(X)
+#undef X
+    return false;
+}
+
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
 {
     if (!b->fast.enabled || b->fast.n_work == 0) return hipSuccess;
@@ -644,12 +658,10 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
 #define X(t, c, s_, sl, d, dl)                                                                                            \
     if (T == t && prm.channels == c && prm.sb == s_ && (prm.src_le != 0) == sl && prm.db == d && (prm.dst_le != 0) == dl) \
         return launch_one<t, c, s_, sl, d, dl>(ctx, b, prm, s);
-    OHGPU_BLOCK_KERNELS(X)
+    OHGPU_BLOCK_BUILT(X)
 #undef X
     return hipErrorInvalidValue;
 }
-
-#endif   // OHGPU_LEGACY_KERNELS
 
 #endif   // host code: part 1 (or the single translation unit)
 

@@ -576,12 +576,16 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     }
     // (segments, messages and one-block work units are round 1's kernel's: they go to the device only for a batch planned while
     // ohgpu_set_kernel_variant(2) is in force, or one the lean kernel cannot run -- 12 MB of the headline's plan, and most of the time its upload took)
+    // (a filter the lean kernel's rounding does not hold -- sum|c| >= 2^29 -- runs on round 1's whatever the variant, where this
+    // library has that kernel for the layout: five stereo layouts in the shipped library, the whole list in a legacy build, which
+    // also takes it under variant 2)
+    const bool round1_built = block_ok && src_block_built(T, ch, sb, src_le, db, dst_le);
 #ifdef OHGPU_LEGACY_KERNELS
-    const bool round1 = block_ok && ((ctx && ctx->variant == 2) || !lean);      // (a filter the lean kernel's rounding does not hold runs on round 1's whatever the variant)
+    const bool round1 = round1_built && ((ctx && ctx->variant == 2) || !lean);
 #else
-    const bool round1 = false;                                                  // (round 1's kernel is not in this library: legacy builds only)
-    if (!lean) return OHGPU_OK;                                                 // (a filter beyond the lean kernel's rounding bound: the generic kernel's)
+    const bool round1 = round1_built && !lean;
 #endif
+    if (!lean && !round1) return OHGPU_OK;                                      // (neither block kernel can take it: the generic kernel's batch)
     // (round 1's kernel, variant 2, keeps one-block units; ramped first, partly filled units last)
     if (round1)
         std::stable_sort(work.begin(), work.end(), [](const SrcWork& x, const SrcWork& y) {
@@ -695,8 +699,6 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     f.mfma_wg = mfma_wg;
     f.mfma_wg_halfband = mfma_wg && wg_hb;
     f.wg_unit_rows = mfma_wg ? rows : 0u;
-    f.n_wg = 0;
-    if (mfma_wg) for (const LeanUnit& u : lean_units) f.n_wg += (u.flags & kWorkEdge) ? 0u : 1u;
     f.d_mf_amat = (mfma || mfma_wg) ? flt->d_mf_amat : nullptr;
     f.d_mf_steps = (mfma || mfma_wg) ? flt->d_mf_steps : nullptr;
     f.fast_out_frames = fast_frames;

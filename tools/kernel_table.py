@@ -63,6 +63,12 @@ def main():
     print("| `src_mfma_wg_kernel<16, 1..3, 1, false, ..>` | `TInt32` planes (24-, 16-, 8-bit samples) | 2 | S24 LE or BE | 32 taps per phase (as above) | the default |")
     for r in rows:
         print(r)
+    text = open(os.path.join(ROOT, "ohpipeline_amd", "csrc", "src_block_common.h")).read()
+    body = text[text.index("#define OHGPU_BLOCK_FALLBACK_KERNELS(X)"):]
+    body = body[:body.index("\n#", 1) if "\n#" in body[1:] else len(body)]
+    for m in re.finditer(r"X\((\d+), (\d+), (\d+), (true|false), (\d+), (true|false)\)", body.split("\n\n")[0]):
+        t, ch, sb, sle, db, dle = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4) == "true", int(m.group(5)), m.group(6) == "true"
+        print(f"| `src_block_kernel<{t}, {ch}, {sb}, {'LE' if sle else 'BE'}, {db}, {'LE' if dle else 'BE'}>` (round 1's) | {fmt(sb, sle)} | {ch} | {fmt(db, dle)} | {t} taps per phase with a phase whose sum of magnitudes reaches 2^29 (`ohgpu_src_design`'s 48 -> 44.1 kHz and 32 -> 48 kHz filters: 2.02 and 2.40 x 2^28) | the fallback: beyond the lean kernel's exact rounding, under any variant |")
     print("| `src_kernel_v1` (generic) | any | 1-8 | any | any | everything else, block-unaligned stream ends, and any batch created under variant 1 |")
 
 
