@@ -108,6 +108,8 @@ def build(force=False, verbose=False, save_temps=False):
                 for part in (range(1, BLOCK_PARTS + 1) if os.path.basename(src) in PARTED else (0,))]
         jobs.sort(key=lambda j: 0 if j[1] else 1)                # the long ones first
         objs = list(ex.map(compile_one, jobs))
+    with open(os.path.join(obj_dir, "linked.txt"), "w") as f:         # (what THIS library is made of: tools/build_variant.sh swaps objects in this list)
+        f.write("\n".join(objs) + "\n")
     link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(link), file=sys.stderr)

@@ -71,11 +71,25 @@ __device__ __forceinline__ void mf_split_frames(const uint32_t (&lo)[8], const u
 // T0 and the low 12 of U cannot carry into bit 28.  The rounding 2^27 rides in the accumulators' initial values.
 __device__ __forceinline__ int mf_recombine(int s0, int s1, int s2, int s3, int s4, int s5)
 {
+#ifndef MF_RECOMBINE_PLAIN
+    // (the two "+ (x >> 16)" as ONE instruction each: an SDWA add whose second source is the sign-extended high word of x -- eight
+    // instructions an output instead of the ten the compiler makes of the C below it (shift, three-operand add): 0.3081 -> 0.3022 ms on
+    // the headline, same box, three alternating pairs, round 5.  The vector pipe's instruction count is what the tiles' phase is made of)
+    const int t0 = (int)(((uint32_t)s1 << 8) + (uint32_t)s0);
+    const int t1 = (int)(((uint32_t)s3 << 8) + (uint32_t)s2);
+    const int t2 = (int)(((uint32_t)s5 << 8) + (uint32_t)s4);
+    int u, w;
+    asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(u) : "v"(t1), "v"(t0));
+    asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(w) : "v"(t2), "v"(u));
+    const int yy2 = (int)(((uint32_t)w << 4) | (((uint32_t)u >> 12) & 15u));
+    return yy2 < -8388608 ? -8388608 : (yy2 > 8388607 ? 8388607 : yy2);
+#else
     const int t0 = (int)(((uint32_t)s1 << 8) + (uint32_t)s0);
     const int u = (int)(((uint32_t)s3 << 8) + (uint32_t)s2) + (t0 >> 16);
     const int w = (int)(((uint32_t)s5 << 8) + (uint32_t)s4) + (u >> 16);
     const int yy = (int)(((uint32_t)w << 4) | (((uint32_t)u >> 12) & 15u));
     return yy < -8388608 ? -8388608 : (yy > 8388607 ? 8388607 : yy);
+#endif
 }
 
 }  // namespace ohgpu

@@ -571,6 +571,23 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                 if constexpr (HB) { s0 = hb_s0; s2 = hb_s2; }
                 else { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + 256); }
                 const v4i (&c)[4] = a[HB ? 0 : set];
+#ifdef MF_WG_BIAS_LATE
+                // (the four products whose accumulators start at zero first: 64 cycles of matrix work between the reads of the two
+                // accumulators' initial values -- issued just above -- and the first instruction that needs one)
+                s1 = MF_MFMA(bd[0], c[1], s1);
+                s3 = MF_MFMA(bd[0], c[3], s3);
+                s4 = MF_MFMA(bd[1], c[3], s4);
+                s5 = MF_MFMA(bd[2], c[3], s5);
+                __builtin_amdgcn_sched_barrier(0);
+                s0 = MF_MFMA(bd[0], c[0], s0);
+                s2 = MF_MFMA(bd[0], c[2], s2);
+                s1 = MF_MFMA(bd[1], c[0], s1);
+                s2 = MF_MFMA(bd[1], c[1], s2);
+                s3 = MF_MFMA(bd[1], c[2], s3);
+                s2 = MF_MFMA(bd[2], c[0], s2);
+                s3 = MF_MFMA(bd[2], c[1], s3);
+                s4 = MF_MFMA(bd[2], c[2], s4);
+#else
                 s0 = MF_MFMA(bd[0], c[0], s0);
                 s1 = MF_MFMA(bd[0], c[1], s1);
                 s2 = MF_MFMA(bd[0], c[2], s2);
@@ -583,6 +600,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                 s3 = MF_MFMA(bd[2], c[1], s3);
                 s4 = MF_MFMA(bd[2], c[2], s4);
                 s5 = MF_MFMA(bd[2], c[3], s5);
+#endif
                 if constexpr (i + 1 < G::kTilesPerWave) {
                     // the next tile's planes, while this one's matrix instructions run
                     constexpr uint32_t set_n = (kFirst + i + 1) / G::kCt - kFirst / G::kCt, ct_n = (kFirst + i + 1) % G::kCt;

@@ -20,7 +20,7 @@ for f in $SRCS; do
   excl="$excl -e /$f\\."
   extra="$extra /tmp/variant_$TAG/$f.o"
 done
-BT=$(ls -t $OBJ/ohgpu_api.hip.*.o | head -1 | sed 's/.*ohgpu_api\.hip\.\([0-9a-f]*\)\..*/\1/')
-objs=$(ls $OBJ/*.$BT.*.o | grep -v $excl)
+[ -f $OBJ/linked.txt ] || python3 ohpipeline_amd/build.py --force > /dev/null      # (the list of objects the tree's library is linked from)
+objs=$(grep -v $excl $OBJ/linked.txt)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ohpipeline_amd/lib/variants/libohgpu.$TAG.so $objs $extra
 ls -la ohpipeline_amd/lib/variants/libohgpu.$TAG.so
