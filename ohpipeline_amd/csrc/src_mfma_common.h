@@ -30,6 +30,26 @@ __device__ __forceinline__ uint32_t mf_here(uint32_t x) { asm volatile("" : "+v"
 
 __device__ __forceinline__ uint32_t mf_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
+// Lanes 2 k and 2 k + 1 each hold two pairs of values, (y0, y1) and (y2, y3): the even lane ends with both lanes' (y0, y1), its own
+// first, the odd lane with both lanes' (y2, y3), the even lane's first -- four v_cndmask_b32_dpp, the neighbour's value read through
+// the select's DPP operand (quad_perm [0, 0, 2, 2]: the even lane's; [1, 1, 3, 3]: the odd lane's).  Written out: the compiler makes a
+// copy, a v_mov_b32_dpp and a select of each.  EXEC must be all ones (the tiles' phase); the s_nop is the two wait states a DPP read
+// needs behind the vector instruction that wrote its register.
+__device__ __forceinline__ void mf_pair_gather(int y0, int y1, int y2, int y3, uint32_t& f0, uint32_t& f1, uint32_t& f2, uint32_t& f3)
+{
+    const uint64_t even = 0x5555555555555555ull;
+    asm("s_nop 1\n\t"
+        "s_mov_b64 vcc, %8\n\t"
+        "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"      // even ? y0 : the even lane's y2
+        "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"      // odd ? y2 : the odd lane's y0
+        "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
+        : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)
+        : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "s"(even)
+        : "vcc", "scc");
+}
+
 // 48 bytes = 8 frames x {L, R} x 3 bytes (twelve dwords as they lie in memory) -> six planes of 8 bytes: pl[3 * channel + byte
 // position in the sample][two dwords of four frames each].  A two-level v_perm_b32 network, two permutes per plane dword.
 __device__ __forceinline__ void mf_split48(const uint32_t (&w)[12], uint32_t (&pl)[6][2])

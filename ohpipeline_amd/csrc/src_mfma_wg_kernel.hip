@@ -140,6 +140,11 @@ constexpr bool kDiagSplitGeneric = true;            // (timing experiments: ster
 #else
 constexpr bool kDiagSplitGeneric = false;
 #endif
+#ifdef MF_WG_OUT_B16
+constexpr bool kWideOut = false;                    // (A/B: round 4's epilogue, six 2-byte LDS stores per tile for every layout)
+#else
+constexpr bool kWideOut = true;                     // stereo and eight channels: a lane's twelve output bytes of a tile in two LDS stores
+#endif
 #ifdef MF_WG_LATE_LOADS
 constexpr bool kLateLoads = true;                   // (A/B: the next unit's loads issued behind the split, as in round 4)
 #else
@@ -256,6 +261,13 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;       // byte of the 24-bit value that is memory byte 0, 1, 2
     constexpr uint32_t sel_lo = kB0 | kB1 << 8 | kB2 << 16 | (4 + kB0) << 24;     // {R, L} -> L's three bytes, R's first
     constexpr uint32_t sel_hi = (4 + kB1) | (4 + kB2) << 8 | 0x0c0c0000u;          // {R, L} -> R's other two
+    // ... and twelve bytes from FOUR values {a, b, c, d} (kWideOut): dword 0 = sel_lo of {b, a}, dword 1 = b's other two bytes and c's
+    // first two, dword 2 = c's last and d's three
+    constexpr uint32_t sel_mid = kB1 | kB2 << 8 | (4 + kB0) << 16 | (4 + kB1) << 24;
+    constexpr uint32_t sel_top = kB2 | (4 + kB0) << 8 | (4 + kB1) << 16 | (4 + kB2) << 24;
+    const bool n_odd = (n & 1u) != 0;
+    // (kWideOut, stereo: the lane's twelve bytes -- the even lane's in row 2 g from its own frame on, the odd lane's in row 2 g + 1 from its even neighbour's frame on)
+    const uint32_t wide_off = n_odd ? G::kRowOutPitch - G::kFb : 0u;
 
     // a workgroup unit = sub-unit `u % kSubUnits` of planner unit `u / kSubUnits`
     struct Unit { int64_t src0, dst0; uint32_t n_blocks, plane, plane_stride; bool ramped, first, edge; };
@@ -626,8 +638,26 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                         y[v] = mu[v >> 1] != 0xffffu ? r : y[v];
                     }
                 }
-                // pack: two permutes and three 16-bit stores per frame into the output image (a frame starts on an even byte)
                 uint8_t* const os = out_lds + ct * ((8u / (uint32_t)(PAIRS == 3 ? 1 : PAIRS)) * G::kRowOutPitch) + 16u * G::kFb * step;
+                if constexpr (kWideOut && PAIRS == 1) {
+                    // Stereo: TWELVE contiguous bytes per lane instead of two frames of six in two rows.  Lanes n and n + 1 (n even) hold
+                    // frames n and n + 1 of pair-rows 2 g and 2 g + 1; the even lane takes both frames of row 2 g, the odd lane both of row
+                    // 2 g + 1 -- four selects with the neighbour's value as their DPP operand (mf_pair_gather) -- and 6 n is a multiple of four for even n: three
+                    // permutes, one ds_write2_b32 and one ds_write_b32 (10 cycles of the path to the LDS, MI355X_MICROARCH.md) where the six
+                    // 2-byte stores took 24.
+                    uint32_t f0, f1, f2, f3;
+                    mf_pair_gather(y[0], y[1], y[2], y[3], f0, f1, f2, f3);
+                    const uint32_t w0 = mf_perm(f1, f0, sel_lo), w1 = mf_perm(f2, f1, sel_mid), w2 = mf_perm(f3, f2, sel_top);
+                    const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)(os + wide_off);
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write_b32 %0, %3 offset:8" : : "v"(at), "v"(w0), "v"(w1), "v"(w2) : "memory");
+                } else if constexpr (kWideOut && PAIRS == 4) {
+                    // Eight channels: pair-rows 2 g and 2 g + 1 are neighbouring pairs of ONE frame -- the lane's four values are twelve
+                    // contiguous bytes at a multiple of four as they stand
+                    const uint32_t w0 = mf_perm((uint32_t)y[1], (uint32_t)y[0], sel_lo), w1 = mf_perm((uint32_t)y[2], (uint32_t)y[1], sel_mid), w2 = mf_perm((uint32_t)y[3], (uint32_t)y[2], sel_top);
+                    const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)os;
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write_b32 %0, %3 offset:8" : : "v"(at), "v"(w0), "v"(w1), "v"(w2) : "memory");
+                } else {
+                // pack: two permutes and three 16-bit stores per frame into the output image (a frame starts on an even byte)
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const uint32_t lo = mf_perm((uint32_t)y[2 * q + 1], (uint32_t)y[2 * q], sel_lo);
@@ -643,6 +673,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     }
                     asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:2\n\tds_write_b16 %0, %2 offset:4"
                                  : : "v"(at), "v"(lo), "v"(hi) : "memory");
+                }
                 }
             }, std::make_integer_sequence<int, (int)G::kTilesPerWave>{});
         };
