@@ -112,4 +112,22 @@ __device__ __forceinline__ int mf_recombine(int s0, int s1, int s2, int s3, int 
 #endif
 }
 
+// ... the same in two parts (the workgroup kernel's pipeline of tiles): U from the first four accumulators, y from U and the last two
+__device__ __forceinline__ int mf_recombine_head(int s0, int s1, int s2, int s3)
+{
+    const int t0 = (int)(((uint32_t)s1 << 8) + (uint32_t)s0);
+    const int t1 = (int)(((uint32_t)s3 << 8) + (uint32_t)s2);
+    int u;
+    asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(u) : "v"(t1), "v"(t0));
+    return u;
+}
+__device__ __forceinline__ int mf_recombine_tail(int u, int s4, int s5)
+{
+    const int t2 = (int)(((uint32_t)s5 << 8) + (uint32_t)s4);
+    int w;
+    asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(w) : "v"(t2), "v"(u));
+    const int yy = (int)(((uint32_t)w << 4) | (((uint32_t)u >> 12) & 15u));
+    return yy < -8388608 ? -8388608 : (yy > 8388607 ? 8388607 : yy);
+}
+
 }  // namespace ohgpu

@@ -145,6 +145,22 @@ constexpr bool kWideOut = false;                    // (A/B: round 4's epilogue,
 #else
 constexpr bool kWideOut = true;                     // stereo and eight channels: a lane's twelve output bytes of a tile in two LDS stores
 #endif
+#ifdef MF_WG_NO_PIPE
+constexpr bool kPipe = false;                       // (A/B: a tile's matrix instructions, then its vector instructions, tile by tile)
+#else
+constexpr bool kPipe = true;                        // a tile's last vector instructions between the next tile's matrix instructions
+#endif
+// wave priorities by phase: the tiles (C), the output's stores and the next input's staging and loads (D, A), the split (S)
+#ifndef MF_WG_PRIO_C
+#define MF_WG_PRIO_C 3
+#endif
+#ifndef MF_WG_PRIO_D
+#define MF_WG_PRIO_D 0
+#endif
+#ifndef MF_WG_PRIO_S
+#define MF_WG_PRIO_S MF_WG_PRIO_D
+#endif
+constexpr int kPrioC = MF_WG_PRIO_C, kPrioD = MF_WG_PRIO_D, kPrioS = MF_WG_PRIO_S;
 #ifdef MF_WG_LATE_LOADS
 constexpr bool kLateLoads = true;                   // (A/B: the next unit's loads issued behind the split, as in round 4)
 #else
@@ -569,58 +585,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             constexpr uint32_t P = decltype(pattern_c)::value;
             constexpr bool RAMPED = decltype(ramped_c)::value;
             constexpr uint32_t kFirst = G::kTilesPerWave * P;           // the pattern's first tile, counted from a multiple of kTilesPerWave steps
-            u32x2 h[6];
-            issue_planes(kc[0], kFirst % G::kCt, h);
-            static_for([&](auto ic) __attribute__((always_inline)) {
-                constexpr uint32_t i = decltype(ic)::value;
-                v4i bd[3];
-                take_planes(h, bd);
-                constexpr uint32_t set = (kFirst + i) / G::kCt - kFirst / G::kCt, ct = (kFirst + i) % G::kCt;
-                static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
-                const uint32_t step = step0 + set;
-                const uint8_t* const bi = my_bias + step * G::kBiasStep;
-                v4i s0, s1 = v4i{0, 0, 0, 0}, s2, s3 = v4i{0, 0, 0, 0}, s4 = v4i{0, 0, 0, 0}, s5 = v4i{0, 0, 0, 0};
-                if constexpr (HB) { s0 = hb_s0; s2 = hb_s2; }
-                else { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + 256); }
-                const v4i (&c)[4] = a[HB ? 0 : set];
-#ifdef MF_WG_BIAS_LATE
-                // (the four products whose accumulators start at zero first: 64 cycles of matrix work between the reads of the two
-                // accumulators' initial values -- issued just above -- and the first instruction that needs one)
-                s1 = MF_MFMA(bd[0], c[1], s1);
-                s3 = MF_MFMA(bd[0], c[3], s3);
-                s4 = MF_MFMA(bd[1], c[3], s4);
-                s5 = MF_MFMA(bd[2], c[3], s5);
-                __builtin_amdgcn_sched_barrier(0);
-                s0 = MF_MFMA(bd[0], c[0], s0);
-                s2 = MF_MFMA(bd[0], c[2], s2);
-                s1 = MF_MFMA(bd[1], c[0], s1);
-                s2 = MF_MFMA(bd[1], c[1], s2);
-                s3 = MF_MFMA(bd[1], c[2], s3);
-                s2 = MF_MFMA(bd[2], c[0], s2);
-                s3 = MF_MFMA(bd[2], c[1], s3);
-                s4 = MF_MFMA(bd[2], c[2], s4);
-#else
-                s0 = MF_MFMA(bd[0], c[0], s0);
-                s1 = MF_MFMA(bd[0], c[1], s1);
-                s2 = MF_MFMA(bd[0], c[2], s2);
-                s3 = MF_MFMA(bd[0], c[3], s3);
-                s1 = MF_MFMA(bd[1], c[0], s1);
-                s2 = MF_MFMA(bd[1], c[1], s2);
-                s3 = MF_MFMA(bd[1], c[2], s3);
-                s4 = MF_MFMA(bd[1], c[3], s4);
-                s2 = MF_MFMA(bd[2], c[0], s2);
-                s3 = MF_MFMA(bd[2], c[1], s3);
-                s4 = MF_MFMA(bd[2], c[2], s4);
-                s5 = MF_MFMA(bd[2], c[3], s5);
-#endif
-                if constexpr (i + 1 < G::kTilesPerWave) {
-                    // the next tile's planes, while this one's matrix instructions run
-                    constexpr uint32_t set_n = (kFirst + i + 1) / G::kCt - kFirst / G::kCt, ct_n = (kFirst + i + 1) % G::kCt;
-                    issue_planes(kc[set_n], ct_n, h);
-                }
-                int y[4];
-#pragma unroll
-                for (int v = 0; v < 4; v++) y[v] = mf_recombine(s0[v], s1[v], s2[v], s3[v], s4[v], s5[v]);
+            // a tile's results from its four outputs y: the ramp, the pack, the stores into the output image
+            auto finish_tile = [&](auto step_set_c, auto ct_c, int (&y)[4]) __attribute__((always_inline)) {
+                constexpr uint32_t ct = decltype(ct_c)::value;
+                const uint32_t step = step0 + (uint32_t)decltype(step_set_c)::value;
                 if constexpr (RAMPED) {
                     // RampApplicator::GetNextSample on the 24-bit value (Msg.cpp:840-895): top 16 bits * Q15 >> 15, low byte zero; the
                     // multiplier of the lane's frame in each of its two rows comes from the unit's plane (0xffff: the frame's message has no ramp)
@@ -675,7 +643,100 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                                  : : "v"(at), "v"(lo), "v"(hi) : "memory");
                 }
                 }
+            };
+            u32x2 h[6];
+            issue_planes(kc[0], kFirst % G::kCt, h);
+            if constexpr (kPipe) {
+                // The tiles as a software pipeline of ONE wave: a tile's twelve matrix instructions in two halves -- (a) the six that
+                // make s0, s1, s2, (b) the six that make s3, s4, s5 -- with the PREVIOUS tile's last twenty-eight vector instructions
+                // (T2, W, y, clamp, pack, store: they need only U, s4, s5 of it) written between them and this tile's first twelve
+                // (T0, T1, U) behind (b): in program order every vector instruction has matrix instructions of another output's
+                // around it that it does not depend on, and the accumulators a half writes are dead by then -- no register more.
+                // (Round 5: a wave alone alternated 192 cycles of matrix pipe and 160 of vector pipe, and with three waves a SIMD the
+                // others filled a third of that: 303 cycles a tile with every global access compiled out.)
+                int u_prev[4];
+                v4i s4p, s5p;
+                static_for([&](auto ic) __attribute__((always_inline)) {
+                    constexpr uint32_t i = decltype(ic)::value;
+                    constexpr bool kHas = i < G::kTilesPerWave, kPrev = i > 0;
+                    constexpr uint32_t ii = kHas ? i : G::kTilesPerWave - 1u;
+                    constexpr uint32_t set = (kFirst + ii) / G::kCt - kFirst / G::kCt, ct = (kFirst + ii) % G::kCt;
+                    constexpr uint32_t ip = kPrev ? i - 1u : 0u;
+                    constexpr uint32_t set_p = (kFirst + ip) / G::kCt - kFirst / G::kCt, ct_p = (kFirst + ip) % G::kCt;
+                    static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
+                    v4i bd[3];
+                    v4i s0, s1 = v4i{0, 0, 0, 0}, s2, s3 = v4i{0, 0, 0, 0}, s4 = v4i{0, 0, 0, 0}, s5 = v4i{0, 0, 0, 0};
+                    const v4i (&c)[4] = a[HB ? 0 : set];
+                    if constexpr (kHas) {
+                        take_planes(h, bd);
+                        const uint8_t* const bi = my_bias + (step0 + set) * G::kBiasStep;
+                        if constexpr (HB) { s0 = hb_s0; s2 = hb_s2; }
+                        else { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + 256); }
+                        s0 = MF_MFMA(bd[0], c[0], s0);
+                        s1 = MF_MFMA(bd[0], c[1], s1);
+                        s2 = MF_MFMA(bd[0], c[2], s2);
+                        s1 = MF_MFMA(bd[1], c[0], s1);
+                        s2 = MF_MFMA(bd[1], c[1], s2);
+                        s2 = MF_MFMA(bd[2], c[0], s2);
+                    }
+                    if constexpr (kPrev) {
+                        int y[4];
+#pragma unroll
+                        for (int v = 0; v < 4; v++) y[v] = mf_recombine_tail(u_prev[v], s4p[v], s5p[v]);
+                        finish_tile(std::integral_constant<uint32_t, set_p>{}, std::integral_constant<uint32_t, ct_p>{}, y);
+                    }
+                    if constexpr (kHas) {
+                        s3 = MF_MFMA(bd[0], c[3], s3);
+                        s3 = MF_MFMA(bd[1], c[2], s3);
+                        s3 = MF_MFMA(bd[2], c[1], s3);
+                        s4 = MF_MFMA(bd[1], c[3], s4);
+                        s4 = MF_MFMA(bd[2], c[2], s4);
+                        s5 = MF_MFMA(bd[2], c[3], s5);
+                        if constexpr (i + 1 < G::kTilesPerWave) {
+                            constexpr uint32_t set_n = (kFirst + i + 1) / G::kCt - kFirst / G::kCt, ct_n = (kFirst + i + 1) % G::kCt;
+                            issue_planes(kc[set_n], ct_n, h);
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; v++) u_prev[v] = mf_recombine_head(s0[v], s1[v], s2[v], s3[v]);
+                        s4p = s4; s5p = s5;
+                    }
+                }, std::make_integer_sequence<int, (int)G::kTilesPerWave + 1>{});
+            } else {
+            static_for([&](auto ic) __attribute__((always_inline)) {
+                constexpr uint32_t i = decltype(ic)::value;
+                v4i bd[3];
+                take_planes(h, bd);
+                constexpr uint32_t set = (kFirst + i) / G::kCt - kFirst / G::kCt, ct = (kFirst + i) % G::kCt;
+                static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
+                const uint32_t step = step0 + set;
+                const uint8_t* const bi = my_bias + step * G::kBiasStep;
+                v4i s0, s1 = v4i{0, 0, 0, 0}, s2, s3 = v4i{0, 0, 0, 0}, s4 = v4i{0, 0, 0, 0}, s5 = v4i{0, 0, 0, 0};
+                if constexpr (HB) { s0 = hb_s0; s2 = hb_s2; }
+                else { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + 256); }
+                const v4i (&c)[4] = a[HB ? 0 : set];
+                s0 = MF_MFMA(bd[0], c[0], s0);
+                s1 = MF_MFMA(bd[0], c[1], s1);
+                s2 = MF_MFMA(bd[0], c[2], s2);
+                s3 = MF_MFMA(bd[0], c[3], s3);
+                s1 = MF_MFMA(bd[1], c[0], s1);
+                s2 = MF_MFMA(bd[1], c[1], s2);
+                s3 = MF_MFMA(bd[1], c[2], s3);
+                s4 = MF_MFMA(bd[1], c[3], s4);
+                s2 = MF_MFMA(bd[2], c[0], s2);
+                s3 = MF_MFMA(bd[2], c[1], s3);
+                s4 = MF_MFMA(bd[2], c[2], s4);
+                s5 = MF_MFMA(bd[2], c[3], s5);
+                if constexpr (i + 1 < G::kTilesPerWave) {
+                    // the next tile's planes, while this one's matrix instructions run
+                    constexpr uint32_t set_n = (kFirst + i + 1) / G::kCt - kFirst / G::kCt, ct_n = (kFirst + i + 1) % G::kCt;
+                    issue_planes(kc[set_n], ct_n, h);
+                }
+                int y[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) y[v] = mf_recombine(s0[v], s1[v], s2[v], s3[v], s4[v], s5[v]);
+                finish_tile(std::integral_constant<uint32_t, set>{}, std::integral_constant<uint32_t, ct>{}, y);
             }, std::make_integer_sequence<int, (int)G::kTilesPerWave>{});
+            }
         };
 #ifndef MF_DIAG_IO_ONLY
         static_for([&](auto pc) __attribute__((always_inline)) {
@@ -686,7 +747,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         }, std::make_integer_sequence<int, (int)G::kCt>{});
 #endif
 #ifndef MF_WG_NO_PRIO
-        __builtin_amdgcn_s_setprio(0);                       // (the tiles run at priority 3: -2 % on the headline, same box, alternating)
+        __builtin_amdgcn_s_setprio(kPrioD);                  // (the tiles run at priority 3: -2 % on the headline in round 4, -4 % in round 5, same box, alternating)
 #endif
         wg_barrier<0>();                                    // the output image is whole; the planes are free
 
@@ -739,6 +800,9 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             // that this is all it gains says the launch does not wait for its loads: tools/micro/run_copy.hip)
             stage_input(raw);
             issue_input(wk_n2, raw);
+#ifndef MF_WG_NO_PRIO
+            if constexpr (kPrioS != kPrioD) __builtin_amdgcn_s_setprio(kPrioS);
+#endif
             wg_barrier<2>();
             split_all(wk_nxt.first);
             wk = wk_nxt;
@@ -754,7 +818,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         issue_input(wk_nxt, raw);
         }
 #ifndef MF_WG_NO_PRIO
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(kPrioC);
 #endif
         wg_barrier<3>();
     }
