@@ -977,6 +977,7 @@ void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size
 {
     SrcRangeResult& r = *out;
     const uint64_t L = src->L, M = src->M, T = src->T;
+    const FastDiv64 by_L(L);
     const ohgpu_src_msg_desc& d0 = descs[0];
     for (size_t i = lo_i; i < hi_i; i++) {
         const ohgpu_src_msg_desc& d = descs[i];
@@ -1020,7 +1021,7 @@ void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size
         }
         if (d.n_frames > 0) {
             const uint64_t t_first = d.out_frame0 * M, t_last = (d.out_frame0 + d.n_frames - 1) * M;
-            const int64_t n0_first = (int64_t)(t_first / L), n0_last = (int64_t)(t_last / L);
+            const int64_t n0_first = (int64_t)by_L.div(t_first), n0_last = (int64_t)by_L.div(t_last);
             const int64_t n_lo = n0_first - (int64_t)(T - 1);
             if (n_lo >= 0 ? (uint64_t)n_lo < d.src_frame0 : d.src_frame0 != 0) {
                 r.fail(set_error(OHGPU_ERR_BOUNDS, "src desc %zu: filter history starts at input frame %lld but the buffer starts at %llu", i,

@@ -507,6 +507,21 @@ struct PlanDigest { uint64_t hash, units, pieces, ramp_jobs; int kernel; };   //
 // its predecessor: the validation pass looked), so the planner neither checks nor sorts
 int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, bool ordered, PlanDigest* digest = nullptr, PlanFusedCheck* fused = nullptr);
 
+// floor(t / d) for a divisor fixed over many t: a 64 x 64 -> 128 multiply by floor((2^64 - 1) / d) and at most two steps up (the
+// estimate is never above and at most two below) -- a third of a hardware divide, and the planner's pass over half a million
+// messages makes two a message.
+struct FastDiv64 {
+    uint64_t d, inv;
+    explicit FastDiv64(uint64_t divisor) : d(divisor), inv(divisor > 1 ? ~0ull / divisor : 0) {}
+    uint64_t div(uint64_t t) const
+    {
+        if (d <= 1) return t;
+        uint64_t q = (uint64_t)(((unsigned __int128)t * inv) >> 64), r = t - q * d;
+        while (r >= d) { q++; r -= d; }
+        return q;
+    }
+};
+
 // The generic kernel's form of a (validated) resampled message: everything 64-bit that can be precomputed on the host.
 inline DevSrcDesc src_convert_desc(const ohgpu_src_msg_desc& d, uint64_t L, uint64_t M)
 {

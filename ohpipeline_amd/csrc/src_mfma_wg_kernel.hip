@@ -115,18 +115,29 @@ struct WgGeom {
     // [step][b0, b1][output 16][4 copies] dwords: an output's two initial values as the four-register C operands of its tile (bits 16.. of
     // the constant ride in ONE accumulator, MfStep: two 16-byte reads per tile, not three; half-band: the same for every output and step --
     // they stay in eight registers, no table)
+    // Stereo, packed (kDma): the pass's run goes from memory STRAIGHT into an LDS buffer of its own (global_load_lds_dwordx4), not
+    // through registers and four 16-byte LDS stores a lane: phase (A) and its barrier are gone, and so are sixteen registers.  The
+    // buffer is the longest run the geometry admits (972 pieces); that three workgroups still share a CU the table of initial values
+    // holds two copies of a value instead of four (read as ds_read2_b64 of the same 8 bytes twice).
+#ifdef MF_WG_NO_DMA
+    static constexpr bool kDma = false;
+#else
+    static constexpr bool kDma = kSpan && PAIRS == 1;
+#endif
     static constexpr uint32_t kBiasSteps = HB ? 0 : kSteps;
-    static constexpr uint32_t kBiasStep = 512;
+    static constexpr uint32_t kBiasCopies = kDma ? 2 : 4;
+    static constexpr uint32_t kBiasStep = 128 * kBiasCopies;          // [b0, b1][output 16][copies] dwords
     static constexpr uint32_t kBiasBytes = kBiasSteps * kBiasStep;
     static constexpr uint32_t kInBytes = kSpan ? kSpanBytes : kSR * kRowInPitch;   // the input image ...
     static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOutPitch;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
-    static constexpr uint32_t kStageBytes = kInBytes > kOutBytes ? kInBytes : kOutBytes;
-    static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kBiasBytes;
+    static constexpr uint32_t kStageBytes = kDma ? kOutBytes : (kInBytes > kOutBytes ? kInBytes : kOutBytes);
+    static constexpr uint32_t kDmaBytes = kDma ? (((kSR - 1) * kOutFrames * kFbIn + kRowIn + 15u) / 16u) * 16u : 0u;
+    static constexpr uint32_t kLdsBytes = kPlaneBytes + kStageBytes + kBiasBytes + kDmaBytes;
     static constexpr uint32_t kGroupsPerCu = ROWS == 32 ? 2 : 3;
     static constexpr uint32_t kSubUnits = kUnitRows / kSR;            // passes per planner unit
     static constexpr uint32_t kOutPieces = kSR * (kRowOut / 16);
     static constexpr uint32_t kStoreRounds = (kOutPieces + kThreads - 1) / kThreads;
-    static_assert(kGroupsPerCu * kLdsBytes <= 160 * 1024, "workgroups per CU");
+    static_assert(kGroupsPerCu * kLdsBytes <= 160 * 1024 && (!kDma || kLdsBytes <= 52 * 1024), "workgroups per CU (the LDS is handed out in granules)");
     static_assert(kTilesPerWave * kWaves == kSteps * kCt, "whole tiles per wave");
     static_assert(kSR * kRowLanes <= kThreads && (kSpan || kRowIn == (2 * kFullRounds + 1) * 8 * 16 * PAIRS) && kSubUnits * kSR == kUnitRows, "lanes per row of the input image, 4.5 (7.5) pieces each");
     // (the union of a pass's rows: at most kOutFrames input frames from one row to the next -- the block geometry src_mfma_wg_supported
@@ -209,6 +220,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     uint8_t* const pl_lds = smem;
     uint8_t* const stage = smem + G::kPlaneBytes;
     uint8_t* const bias_lds = stage + G::kStageBytes;
+    uint8_t* const dma_lds = bias_lds + G::kBiasBytes;                // (kDma: the pass's input run, piece for piece)
+    uint8_t* const in_img = G::kDma ? dma_lds : stage;                // where the split finds a packed pass's run
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -220,7 +233,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     for (uint32_t i = tid; i < G::kBiasSteps * 32u; i += G::kThreads) {
         const uint32_t t = i / 32u, r = i - 32u * t;
         const uint32_t v = steps[t].b0[r];                 // (b0 and b1 lie one after the other)
-        ((u32x4*)bias_lds)[i] = u32x4{v, v, v, v};
+        if constexpr (G::kDma) ((u32x2*)bias_lds)[i] = u32x2{v, v};
+        else ((u32x4*)bias_lds)[i] = u32x4{v, v, v, v};
     }
     // this wave's A operands, for good
     v4i a[G::kASets][4];
@@ -244,7 +258,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     // (half-band: K groups 0..2 are the even-frame chunks kc .. kc + 2, group 3 the odd-frame chunk kc + 1 = plane chunk 10 + kc + 1)
     const uint32_t g_chunk = HB ? (g < 3u ? g : 11u) : g;
     const uint8_t* const b_lds = pl_lds + g_chunk * G::kChunk + n * 8u;           // + kc * chunk + digit * kDigit + ((half * kHalf + tile * 128) ^ parity of the chunk * 128)
-    const uint8_t* const my_bias = bias_lds + 16u * n;                            // + step * 512: b0; b1 at + 256
+    const uint8_t* const my_bias = bias_lds + 4u * G::kBiasCopies * n;            // + step * kBiasStep: b0; b1 half a step further
     // (half-band: the two values, once)
     const int hb0 = HB ? (int)steps[0].b0[n] : 0, hb1 = HB ? (int)steps[0].b1[n] : 0;
     const v4i hb_s0 = v4i{hb0, hb0, hb0, hb0}, hb_s2 = v4i{hb1, hb1, hb1, hb1};
@@ -352,6 +366,28 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         }
 #endif
     };
+    // kDma: the pass's run, memory -> LDS.  A wave's lanes fill a contiguous KB per instruction (LDS address = M0 + 16 lane); lanes past
+    // the run's end sit out.  A unit at an end of the arena brings its pieces through registers, checked, as ever.
+    auto issue_dma = [&](const Unit& w) __attribute__((always_inline)) {
+#ifndef MF_DIAG_NO_LOAD
+        if (w.edge) {
+#pragma unroll
+            for (int k = 0; k < (int)G::kInRounds; k++) {
+                const uint32_t p = k + 1 < (int)G::kInRounds ? tid + 256u * (uint32_t)k : span_p3;
+                *(u32x4*)(dma_lds + 16u * p) = wg_load_piece_checked(src, w.src0 + (int64_t)(16u * p), src_arena_bytes);
+            }
+        } else {
+            const uint8_t* const base = src + w.src0;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8_t)dma_lds + 1024u * wave;
+#pragma unroll
+            for (int k = 0; k < (int)G::kInRounds; k++) {
+                const uint32_t p = tid + 256u * (uint32_t)k;
+                if (k + 1 < (int)G::kInRounds || p < span_pieces)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(16u * p), "s"(base), "s"(lds0 + 4096u * (uint32_t)k) : "memory", "m0");
+            }
+        }
+#endif
+    };
     auto stage_input = [&](const u32x4 (&raw)[G::kInRounds]) __attribute__((always_inline)) {
 #ifdef MF_DIAG_NO_STAGE
         return;
@@ -423,7 +459,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         if constexpr (G::kS16) {
             // 16-bit stereo: a frame is one dword {L lo, L hi, R lo, R hi} (or hi first); a 4 x 4 byte transpose per four frames gives the
             // four byte planes, and the 24-bit sample is the 16 bits over a zero byte -- digit 0 is the offset digit of zero everywhere
-            const uint8_t* const from = stage + sp_span0 + 32u * hc;
+            const uint8_t* const from = in_img + sp_span0 + 32u * hc;
             const u32x4 lo4 = *(const u32x4_a4*)from, hi4 = *(const u32x4_a4*)(from + 16);
             const uint32_t f[8] = {zero ? 0u : lo4.x, zero ? 0u : lo4.y, zero ? 0u : lo4.z, zero ? 0u : lo4.w,
                                    zero ? 0u : hi4.x, zero ? 0u : hi4.y, zero ? 0u : hi4.z, zero ? 0u : hi4.w};
@@ -471,10 +507,10 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             uint32_t d[13];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const u32x4 q = *(const u32x4_a4*)(stage + at + 16 * k);
+                const u32x4 q = *(const u32x4_a4*)(in_img + at + 16 * k);
                 d[4 * k] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
             }
-            d[12] = *(const uint32_t*)(stage + at + 48);
+            d[12] = *(const uint32_t*)(in_img + at + 48);
             uint32_t w[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) w[k] = zero ? 0u : __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
@@ -490,7 +526,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             uint32_t lo[8], hi[8];
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const u32x2 e = *(const u32x2_a4*)(stage + at_e + 2 * (int)G::kFb * m), o = *(const u32x2_a4*)(stage + at_o + 2 * (int)G::kFb * m);
+                const u32x2 e = *(const u32x2_a4*)(in_img + at_e + 2 * (int)G::kFb * m), o = *(const u32x2_a4*)(in_img + at_o + 2 * (int)G::kFb * m);
                 const uint64_t ve = (((uint64_t)e.y << 32) | e.x) >> sh_e, vo = (((uint64_t)o.y << 32) | o.x) >> sh_o;
                 lo[2 * m] = zero ? 0u : (uint32_t)ve; hi[2 * m] = zero ? 0u : (uint32_t)(ve >> 32);
                 lo[2 * m + 1] = zero ? 0u : (uint32_t)vo; hi[2 * m + 1] = zero ? 0u : (uint32_t)(vo >> 32);
@@ -543,12 +579,23 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     uint32_t u_nxt = u_cur + n_groups;                     // the unit whose input is in flight
     Unit wk = fetch_unit(u_cur);
     u32x4 raw[G::kInRounds];
+    Unit wk_nxt = wk;
+    if constexpr (G::kDma) {
+        issue_dma(wk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // (the bias table; the run)
+        split_all(wk.first);
+        wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
+        wg_barrier();
+        if (u_nxt < n_work) issue_dma(wk_nxt);              // (uniform)
+    } else {
     issue_input(wk, raw);
     __syncthreads();                                        // (the bias table)
     stage_and_split(raw, wk.first);
-    Unit wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
+    wk_nxt = fetch_unit(u_nxt < n_work ? u_nxt : u_cur);
     issue_input(wk_nxt, raw);                               // (past the last unit: the current one again, never used)
     wg_barrier();
+    }
 
     while (true) {
         // ---- (C) this wave's five tiles of the unit ----
@@ -575,6 +622,13 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                          : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5])
                          : "v"(at), "n"(G::kHalf), "n"(G::kDigit), "n"(G::kDigit + G::kHalf), "n"(2 * G::kDigit), "n"(2 * G::kDigit + G::kHalf)
                          : "memory");
+        };
+        // kDma: an output's two initial values from the table of two copies -- the same eight bytes twice fill the four registers of a
+        // C operand (ds_read2_b64 with both offsets alike).  Written out, so the wait is the caller's: take_planes' comes next.
+        auto read_bias2 = [&](const uint8_t* bi, v4i& s0, v4i& s2) __attribute__((always_inline)) {
+            const uint32_t at = (uint32_t)(uintptr_t)(lds_u8_t)bi;
+            asm volatile("ds_read2_b64 %0, %2\n\tds_read2_b64 %1, %2 offset0:%3 offset1:%3"
+                         : "=&v"(s0), "=&v"(s2) : "v"(at), "n"(G::kBiasStep / 16) : "memory");
         };
         auto take_planes = [&](u32x2 (&h)[6], v4i (&bd)[3]) __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]) : : "memory");
@@ -668,10 +722,11 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     v4i s0, s1 = v4i{0, 0, 0, 0}, s2, s3 = v4i{0, 0, 0, 0}, s4 = v4i{0, 0, 0, 0}, s5 = v4i{0, 0, 0, 0};
                     const v4i (&c)[4] = a[HB ? 0 : set];
                     if constexpr (kHas) {
-                        take_planes(h, bd);
                         const uint8_t* const bi = my_bias + (step0 + set) * G::kBiasStep;
+                        if constexpr (G::kDma) read_bias2(bi, s0, s2);         // (in front of the wait in take_planes)
+                        take_planes(h, bd);
                         if constexpr (HB) { s0 = hb_s0; s2 = hb_s2; }
-                        else { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + 256); }
+                        else if constexpr (!G::kDma) { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + G::kBiasStep / 2); }
                         s0 = MF_MFMA(bd[0], c[0], s0);
                         s1 = MF_MFMA(bd[0], c[1], s1);
                         s2 = MF_MFMA(bd[0], c[2], s2);
@@ -705,14 +760,15 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             static_for([&](auto ic) __attribute__((always_inline)) {
                 constexpr uint32_t i = decltype(ic)::value;
                 v4i bd[3];
-                take_planes(h, bd);
                 constexpr uint32_t set = (kFirst + i) / G::kCt - kFirst / G::kCt, ct = (kFirst + i) % G::kCt;
                 static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
                 const uint32_t step = step0 + set;
                 const uint8_t* const bi = my_bias + step * G::kBiasStep;
                 v4i s0, s1 = v4i{0, 0, 0, 0}, s2, s3 = v4i{0, 0, 0, 0}, s4 = v4i{0, 0, 0, 0}, s5 = v4i{0, 0, 0, 0};
+                if constexpr (G::kDma) read_bias2(bi, s0, s2);                 // (in front of the wait in take_planes)
+                take_planes(h, bd);
                 if constexpr (HB) { s0 = hb_s0; s2 = hb_s2; }
-                else { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + 256); }
+                else if constexpr (!G::kDma) { s0 = *(const v4i*)bi; s2 = *(const v4i*)(bi + G::kBiasStep / 2); }
                 const v4i (&c)[4] = a[HB ? 0 : set];
                 s0 = MF_MFMA(bd[0], c[0], s0);
                 s1 = MF_MFMA(bd[0], c[1], s1);
@@ -749,7 +805,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #ifndef MF_WG_NO_PRIO
         __builtin_amdgcn_s_setprio(kPrioD);                  // (the tiles run at priority 3: -2 % on the headline in round 4, -4 % in round 5, same box, alternating)
 #endif
-        wg_barrier<0>();                                    // the output image is whole; the planes are free
+        if constexpr (G::kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this wave's pieces of the next run have landed; the last pass's stores with them, long since)
+        wg_barrier<0>();                                    // the output image is whole; the planes are free (kDma: and the next run is in its buffer)
 
         // ---- (D) the unit leaves as lane-contiguous pieces.  vmcnt counts loads and stores together, in issue order: the next
         // unit's input -- requested a whole phase (C) ago -- is waited for HERE, in front of the stores, not behind them ----
@@ -757,8 +814,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         const uint32_t u_n2 = u_nxt + n_groups;
         Unit wk_n2 = wk;
         if constexpr (G::kSpan && !kLateLoads) wk_n2 = fetch_unit(u_n2 < n_work ? u_n2 : u_cur);
-        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
-        if constexpr (G::kInRounds > 3) asm volatile("" : "+v"(raw[3]));
+        if constexpr (!G::kDma) asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]));
+        if constexpr (G::kInRounds > 3 && !G::kDma) asm volatile("" : "+v"(raw[3]));
         if constexpr (G::kInRounds > 4) asm volatile("" : "+v"(raw[4]));
         if constexpr (G::kInRounds > 5) asm volatile("" : "+v"(raw[5]));
         if constexpr (G::kInRounds > 6) asm volatile("" : "+v"(raw[6]), "+v"(raw[7]));
@@ -790,6 +847,22 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         // (the output image has been read.  Packed sources' input image is the pass's run piece for piece, and the output image is too:
         // a lane stages into the very slots it has just emptied -- LDS operations of a wave complete in order -- so nothing has to
         // wait for another wave here; the row-by-row images of the planar and half-band forms do)
+        if constexpr (G::kDma) {
+            // (S) straight away: the split reads the run's buffer and writes the planes, (D) read the output image -- nothing of one is
+            // the other's, so no barrier stands between them: two a pass, not three
+            if (u_nxt >= n_work) break;                     // (uniform)
+            split_all(wk_nxt.first);
+            wk = wk_nxt;
+            wk_nxt = wk_n2;
+            u_cur = u_nxt;
+            u_nxt += n_groups;
+#ifndef MF_WG_NO_PRIO
+            __builtin_amdgcn_s_setprio(kPrioC);
+#endif
+            wg_barrier<3>();                                // the planes are whole; the run's buffer and the output image are free
+            if (u_nxt < n_work) issue_dma(wk_nxt);          // (uniform)
+            continue;
+        }
         if constexpr (!G::kSpan || !G::kOutLinear) wg_barrier<1>();
         if (u_nxt >= n_work) break;                         // (uniform)
 

@@ -226,7 +226,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         bool ok = true;
         // the fused check (PlanFusedCheck): what the stretch's messages were found to be, and the next one not yet looked at
         SrcRangeResult chk;
-        size_t checked_upto = 0;
+        size_t checked_upto = 0, check_end = 0;
     };
     // lean kernel: one plane of multipliers per ramped unit -- rows * L_blk entries (uint16, 0xffff = no ramp on that frame)
     // (the kernel loads eight entries at a time; a row is a whole number of loads when L_blk is a multiple of 8, else the slack covers the last one)
@@ -306,15 +306,19 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     const bool direct_units = mfma_wg;
     // (fused check: a message is validated the first time the pass looks at it -- in message order, each once; a stretch stops at its
     // first bad descriptor, or at the first that is not of the batch's layout or out of order)
+    // (... a run of them at a time: one call and its set-up per 128 messages, not per message.  A bad descriptor further on in the run
+    // stops the stretch before the pass reaches it -- the plan is thrown away either way, and the first bad one is still the first)
     auto looked_at = [&](Stretch& o, size_t k) -> bool {
         if (!fused || k < o.checked_upto) return true;
-        src_check_range(fused->src, descs, k, k + 1, b->src_arena_bytes, b->dst_arena_bytes, nullptr, &o.chk);
-        o.checked_upto = k + 1;
+        const size_t upto = std::min(k + 128, o.check_end);
+        src_check_range(fused->src, descs, k, upto, b->src_arena_bytes, b->dst_arena_bytes, nullptr, &o.chk);
+        o.checked_upto = upto;
         return o.chk.err == OHGPU_OK && o.chk.uniform && o.chk.ordered;
     };
     auto plan_stretch = [&](size_t i_begin, size_t i_end, Stretch& o) {
             size_t i = i_begin;
             o.checked_upto = i_begin;
+            o.check_end = i_end;
             while (i < i_end) {
             if (!looked_at(o, i)) return;
             // grow a run of messages that tile a contiguous output range of one stream
