@@ -115,14 +115,15 @@ struct WgGeom {
     // [step][b0, b1][output 16][4 copies] dwords: an output's two initial values as the four-register C operands of its tile (bits 16.. of
     // the constant ride in ONE accumulator, MfStep: two 16-byte reads per tile, not three; half-band: the same for every output and step --
     // they stay in eight registers, no table)
-    // Stereo, packed (kDma): the pass's run goes from memory STRAIGHT into an LDS buffer of its own (global_load_lds_dwordx4), not
-    // through registers and four 16-byte LDS stores a lane: phase (A) and its barrier are gone, and so are sixteen registers.  The
-    // buffer is the longest run the geometry admits (972 pieces); that three workgroups still share a CU the table of initial values
-    // holds two copies of a value instead of four (read as ds_read2_b64 of the same 8 bytes twice).
+    // Packed sources through the polyphase filters (kDma): the pass's run goes from memory STRAIGHT into an LDS buffer of its own
+    // (global_load_lds_dwordx4), not through registers and four 16-byte LDS stores a lane: phase (A) and its barrier are gone, and so
+    // are sixteen registers.  The buffer is the longest run the geometry admits (stereo 972 pieces, six channels 936, eight 1008); that
+    // three workgroups still share a CU -- six channels: 52 KB each to the byte -- the table of initial values holds two copies of a
+    // value instead of four (read as ds_read2_b64 of the same 8 bytes twice).
 #ifdef MF_WG_NO_DMA
     static constexpr bool kDma = false;
 #else
-    static constexpr bool kDma = kSpan && PAIRS == 1;
+    static constexpr bool kDma = kSpan;
 #endif
     static constexpr uint32_t kBiasSteps = HB ? 0 : kSteps;
     static constexpr uint32_t kBiasCopies = kDma ? 2 : 4;
@@ -382,8 +383,11 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #pragma unroll
             for (int k = 0; k < (int)G::kInRounds; k++) {
                 const uint32_t p = tid + 256u * (uint32_t)k;
-                if (k + 1 < (int)G::kInRounds || p < span_pieces)
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(16u * p), "s"(base), "s"(lds0 + 4096u * (uint32_t)k) : "memory", "m0");
+                if (k + 1 < (int)G::kInRounds || p < span_pieces) {
+                    // (stereo: non-temporal, six and eight channels plain -- issue_input has why)
+                    if constexpr (PAIRS == 1) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(16u * p), "s"(base), "s"(lds0 + 4096u * (uint32_t)k) : "memory", "m0");
+                    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(16u * p), "s"(base), "s"(lds0 + 4096u * (uint32_t)k) : "memory", "m0");
+                }
             }
         }
 #endif
