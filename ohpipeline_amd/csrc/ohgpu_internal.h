@@ -479,34 +479,6 @@ bool src_block_geometry(uint32_t L, uint32_t T, uint32_t ch, uint32_t sb, uint32
 void build_ramp_table(uint16_t out[512]);
 int  design_src(uint32_t rate_in, uint32_t rate_out, uint32_t T, double beta, double f_pass,
                 std::vector<int32_t>* coef_q28, uint32_t* L, uint32_t* M);
-// What a pass over messages [lo, hi) of a resampled batch finds (src_check_range, csrc/ohgpu_api.hip): the first bad descriptor's
-// error, the batch's totals, whether the messages share descs[0]'s layout and come in the planner's order.
-struct SrcRangeResult {
-    int err = OHGPU_OK;
-    char msg[512] = "";
-    uint64_t in_frames = 0, out_frames = 0, src_bytes_touched = 0, dst_bytes_written = 0;
-    uint32_t max_frames = 0;
-    bool uniform = true;
-    bool ordered = true;        // every message of the range is not before its predecessor in the planner's order (meaningful for a uniform batch)
-    void fail(int code) { err = code; snprintf(msg, sizeof(msg), "%s", ohgpu_last_error()); }
-};
-void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t lo_i, size_t hi_i, uint64_t src_arena_bytes,
-                     uint64_t dst_arena_bytes, DevSrcDesc* dev, SrcRangeResult* out);
-// The planner checking the messages ITSELF, in the pass that cuts them into segments (a batch of half a million descriptors is 32 MB:
-// a pass of its own over them is a third of the plan's time).  In: the filter (the arenas are the batch's).  Out: `checked` = every
-// message was visited; `total` = what src_check_range found over all of them (its err / msg = the first bad descriptor's, in message
-// order); `retry` = the messages are not what this pass assumes -- one layout, the planner's order -- and the caller must take the
-// two-pass route (validation, then plan_src_fast with what it found).
-struct PlanFusedCheck {
-    const ohgpu_src* src = nullptr;
-    bool checked = false, retry = false;
-    SrcRangeResult total;
-};
-struct PlanDigest { uint64_t hash, units, pieces, ramp_jobs; int kernel; };   // ohgpu_src_plan_digest: a plan without a device
-// `ordered`: the caller's messages are known to be in the planner's order already (src_msg_before never holds for a message against
-// its predecessor: the validation pass looked), so the planner neither checks nor sorts
-int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, bool ordered, PlanDigest* digest = nullptr, PlanFusedCheck* fused = nullptr);
-
 // floor(t / d) for a divisor fixed over many t: a 64 x 64 -> 128 multiply by floor((2^64 - 1) / d) and at most two steps up (the
 // estimate is never above and at most two below) -- a third of a hardware divide, and the planner's pass over half a million
 // messages makes two a message.
@@ -521,6 +493,76 @@ struct FastDiv64 {
         return q;
     }
 };
+
+// What a pass over messages [lo, hi) of a resampled batch finds (src_check_range, csrc/ohgpu_api.hip): the first bad descriptor's
+// error, the batch's totals, whether the messages share descs[0]'s layout and come in the planner's order.
+struct SrcRangeResult {
+    int err = OHGPU_OK;
+    char msg[512] = "";
+    uint64_t in_frames = 0, out_frames = 0, src_bytes_touched = 0, dst_bytes_written = 0;
+    uint32_t max_frames = 0;
+    bool uniform = true;
+    bool ordered = true;        // every message of the range is not before its predecessor in the planner's order (meaningful for a uniform batch)
+    void fail(int code) { err = code; snprintf(msg, sizeof(msg), "%s", ohgpu_last_error()); }
+};
+void src_check_range(const ohgpu_src* src, const ohgpu_src_msg_desc* descs, size_t lo_i, size_t hi_i, uint64_t src_arena_bytes,
+                     uint64_t dst_arena_bytes, DevSrcDesc* dev, SrcRangeResult* out);
+// The usual message of a batch -- descs[0]'s layout (descs[0] has been through src_check_range), packed source, every test passed --
+// checked in a few dozen cycles, in line, by the pass that also plans it: the eight bytes from `attenuation` to `flags` against
+// descs[0]'s (all but the ramp and zero-LSB bits: what equals a validated message's is valid, and of its layout), the ranges, the
+// window by FastDiv64; `r` gets the message's share of the totals, the caller its stream's two bases.  false = not that kind of
+// message, nothing added: src_check_range says what it is (a bad one, one of another layout, or a good one of a rarer kind).
+struct SrcQuickCheck {
+    uint64_t L, M, T, src_arena, dst_arena, ok_word, fb_src, fb_dst;
+    FastDiv64 by_L;
+    bool usable;
+    static constexpr uint64_t kWordMask = ~((uint64_t)(OHGPU_FLAG_RAMP | OHGPU_FLAG_ZERO_LSB32) << 56);
+    static uint64_t word_of(const ohgpu_src_msg_desc& d) { uint64_t w; memcpy(&w, &d.attenuation, 8); return w; }
+    SrcQuickCheck(uint64_t L_, uint64_t M_, uint64_t T_, const ohgpu_src_msg_desc& d0, uint64_t src_arena_bytes, uint64_t dst_arena_bytes)
+        : L(L_), M(M_), T(T_), src_arena(src_arena_bytes), dst_arena(dst_arena_bytes), ok_word(word_of(d0) & kWordMask),
+          fb_src((uint64_t)d0.channels * (d0.src_bits / 8)), fb_dst((uint64_t)d0.channels * (d0.dst_bits / 8)), by_L(L_),
+          usable(!(d0.flags & OHGPU_FLAG_SRC_PLANAR32))
+    {
+        static_assert(offsetof(ohgpu_src_msg_desc, attenuation) == 48 && offsetof(ohgpu_src_msg_desc, flags) == 55 && sizeof(ohgpu_src_msg_desc) == 64, "the eight bytes from attenuation to flags");
+    }
+    __attribute__((always_inline)) bool pass(const ohgpu_src_msg_desc& d, SrcRangeResult& r, int64_t* sbase, int64_t* dbase) const
+    {
+        if ((word_of(d) & kWordMask) != ok_word || d.src_plane_stride != 0) return false;
+        if (d.ramp_start > OHGPU_RAMP_MAX || d.ramp_end > OHGPU_RAMP_MAX || ((d.flags & OHGPU_FLAG_RAMP) && d.n_frames > 131071u)) return false;
+        if (d.out_frame0 > (1ull << 48) || d.src_frame0 > (1ull << 48) || d.src_frames > (1ull << 40)) return false;
+        const uint64_t src_bytes = d.src_frames * fb_src, dst_bytes = (uint64_t)d.n_frames * fb_dst;
+        if (d.src_offset > src_arena || src_bytes > src_arena - d.src_offset || d.dst_offset > dst_arena || dst_bytes > dst_arena - d.dst_offset) return false;
+        if (d.n_frames > 0) {
+            const int64_t n0_first = (int64_t)by_L.div(d.out_frame0 * M), n0_last = (int64_t)by_L.div((d.out_frame0 + d.n_frames - 1) * M);
+            const int64_t n_lo = n0_first - (int64_t)(T - 1);
+            if (n_lo >= 0 ? (uint64_t)n_lo < d.src_frame0 : d.src_frame0 != 0) return false;
+            if ((uint64_t)n0_last >= d.src_frame0 + d.src_frames) return false;
+            r.in_frames += (uint64_t)(n0_last - n0_first + 1);
+            r.src_bytes_touched += (uint64_t)(n0_last - (n_lo < 0 ? 0 : n_lo) + 1) * fb_src;
+        }
+        r.out_frames += d.n_frames;
+        r.dst_bytes_written += dst_bytes;
+        if (d.n_frames > r.max_frames) r.max_frames = d.n_frames;
+        *sbase = (int64_t)d.src_offset - (int64_t)(d.src_frame0 * fb_src);
+        *dbase = (int64_t)d.dst_offset - (int64_t)(d.out_frame0 * fb_dst);
+        return true;
+    }
+};
+
+// The planner checking the messages ITSELF, in the pass that cuts them into segments (a batch of half a million descriptors is 32 MB:
+// a pass of its own over them is a third of the plan's time).  In: the filter (the arenas are the batch's).  Out: `checked` = every
+// message was visited; `total` = what src_check_range found over all of them (its err / msg = the first bad descriptor's, in message
+// order); `retry` = the messages are not what this pass assumes -- one layout, the planner's order -- and the caller must take the
+// two-pass route (validation, then plan_src_fast with what it found).
+struct PlanFusedCheck {
+    const ohgpu_src* src = nullptr;
+    bool checked = false, retry = false;
+    SrcRangeResult total;
+};
+struct PlanDigest { uint64_t hash, units, pieces, ramp_jobs; int kernel; };   // ohgpu_src_plan_digest: a plan without a device
+// `ordered`: the caller's messages are known to be in the planner's order already (src_msg_before never holds for a message against
+// its predecessor: the validation pass looked), so the planner neither checks nor sorts
+int  plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* descs, size_t n, bool ordered, PlanDigest* digest = nullptr, PlanFusedCheck* fused = nullptr);
 
 // The generic kernel's form of a (validated) resampled message: everything 64-bit that can be precomputed on the host.
 inline DevSrcDesc src_convert_desc(const ohgpu_src_msg_desc& d, uint64_t L, uint64_t M)

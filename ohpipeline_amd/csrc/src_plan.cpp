@@ -227,6 +227,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
         // the fused check (PlanFusedCheck): what the stretch's messages were found to be, and the next one not yet looked at
         SrcRangeResult chk;
         size_t checked_upto = 0, check_end = 0;
+        // the message last visited (`visit` below): its position and its stream's bases; and, for the order test, its predecessor's
+        size_t vis_k = (size_t)-1;
+        int64_t vis_sb = 0, vis_db = 0;
     };
     // lean kernel: one plane of multipliers per ramped unit -- rows * L_blk entries (uint16, 0xffff = no ramp on that frame)
     // (the kernel loads eight entries at a time; a row is a whole number of loads when L_blk is a multiple of 8, else the slack covers the last one)
@@ -308,34 +311,83 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     // first bad descriptor, or at the first that is not of the batch's layout or out of order)
     // (... a run of them at a time: one call and its set-up per 128 messages, not per message.  A bad descriptor further on in the run
     // stops the stretch before the pass reaches it -- the plan is thrown away either way, and the first bad one is still the first)
+#ifdef OHGPU_PLAN_TIMING
+    static thread_local uint64_t tsc_check, tsc_grow, tsc_units, tsc_rem;
+    tsc_check = tsc_grow = tsc_units = tsc_rem = 0;
+#define PLAN_TSC(acc, stmt) { const uint64_t t0_ = __builtin_ia32_rdtsc(); stmt; acc += __builtin_ia32_rdtsc() - t0_; }
+#else
+#define PLAN_TSC(acc, stmt) { stmt; }
+#endif
     auto looked_at = [&](Stretch& o, size_t k) -> bool {
         if (!fused || k < o.checked_upto) return true;
         const size_t upto = std::min(k + 128, o.check_end);
-        src_check_range(fused->src, descs, k, upto, b->src_arena_bytes, b->dst_arena_bytes, nullptr, &o.chk);
+        PLAN_TSC(tsc_check, src_check_range(fused->src, descs, k, upto, b->src_arena_bytes, b->dst_arena_bytes, nullptr, &o.chk));
         o.checked_upto = upto;
         return o.chk.err == OHGPU_OK && o.chk.uniform && o.chk.ordered;
+    };
+    // The pass's look at message k: its stream's bases, and -- fused check -- whether the pass may go on.  The usual message (packed
+    // source, descs[0]'s layout, nothing wrong) is checked in line (SrcQuickCheck) and tested against its predecessor for the planner's
+    // order with the bases both need anyway; any other goes to src_check_range, message by message (planar batches: a run at a time).
+    const bool quick_ok = fused && !planar && n > 0;
+    const SrcQuickCheck quick(fused ? fused->src->L : L, fused ? fused->src->M : M, fused ? fused->src->T : T, descs[0], b->src_arena_bytes, b->dst_arena_bytes);
+    auto visit = [&](Stretch& o, size_t k, int64_t* sb, int64_t* db) __attribute__((always_inline)) -> bool {
+        if (k == o.vis_k) { *sb = o.vis_sb; *db = o.vis_db; return true; }
+        const ohgpu_src_msg_desc& d = descs[order[k]];
+        if (!quick_ok) {
+            if (!looked_at(o, k)) return false;
+            *sb = src_base_of(d); *db = dst_base_of(d);
+        } else {
+            // (fused: order[] is the identity -- the caller's order is the claim being checked)
+            bool slow = !quick.pass(d, o.chk, sb, db);
+            if (!slow && k > 0) {
+                // the planner's order against the predecessor (src_msg_before): the last message visited, or -- a stretch's first -- the
+                // one in front of the stretch
+                int64_t psb, pdb;
+                const ohgpu_src_msg_desc& pd = descs[k - 1];
+                if (k - 1 == o.vis_k) { psb = o.vis_sb; pdb = o.vis_db; }
+                else { psb = src_base_of(pd); pdb = dst_base_of(pd); }
+                const bool before = *sb != psb ? *sb < psb : (*db != pdb ? *db < pdb : d.out_frame0 < pd.out_frame0);
+                if (before) o.chk.ordered = false;
+            }
+            if (slow) {
+                PLAN_TSC(tsc_check, src_check_range(fused->src, descs, k, k + 1, b->src_arena_bytes, b->dst_arena_bytes, nullptr, &o.chk));
+                *sb = src_base_of(d); *db = dst_base_of(d);
+            }
+            if (o.chk.err != OHGPU_OK || !o.chk.uniform || !o.chk.ordered) return false;
+        }
+        o.vis_k = k; o.vis_sb = *sb; o.vis_db = *db;
+        return true;
     };
     auto plan_stretch = [&](size_t i_begin, size_t i_end, Stretch& o) {
             size_t i = i_begin;
             o.checked_upto = i_begin;
             o.check_end = i_end;
             while (i < i_end) {
-            if (!looked_at(o, i)) return;
             // grow a run of messages that tile a contiguous output range of one stream
             size_t e = i + 1;
             const ohgpu_src_msg_desc& d0 = descs[order[i]];
-            const int64_t sbase = src_base_of(d0), dbase = dst_base_of(d0);
+            int64_t sbase, dbase;
+            if (!visit(o, i, &sbase, &dbase)) return;
             if (d0.n_frames != 0 && (d0.out_frame0 * M) / L < T - 1u) o.stream_start = true;     // (a run's first message reaches furthest back)
             uint64_t next_out = d0.out_frame0 + d0.n_frames;
             bool zero_len = d0.n_frames == 0;
+#ifdef OHGPU_PLAN_TIMING
+            const uint64_t tg0 = __builtin_ia32_rdtsc();
+#endif
             while (!zero_len && e < i_end) {
-                if (!looked_at(o, e)) return;
+                int64_t sb_e, db_e;
+                __builtin_prefetch(&descs[order[e + 32 < i_end ? e + 32 : e]]);
+                if (!visit(o, e, &sb_e, &db_e)) return;
                 const ohgpu_src_msg_desc& d = descs[order[e]];
-                if (d.n_frames == 0 || src_base_of(d) != sbase || dst_base_of(d) != dbase || d.out_frame0 != next_out ||
+                if (d.n_frames == 0 || sb_e != sbase || db_e != dbase || d.out_frame0 != next_out ||
                     d.src_plane_stride != d0.src_plane_stride) break;
                 next_out += d.n_frames;
                 e++;
             }
+#ifdef OHGPU_PLAN_TIMING
+            const uint64_t tg1 = __builtin_ia32_rdtsc();
+            tsc_grow += tg1 - tg0;
+#endif
             const uint64_t m_begin = d0.out_frame0, m_end = next_out;
             uint64_t blk_lo = (m_begin + L_blk - 1) / L_blk, blk_hi = m_end / L_blk;
             // (a stream whose output does not start on a 64-byte boundary is written with unaligned 16-byte stores: they run at
@@ -353,28 +405,40 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 o.seg_plane_stride.push_back((uint32_t)d0.src_plane_stride);
                 o.seg_runs.push_back(SegRun{seg_index, blk_lo, blk_hi, (uint32_t)o.work.size()});
                 uint32_t mi = (uint32_t)i;                    // message that holds the unit's first output frame
+                while (mi + 1 < sg.msg_end && descs[order[mi + 1]].out_frame0 <= blk_lo * L_blk) mi++;
+                const uint32_t* const ord = order.data();
                 for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
                     SrcWork w;
                     w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
-                    while (mi + 1 < sg.msg_end && descs[order[mi + 1]].out_frame0 <= bk * L_blk) mi++;
                     w.msg_first = mi;
                     // cost class, for the order below: a wave that meets a ramped message goes through the per-output ramp path
                     // for all of its lanes, which makes such a unit two to three times as long as a plain one
+                    // (ONE walk over the unit's messages finds that and the next unit's first message -- the last that starts at or
+                    // before the unit's end: within a segment every message is longer than nothing and they come in output order)
                     const uint64_t u_lo = bk * L_blk, u_hi = (bk + w.n_blocks) * L_blk;
                     bool ramped = false;
-                    for (uint32_t m = mi; m < sg.msg_end && descs[order[m]].out_frame0 < u_hi && !ramped; m++)
-                        ramped = (descs[order[m]].flags & OHGPU_FLAG_RAMP) && descs[order[m]].out_frame0 + descs[order[m]].n_frames > u_lo;
+                    uint32_t m = mi;
+                    for (; m < sg.msg_end && descs[ord[m]].out_frame0 < u_hi; m++) {
+                        const ohgpu_src_msg_desc& dm = descs[ord[m]];
+                        ramped |= (dm.flags & OHGPU_FLAG_RAMP) && dm.out_frame0 + dm.n_frames > u_lo;
+                    }
+                    const uint32_t mi_next = m < sg.msg_end && descs[ord[m]].out_frame0 == u_hi ? m : m - 1u;
                     w.flags = ramped ? kWorkRamped : 0u;
                     w.plane = 0; w.pad = 0;
                     if (unit_leaves_arena(sbase, d0.src_plane_stride, bk, w.n_blocks, 1)) w.flags |= kWorkChecked;
                     if (direct_units) o.ok = o.ok && emit_unit(o.units, o.jobs, o.planes, sbase, dbase, (uint32_t)d0.src_plane_stride, bk, w.n_blocks, 1, w.flags, mi, sg.msg_end);
                     else o.work.push_back(w);
+                    mi = mi_next;
                 }
                 o.fast_frames += (blk_hi - blk_lo) * L_blk;
             } else {
                 blk_lo = blk_hi = 0;   // everything goes to the generic kernel
             }
             const uint64_t fast_lo = fast_ok ? blk_lo * L_blk : m_end, fast_hi = fast_ok ? blk_hi * L_blk : m_end;
+#ifdef OHGPU_PLAN_TIMING
+            const uint64_t tg2 = __builtin_ia32_rdtsc();
+            tsc_units += tg2 - tg1;
+#endif
             for (size_t k = i; k < e; k++) {
                 const ohgpu_src_msg_desc& d = descs[order[k]];
                 if (d.n_frames == 0) continue;
@@ -383,6 +447,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 if (lo < fast_lo) { o.rem.push_back(make_piece(d, lo, std::min(hi, fast_lo), L, M)); o.rem_msg.push_back(order[k]); }
                 if (hi > fast_hi) { o.rem.push_back(make_piece(d, std::max(lo, fast_hi), hi, L, M)); o.rem_msg.push_back(order[k]); }
             }
+#ifdef OHGPU_PLAN_TIMING
+            tsc_rem += __builtin_ia32_rdtsc() - tg2;
+#endif
             i = e;
         }
     };
@@ -449,6 +516,10 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     }
     if (direct_units ? lean_units.empty() : work.empty()) return OHGPU_OK;
     mark("segments");
+#ifdef OHGPU_PLAN_TIMING
+    fprintf(stderr, "[plan timing]   (this thread's cycles: check %.2f M, grow less check %.2f M, units %.2f M, remainder %.2f M)\n",
+            tsc_check * 1e-6, (tsc_grow - tsc_check) * 1e-6, tsc_units * 1e-6, tsc_rem * 1e-6);
+#endif
     // ---- the lean kernel's units.  A unit is `rows` rows; a row is `kb` CONSECUTIVE blocks of its stream.  With kb = 1 (round
     // 2) every block pays a filter length of warm-up advances and re-reads that much history (32 frames per 147), and every
     // 160 outputs a unit set-up; a row of kb blocks pays them once.  But long units make the end of the launch coarse -- round
