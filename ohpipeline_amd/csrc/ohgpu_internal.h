@@ -180,21 +180,22 @@ inline unsigned plan_threads(size_t n, size_t per_thread)
     if (ohgpu::plan_thread_cap() > 0 && t > (size_t)ohgpu::plan_thread_cap()) t = (size_t)ohgpu::plan_thread_cap();
     return (unsigned)t;
 }
-// f(thread, lo, hi) over [0, n) cut into n_thr contiguous ranges, range t on thread t of the library's planning pool (range 0 on
-// the caller's).  The pool's threads are started on first use and sleep between jobs: starting sixteen threads per pass cost more
-// than the passes of a half-million-message plan.
-void run_on_pool(unsigned n_thr, void (*job)(void* arg, unsigned t), void* arg);     // csrc/ohgpu_api.hip
+// f(range, lo, hi) over [0, n) cut into n_ranges contiguous ranges, run by up to `threads` threads of the library's planning pool (the
+// caller's among them), each claiming the next range when it has done one.  The pool's threads are started on first use and sleep
+// between jobs: starting sixteen threads per pass cost more than the passes of a half-million-message plan.
+void run_on_pool(unsigned n_ranges, unsigned threads, void (*job)(void* arg, unsigned t), void* arg);     // csrc/ohgpu_api.hip
 template <typename F>
-inline void parallel_ranges(size_t n, unsigned n_thr, F&& f)
+inline void parallel_ranges(size_t n, unsigned n_ranges, unsigned threads, F&& f)
 {
-    if (n_thr <= 1) { f(0u, (size_t)0, n); return; }
-    if (n_thr > 16) n_thr = 16;                            // (the pool's size)
-    struct Ctx { F* f; size_t n; unsigned n_thr; } c{&f, n, n_thr};
-    run_on_pool(n_thr, [](void* a, unsigned t) {
+    if (n_ranges <= 1) { f(0u, (size_t)0, n); return; }
+    struct Ctx { F* f; size_t n; unsigned n_ranges; } c{&f, n, n_ranges};
+    run_on_pool(n_ranges, threads, [](void* a, unsigned t) {
         Ctx* c = (Ctx*)a;
-        (*c->f)(t, c->n * t / c->n_thr, c->n * (t + 1) / c->n_thr);
+        (*c->f)(t, c->n * t / c->n_ranges, c->n * (t + 1) / c->n_ranges);
     }, &c);
 }
+template <typename F>
+inline void parallel_ranges(size_t n, unsigned n_thr, F&& f) { parallel_ranges(n, n_thr, n_thr, static_cast<F&&>(f)); }
 
 // x / d == umulhi(x, m) >> s for every x < 2^31 (d >= 2; m == 0 stands for d == 1): with 2^(l-1) < d <= 2^l and
 // m = floor(2^(31+l) / d) + 1 the error term x * (m * d - 2^(31+l)) stays below 2^(31+l).  Host side of the line kernels.

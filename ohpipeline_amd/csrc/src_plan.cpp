@@ -185,8 +185,26 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     auto mark = [](const char*) {};
 #endif
     // order messages by (stream, output position); a stream is identified by where its absolute frame 0 lives
-    std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
+    // (a batch whose messages are in order already -- the usual one -- reads its "order" from a table of 0, 1, 2, .. kept from plan to
+    // plan: allocating and filling one per plan was 0.09 of the headline's 1.3 ms.  Up to a million entries; a plan holds the table
+    // it got while another thread's larger batch replaces it)
+    std::shared_ptr<const std::vector<uint32_t>> identity;
+    std::vector<uint32_t> order_own;
+    if (ordered && n <= (1u << 20)) {
+        static std::mutex mu;
+        static std::shared_ptr<const std::vector<uint32_t>> table;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!table || table->size() < n) {
+            auto grown = std::make_shared<std::vector<uint32_t>>(std::max<size_t>(n, 65536));
+            std::iota(grown->begin(), grown->end(), 0u);
+            table = grown;
+        }
+        identity = table;
+    } else {
+        order_own.resize(n);
+        std::iota(order_own.begin(), order_own.end(), 0u);
+    }
+    const uint32_t* const order = identity ? identity->data() : order_own.data();
     auto src_base_of = [&](const ohgpu_src_msg_desc& d) { return (int64_t)d.src_offset - (int64_t)(d.src_frame0 * fb_src); };
     // (planar: two messages of a stream also agree on the distance between its planes; a 4 GiB reach per unit is the lean kernel's)
     if (planar) {
@@ -204,7 +222,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
     };
     // (a caller that lists its streams one after the other, each in time order -- the usual case -- is in order already, and the
     // validation pass has seen that: no pass of this planner's, no sort of half a million messages)
-    if (!ordered) std::sort(order.begin(), order.end(), before);
+    if (!ordered) std::sort(order_own.begin(), order_own.end(), before);
 
     mark("order");
     struct SegRun { uint32_t seg; uint64_t blk_lo, blk_hi; uint32_t work_begin; };   // a segment's whole blocks and where its units start in `work`
@@ -406,7 +424,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
                 o.seg_runs.push_back(SegRun{seg_index, blk_lo, blk_hi, (uint32_t)o.work.size()});
                 uint32_t mi = (uint32_t)i;                    // message that holds the unit's first output frame
                 while (mi + 1 < sg.msg_end && descs[order[mi + 1]].out_frame0 <= blk_lo * L_blk) mi++;
-                const uint32_t* const ord = order.data();
+                const uint32_t* const ord = order;
                 for (uint64_t bk = blk_lo; bk < blk_hi; bk += rows) {
                     SrcWork w;
                     w.first_block = bk; w.seg = seg_index; w.n_blocks = (uint32_t)std::min<uint64_t>(rows, blk_hi - bk);
@@ -453,7 +471,9 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             i = e;
         }
     };
-    const unsigned n_stretch = plan_threads(n, 32768);
+    // (four stretches a thread: the threads claim them as they go, so one that wakes late or shares its core takes fewer)
+    const unsigned stretch_threads = plan_threads(n, 32768);
+    const unsigned n_stretch = stretch_threads <= 1 ? 1u : (unsigned)std::min<size_t>(4u * stretch_threads, std::max<size_t>(n / 8192, stretch_threads));
     std::vector<Stretch> parts(n_stretch);
     {
         std::vector<size_t> cut(n_stretch + 1, n);
@@ -464,7 +484,7 @@ int plan_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b, const ohgpu_src_msg_desc* desc
             cut[t] = k;
         }
         for (unsigned t = 1; t <= n_stretch; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-        parallel_ranges(n_stretch, n_stretch, [&](unsigned, size_t lo, size_t hi) {
+        parallel_ranges(n_stretch, n_stretch, stretch_threads, [&](unsigned, size_t lo, size_t hi) {
             for (size_t t = lo; t < hi; t++) if (cut[t] < cut[t + 1]) plan_stretch(cut[t], cut[t + 1], parts[t]);
         });
     }

@@ -186,3 +186,27 @@ def test_a_period_a_whole_number_of_blocks_later_has_the_same_plan():
     # the streams' own first period is another plan (kWorkFirst)
     capi.set_plan_threads(1)
     assert capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db, coef_q28=ref.coef_q28)["digest"] != one["digest"]
+
+
+def test_the_pool_survives_many_short_jobs_from_two_callers():
+    """The pool's threads claim a job's ranges as they wake (csrc/ohgpu_api.hip PlanPool): a helper that wakes after its job has
+    finished must not touch it, and two callers take turns.  Many short plans from two threads at once, every digest the same."""
+    import threading
+    ref, d, sb, db = headline_like(128, 6.0)                # ~154 000 messages: several threads' worth for every pass
+    assert d.size > 140000
+    capi.set_plan_threads(1)
+    want = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
+    capi.set_plan_threads(16)
+    bad = []
+
+    def caller():
+        for _ in range(60):
+            if capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db) != want:
+                bad.append(1)
+
+    threads = [threading.Thread(target=caller) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad
