@@ -14,14 +14,16 @@
 // 16 output frames, a tile 16 outputs x 16 columns = 8 channel PAIRS; a step's coefficient image is the same for every block: a
 // wave owns five of the pass's 20 tiles in step-major order and keeps the A operands of the three steps they touch in registers for
 // the whole launch -- no table is read in the loop.  Per pass the workgroup
-//   (A) copies the rows' input from registers (loaded a pass ahead: packed sources as ONE run of 16-byte pieces, the union of the
-//       overlapping rows) into an LDS image,
+//   (A) has the rows' input in an LDS image: packed sources through the polyphase filters as ONE run of 16-byte pieces, the union of
+//       the overlapping rows, fetched a pass ahead STRAIGHT into a buffer of its own (global_load_lds_dwordx4: WgGeom::kDma, round 5);
+//       the planar and half-band forms row by row through registers (loaded a pass ahead) and 16-byte LDS stores,
 //   (S) splits it into the digit planes (lane = eight frames of one channel pair: src_mfma_common.h),
-//   (C) runs the 20 tiles, packed results into an LDS image of the pass's output,
+//   (C) runs the 20 tiles -- a wave's five as a software pipeline, a tile's last vector instructions between the next tile's matrix
+//       instructions -- packed results into an LDS image of the pass's output, twelve bytes a lane and tile in two stores,
 //   (D) writes that image out: 15 KB contiguous, whole 16-byte pieces, non-temporal,
-// with a workgroup barrier between the phases (none between (D) and (A) for packed sources: a lane refills the slots it emptied);
-// the input image and the output image share their LDS (42.5 KB a workgroup, three workgroups per CU), the next pass's input is in
-// flight in registers during (C) and (D).
+// with a workgroup barrier behind (S) and behind (C) -- (D) and (S) touch nothing of each other's, so kDma needs none between them;
+// the row-by-row forms, whose input image and output image share their LDS, have one more behind (A) -- three workgroups per CU
+// (kDma: 50-52 KB of LDS each), the next pass's input in flight during (C).
 // Six and eight channels (PAIRS = 3, 4) are the same sixteen pair-rows cut differently: 5 stream rows x 3 pairs (the sixteenth
 // column pair idles) or 4 x 4; only the addresses of the split's reads and of the tiles' stores know.  HB is the 96 -> 48 kHz
 // half-band decimator on the same tiles (WgGeom below), PLANAR the FLAC decoder's TInt32 planes as the source.
@@ -718,7 +720,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     constexpr uint32_t i = decltype(ic)::value;
                     constexpr bool kHas = i < G::kTilesPerWave, kPrev = i > 0;
                     constexpr uint32_t ii = kHas ? i : G::kTilesPerWave - 1u;
-                    constexpr uint32_t set = (kFirst + ii) / G::kCt - kFirst / G::kCt, ct = (kFirst + ii) % G::kCt;
+                    constexpr uint32_t set = (kFirst + ii) / G::kCt - kFirst / G::kCt;
                     constexpr uint32_t ip = kPrev ? i - 1u : 0u;
                     constexpr uint32_t set_p = (kFirst + ip) / G::kCt - kFirst / G::kCt, ct_p = (kFirst + ip) % G::kCt;
                     static_assert(set < G::kKcSets, "a wave's tiles touch kKcSets steps");
