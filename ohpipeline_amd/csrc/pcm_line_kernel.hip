@@ -679,11 +679,16 @@ static hipError_t launch_line(const ohgpu_ctx* ctx, const ohgpu_batch* b, uint32
     // workgroups (tools/micro/run_copy.hip: the same bytes at 5.6 TB/s from two to four workgroups per CU, 4.6-4.9 from eight to
     // thirty-two): four per CU took the default mix (5 % of the messages ramped) from 0.2877 to 0.2723 ms, same box, turn and turn
     // about (three: 0.2872, two: 0.366).  A launch whose chunks are mostly ramped or attenuated has arithmetic to hide behind other
-    // waves' loads: every message ramped 0.2949 at eight per CU, 0.2877 at six, 0.3167 at four.
+    // waves' loads: every message ramped 0.2949 at eight per CU, 0.2877 at six, 0.3167 at four.  And four is the better number only
+    // for the LARGE plain launch: by chunks (same box, gpurun_out/r5/exp_line3.log, exp_line4.log, ms at 4 / 5 / 6 / 8 per CU) 128 k
+    // 0.0631 / 0.0603 / 0.0613 / 0.0616; 256 k 0.158 / 0.143 / 0.135 / 0.135 -- Songcast frames of 256 k stereo messages 0.164 /
+    // - / 0.150 / 0.152, the sender's S32 -> S24 pack 0.168 / - / 0.156 / 0.160 --; 512 k 0.261 / 0.262 / 0.265 / 0.279, S32 -> S24
+    // 0.310 / 0.312 / 0.323 / 0.335; 1 M within the noise.  Round 5's profiles of the Songcast and sender-pack benches are what
+    // showed it (6 % behind round 3's on a launch size the occupancy had not been tried on).
 #ifdef OHGPU_LINE_GROUPS_PER_CU
     const uint32_t per_cu = OHGPU_LINE_GROUPS_PER_CU;
 #else
-    const uint32_t per_cu = heavy_percent >= 30u ? 6u : 4u;
+    const uint32_t per_cu = heavy_percent >= 30u || count < 400000u ? 6u : 4u;
 #endif
     if (grid > cus * per_cu) grid = cus * per_cu;
     hipLaunchKernelGGL((pcm_line_kernel<SB, DB>), dim3(grid), dim3(kLineWaves * 64), 0, s,
