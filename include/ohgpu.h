@@ -401,6 +401,14 @@ int ohgpu_src_plan_digest(uint32_t L, uint32_t M, uint32_t taps_per_phase, const
  * data path depends on.  The name is written to out[0, cap) NUL-terminated (truncated if it does not fit). */
 int ohgpu_src_batch_kernel_name(ohgpu_ctx* ctx, const ohgpu_batch* batch, char* out, size_t cap);
 
+/* How many workgroups of the batch's resampler kernel the device keeps on a CU at once (hipOccupancyMaxActiveBlocksPerMultiprocessor
+ * of the instantiation the batch runs, with its LDS), how many its geometry was laid out for, and its LDS bytes per workgroup.  The
+ * workgroup matrix kernel is sized to the LDS: three workgroups per CU at 50.7-52.0 KB each (csrc/src_mfma_wg_kernel.hip WgGeom);
+ * one granule more and the device would keep two, a third of the throughput gone without an error anywhere -- tests/test_gpu_parity.py
+ * holds every layout to its design.  OHGPU_ERR_UNSUPPORTED for a batch that runs on another kernel; nothing is launched.  (A
+ * diagnostic like ohgpu_measure_shader_clock: no reference interface behind it.) */
+int ohgpu_src_batch_occupancy(ohgpu_ctx* ctx, const ohgpu_batch* batch, int* workgroups_per_cu, int* designed_for, uint32_t* lds_bytes);
+
 /* The shader clock the device holds right now, in MHz: a short kernel on every CU (about 0.2 ms of dependent vector work,
  * queued on `stream` like any launch) compares the shader cycle counter (s_memtime) with the constant 100 MHz reference counter
  * (s_memrealtime) and the call waits for it.  For a benchmark to report next to a kernel time, so that a slow box can be told

@@ -116,6 +116,7 @@ SYMBOLS = {
     "ohgpu_src_plan_digest": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int,
                                         _vp, C.c_int, _u64p, _u64p, _u64p, C.POINTER(C.c_int)]),
     "ohgpu_src_batch_kernel_name": (C.c_int, [_vp, _vp, C.c_char_p, C.c_size_t]),
+    "ohgpu_src_batch_occupancy": (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "ohgpu_measure_shader_clock": (C.c_int, [_vp, _vp, C.POINTER(C.c_double)]),
     "ohgpu_device_allocations": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ohgpu_src_process_host": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_uint64, _vp, C.c_uint64]),
@@ -443,6 +444,11 @@ class Context:
         buf = C.create_string_buffer(256)
         check(lib().ohgpu_src_batch_kernel_name(self._h, batch, buf, 256))
         return buf.value.decode()
+
+    def src_occupancy(self, batch):
+        g, want, lds = C.c_int(0), C.c_int(0), C.c_uint32(0)
+        check(lib().ohgpu_src_batch_occupancy(self._h, batch, C.byref(g), C.byref(want), C.byref(lds)))
+        return {"workgroups_per_cu": int(g.value), "designed_for": int(want.value), "lds_bytes": int(lds.value)}
 
     def device_allocations(self):
         n = C.c_uint64(0)

@@ -1342,6 +1342,20 @@ int ohgpu_src_batch_kernel_name(ohgpu_ctx* ctx, const ohgpu_batch* batch, char* 
     return OHGPU_OK;
 }
 
+int ohgpu_src_batch_occupancy(ohgpu_ctx* ctx, const ohgpu_batch* batch, int* workgroups_per_cu, int* designed_for, uint32_t* lds_bytes)
+{
+    CTX_GUARD("ohgpu_src_batch_occupancy");
+    if (!batch || batch->kind != kBatchSrc || !workgroups_per_cu) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_occupancy: bad argument");
+    const ohgpu_batch* one = batch->parts.empty() ? batch : batch->parts.front();
+    if (src_kernel_choice(ctx, one) != kSrcWg) return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_batch_occupancy: the batch does not run on the workgroup kernel (%s)", src_kernel_of(ctx, one));
+    WgOccupancy q;
+    OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, one, nullptr, nullptr, nullptr, &q));
+    *workgroups_per_cu = q.groups_per_cu;
+    if (designed_for) *designed_for = q.designed_for;
+    if (lds_bytes) *lds_bytes = q.lds_bytes;
+    return OHGPU_OK;
+}
+
 // ohgpu_measure_shader_clock: every wave runs a chain of dependent integer multiply-adds (about 0.2 ms at 2.4 GHz); wave 0 of every
 // workgroup reports the shader cycles and the 100 MHz reference ticks its chain took.
 __global__ __launch_bounds__(256) void clock_probe_kernel(uint64_t* __restrict__ out, uint32_t iters)

@@ -454,7 +454,9 @@ hipError_t launch_src_v1(const ohgpu_ctx* ctx, const void* d_descs, size_t n, co
 hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit = 0);   // csrc/src_mfma_kernel.hip, legacy builds only (units [first_unit, n_lean))
-hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);   // csrc/src_mfma_wg_kernel.hip
+// (`query`: nothing is launched; the instantiation the batch would run is asked what the device grants it -- ohgpu_src_batch_occupancy)
+struct WgOccupancy { int groups_per_cu = 0, designed_for = 0; uint32_t lds_bytes = 0; };
+hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, WgOccupancy* query = nullptr);   // csrc/src_mfma_wg_kernel.hip
 bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar, bool halfband);
 bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, uint32_t sb, uint32_t unit_rows, bool planar, uint64_t plane_stride, bool halfband);
 bool build_mfma_halfband(const int32_t* coef_q28, uint32_t L_blk, std::vector<MfStep>* steps, std::vector<uint8_t>* amat);   // csrc/src_mfma_kernel.hip

@@ -922,7 +922,7 @@ bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t 
 }
 
 template <int PLANAR, int PAIRS, bool HB, bool SRC_LE, bool DST_LE>
-static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s)
+static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& p, hipStream_t s, WgOccupancy* query)
 {
     using G = WgGeom<OHGPU_WG_ROWS, PLANAR, PAIRS, HB>;
     auto kernel = src_mfma_wg_kernel<OHGPU_WG_ROWS, PLANAR, PAIRS, HB, SRC_LE, DST_LE>;
@@ -935,6 +935,14 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     if (gsz > n_units) gsz = n_units;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLdsBytes);
     if (e != hipSuccess) return e;
+    if (query) {                                             // (ohgpu_src_batch_occupancy: what the device grants this instantiation, nothing launched)
+        int groups = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&groups, (const void*)kernel, (int)G::kThreads, (size_t)G::kLdsBytes);
+        query->groups_per_cu = groups;
+        query->designed_for = (int)G::kGroupsPerCu;
+        query->lds_bytes = G::kLdsBytes;
+        return e;
+    }
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s,
                        (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
                        (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * (G::kPlanes ? 4u : G::kFbIn), p.src_arena_bytes);
@@ -942,35 +950,35 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
 }
 
 template <int PAIRS, bool HB>
-static hipError_t launch_wg_packed(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& prm, hipStream_t s)
+static hipError_t launch_wg_packed(const ohgpu_ctx* ctx, const ohgpu_batch* b, const SrcFastParams& prm, hipStream_t s, WgOccupancy* q)
 {
-    if (prm.src_le) return prm.dst_le ? launch_wg_one<0, PAIRS, HB, true, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, HB, true, false>(ctx, b, prm, s);
-    return prm.dst_le ? launch_wg_one<0, PAIRS, HB, false, true>(ctx, b, prm, s) : launch_wg_one<0, PAIRS, HB, false, false>(ctx, b, prm, s);
+    if (prm.src_le) return prm.dst_le ? launch_wg_one<0, PAIRS, HB, true, true>(ctx, b, prm, s, q) : launch_wg_one<0, PAIRS, HB, true, false>(ctx, b, prm, s, q);
+    return prm.dst_le ? launch_wg_one<0, PAIRS, HB, false, true>(ctx, b, prm, s, q) : launch_wg_one<0, PAIRS, HB, false, false>(ctx, b, prm, s, q);
 }
 
-hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s)
+hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, WgOccupancy* q)
 {
     SrcFastParams prm = b->fast.params;
     prm.src = src;
     prm.dst = dst;
     if (b->src_planar) {
         switch (prm.sb) {                                    // (the stream's bytes per sample)
-        case 3: return prm.dst_le ? launch_wg_one<1, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<1, 1, false, true, false>(ctx, b, prm, s);
-        case 2: return prm.dst_le ? launch_wg_one<2, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<2, 1, false, true, false>(ctx, b, prm, s);
-        case 1: return prm.dst_le ? launch_wg_one<3, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<3, 1, false, true, false>(ctx, b, prm, s);
+        case 3: return prm.dst_le ? launch_wg_one<1, 1, false, true, true>(ctx, b, prm, s, q) : launch_wg_one<1, 1, false, true, false>(ctx, b, prm, s, q);
+        case 2: return prm.dst_le ? launch_wg_one<2, 1, false, true, true>(ctx, b, prm, s, q) : launch_wg_one<2, 1, false, true, false>(ctx, b, prm, s, q);
+        case 1: return prm.dst_le ? launch_wg_one<3, 1, false, true, true>(ctx, b, prm, s, q) : launch_wg_one<3, 1, false, true, false>(ctx, b, prm, s, q);
         default: return hipErrorInvalidValue;
         }
     }
     const bool hb = b->fast.mfma_wg_halfband;
     if (prm.sb == 2) {                                       // packed 16-bit stereo (WgGeom: source format 4)
         if (prm.channels != 2 || hb) return hipErrorInvalidValue;
-        if (prm.src_le) return prm.dst_le ? launch_wg_one<4, 1, false, true, true>(ctx, b, prm, s) : launch_wg_one<4, 1, false, true, false>(ctx, b, prm, s);
-        return prm.dst_le ? launch_wg_one<4, 1, false, false, true>(ctx, b, prm, s) : launch_wg_one<4, 1, false, false, false>(ctx, b, prm, s);
+        if (prm.src_le) return prm.dst_le ? launch_wg_one<4, 1, false, true, true>(ctx, b, prm, s, q) : launch_wg_one<4, 1, false, true, false>(ctx, b, prm, s, q);
+        return prm.dst_le ? launch_wg_one<4, 1, false, false, true>(ctx, b, prm, s, q) : launch_wg_one<4, 1, false, false, false>(ctx, b, prm, s, q);
     }
     switch (prm.channels) {
-    case 2: return hb ? launch_wg_packed<1, true>(ctx, b, prm, s) : launch_wg_packed<1, false>(ctx, b, prm, s);
-    case 6: return hb ? launch_wg_packed<3, true>(ctx, b, prm, s) : launch_wg_packed<3, false>(ctx, b, prm, s);
-    case 8: return hb ? launch_wg_packed<4, true>(ctx, b, prm, s) : launch_wg_packed<4, false>(ctx, b, prm, s);
+    case 2: return hb ? launch_wg_packed<1, true>(ctx, b, prm, s, q) : launch_wg_packed<1, false>(ctx, b, prm, s, q);
+    case 6: return hb ? launch_wg_packed<3, true>(ctx, b, prm, s, q) : launch_wg_packed<3, false>(ctx, b, prm, s, q);
+    case 8: return hb ? launch_wg_packed<4, true>(ctx, b, prm, s, q) : launch_wg_packed<4, false>(ctx, b, prm, s, q);
     default: return hipErrorInvalidValue;
     }
 }

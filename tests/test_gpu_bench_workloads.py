@@ -178,6 +178,25 @@ def test_workgroup_matrix_kernel_takes_packed_s24_of_two_six_and_eight_channels(
     run_groups(ctx, [g], kernel="src_mfma_wg_kernel")
 
 
+@pytest.mark.parametrize("rate, channels, src_bits", [(44100, 2, 24), (44100, 6, 24), (44100, 8, 24), (96000, 2, 24), (96000, 6, 24),
+                                                      (96000, 8, 24), (44100, 2, 16)])
+def test_the_device_keeps_as_many_workgroups_per_cu_as_the_kernel_is_laid_out_for(ctx, rate, channels, src_bits):
+    """The workgroup matrix kernel is sized to the LDS -- three workgroups per CU at 50.7-52.0 KB each since its input run has a
+    buffer of its own (csrc/src_mfma_wg_kernel.hip WgGeom::kDma) -- and with a granule too many the device would keep two: a third of the
+    throughput gone, no error anywhere.  ohgpu_src_batch_occupancy asks the device what it grants the instantiation the batch runs."""
+    g = bench.Group(capi, rate, channels, range(40, 44), int(round(0.4 * rate)), src_bits=src_bits, src_endian=capi.ENDIAN_LITTLE,
+                    dst_bits=24, dst_endian=capi.ENDIAN_BIG)
+    g.src = np.zeros(g.src_bytes, dtype=np.uint8)
+    g.attach(ctx)
+    try:
+        assert ctx.src_kernel_name(g.batch) == "src_mfma_wg_kernel"
+        occ = ctx.src_occupancy(g.batch)
+    finally:
+        g.detach(ctx)
+    assert occ["designed_for"] == 3 and occ["workgroups_per_cu"] >= occ["designed_for"], occ
+    assert occ["lds_bytes"] <= 52 * 1024, occ
+
+
 @pytest.mark.parametrize("channels, src_le, dst_le", [(6, True, False), (2, False, True)])
 def test_a_plan_only_the_workgroup_kernel_reads_never_reaches_another_kernel(ctx, channels, src_le, dst_le):
     """Six-channel units are cut 30 rows long for the workgroup kernel, and big-endian-in / little-endian-out has no other block
