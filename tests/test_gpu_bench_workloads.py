@@ -178,6 +178,46 @@ def test_workgroup_matrix_kernel_takes_packed_s24_of_two_six_and_eight_channels(
     run_groups(ctx, [g], kernel="src_mfma_wg_kernel")
 
 
+@pytest.mark.parametrize("channels", [2, 6, 8])
+@pytest.mark.parametrize("rate", [47700, 43800])
+def test_the_shortest_and_the_longest_input_run_the_workgroup_kernel_admits(ctx, rate, channels):
+    """A pass's input is ONE run -- the union of its rows -- fetched into an LDS buffer sized for the longest the geometry admits
+    (csrc/src_mfma_wg_kernel.hip WgGeom::kDmaBytes, kSpanRounds).  The headline's 147 input frames per block of 160 outputs sit in the
+    middle; 47.7 kHz -> 48 kHz is 159 per block (the longest run: 967 of stereo's 972 pieces, 1004 of eight channels' 1008), 43.8 kHz
+    (73 : 80) is 146 (the shortest a ratio can make of a block of 160: the last round of loads has the fewest lanes).  Odd rates,
+    ordinary filters -- but ratios this
+    close to one make phases whose sum |c| passes 2^29, which keeps a batch off the matrix kernel (the planner ties it to the lean
+    kernel's bound), so the designed table is taken at three quarters, in the oracle's table and in the library's alike.  Streams
+    short enough that units sit at both ends of the arena."""
+    g = bench.Group(capi, rate, channels, range(70, 73), int(round(0.37 * rate)), src_bits=24, src_endian=capi.ENDIAN_LITTLE,
+                    dst_bits=24, dst_endian=capi.ENDIAN_BIG)
+    assert (g.L, g.M) in ((160, 159), (80, 73))
+    ref = O.Src(g.rate_in, bench.RATE_OUT, g.taps, bench.BETA, bench.F_PASS)
+    table = np.ctypeslib.as_array(O.lib().ohp_src_coef_q28(ref.h), shape=(g.L * g.taps,))       # (the oracle's own table, in place)
+    table[:] = (table.astype(np.int64) * 3) // 4
+    coef = np.array(table, dtype=np.int32)
+    assert max(int(np.abs(coef[p * g.taps:(p + 1) * g.taps].astype(np.int64)).sum()) for p in range(g.L)) < 2 ** 29
+    per = g.in_frames * channels
+    g.src = np.concatenate([noise_le(sid, per, 24).reshape(-1) for sid in g.stream_ids])
+    h = ctx.src_create(g.L, g.M, g.taps, coef)
+    d_src, d_dst = ctx.upload(g.src), ctx.malloc(g.dst_bytes)
+    ctx.memset(d_dst, 0, g.dst_bytes)
+    b = ctx.src_batch(h, g.descs, g.src_bytes, g.dst_bytes)
+    try:
+        assert ctx.src_kernel_name(b) == "src_mfma_wg_kernel"
+        ctx.src_run(b, d_src, d_dst)
+        got = ctx.download(d_dst, g.dst_bytes)
+    finally:
+        ctx.batch_destroy(b)
+        ctx.src_destroy(h)
+        ctx.free(d_src)
+        ctx.free(d_dst)
+    want = np.zeros(g.dst_bytes, dtype=np.uint8)
+    assert ref.process_batch(g.descs.view(O.SRC_MSG_DESC), g.src, want) == 0
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (rate, channels, int(bad.size), int(bad[0]))
+
+
 @pytest.mark.parametrize("rate, channels, src_bits", [(44100, 2, 24), (44100, 6, 24), (44100, 8, 24), (96000, 2, 24), (96000, 6, 24),
                                                       (96000, 8, 24), (44100, 2, 16)])
 def test_the_device_keeps_as_many_workgroups_per_cu_as_the_kernel_is_laid_out_for(ctx, rate, channels, src_bits):
