@@ -335,6 +335,14 @@ int ohgpu_src_batch_create(ohgpu_ctx* ctx, const ohgpu_src* src, const ohgpu_src
  * OHGPU_ERR_INVALID (nothing is launched).  Different batches are independent.  The same holds for
  * ohgpu_flywheel_batch_run (the batch owns Burg's workspace). */
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream);
+/* The same with two events of the caller's (ohgpu_event_create) that bracket the batch's device work on `stream`: a batch that is one
+ * launch of the workgroup matrix kernel carries them ON ITS DISPATCH (hipExtLaunchKernelGGL: the dispatch's own start and end
+ * timestamps, no packet more in the queue -- two ohgpu_event_record calls around every launch cost a benchmark's back-to-back launches
+ * 5 us each, 1.7 % of the headline's); any other batch gets them recorded in front of its first launch and behind its last.
+ * ohgpu_event_elapsed_ms(start, stop) is the batch's device time either way.  A measurement's tool (bench.py's roofline): the audio
+ * is ohgpu_src_batch_run's. */
+int ohgpu_src_batch_run_timed(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream,
+                              void* start_event, void* stop_event);
 
 /* ---- the same batch, the next period ----
  * A caller that brings new audio every period in the same shape -- the same streams, the same tiling into messages, a whole number

@@ -107,6 +107,7 @@ SYMBOLS = {
     "ohgpu_src_mfma_halfband_tables": (C.c_int, [_vp, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),
     "ohgpu_src_batch_create": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, C.c_uint64, _vpp]),
     "ohgpu_src_batch_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ohgpu_src_batch_run_timed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ohgpu_src_batch_plan": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_src_batch_units": (C.c_int, [_vp, _u64p, _u64p]),
     "ohgpu_set_plan_threads": (C.c_int, [C.c_int]),
@@ -471,5 +472,9 @@ class Context:
         check(lib().ohgpu_measure_shader_clock(self._h, stream, C.byref(mhz)))
         return float(mhz.value)
 
-    def src_run(self, batch, d_src, d_dst, stream=None):
-        check(lib().ohgpu_src_batch_run(self._h, batch, d_src, d_dst, stream))
+    def src_run(self, batch, d_src, d_dst, stream=None, events=None):
+        """`events` = (start, stop) of ctx.event(): they bracket the batch's device work (on the dispatch itself where the batch is one launch)."""
+        if events is not None:
+            check(lib().ohgpu_src_batch_run_timed(self._h, batch, d_src, d_dst, stream, events[0], events[1]))
+        else:
+            check(lib().ohgpu_src_batch_run(self._h, batch, d_src, d_dst, stream))

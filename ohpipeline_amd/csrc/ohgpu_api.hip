@@ -603,17 +603,17 @@ int ohgpu_pcm_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
 // has not finished; remember this one.
 static int claim_single_launch(const ohgpu_batch* b, hipStream_t s, const char* who)
 {
-    if (b->last_done != nullptr && b->last_stream != s && hipEventQuery(b->last_done) == hipErrorNotReady)
+    if (batch_busy_on_another_stream(b, s))
         return set_error(OHGPU_ERR_INVALID, "%s: the batch is still running on another stream (its unit counters / workspace serve one "
                          "launch at a time: wait for it, use the same stream, or create a second batch)", who);
-    if (b->last_done == nullptr && hipEventCreateWithFlags(&b->last_done, hipEventDisableTiming) != hipSuccess) {
+    if (b->last_done == nullptr && hipEventCreate(&b->last_done) != hipSuccess) {       // (it rides on a dispatch as its stop event: src_batch_run)
         b->last_done = nullptr;
         return set_error(OHGPU_ERR_DEVICE, "%s: hipEventCreate failed", who);
     }
     b->last_stream = s;
     return OHGPU_OK;
 }
-static void launched(const ohgpu_batch* b, hipStream_t s) { if (b->last_done) (void)hipEventRecord(b->last_done, s); }
+static void launched(const ohgpu_batch* b, hipStream_t s) { b->last_untracked = false; if (b->last_done) (void)hipEventRecord(b->last_done, s); }
 
 int ohgpu_batch_destroy(ohgpu_ctx* ctx, ohgpu_batch* batch)
 {
@@ -1395,34 +1395,65 @@ int ohgpu_measure_shader_clock(ohgpu_ctx* ctx, void* stream, double* mhz)
     return OHGPU_OK;
 }
 
+static int src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream)
+{
+    return src_batch_run(ctx, batch, src_base, dst_base, stream, nullptr, nullptr);
+}
+
+int ohgpu_src_batch_run_timed(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream, void* start_event, void* stop_event)
+{
+    if (!start_event || !stop_event) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run_timed: null event");
+    return src_batch_run(ctx, batch, src_base, dst_base, stream, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+}
+
+// (ev_start / ev_stop: both or neither.  A batch that is ONE launch of the workgroup matrix kernel carries them on its dispatch; any other
+// -- several layouts, block-unaligned pieces on the generic kernel behind the block kernel, another kernel -- gets them recorded in
+// front of its first launch and behind its last)
+static int src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* src_base, void* dst_base, void* stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     CTX_GUARD("ohgpu_src_batch_run");
     if (!batch || batch->kind != kBatchSrc) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: not a src batch");
-    if (batch->n == 0) return OHGPU_OK;
-    if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
     hipStream_t s = pick_stream(ctx, stream);
+    if (batch->n == 0) {
+        if (ev_start) { OHGPU_HIP_TRY(hipEventRecord(ev_start, s)); OHGPU_HIP_TRY(hipEventRecord(ev_stop, s)); }
+        return OHGPU_OK;
+    }
+    if (!src_base || !dst_base) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: null arena pointer");
     if (ctx->variant != 1 && !batch->parts.empty()) {               // one uniform batch per layout
         // "nothing is launched" on refusal holds for the whole batch: every part is asked first whether it is free (a part still
         // running on another stream refuses), and only then does the first one launch
         for (const ohgpu_batch* part : batch->parts)
-            if (part->last_done != nullptr && part->last_stream != s && hipEventQuery(part->last_done) == hipErrorNotReady)
+            if (batch_busy_on_another_stream(part, s))
                 return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_run: a part of the batch is still running on another stream (its unit counters "
                                  "serve one launch at a time: wait for it, use the same stream, or create a second batch); nothing was launched");
+        if (ev_start) OHGPU_HIP_TRY(hipEventRecord(ev_start, s));
         for (const ohgpu_batch* part : batch->parts) {
             const int err = ohgpu_src_batch_run(ctx, part, src_base, dst_base, s);
             if (err != OHGPU_OK) return err;                        // (a device error: the destination may be partly written, as for any failed launch)
         }
+        if (ev_stop) OHGPU_HIP_TRY(hipEventRecord(ev_stop, s));
         return OHGPU_OK;
     }
     const SrcKernel which = src_kernel_choice(ctx, batch, ((uintptr_t)src_base & 15u) == 0);
+    // (a batch that is ONE launch of the workgroup matrix kernel: its dispatch carries an event -- the caller's two, or the batch's
+    // "last launch done" -- instead of a marker packet behind it: back-to-back launches were 10 us apart with the marker)
+    const bool one_launch = which == kSrcWg && batch->fast.n_rem == 0;
+    const bool on_dispatch = ev_start && one_launch;
+    if (ev_start && !on_dispatch) OHGPU_HIP_TRY(hipEventRecord(ev_start, s));
     if (which != kSrcGeneric) {
         const int claim = claim_single_launch(batch, s, "ohgpu_src_batch_run");        // (the block kernels' unit counters are the batch's)
         if (claim != OHGPU_OK) return claim;
         if (batch->fast.planes_ready) OHGPU_HIP_TRY(hipStreamWaitEvent(s, batch->fast.planes_ready, 0));     // (the ramp planes are filled on the context's stream)
         // whole phase-aligned blocks on the chosen block kernel, block-unaligned heads/tails on the generic one
         switch (which) {
-        case kSrcWg: OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
+        case kSrcWg: {
+            WgOccupancy x;
+            x.query = false; x.start = on_dispatch ? ev_start : nullptr; x.stop = on_dispatch ? ev_stop : batch->last_done;
+            OHGPU_HIP_TRY(launch_src_mfma_wg(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s, one_launch ? &x : nullptr));
+            break;
+        }
 #ifdef OHGPU_LEGACY_KERNELS
         case kSrcMfma: OHGPU_HIP_TRY(launch_src_mfma(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
 #endif
@@ -1430,7 +1461,8 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         default: OHGPU_HIP_TRY(launch_src_lean(ctx, batch, (const uint8_t*)src_base, (uint8_t*)dst_base, s)); break;
         }
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->fast.d_rem, batch->fast.n_rem, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
-        launched(batch, s);
+        if (!one_launch) launched(batch, s);
+        else batch->last_untracked = on_dispatch;            // (else: last_done rode on the dispatch)
     } else {
         if (!batch->host_descs)
             return set_error(OHGPU_ERR_UNSUPPORTED, "ohgpu_src_batch_run: this batch was planned for the block kernels and keeps no per-message descriptors for the "
@@ -1446,6 +1478,7 @@ int ohgpu_src_batch_run(ohgpu_ctx* ctx, const ohgpu_batch* batch, const void* sr
         }
         OHGPU_HIP_TRY(launch_src_v1(ctx, batch->d_descs, batch->n, batch->src, (const uint8_t*)src_base, (uint8_t*)dst_base, s));
     }
+    if (ev_stop && !on_dispatch) OHGPU_HIP_TRY(hipEventRecord(ev_stop, s));
     return OHGPU_OK;
 }
 
@@ -1492,7 +1525,7 @@ int ohgpu_src_batch_set_ramps(ohgpu_ctx* ctx, ohgpu_batch* b, const uint16_t* ra
     // (only the messages that carry a ramp are looked at: the flags are the plan's)
     for (uint32_t m : f.job_msg) if (ramp_start[m] > OHGPU_RAMP_MAX || ramp_end[m] > OHGPU_RAMP_MAX) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_set_ramps: message %u: ramp beyond Ramp::kMax", m);
     for (uint32_t m : f.rem_msg) if (ramp_start[m] > OHGPU_RAMP_MAX || ramp_end[m] > OHGPU_RAMP_MAX) return set_error(OHGPU_ERR_INVALID, "ohgpu_src_batch_set_ramps: message %u: ramp beyond Ramp::kMax", m);
-    if (b->last_done) OHGPU_HIP_TRY(hipEventSynchronize(b->last_done));          // (the batch's last launch reads what is rewritten here)
+    OHGPU_HIP_TRY(batch_wait_last_launch(b));                                    // (the batch's last launch reads what is rewritten here)
     hipStream_t s0 = ctx->stream;
     if (f.enabled) {
         for (size_t k = 0; k < f.host_jobs.size(); k++) { f.host_jobs[k].ramp_start = ramp_start[f.job_msg[k]]; f.host_jobs[k].ramp_end = ramp_end[f.job_msg[k]]; }

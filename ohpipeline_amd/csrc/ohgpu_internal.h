@@ -408,6 +408,9 @@ struct ohgpu_batch {
     // (ohgpu_*_batch_run, OHGPU_ERR_INVALID) instead of silently sharing them.
     mutable hipStream_t last_stream = nullptr;
     mutable hipEvent_t  last_done = nullptr;
+    // (the last launch carried the CALLER's events on its dispatch -- ohgpu_src_batch_run_timed -- and not last_done: "has it finished"
+    // is then asked of last_stream itself)
+    mutable bool last_untracked = false;
 };
 
 namespace ohgpu {
@@ -455,7 +458,9 @@ hipError_t launch_src_block(const ohgpu_ctx* ctx, const ohgpu_batch* b, const ui
 hipError_t launch_src_lean(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s);
 hipError_t launch_src_mfma(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, uint32_t first_unit = 0);   // csrc/src_mfma_kernel.hip, legacy builds only (units [first_unit, n_lean))
 // (`query`: nothing is launched; the instantiation the batch would run is asked what the device grants it -- ohgpu_src_batch_occupancy)
-struct WgOccupancy { int groups_per_cu = 0, designed_for = 0; uint32_t lds_bytes = 0; };
+// (`start` / `stop`: the launch itself carries the two events -- hipExtLaunchKernelGGL: its dispatch's own timestamps, no packet more
+// in the queue -- ohgpu_src_batch_run_timed)
+struct WgOccupancy { bool query = true; int groups_per_cu = 0, designed_for = 0; uint32_t lds_bytes = 0; hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t launch_src_mfma_wg(const ohgpu_ctx* ctx, const ohgpu_batch* b, const uint8_t* src, uint8_t* dst, hipStream_t s, WgOccupancy* query = nullptr);   // csrc/src_mfma_wg_kernel.hip
 bool src_mfma_wg_supported(uint32_t L_blk, uint32_t M_blk, uint32_t ch, uint32_t sb, uint32_t db, bool planar, bool halfband);
 bool src_mfma_wg_unit_inside(int64_t src_row0, uint32_t row_src_bytes, uint64_t src_arena_bytes, uint32_t ch, uint32_t sb, uint32_t unit_rows, bool planar, uint64_t plane_stride, bool halfband);
@@ -606,6 +611,18 @@ inline bool src_msg_before(const ohgpu_src_msg_desc& x, const ohgpu_src_msg_desc
 }
 
 void free_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b);
+// a batch's last launch: still running on a stream other than `s`?  /  wait for it
+inline bool batch_busy_on_another_stream(const ohgpu_batch* b, hipStream_t s)
+{
+    if (b->last_stream == s) return false;
+    if (b->last_untracked) return hipStreamQuery(b->last_stream) == hipErrorNotReady;
+    return b->last_done != nullptr && hipEventQuery(b->last_done) == hipErrorNotReady;
+}
+inline hipError_t batch_wait_last_launch(const ohgpu_batch* b)
+{
+    if (b->last_untracked) return hipStreamSynchronize(b->last_stream);
+    return b->last_done ? hipEventSynchronize(b->last_done) : hipSuccess;
+}
 void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b);
 
 }  // namespace ohgpu

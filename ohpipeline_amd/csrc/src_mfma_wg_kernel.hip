@@ -30,6 +30,7 @@
 // Units whose input image does not lie wholly inside the source arena (kWorkEdge: the first of the first stream, the last of
 // the last) fetch their pieces through a checked, out-of-line load.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -935,13 +936,20 @@ static hipError_t launch_wg_one(const ohgpu_ctx* ctx, const ohgpu_batch* b, cons
     if (gsz > n_units) gsz = n_units;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLdsBytes);
     if (e != hipSuccess) return e;
-    if (query) {                                             // (ohgpu_src_batch_occupancy: what the device grants this instantiation, nothing launched)
+    if (query && query->query) {                             // (ohgpu_src_batch_occupancy: what the device grants this instantiation, nothing launched)
         int groups = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&groups, (const void*)kernel, (int)G::kThreads, (size_t)G::kLdsBytes);
         query->groups_per_cu = groups;
         query->designed_for = (int)G::kGroupsPerCu;
         query->lds_bytes = G::kLdsBytes;
         return e;
+    }
+    if (query && query->stop) {
+        // (ohgpu_src_batch_run_timed: the two events ride on the dispatch -- its own start and end timestamps, nothing else in the queue)
+        hipExtLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s, query->start, query->stop, 0,
+                              (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,
+                              (const uint16_t*)f.d_planes, f.plane_stride, p.src, p.dst, p.M_blk * (G::kPlanes ? 4u : G::kFbIn), p.src_arena_bytes);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(kernel, dim3(gsz), dim3(G::kThreads), G::kLdsBytes, s,
                        (const LeanUnit*)f.d_lean_units, n_units, (const uint8_t*)f.d_mf_amat, (const MfStep*)f.d_mf_steps,

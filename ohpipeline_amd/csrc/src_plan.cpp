@@ -25,7 +25,7 @@ void free_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b)
     // (every d_* below points into the slab, and the slab goes back to the context's cache of device blocks for the next batch to
     // write into: nothing of this one may still be running -- the planes' fill, the last launch)
     if (f.planes_ready) { (void)hipEventSynchronize(f.planes_ready); (void)hipEventDestroy(f.planes_ready); }
-    if (f.d_slab && b->last_done) (void)hipEventSynchronize(b->last_done);
+    if (f.d_slab) (void)batch_wait_last_launch(b);
     if (f.d_slab) { if (ctx) ctx_dev_free(ctx, f.d_slab); else (void)hipFree(f.d_slab); }
     f = SrcFastPlan();
 }

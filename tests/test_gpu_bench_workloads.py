@@ -237,6 +237,31 @@ def test_the_device_keeps_as_many_workgroups_per_cu_as_the_kernel_is_laid_out_fo
     assert occ["lds_bytes"] <= 52 * 1024, occ
 
 
+@pytest.mark.parametrize("rate, n_streams", [(44100, 6), (44100, 1), (88200, 3)])
+def test_a_timed_run_is_the_same_run_with_its_time_on_the_events(ctx, rate, n_streams):
+    """ohgpu_src_batch_run_timed: the caller's two events bracket the batch's device work -- on the dispatch itself for a batch that is
+    one launch of the workgroup matrix kernel (44.1 kHz stereo in whole blocks), recorded around the launches otherwise (a stream
+    whose length leaves block-unaligned pieces for the generic kernel; 88.2 kHz: the lean kernel).  The audio is the plain run's."""
+    g = bench.Group(capi, rate, 2, range(90, 90 + n_streams), int(round(0.53 * rate)) + (0 if n_streams > 1 else 77))
+    per = g.in_frames * 2
+    g.src = np.concatenate([noise_le(sid, per, 24).reshape(-1) for sid in g.stream_ids])
+    g.attach(ctx)
+    try:
+        ctx.src_run(g.batch, g.d_src, g.d_dst)
+        want = ctx.download(g.d_dst, g.dst_bytes)
+        ctx.memset(g.d_dst, 0, g.dst_bytes)
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.src_run(g.batch, g.d_src, g.d_dst, events=(e0, e1))
+        ms = ctx.elapsed_ms(e0, e1)
+        got = ctx.download(g.d_dst, g.dst_bytes)
+        ctx.event_destroy(e0)
+        ctx.event_destroy(e1)
+    finally:
+        g.detach(ctx)
+    assert np.array_equal(got, want)
+    assert 0.0 < ms < 50.0, ms
+
+
 @pytest.mark.parametrize("channels, src_le, dst_le", [(6, True, False), (2, False, True)])
 def test_a_plan_only_the_workgroup_kernel_reads_never_reaches_another_kernel(ctx, channels, src_le, dst_le):
     """Six-channel units are cut 30 rows long for the workgroup kernel, and big-endian-in / little-endian-out has no other block
