@@ -612,15 +612,18 @@ inline bool src_msg_before(const ohgpu_src_msg_desc& x, const ohgpu_src_msg_desc
 
 void free_src_fast(ohgpu_ctx* ctx, ohgpu_batch* b);
 // a batch's last launch: still running on a stream other than `s`?  /  wait for it
+// (after a timed run nothing of the library's marks the launch's end, and the caller's stream may be gone by the time anyone asks:
+// the device as a whole is waited for instead -- a diagnostic's price, paid only by a destroy, a rewrite of the ramps or a change of
+// stream right behind a timed run)
 inline bool batch_busy_on_another_stream(const ohgpu_batch* b, hipStream_t s)
 {
     if (b->last_stream == s) return false;
-    if (b->last_untracked) return hipStreamQuery(b->last_stream) == hipErrorNotReady;
+    if (b->last_untracked) { (void)hipDeviceSynchronize(); b->last_untracked = false; return false; }
     return b->last_done != nullptr && hipEventQuery(b->last_done) == hipErrorNotReady;
 }
 inline hipError_t batch_wait_last_launch(const ohgpu_batch* b)
 {
-    if (b->last_untracked) return hipStreamSynchronize(b->last_stream);
+    if (b->last_untracked) { b->last_untracked = false; return hipDeviceSynchronize(); }
     return b->last_done ? hipEventSynchronize(b->last_done) : hipSuccess;
 }
 void free_ohm(ohgpu_ctx* ctx, ohgpu_batch* b);

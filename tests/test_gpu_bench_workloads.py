@@ -262,6 +262,37 @@ def test_a_timed_run_is_the_same_run_with_its_time_on_the_events(ctx, rate, n_st
     assert 0.0 < ms < 50.0, ms
 
 
+def test_a_timed_run_leaves_nothing_behind_that_needs_its_stream(ctx):
+    """After ohgpu_src_batch_run_timed the batch's "last launch done" is not an event of the library's (the caller's two rode on the
+    dispatch): a run on ANOTHER stream, a rewrite of the ramps and the destroy must still wait for that launch -- and must not ask
+    the first stream, which the caller may have destroyed by then."""
+    g = bench.Group(capi, 44100, 2, range(120, 126), int(round(0.53 * 44100)))
+    per = g.in_frames * 2
+    g.src = np.concatenate([noise_le(sid, per, 24).reshape(-1) for sid in g.stream_ids])
+    g.attach(ctx)
+    try:
+        ctx.src_run(g.batch, g.d_src, g.d_dst)
+        want = ctx.download(g.d_dst, g.dst_bytes)
+        ctx.memset(g.d_dst, 0, g.dst_bytes)
+        ctx.sync()
+        s1, s2 = ctx.stream_create(), ctx.stream_create()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.src_run(g.batch, g.d_src, g.d_dst, stream=s1, events=(e0, e1))
+        assert ctx.elapsed_ms(e0, e1) > 0.0                  # (synchronises on the stop event)
+        ctx.stream_destroy(s1)
+        ctx.src_run(g.batch, g.d_src, g.d_dst, stream=s2)    # another stream: the library waits for the device, not for s1
+        ctx.sync()
+        got = ctx.download(g.d_dst, g.dst_bytes)
+        e2, e3 = ctx.event(), ctx.event()
+        ctx.src_run(g.batch, g.d_src, g.d_dst, stream=s2, events=(e2, e3))
+        ctx.stream_destroy(s2)                               # (destroying a stream waits for its work)
+        for e in (e0, e1, e2, e3):
+            ctx.event_destroy(e)
+    finally:
+        g.detach(ctx)                                        # (the batch's destroy behind a timed run whose stream is gone)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("channels, src_le, dst_le", [(6, True, False), (2, False, True)])
 def test_a_plan_only_the_workgroup_kernel_reads_never_reaches_another_kernel(ctx, channels, src_le, dst_le):
     """Six-channel units are cut 30 rows long for the workgroup kernel, and big-endian-in / little-endian-out has no other block
