@@ -210,3 +210,69 @@ def test_the_pool_survives_many_short_jobs_from_two_callers():
     for t in threads:
         t.join()
     assert not bad
+
+
+DEFECTS = [
+    ("ramp_start", lambda d, k: d["ramp_start"].__setitem__(k, 0x4001)),
+    ("ramped message too long", lambda d, k: (d["flags"].__setitem__(k, d["flags"][k] | capi.FLAG_RAMP), d["n_frames"].__setitem__(k, 131072))),
+    ("attenuation", lambda d, k: d["attenuation"].__setitem__(k, 255)),
+    ("flag bits", lambda d, k: d["flags"].__setitem__(k, 0x80)),
+    ("plane stride without the flag", lambda d, k: d["src_plane_stride"].__setitem__(k, 4096)),
+    ("frame index out of range", lambda d, k: d["out_frame0"].__setitem__(k, (1 << 48) + 1)),
+    ("history missing", lambda d, k: d["src_frame0"].__setitem__(k, int(d["out_frame0"][k]) * 147 // 160 + 1)),
+    ("window too short", lambda d, k: d["src_frames"].__setitem__(k, 8)),
+    ("source beyond the arena", lambda d, k: d["src_offset"].__setitem__(k, (1 << 40))),
+    ("destination beyond the arena", lambda d, k: d["dst_offset"].__setitem__(k, (1 << 40))),
+    ("bit depth", lambda d, k: d["src_bits"].__setitem__(k, 12)),
+    ("endian", lambda d, k: d["dst_endian"].__setitem__(k, 7)),
+]
+
+
+@pytest.mark.parametrize("what, spoil", DEFECTS, ids=[w for w, _ in DEFECTS])
+def test_every_kind_of_bad_descriptor_is_the_same_error_on_both_routes(what, spoil):
+    """A batch of 4096 messages or more is checked by the planner's own pass, the usual message in line (SrcQuickCheck) and anything
+    else by src_check_range; a smaller one by src_check_range alone, ahead of the planner.  The same defect must be the same
+    error -- code and text -- on both routes, named by the message's index, on one thread and on several."""
+    ref, d, sb, db = headline_like(64, 3.0)                 # ~38 000 messages: the fused route
+    n_msgs = d.size // 64
+    small = d[:3 * n_msgs].copy()[:3000]                    # under 4096: the two-pass route (whole messages of the first streams)
+    k_small = 1234
+    spoil(small, k_small)
+    with pytest.raises(capi.OhGpuError) as e_small:
+        capi.src_plan_digest(ref.L, ref.M, ref.T, small, sb, db)
+    text_small = str(e_small.value)
+    assert f"src desc {k_small}:" in text_small
+    for threads in (1, 6):
+        capi.set_plan_threads(threads)
+        for k_big in (k_small, d.size * 2 // 3 + 17):
+            big = d.copy()
+            spoil(big, k_big)
+            with pytest.raises(capi.OhGpuError) as e_big:
+                capi.src_plan_digest(ref.L, ref.M, ref.T, big, sb, db)
+            assert e_big.value.code == e_small.value.code, (what, threads)
+            if k_big == k_small:
+                assert str(e_big.value) == text_small, (what, threads)
+            else:
+                assert f"src desc {k_big}:" in str(e_big.value), (what, threads, str(e_big.value))
+
+
+def test_a_message_of_another_layout_or_out_of_order_sends_the_batch_the_two_pass_way_with_the_same_plan():
+    """Not errors: a message whose layout differs (the batch is then planned per layout) and messages out of the planner's order (it
+    sorts).  The fused route must notice both and hand over; the digests are what the two-pass route makes of the same batch."""
+    ref, d, sb, db = headline_like(64, 3.0)
+    n_msgs = d.size // 64
+    capi.set_plan_threads(1)
+    want = capi.src_plan_digest(ref.L, ref.M, ref.T, d, sb, db)
+    # two streams' messages swapped wholesale: the same plan as in order
+    swapped = d.copy()
+    swapped[5 * n_msgs:6 * n_msgs], swapped[40 * n_msgs:41 * n_msgs] = d[40 * n_msgs:41 * n_msgs].copy(), d[5 * n_msgs:6 * n_msgs].copy()
+    for threads in (1, 5):
+        capi.set_plan_threads(threads)
+        assert capi.src_plan_digest(ref.L, ref.M, ref.T, swapped, sb, db) == want
+    # one stream little-endian out: two layouts, no error, the same on any thread count
+    mixed = d.copy()
+    mixed["dst_endian"][20 * n_msgs:21 * n_msgs] = capi.ENDIAN_LITTLE
+    capi.set_plan_threads(1)
+    one = capi.src_plan_digest(ref.L, ref.M, ref.T, mixed, sb, db)
+    capi.set_plan_threads(7)
+    assert capi.src_plan_digest(ref.L, ref.M, ref.T, mixed, sb, db) == one
