@@ -85,7 +85,32 @@ struct WgGeom {
     static constexpr bool kSpan = !kPlanes && !HB;
     static constexpr uint32_t kSpanRounds = kS16 ? 3 : 4;             // (16-bit stereo: at most 648 pieces)
     static constexpr uint32_t kSpanBytes = kSpanRounds * 256u * 16u;
-    static constexpr uint32_t kInRounds = kPlanes ? 6 : (kSpan ? kSpanRounds : kFullRounds + 1);
+    // The half-band form's rows overlap too -- a row starts 256 frames after its predecessor, its image is 320 long -- and can be fetched
+    // as ONE run as well (kHbRun): a fifth fewer pieces loaded, and staged in two sections cut BY ROWS (the run's first kHbRows0 rows,
+    // then the rest; the 64 frames the two share are staged twice), since the run and the planes do not fit the LDS side by side.
+    // Round 5, same box, turn and turn about (gpurun_out/r5/exp_hbrun.log, ms): six channels 1.825 -> 1.752 (-4 %), stereo 0.574 -> 0.583
+    // (+1.5 %: sixteen rows, and the split's sixteen lanes a row apart pay for the run's fixed row distance even with the spare bytes
+    // below), eight channels 2.20-2.30 -> 2.31-2.33 (its first section is one row: 160 tasks for 256 lanes).  So: six channels.
+#if defined(MF_WG_HB_ROWS)
+    static constexpr bool kHbRun = false;               // (A/B: every row's image fetched on its own, staged in two sections cut by chunks)
+#elif defined(MF_WG_HB_RUN_ALL)
+    static constexpr bool kHbRun = HB;                  // (A/B: every channel count)
+#else
+    static constexpr bool kHbRun = HB && PAIRS == 3;
+#endif
+    static constexpr uint32_t kHbAdv = 256u * kFb;                                   // bytes from a row's image to the next row's
+    static constexpr uint32_t kHbRunBytes = (kSR - 1u) * kHbAdv + kRowIn;            // the rows' union: 24960 (stereo), 24192, 26112
+    static constexpr uint32_t kHbRunPieces = kHbRunBytes / 16u;
+    static constexpr uint32_t kHbRunRounds = (kHbRunPieces + 255u) / 256u;
+    static constexpr uint32_t kHbRows0 = PAIRS == 1 ? 6u : (PAIRS == 3 ? 2u : 1u);   // (240 / 240 / 160 split tasks: one round of the lanes; the rest: two)
+    static constexpr uint32_t kHbSec0Hi = (kHbRows0 - 1u) * kHbAdv + kRowIn;         // section 0 = the run's bytes [0, kHbSec0Hi)
+    static constexpr uint32_t kHbSec1Lo = kHbRows0 * kHbAdv;                         // section 1 = [kHbSec1Lo, kHbRunBytes)
+    // (in LDS every 256 frames of the run are followed by 16 spare bytes: a row's image starts 256 frames x 6, 18 or 24 bytes after its
+    // predecessor's -- a multiple of 256 bytes, every row on the same banks -- and sixteen lanes of the split read sixteen rows at once:
+    // without the spare bytes the stereo half-band group took 0.82 ms instead of 0.57.  A row's image then has its hole behind chunk 15)
+    static constexpr uint32_t kHbStage = (kHbSec0Hi > kHbRunBytes - kHbSec1Lo ? kHbSec0Hi : kHbRunBytes - kHbSec1Lo) + 16u * kSR;
+    static_assert(!kHbRun || (kHbRunBytes % 16u == 0 && kHbSec0Hi % 16u == 0 && kHbSec1Lo % 16u == 0), "whole pieces");
+    static constexpr uint32_t kInRounds = kPlanes ? 6 : (kSpan ? kSpanRounds : (kHbRun ? kHbRunRounds : kFullRounds + 1));
     static constexpr uint32_t kRoundsA = HB ? 5 : kInRounds;          // half-band: the rounds of the first staging (the second: kRoundsA - 1 ..)
     static constexpr uint32_t kChunksA = HB ? 13 : kImgChunks;        // ... and the input chunks it holds whole
     static constexpr uint32_t kRowInPitch = kPlanes ? 2 * kWgPlaneIn + 16 : (HB ? kRoundsA * kRound + 16 : kRowIn + 16);   // (sixteen stereo rows, 16 bytes each, then meet all 64 banks once)
@@ -132,7 +157,7 @@ struct WgGeom {
     static constexpr uint32_t kBiasCopies = kDma ? 2 : 4;
     static constexpr uint32_t kBiasStep = 128 * kBiasCopies;          // [b0, b1][output 16][copies] dwords
     static constexpr uint32_t kBiasBytes = kBiasSteps * kBiasStep;
-    static constexpr uint32_t kInBytes = kSpan ? kSpanBytes : kSR * kRowInPitch;   // the input image ...
+    static constexpr uint32_t kInBytes = kSpan ? kSpanBytes : (kHbRun ? kHbStage : kSR * kRowInPitch);   // the input image ...
     static constexpr uint32_t kOutBytes = (ROWS + PAIRS - 1) / PAIRS * kRowOutPitch;     // ... and the output image that lies over it (six channels: the idle pair-row's stores land behind the fifth row)
     static constexpr uint32_t kStageBytes = kDma ? kOutBytes : (kInBytes > kOutBytes ? kInBytes : kOutBytes);
     static constexpr uint32_t kDmaBytes = kDma ? (((kSR - 1) * kOutFrames * kFbIn + kRowIn + 15u) / 16u) * 16u : 0u;
@@ -290,6 +315,8 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
     const uint32_t span_pieces = ((G::kSR - 1u) * row_src_bytes + G::kRowIn + 15u) >> 4;
     constexpr uint32_t kSpanLast = (G::kSpan ? G::kSpanRounds - 1u : 0u) * 256u;
     const uint32_t span_p3 = kSpanLast + tid < span_pieces ? kSpanLast + tid : tid;  // (the last round's lanes past the end repeat their first piece)
+    constexpr uint32_t kHbLast = (G::kHbRun ? G::kHbRunRounds - 1u : 0u) * 256u;
+    const uint32_t hb_p_last = kHbLast + tid < G::kHbRunPieces ? kHbLast + tid : tid;  // (kHbRun: the same for the half-band run)
 
     // pack: a frame's six bytes from its two 24-bit values, L then R, each most significant byte first (big endian) or last
     constexpr uint32_t kB0 = DST_LE ? 0 : 2, kB1 = 1, kB2 = DST_LE ? 2 : 0;       // byte of the 24-bit value that is memory byte 0, 1, 2
@@ -335,6 +362,7 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
 #pragma unroll
             for (int k = 0; k < (int)G::kInRounds; k++) {
                 const int64_t at = G::kPlanes ? (int64_t)(in_src + 256u * (uint32_t)(k % 3)) + (int64_t)(k / 3) * w.plane_stride
+                                 : G::kHbRun ? (int64_t)(16u * (k + 1 < (int)G::kInRounds ? tid + 256u * (uint32_t)k : hb_p_last))
                                  : G::kSpan ? (int64_t)(16u * (k + 1 < (int)G::kInRounds ? tid + 256u * (uint32_t)k : span_p3))
                                           : (int64_t)(k < (int)G::kFullRounds ? in_src + G::kRound * (uint32_t)k : in_src + in_last);
                 raw[k] = wg_load_piece_checked(src, w.src0 + at, src_arena_bytes);
@@ -361,6 +389,12 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
                     for (int k = 0; k + 1 < (int)G::kInRounds; k++) raw[k] = *(const u32x4_u*)(base + o + 4096 * k);
                     raw[G::kInRounds - 1] = *(const u32x4_u*)(base + mf_here(16u * span_p3));
                 }
+            } else if constexpr (G::kHbRun) {
+                // (the rows' union, piece for piece; the last round's lanes past its end repeat their first piece)
+                const uint32_t o = mf_here(16u * tid);
+#pragma unroll
+                for (int k = 0; k + 1 < (int)G::kInRounds; k++) raw[k] = *(const u32x4_u*)(base + o + 4096 * k);
+                raw[G::kInRounds - 1] = *(const u32x4_u*)(base + mf_here(16u * hb_p_last));
             } else {
                 const uint32_t o = mf_here(in_src);
 #pragma unroll
@@ -414,7 +448,16 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         return;
 #endif
         constexpr int SEC = decltype(sec_c)::value;
-        if constexpr (SEC == 0) {
+        if constexpr (G::kHbRun) {
+            // section SEC of the run: its pieces to where the section starts at 0 (a round wholly outside it is no code at all)
+            constexpr uint32_t kLo = SEC == 0 ? 0u : G::kHbSec1Lo, kHi = SEC == 0 ? G::kHbSec0Hi : G::kHbRunBytes;
+#pragma unroll
+            for (int k = 0; k < (int)G::kInRounds; k++) {
+                if (4096u * (uint32_t)k + 4096u <= kLo || 4096u * (uint32_t)k >= kHi) continue;
+                const uint32_t p = k + 1 < (int)G::kInRounds ? tid + 256u * (uint32_t)k : hb_p_last;
+                if (16u * p >= kLo && 16u * p < kHi) *(u32x4*)(stage + (16u * p - kLo) + 16u * ((16u * p) / G::kHbAdv - kLo / G::kHbAdv)) = raw[k];
+            }
+        } else if constexpr (SEC == 0) {
 #pragma unroll
             for (int k = 0; k < (int)G::kRoundsA; k++) *(u32x4*)(stage + in_lds + (int)G::kRound * k) = raw[k];
         } else {
@@ -448,11 +491,48 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
             *(u32x4*)(to + digit * G::kDigit) = u32x4{pl[bpos][0] ^ flip, pl[bpos][1] ^ flip, pl[3 + bpos][0] ^ flip, pl[3 + bpos][1] ^ flip};
         }
     };
+    // kHbRun: task t of a section = (pair-row t % its pair-rows, input chunk and parity t / them) over ALL twenty chunks of the rows the
+    // section holds; the row's image starts at (row) x 256 frames of the run, less where the section starts
+    auto split_hb_run_task = [&](auto sec_c, uint32_t t, bool first) __attribute__((always_inline)) {
+        constexpr int SEC = decltype(sec_c)::value;
+        constexpr uint32_t kRows = SEC == 0 ? G::kHbRows0 : G::kSR - G::kHbRows0, kPr = kRows * (uint32_t)PAIRS;
+        constexpr uint32_t kPr0 = SEC == 0 ? 0u : G::kHbRows0 * (uint32_t)PAIRS, kLo = SEC == 0 ? 0u : G::kHbSec1Lo;
+        const uint32_t t2 = t / kPr, pr = kPr0 + (t - t2 * kPr), ic = t2 >> 1, par = t2 & 1u;
+        const uint32_t srow = pr / (uint32_t)PAIRS, pair = pr - srow * (uint32_t)PAIRS;
+        const bool zero = first && srow == 0 && ic < 4u;            // the stream's block 0: the 64 frames before it read as zeros
+        // (the row's own 16 spare bytes per 256 frames in front of it, and one more set behind its sixteenth chunk)
+        const uint32_t byte0 = srow * G::kHbAdv - kLo + 16u * (srow - kLo / G::kHbAdv) + (ic >= 16u ? 16u : 0u) + ic * (16u * G::kFb) + par * G::kFb + 6u * pair;
+        const uint32_t at = byte0 & ~3u, sh = (byte0 & 2u) * 8u;
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const u32x2 e = *(const u32x2_a4*)(stage + at + 2 * (int)G::kFb * m);
+            const uint64_t v = (((uint64_t)e.y << 32) | e.x) >> sh;
+            lo[m] = zero ? 0u : (uint32_t)v; hi[m] = zero ? 0u : (uint32_t)(v >> 32);
+        }
+        uint32_t pl[6][2];
+        mf_split_frames(lo, hi, pl);
+        const uint32_t c = par * 10u + (ic >> 1);
+        uint8_t* const to = pl_lds + c * G::kChunk + (((ic & 1u) * G::kHalf + pr * 16u) ^ ((c & 1u) * 128u));     // + digit * kDigit
+#pragma unroll
+        for (int bpos = 0; bpos < 3; bpos++) {
+            const int digit = SRC_LE ? bpos : 2 - bpos;
+            const uint32_t flip = digit < 2 ? 0x80808080u : 0u;
+            *(u32x4*)(to + digit * G::kDigit) = u32x4{pl[bpos][0] ^ flip, pl[bpos][1] ^ flip, pl[3 + bpos][0] ^ flip, pl[3 + bpos][1] ^ flip};
+        }
+    };
     auto split_section = [&](auto sec_c, bool first) __attribute__((always_inline)) {
 #ifdef MF_DIAG_NO_SPLIT
         return;
 #endif
         constexpr int SEC = decltype(sec_c)::value;
+        if constexpr (G::kHbRun) {
+            constexpr uint32_t kTasksRun = (SEC == 0 ? G::kHbRows0 : G::kSR - G::kHbRows0) * (uint32_t)PAIRS * 40u;
+#pragma unroll
+            for (uint32_t k = 0; k * G::kThreads < kTasksRun; k++)
+                if (k * G::kThreads + tid < kTasksRun) split_hb_run_task(sec_c, k * G::kThreads + tid, first);
+            return;
+        }
         constexpr uint32_t kFirstChunk = SEC == 0 ? 0u : G::kChunksA, kChunks = SEC == 0 ? G::kChunksA : G::kImgChunks - G::kChunksA;
         constexpr uint32_t kTasks = kChunks * 2u * (uint32_t)ROWS, kByte0 = SEC == 0 ? 0u : (G::kRoundsA - 1u) * G::kRound;
 #pragma unroll
@@ -825,7 +905,9 @@ void src_mfma_wg_kernel(const LeanUnit* __restrict__ units, const uint32_t n_wor
         if constexpr (G::kInRounds > 3 && !G::kDma) asm volatile("" : "+v"(raw[3]));
         if constexpr (G::kInRounds > 4) asm volatile("" : "+v"(raw[4]));
         if constexpr (G::kInRounds > 5) asm volatile("" : "+v"(raw[5]));
-        if constexpr (G::kInRounds > 6) asm volatile("" : "+v"(raw[6]), "+v"(raw[7]));
+        if constexpr (G::kInRounds > 6) asm volatile("" : "+v"(raw[6]));
+        if constexpr (G::kInRounds > 7) asm volatile("" : "+v"(raw[7]));
+        static_assert(G::kInRounds <= 8, "the rounds of loads kept alive across (D)");
         {
             uint8_t* const unit_dst = dst + wk.dst0;
             const uint32_t out_bytes = n_blocks * G::kRowOut;
